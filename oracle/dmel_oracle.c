@@ -1,0 +1,341 @@
+/*
+ * dmel_oracle.c -- CPU restatement of the reference's DMEL hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is the parity oracle: only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may call it.  The product (the HIP library behind include/dmel.h and the
+ * dmel_amd package) never links, imports or falls back to anything in oracle/.
+ *
+ * What it restates (all citations are into /root/reference):
+ *   next_pow2            time_frequency.py:39, 60-65   n_fft = 1 << (int(6*|lambd|) - 1).bit_length()
+ *   window               time_frequency.py:21-30       w[m] = exp(-0.5*((m - N/2)/(lambd+1e-15))^2), fp32
+ *   framing + STFT       time_frequency.py:48          torch.stft(center=True, pad_mode='constant')
+ *   power                time_frequency.py:53          |s|^2
+ *   DC removal, |lambd|  models.py:38                  x[idx] - mean(x[idx]); abs(lambd)
+ *   mel filterbank       models.py:42-48               torchaudio 0.13.1 functional.melscale_fbanks
+ *                                                      (htk, norm=None) -- NOT in /root/reference and
+ *                                                      absent from the image: restated from the
+ *                                                      published algorithm, PARITY-UNPINNED.
+ *   contraction          models.py:53                  (T x F) @ (F x M), laid out (B,1,M,T)
+ *   log compression      models.py:73                  log(s + 1e-10)
+ *   d/d lambd            train.py:47 (autograd)        closed form of SURVEY.md 3.2, carried in
+ *                                                      forward mode (one trainable scalar)
+ *
+ * Pinning: tests/test_oracle_golden.py checks every function here against the fixtures in
+ * tests/golden/NAME.npz, which tests/golden/make_golden.py captured from the reference's own
+ * models.MelSpectrogramLayer + torch autograd in the dev container.
+ *
+ * Arithmetic: inputs, window and filterbank are rounded to fp32 exactly where the reference
+ * holds fp32 tensors; the DFT, |.|^2, the contraction and the reductions run in fp64, so the
+ * oracle sits ~1e-7 from exact arithmetic on those fp32 operands and ~1e-5 (the reference's own
+ * fp32 noise floor) from the reference outputs.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define DMEL_ORACLE_OK 0
+#define DMEL_ORACLE_EINVAL 1
+#define DMEL_ORACLE_ENOMEM 2
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* time_frequency.py:60-65 with the argument built as at :39: (lambd * n_stds) is an fp32 tensor
+ * product, .numpy() keeps fp32, int() truncates toward zero. */
+int dmel_oracle_n_fft(float lambd_raw)
+{
+    float a = fabsf(lambd_raw);          /* models.py:38 torch.abs(self.lambd) */
+    float prod = a * 6.0f;               /* fp32 multiply */
+    long long x = (long long)prod;       /* int(): truncation */
+    long long v = x - 1;
+    int bits = 0;
+    if (v < 0) {                         /* python: (-1).bit_length() == 1 */
+        bits = 1;
+    } else {
+        while (v > 0) { bits++; v >>= 1; }
+    }
+    return (int)(1LL << bits);
+}
+
+int dmel_oracle_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+void dmel_oracle_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+/* time_frequency.py:21-30.  w in fp32 exactly as the reference evaluates it; dw = d w / d a
+ * (a = |lambd|) in fp64 from the fp32 w.  normalize != 0 applies :25 and its derivative. */
+int dmel_oracle_window(float lambd_raw, int n_fft, int normalize, float* w, double* dw)
+{
+    if (n_fft < 1 || !w) return DMEL_ORACLE_EINVAL;
+    float a = fabsf(lambd_raw);
+    float denom = a + 1e-15f;
+    double nrm2 = 0.0, wdw = 0.0;
+    for (int m = 0; m < n_fft; ++m) {
+        float d = (float)m - (float)n_fft / 2.0f;
+        float t = d / denom;
+        float e = -0.5f * (t * t);
+        w[m] = expf(e);
+        double dd = (double)d;
+        double den = (double)denom;
+        double dwm = (double)w[m] * dd * dd / (den * den * den);
+        if (dw) dw[m] = dwm;
+        nrm2 += (double)w[m] * (double)w[m];
+        wdw += (double)w[m] * dwm;
+    }
+    if (normalize) {
+        double nrm = sqrt(nrm2);
+        for (int m = 0; m < n_fft; ++m) {
+            double wm = (double)w[m];
+            if (dw) dw[m] = dw[m] / nrm - wm * wdw / (nrm * nrm * nrm);
+            w[m] = (float)(wm / nrm);
+        }
+    }
+    return DMEL_ORACLE_OK;
+}
+
+/* torch.linspace on CPU (fp32): symmetric evaluation around the midpoint. */
+static void linspace_f32(float start, float end, int steps, float* out)
+{
+    if (steps == 1) { out[0] = start; return; }
+    float step = (end - start) / (float)(steps - 1);
+    int half = steps / 2;
+    for (int i = 0; i < steps; ++i)
+        out[i] = (i < half) ? (start + step * (float)i) : (end - step * (float)(steps - i - 1));
+}
+
+/* torchaudio 0.13.1 functional.melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate,
+ * norm=None, mel_scale="htk"), called at models.py:42-48.  fb is (n_freqs x n_mels) row-major
+ * fp32.  all_freqs = linspace(0, sample_rate // 2, n_freqs). */
+int dmel_oracle_mel_fbanks(int n_freqs, double f_min, double f_max, int n_mels, int sample_rate, float* fb)
+{
+    if (n_freqs < 1 || n_mels < 1 || !fb) return DMEL_ORACLE_EINVAL;
+    float* all_freqs = (float*)malloc(sizeof(float) * (size_t)n_freqs);
+    float* m_pts = (float*)malloc(sizeof(float) * (size_t)(n_mels + 2));
+    float* f_pts = (float*)malloc(sizeof(float) * (size_t)(n_mels + 2));
+    if (!all_freqs || !m_pts || !f_pts) { free(all_freqs); free(m_pts); free(f_pts); return DMEL_ORACLE_ENOMEM; }
+    linspace_f32(0.0f, (float)(sample_rate / 2), n_freqs, all_freqs);
+    double m_min = 2595.0 * log10(1.0 + (f_min / 700.0));     /* python floats: fp64 */
+    double m_max = 2595.0 * log10(1.0 + (f_max / 700.0));
+    linspace_f32((float)m_min, (float)m_max, n_mels + 2, m_pts);
+    for (int i = 0; i < n_mels + 2; ++i)                       /* fp32 tensor ops */
+        f_pts[i] = 700.0f * (powf(10.0f, m_pts[i] / 2595.0f) - 1.0f);
+    for (int f = 0; f < n_freqs; ++f) {
+        for (int m = 0; m < n_mels; ++m) {
+            float f_diff_lo = f_pts[m + 1] - f_pts[m];
+            float f_diff_hi = f_pts[m + 2] - f_pts[m + 1];
+            float slope_lo = f_pts[m] - all_freqs[f];
+            float slope_hi = f_pts[m + 2] - all_freqs[f];
+            float down = (-1.0f * slope_lo) / f_diff_lo;
+            float up = slope_hi / f_diff_hi;
+            float v = down < up ? down : up;
+            fb[(size_t)f * n_mels + m] = v > 0.0f ? v : 0.0f;
+        }
+    }
+    free(all_freqs); free(m_pts); free(f_pts);
+    return DMEL_ORACLE_OK;
+}
+
+/* in-place iterative radix-2 DIT complex FFT, fp64, forward sign exp(-2 pi i k n / N). */
+static void fft_c2c(double* re, double* im, int n, const double* cs, const double* sn)
+{
+    for (int i = 1, j = 0; i < n; ++i) {
+        int bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) {
+            double t = re[i]; re[i] = re[j]; re[j] = t;
+            t = im[i]; im[i] = im[j]; im[j] = t;
+        }
+    }
+    for (int len = 2; len <= n; len <<= 1) {
+        int half = len >> 1, stride = n / len;
+        for (int s = 0; s < n; s += len) {
+            for (int k = 0; k < half; ++k) {
+                double wr = cs[k * stride], wi = -sn[k * stride];
+                int p = s + k, q = p + half;
+                double tr = re[q] * wr - im[q] * wi;
+                double ti = re[q] * wi + im[q] * wr;
+                re[q] = re[p] - tr; im[q] = im[p] - ti;
+                re[p] += tr; im[p] += ti;
+            }
+        }
+    }
+}
+
+/*
+ * Forward of the layer (+ optional fused log) and, if `tangent` != NULL, the forward-mode
+ * derivative d out / d lambd_raw of every output element.
+ *
+ *   x        (B, L) fp32 row-major               models.py:33
+ *   out      (B, 1, n_mels, T) fp32, T = L/hop+1 models.py:30,36
+ *   tangent  same shape or NULL
+ *   f_max < 0 means "sample_rate // 2"           models.py:25
+ *   apply_log: out = log(mel + eps)              models.py:73 (eps = 1e-10 there)
+ *
+ * n_fft is derived from lambd exactly as the reference does (power of two, so radix-2 is exact
+ * in structure).  Returns 0 on success.
+ */
+int dmel_oracle_forward(const float* x, int B, int L, float lambd_raw, int hop, int n_mels,
+                        int sample_rate, double f_min, double f_max, int normalize_window,
+                        int apply_log, double eps, float* out, float* tangent)
+{
+    if (!x || !out || B < 0 || L < 1 || hop < 1 || n_mels < 1 || sample_rate < 2) return DMEL_ORACLE_EINVAL;
+    const int N = dmel_oracle_n_fft(lambd_raw);
+    const int F = N / 2 + 1;
+    const int T = L / hop + 1;
+    const int pad = N / 2;
+    if (f_max < 0) f_max = (double)(sample_rate / 2);
+    const double sgn = (lambd_raw > 0) - (lambd_raw < 0);   /* d|l|/dl, torch.abs backward: 0 at 0 */
+
+    float* w = (float*)malloc(sizeof(float) * (size_t)N);
+    double* dw = (double*)malloc(sizeof(double) * (size_t)N);
+    float* fb = (float*)malloc(sizeof(float) * (size_t)F * n_mels);
+    double* cs = (double*)malloc(sizeof(double) * (size_t)N);
+    double* sn = (double*)malloc(sizeof(double) * (size_t)N);
+    int* flo = (int*)malloc(sizeof(int) * (size_t)n_mels);
+    int* fhi = (int*)malloc(sizeof(int) * (size_t)n_mels);
+    float* mean = (float*)malloc(sizeof(float) * (size_t)(B > 0 ? B : 1));
+    int rc = DMEL_ORACLE_OK;
+    if (!w || !dw || !fb || !cs || !sn || !flo || !fhi || !mean) { rc = DMEL_ORACLE_ENOMEM; goto done; }
+
+    dmel_oracle_window(lambd_raw, N, normalize_window, w, dw);
+    rc = dmel_oracle_mel_fbanks(F, f_min, f_max, n_mels, sample_rate, fb);
+    if (rc) goto done;
+    for (int k = 0; k < N; ++k) { cs[k] = cos(2.0 * M_PI * k / N); sn[k] = sin(2.0 * M_PI * k / N); }
+    /* support of each mel column (the matrix is banded; skipping exact zeros changes nothing) */
+    for (int m = 0; m < n_mels; ++m) {
+        int lo = F, hi = -1;
+        for (int f = 0; f < F; ++f) if (fb[(size_t)f * n_mels + m] != 0.0f) { if (f < lo) lo = f; hi = f; }
+        flo[m] = lo; fhi[m] = hi;
+    }
+    /* models.py:38: x[idx] - mean(x[idx]) in the input dtype (fp32 here) */
+    for (int b = 0; b < B; ++b) {
+        double s = 0.0;
+        for (int i = 0; i < L; ++i) s += (double)x[(size_t)b * L + i];
+        mean[b] = (float)(s / (double)L);
+    }
+
+#pragma omp parallel
+    {
+        double* re = (double*)malloc(sizeof(double) * (size_t)N);
+        double* im = (double*)malloc(sizeof(double) * (size_t)N);
+        double* P = (double*)malloc(sizeof(double) * (size_t)F);
+        double* D = (double*)malloc(sizeof(double) * (size_t)F);
+#pragma omp for schedule(static) collapse(2)
+        for (int b = 0; b < B; ++b) {
+            for (int t = 0; t < T; ++t) {
+                if (!re || !im || !P || !D) continue;
+                const float* xb = x + (size_t)b * L;
+                /* frame t covers padded samples [t*hop, t*hop+N) = original [t*hop-pad, ...) */
+                for (int n = 0; n < N; ++n) {
+                    long long s = (long long)t * hop - pad + n;
+                    float v = (s >= 0 && s < L) ? (xb[s] - mean[b]) : 0.0f;
+                    re[n] = (double)(v * w[n]);         /* torch.stft: fp32 frame * fp32 window */
+                    im[n] = (double)v * dw[n];          /* packed second real signal: x~ * w'   */
+                }
+                fft_c2c(re, im, N, cs, sn);
+                /* Z = FFT(a + i b), a = x~ w, b = x~ w'.  X = FFT(a), X' = FFT(b):
+                 *   X[k] = (Z[k] + conj Z[N-k]) / 2,  X'[k] = (Z[k] - conj Z[N-k]) / (2i)      */
+                for (int k = 0; k < F; ++k) {
+                    int nk = (N - k) & (N - 1);
+                    double sr = re[k] + re[nk], si = im[k] - im[nk];
+                    double dr = re[k] - re[nk], di = im[k] + im[nk];
+                    double xr = 0.5 * sr, xi = 0.5 * si;        /* X  */
+                    double yr = 0.5 * di, yi = -0.5 * dr;       /* X' */
+                    P[k] = xr * xr + xi * xi;                   /* time_frequency.py:53 */
+                    D[k] = 2.0 * (xr * yr + xi * yi);           /* d|X|^2/da */
+                }
+                for (int m = 0; m < n_mels; ++m) {
+                    double mel = 0.0, dmel = 0.0;
+                    for (int f = flo[m]; f <= fhi[m]; ++f) {
+                        double c = (double)fb[(size_t)f * n_mels + m];
+                        mel += c * P[f];
+                        dmel += c * D[f];
+                    }
+                    dmel *= sgn;
+                    size_t o = ((size_t)b * n_mels + m) * T + t;
+                    if (apply_log) {
+                        out[o] = (float)log(mel + eps);
+                        if (tangent) tangent[o] = (float)(dmel / (mel + eps));
+                    } else {
+                        out[o] = (float)mel;
+                        if (tangent) tangent[o] = (float)dmel;
+                    }
+                }
+            }
+        }
+        free(re); free(im); free(P); free(D);
+    }
+done:
+    free(w); free(dw); free(fb); free(cs); free(sn); free(flo); free(fhi); free(mean);
+    return rc;
+}
+
+/* lambd.grad = sum over every output element of grad_out * d out / d lambd (train.py:47). */
+double dmel_oracle_backward(const float* grad_out, const float* tangent, long long count)
+{
+    double s = 0.0;
+#pragma omp parallel for reduction(+ : s) schedule(static)
+    for (long long i = 0; i < count; ++i) s += (double)grad_out[i] * (double)tangent[i];
+    return s;
+}
+
+/* Power spectrogram only (time_frequency.py:32-58, optimized branch), (B, F, T) fp32: used by the
+ * tests to pin the framing/DFT stage separately from the filterbank. */
+int dmel_oracle_spectrogram(const float* x, int B, int L, float lambd_raw, int hop, int normalize_window,
+                            int remove_dc, float* spec)
+{
+    if (!x || !spec || B < 0 || L < 1 || hop < 1) return DMEL_ORACLE_EINVAL;
+    const int N = dmel_oracle_n_fft(lambd_raw);
+    const int F = N / 2 + 1, T = L / hop + 1, pad = N / 2;
+    float* w = (float*)malloc(sizeof(float) * (size_t)N);
+    double* cs = (double*)malloc(sizeof(double) * (size_t)N);
+    double* sn = (double*)malloc(sizeof(double) * (size_t)N);
+    if (!w || !cs || !sn) { free(w); free(cs); free(sn); return DMEL_ORACLE_ENOMEM; }
+    dmel_oracle_window(lambd_raw, N, normalize_window, w, NULL);
+    for (int k = 0; k < N; ++k) { cs[k] = cos(2.0 * M_PI * k / N); sn[k] = sin(2.0 * M_PI * k / N); }
+#pragma omp parallel
+    {
+        double* re = (double*)malloc(sizeof(double) * (size_t)N);
+        double* im = (double*)malloc(sizeof(double) * (size_t)N);
+#pragma omp for schedule(static)
+        for (int b = 0; b < B; ++b) {
+            const float* xb = x + (size_t)b * L;
+            double s = 0.0;
+            for (int i = 0; i < L; ++i) s += (double)xb[i];
+            float mean = remove_dc ? (float)(s / (double)L) : 0.0f;
+            for (int t = 0; t < T && re && im; ++t) {
+                for (int n = 0; n < N; ++n) {
+                    long long sidx = (long long)t * hop - pad + n;
+                    float v = (sidx >= 0 && sidx < L) ? (xb[sidx] - mean) : 0.0f;
+                    re[n] = (double)(v * w[n]);
+                    im[n] = 0.0;
+                }
+                fft_c2c(re, im, N, cs, sn);
+                for (int k = 0; k < F; ++k)
+                    spec[((size_t)b * F + k) * T + t] = (float)(re[k] * re[k] + im[k] * im[k]);
+            }
+        }
+        free(re); free(im);
+    }
+    free(w); free(cs); free(sn);
+    return DMEL_ORACLE_OK;
+}

@@ -1,0 +1,114 @@
+"""ctypes binding of oracle/dmel_oracle.c.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
+the product path (dmel_amd) never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libdmel_oracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "dmel_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libdmel_oracle.so"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        fp = C.POINTER(C.c_float)
+        dp = C.POINTER(C.c_double)
+        L.dmel_oracle_n_fft.argtypes = [C.c_float]
+        L.dmel_oracle_n_fft.restype = C.c_int
+        L.dmel_oracle_threads.restype = C.c_int
+        L.dmel_oracle_set_threads.argtypes = [C.c_int]
+        L.dmel_oracle_window.argtypes = [C.c_float, C.c_int, C.c_int, fp, dp]
+        L.dmel_oracle_window.restype = C.c_int
+        L.dmel_oracle_mel_fbanks.argtypes = [C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, fp]
+        L.dmel_oracle_mel_fbanks.restype = C.c_int
+        L.dmel_oracle_forward.argtypes = [fp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
+                                          C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, fp, fp]
+        L.dmel_oracle_forward.restype = C.c_int
+        L.dmel_oracle_backward.argtypes = [fp, fp, C.c_longlong]
+        L.dmel_oracle_backward.restype = C.c_double
+        L.dmel_oracle_spectrogram.argtypes = [fp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, fp]
+        L.dmel_oracle_spectrogram.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def n_fft(lambd: float) -> int:
+    return int(lib().dmel_oracle_n_fft(np.float32(lambd)))
+
+
+def threads() -> int:
+    return int(lib().dmel_oracle_threads())
+
+
+def set_threads(n: int) -> None:
+    lib().dmel_oracle_set_threads(int(n))
+
+
+def window(lambd: float, n: int, normalize: bool = False):
+    w = np.empty(n, np.float32)
+    dw = np.empty(n, np.float64)
+    rc = lib().dmel_oracle_window(np.float32(lambd), n, int(normalize), _fp(w), dw.ctypes.data_as(C.POINTER(C.c_double)))
+    assert rc == 0
+    return w, dw
+
+
+def mel_fbanks(n_freqs: int, f_min: float, f_max: float, n_mels: int, sample_rate: int) -> np.ndarray:
+    fb = np.empty((n_freqs, n_mels), np.float32)
+    rc = lib().dmel_oracle_mel_fbanks(n_freqs, float(f_min), float(f_max), n_mels, sample_rate, _fp(fb))
+    assert rc == 0
+    return fb
+
+
+def forward(x: np.ndarray, lambd: float, hop: int, n_mels: int, sample_rate: int, f_min: float = 0.0,
+            f_max: float | None = None, normalize_window: bool = False, apply_log: bool = False,
+            eps: float = 1e-10, want_tangent: bool = True):
+    """Returns (out, tangent) with shape (B,1,n_mels,L//hop+1); tangent = d out / d lambd."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    B, L = x.shape
+    T = L // hop + 1
+    out = np.empty((B, 1, n_mels, T), np.float32)
+    tan = np.empty_like(out) if want_tangent else None
+    rc = lib().dmel_oracle_forward(_fp(x), B, L, np.float32(lambd), hop, n_mels, sample_rate, float(f_min),
+                                   -1.0 if f_max is None else float(f_max), int(normalize_window),
+                                   int(apply_log), float(eps), _fp(out), _fp(tan) if want_tangent else None)
+    if rc != 0:
+        raise RuntimeError(f"dmel_oracle_forward failed rc={rc}")
+    return out, tan
+
+
+def backward(grad_out: np.ndarray, tangent: np.ndarray) -> float:
+    g = np.ascontiguousarray(grad_out, dtype=np.float32)
+    t = np.ascontiguousarray(tangent, dtype=np.float32)
+    assert g.shape == t.shape
+    return float(lib().dmel_oracle_backward(_fp(g), _fp(t), g.size))
+
+
+def spectrogram(x: np.ndarray, lambd: float, hop: int, normalize_window: bool = False, remove_dc: bool = False):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    B, L = x.shape
+    N = n_fft(lambd)
+    spec = np.empty((B, N // 2 + 1, L // hop + 1), np.float32)
+    rc = lib().dmel_oracle_spectrogram(_fp(x), B, L, np.float32(lambd), hop, int(normalize_window), int(remove_dc), _fp(spec))
+    assert rc == 0
+    return spec

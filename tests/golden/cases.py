@@ -1,0 +1,97 @@
+"""Golden-vector case table.
+
+Inputs are regenerated from ``synth`` (deterministic), expected outputs live in
+``tests/golden/<name>.npz`` and were produced by ``make_golden.py`` running the
+reference's own ``models.MelSpectrogramLayer`` / ``time_frequency`` on CPU.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(os.path.dirname(_HERE))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+
+import dmel_amd  # noqa: E402  (importlib shim at the repo root)
+from dmel_amd import synth  # noqa: E402
+
+FULL_LIMIT = 65536      # store the whole mel tensor up to this many elements
+N_SAMPLED = 16384       # otherwise this many fixed pseudo-random positions
+
+
+def _case(name, B, L, sr, lambd, hop, n_mels, kind="noise", normalize_window=False,
+          dtype="float32", seed=0, f_min=0.0, f_max=None):
+    return dict(name=name, B=B, L=L, sr=sr, lambd=lambd, hop=hop, n_mels=n_mels, kind=kind,
+                normalize_window=normalize_window, dtype=dtype, seed=seed, f_min=f_min, f_max=f_max)
+
+
+CASES = [
+    # G1 = BASELINE config 1 exactly
+    _case("g1_c1", 4, 16000, 16000, 64.0, 256, 64),
+    # G2 = config 2 shape at B=8
+    _case("g2_c2", 8, 16000, 16000, 128.0, 512, 128, seed=2),
+    # G3 = config 3 shape at B=2
+    _case("g3_c3", 2, 160000, 16000, 256.0, 512, 128, seed=3),
+    # G4 = ESC-50-shaped (config 5), both hop conventions
+    _case("g4_esc_hop441", 2, 220500, 44100, 256.0, 441, 128, seed=4),
+    _case("g4_esc_hop512", 2, 220500, 44100, 256.0, 512, 128, seed=5),
+    # G5 = the paper's sizes (search_spaces.py:7-31): sr 8000, hop 80, n_mels 64
+    _case("g5_n128", 2, 8000, 8000, 8000 * 0.01 / 6, 80, 64, seed=6),
+    _case("g5_n512", 2, 8000, 8000, 8000 * 0.035 / 6, 80, 64, seed=7),
+    _case("g5_n4096", 2, 40000, 8000, 8000 * 0.3 / 6, 80, 64, seed=8),
+    # G6 = edges
+    _case("g6_normwin", 2, 16000, 16000, 64.0, 256, 64, normalize_window=True, seed=9),
+    _case("g6_neglambd", 2, 16000, 16000, -64.0, 256, 64, seed=10),
+    _case("g6_pow2_512p0", 2, 8000, 16000, 512.0 / 6.0, 256, 64, seed=11),
+    _case("g6_pow2_512p9", 2, 8000, 16000, 512.9 / 6.0, 256, 64, seed=12),
+    _case("g6_pow2_513p0", 2, 8000, 16000, 513.0 / 6.0, 256, 64, seed=13),
+    _case("g6_zero", 2, 16000, 16000, 64.0, 256, 64, kind="zero", seed=14),
+    _case("g6_fp64", 2, 16000, 16000, 64.0, 256, 64, dtype="float64", seed=15),
+    _case("g6_tone_dc", 3, 16000, 16000, 100.0, 160, 80, kind="tone", seed=16),
+    _case("g6_fminmax", 2, 12000, 16000, 40.0, 200, 40, seed=17, f_min=125.0, f_max=7000.0),
+    _case("g6_n256_ragged", 3, 5003, 22050, 30.0, 97, 48, seed=18),
+    _case("g6_n2048_short", 2, 3000, 16000, 300.0, 128, 128, seed=19),
+    _case("g6_n64", 2, 4000, 8000, 9.0, 40, 20, seed=20),
+    _case("g6_n32", 2, 2000, 8000, 5.0, 16, 10, seed=21),
+]
+
+BY_NAME = {c["name"]: c for c in CASES}
+
+
+def make_input(case) -> np.ndarray:
+    B, L = case["B"], case["L"]
+    if case["kind"] == "noise":
+        x = synth.waveforms(B, L, seed=case["seed"])
+    elif case["kind"] == "zero":
+        x = np.zeros((B, L), dtype=np.float32)
+    elif case["kind"] == "tone":
+        x = synth.tone_mix(B, L, case["sr"], seed=case["seed"])
+    else:
+        raise ValueError(case["kind"])
+    return x.astype(case["dtype"])
+
+
+def out_shape(case):
+    return (case["B"], 1, case["n_mels"], case["L"] // case["hop"] + 1)
+
+
+def make_cotangent(case) -> np.ndarray:
+    return synth.cotangent(out_shape(case), seed=1000 + case["seed"])
+
+
+def sample_index(case) -> np.ndarray | None:
+    """Flat positions stored for big outputs (None = stored in full)."""
+    n = int(np.prod(out_shape(case)))
+    if n <= FULL_LIMIT:
+        return None
+    u = synth.uniform01(N_SAMPLED, seed=777 + case["seed"])
+    return np.minimum((u * n).astype(np.int64), n - 1)
+
+
+def load(case) -> dict:
+    z = np.load(os.path.join(_HERE, case["name"] + ".npz"))
+    return {k: z[k] for k in z.files}

@@ -1,0 +1,137 @@
+#!/usr/bin/env python3
+"""Capture golden vectors from the REFERENCE itself (dev container only).
+
+Runs ``/root/reference``'s own ``models.MelSpectrogramLayer.forward`` (models.py:33-56),
+``time_frequency.differentiable_spectrogram`` (time_frequency.py:32-58) and torch autograd on
+CPU for every case in ``cases.py`` and writes ``tests/golden/<name>.npz``.  The reference is
+imported read-only from where it lies; nothing of it is copied into this repo, only the
+numeric outputs.  ``/root/reference`` does not exist on the GPU box, so this script is never
+run there; tests consume the committed ``.npz`` files.
+
+One third-party piece is NOT available: ``torchaudio`` (pinned 0.13.1, requirements.txt:8) is
+absent from this image and there is no network.  ``models.py:42`` calls
+``torchaudio.functional.melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate)`` with the
+defaults ``norm=None, mel_scale="htk"``; the stand-in below restates that published algorithm
+(torchaudio/functional/functional.py, ``melscale_fbanks`` + ``_create_triangular_filterbank``)
+op for op in fp32 torch.  The filterbank table is therefore PARITY-UNPINNED (formula only);
+everything else in these fixtures comes out of the reference's own code and torch.
+
+Usage:  python tests/golden/make_golden.py [case-name ...]
+"""
+from __future__ import annotations
+
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import cases as C  # noqa: E402
+
+REFERENCE = "/root/reference"
+
+
+def _melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate, norm=None, mel_scale="htk"):
+    """torchaudio 0.13.1 functional.melscale_fbanks, htk / norm=None branch."""
+    assert norm is None and mel_scale == "htk"
+    all_freqs = torch.linspace(0, sample_rate // 2, n_freqs)
+    m_min = 2595.0 * math.log10(1.0 + (f_min / 700.0))
+    m_max = 2595.0 * math.log10(1.0 + (f_max / 700.0))
+    m_pts = torch.linspace(m_min, m_max, n_mels + 2)
+    f_pts = 700.0 * (10.0 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    zero = torch.zeros(1)
+    down_slopes = (-1.0 * slopes[:, :-2]) / f_diff[:-1]
+    up_slopes = slopes[:, 2:] / f_diff[1:]
+    return torch.max(zero, torch.min(down_slopes, up_slopes))
+
+
+def _install_torchaudio_standin():
+    ta = types.ModuleType("torchaudio")
+    fn = types.ModuleType("torchaudio.functional")
+    tr = types.ModuleType("torchaudio.transforms")
+    fn.melscale_fbanks = _melscale_fbanks
+
+    class _Unavailable:  # panns.py:141-142 / models.py:300 only touch these in code we never run
+        def __init__(self, *a, **k):
+            raise RuntimeError("torchaudio.transforms is not available in this image")
+
+    tr.TimeMasking = tr.FrequencyMasking = tr.MelSpectrogram = _Unavailable
+    ta.functional, ta.transforms = fn, tr
+    sys.modules["torchaudio"] = ta
+    sys.modules["torchaudio.functional"] = fn
+    sys.modules["torchaudio.transforms"] = tr
+
+
+def import_reference():
+    _install_torchaudio_standin()
+    if REFERENCE not in sys.path:
+        sys.path.insert(0, REFERENCE)
+    sys.dont_write_bytecode = True
+    import models  # the reference's models.py
+    import time_frequency  # the reference's time_frequency.py
+    return models, time_frequency
+
+
+def run_case(models, tf, case):
+    torch.set_num_threads(8)
+    x_np = C.make_input(case)
+    x = torch.from_numpy(x_np)
+    g = torch.from_numpy(C.make_cotangent(case))
+    layer = models.MelSpectrogramLayer(
+        init_lambd=torch.tensor(float(case["lambd"]), dtype=torch.float32),
+        n_mels=case["n_mels"], n_points=case["L"], sample_rate=case["sr"],
+        f_min=case["f_min"], f_max=case["f_max"], hop_length=case["hop"], device="cpu",
+        optimized=True, normalize_window=case["normalize_window"])
+    n_fft = tf.next_power_of_2((torch.abs(layer.lambd) * 6).detach().cpu().numpy())
+
+    mel = layer(x)                                   # models.py:33-56
+    y = torch.log(mel + 1e-10)                       # models.py:73
+    (dl_log,) = torch.autograd.grad((y * g).sum(), layer.lambd, retain_graph=True)
+    (dl_lin,) = torch.autograd.grad((mel * g).sum(), layer.lambd)
+
+    mel_np = mel.detach().numpy().astype(np.float32)
+    out = dict(n_fft=np.int64(n_fft), dlam_log=np.float32(dl_log.item()), dlam_lin=np.float32(dl_lin.item()),
+               lambd=np.float32(case["lambd"]),
+               mel_sum=mel_np.astype(np.float64).reshape(case["B"], -1).sum(1),
+               y_sum=y.detach().numpy().astype(np.float64).reshape(case["B"], -1).sum(1))
+    idx = C.sample_index(case)
+    if idx is None:
+        out["mel"] = mel_np
+    else:
+        out["mel_sampled"] = mel_np.reshape(-1)[idx]
+    return out
+
+
+def run_dspec(models, tf):
+    """G7: DSPEC non-optimized layer (models.py:171-200), L=128, hop=1, lambd=6.38."""
+    from dmel_amd import synth
+    x = torch.from_numpy(synth.waveforms(2, 128, seed=77, scale=1.0))
+    layer = models.SpectrogramLayer(torch.tensor(6.38), optimized=False, hop_length=1)
+    s = layer(x)
+    g = torch.from_numpy(synth.cotangent(tuple(s.shape), seed=78))
+    (dl,) = torch.autograd.grad((s * g).sum(), layer.lambd)
+    return dict(spec=s.detach().numpy().astype(np.float32), dlam_lin=np.float32(dl.item()))
+
+
+def main(argv):
+    models, tf = import_reference()
+    names = argv[1:] or [c["name"] for c in C.CASES] + ["g7_dspec"]
+    for name in names:
+        if name == "g7_dspec":
+            out = run_dspec(models, tf)
+        else:
+            out = run_case(models, tf, C.BY_NAME[name])
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        extra = {k: (v.item() if np.ndim(v) == 0 else v.shape) for k, v in out.items()}
+        print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB  {extra}")
+
+
+if __name__ == "__main__":
+    main(sys.argv)
