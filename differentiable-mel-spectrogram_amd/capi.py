@@ -1,0 +1,190 @@
+"""ctypes binding of libdmel_hip.so (include/dmel.h).
+
+This is the only way the Python layer reaches the kernels: raw device pointers, sizes and a
+stream handle go through the C ABI.  There is no CPU fallback: if the shared object is missing or
+no gfx950 device is visible, the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libdmel_hip.so")
+
+DMEL_OK = 0
+DMEL_ERR_INVALID_ARGUMENT = 1
+DMEL_ERR_UNSUPPORTED = 2
+DMEL_ERR_HIP = 3
+DMEL_ERR_NO_DEVICE = 4
+DMEL_ERR_OUT_OF_MEMORY = 5
+DMEL_FLAG_LOG = 1
+
+# every symbol include/dmel.h declares (tests check the library exports exactly these)
+SYMBOLS = (
+    "dmel_abi_version", "dmel_n_fft", "dmel_window_host", "dmel_mel_fbanks_host", "dmel_last_error",
+    "dmel_device_count", "dmel_plan_create", "dmel_plan_destroy", "dmel_plan_set_filterbank",
+    "dmel_forward", "dmel_backward", "dmel_spectrogram", "dmel_plan_get_info",
+    "dmel_plan_set_profiling", "dmel_plan_get_profile",
+)
+
+
+class DmelConfig(C.Structure):
+    _fields_ = [("n_points", C.c_int32), ("hop_length", C.c_int32), ("n_mels", C.c_int32),
+                ("sample_rate", C.c_int32), ("f_min", C.c_double), ("f_max", C.c_double),
+                ("normalize_window", C.c_int32), ("max_batch", C.c_int32)]
+
+
+class DmelPlanInfo(C.Structure):
+    _fields_ = [("n_fft", C.c_int32), ("n_freqs", C.c_int32), ("n_time", C.c_int32),
+                ("frames_per_tile", C.c_int32), ("grid_fwd", C.c_int32), ("fb_blocks", C.c_int32),
+                ("fb_blocks_dense", C.c_int32), ("lds_bytes", C.c_int32), ("kernel_path", C.c_int32)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class DmelProfile(C.Structure):
+    _fields_ = [("prep_ms", C.c_double), ("fwd_ms", C.c_double), ("bwd_ms", C.c_double),
+                ("prep_launches", C.c_int32), ("fwd_launches", C.c_int32), ("bwd_launches", C.c_int32)]
+
+
+class DmelError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"libdmel_hip: status {status}: {message}")
+        self.status = status
+
+
+_lib = None
+
+
+def load():
+    """dlopen libdmel_hip.so.  Raises if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build the HIP library first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or python differentiable-mel-spectrogram_amd/build.py). "
+            "There is no CPU fallback for the DMEL layer.")
+    L = C.CDLL(LIB_PATH)
+    vp, fp = C.c_void_p, C.POINTER(C.c_float)
+    L.dmel_abi_version.restype = C.c_int32
+    L.dmel_n_fft.argtypes = [C.c_float]
+    L.dmel_n_fft.restype = C.c_int32
+    L.dmel_window_host.argtypes = [C.c_float, C.c_int32, C.c_int32, fp, fp]
+    L.dmel_window_host.restype = C.c_int
+    L.dmel_mel_fbanks_host.argtypes = [C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32, fp]
+    L.dmel_mel_fbanks_host.restype = C.c_int
+    L.dmel_last_error.restype = C.c_char_p
+    L.dmel_device_count.restype = C.c_int32
+    L.dmel_plan_create.argtypes = [C.POINTER(DmelConfig), C.POINTER(vp)]
+    L.dmel_plan_create.restype = C.c_int
+    L.dmel_plan_destroy.argtypes = [vp]
+    L.dmel_plan_destroy.restype = C.c_int
+    L.dmel_plan_set_filterbank.argtypes = [vp, C.c_int32, fp]
+    L.dmel_plan_set_filterbank.restype = C.c_int
+    L.dmel_forward.argtypes = [vp, vp, C.c_int32, C.c_float, C.c_uint32, C.c_double, vp, vp, vp]
+    L.dmel_forward.restype = C.c_int
+    L.dmel_backward.argtypes = [vp, vp, vp, C.c_int64, C.c_int32, vp, vp]
+    L.dmel_backward.restype = C.c_int
+    L.dmel_spectrogram.argtypes = [vp, vp, C.c_int32, C.c_float, C.c_int32, vp, vp]
+    L.dmel_spectrogram.restype = C.c_int
+    L.dmel_plan_get_info.argtypes = [vp, C.POINTER(DmelPlanInfo)]
+    L.dmel_plan_get_info.restype = C.c_int
+    L.dmel_plan_set_profiling.argtypes = [vp, C.c_int32]
+    L.dmel_plan_set_profiling.restype = C.c_int
+    L.dmel_plan_get_profile.argtypes = [vp, C.POINTER(DmelProfile)]
+    L.dmel_plan_get_profile.restype = C.c_int
+    _lib = L
+    return L
+
+
+def _check(status: int):
+    if status != DMEL_OK:
+        raise DmelError(status, (load().dmel_last_error() or b"").decode("utf-8", "replace"))
+
+
+def n_fft(lambd: float) -> int:
+    return int(load().dmel_n_fft(C.c_float(float(lambd))))
+
+
+def device_count() -> int:
+    return int(load().dmel_device_count())
+
+
+def window_host(lambd: float, n: int, normalize: bool = False):
+    import numpy as np
+    w = np.empty(n, np.float32)
+    dw = np.empty(n, np.float32)
+    _check(load().dmel_window_host(float(lambd), n, int(normalize), w.ctypes.data_as(C.POINTER(C.c_float)),
+                                   dw.ctypes.data_as(C.POINTER(C.c_float))))
+    return w, dw
+
+
+def mel_fbanks_host(n_freqs: int, f_min: float, f_max: float, n_mels: int, sample_rate: int):
+    import numpy as np
+    fb = np.empty((n_freqs, n_mels), np.float32)
+    _check(load().dmel_mel_fbanks_host(n_freqs, float(f_min), float(f_max), n_mels, sample_rate,
+                                       fb.ctypes.data_as(C.POINTER(C.c_float))))
+    return fb
+
+
+class Plan:
+    """Owner of a dmel_plan handle (MelSpectrogramLayer.__init__ state, models.py:15-30)."""
+
+    def __init__(self, n_points: int, hop_length: int, n_mels: int, sample_rate: int, f_min: float = 0.0,
+                 f_max: float | None = None, normalize_window: bool = False, max_batch: int = 0):
+        self._h = C.c_void_p()
+        cfg = DmelConfig(int(n_points), int(hop_length), int(n_mels), int(sample_rate), float(f_min),
+                         -1.0 if f_max is None else float(f_max), int(bool(normalize_window)), int(max_batch))
+        _check(load().dmel_plan_create(C.byref(cfg), C.byref(self._h)))
+        self.n_time = int(n_points) // int(hop_length) + 1
+        self.n_mels = int(n_mels)
+        self.n_points = int(n_points)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            load().dmel_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def forward(self, x_ptr: int, batch: int, lambd: float, out_ptr: int, tangent_ptr: int | None,
+                log: bool, eps: float, stream: int):
+        _check(load().dmel_forward(self._h, x_ptr, batch, C.c_float(float(lambd)), DMEL_FLAG_LOG if log else 0,
+                                   float(eps), out_ptr, tangent_ptr, stream))
+
+    def backward(self, grad_ptr: int, tangent_ptr: int, count: int, dlambd_ptr: int, stream: int, accumulate: bool = False):
+        _check(load().dmel_backward(self._h, grad_ptr, tangent_ptr, int(count), int(accumulate), dlambd_ptr, stream))
+
+    def spectrogram(self, x_ptr: int, batch: int, lambd: float, spec_ptr: int, stream: int, remove_dc: bool = False):
+        _check(load().dmel_spectrogram(self._h, x_ptr, batch, C.c_float(float(lambd)), int(remove_dc), spec_ptr, stream))
+
+    def set_filterbank(self, n_fft_: int, fb):
+        import numpy as np
+        if fb is None:
+            _check(load().dmel_plan_set_filterbank(self._h, int(n_fft_), None))
+            return
+        fb = np.ascontiguousarray(fb, dtype=np.float32)
+        if fb.shape != (n_fft_ // 2 + 1, self.n_mels):
+            raise ValueError(f"filterbank must be ({n_fft_ // 2 + 1}, {self.n_mels}), got {fb.shape}")
+        _check(load().dmel_plan_set_filterbank(self._h, int(n_fft_), fb.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def set_profiling(self, enable: bool):
+        _check(load().dmel_plan_set_profiling(self._h, int(bool(enable))))
+
+    def get_profile(self) -> dict:
+        pr = DmelProfile()
+        _check(load().dmel_plan_get_profile(self._h, C.byref(pr)))
+        return {k: getattr(pr, k) for k, _ in pr._fields_}
+
+    def info(self) -> dict:
+        inf = DmelPlanInfo()
+        _check(load().dmel_plan_get_info(self._h, C.byref(inf)))
+        return inf.as_dict()

@@ -1,0 +1,498 @@
+// dmel_api.cpp -- host side of libdmel_hip.so: the C ABI of include/dmel.h.
+//
+// Owns everything that is not a kernel: n_fft derivation (time_frequency.py:39,60-65), the HTK mel
+// filterbank of models.py:42-48 and its packing into non-zero MFMA B-fragments, FFT twiddle tables,
+// per-plan workspace, argument checking and kernel dispatch.  No torch types, no oracle code.
+#include "../../include/dmel.h"
+#include "dmel_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+dmel_status fail(dmel_status st, const std::string& msg)
+{
+    g_err = msg;
+    return st;
+}
+
+#define DMEL_HIP(expr)                                                                             \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(DMEL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+// torch.linspace (fp32, CPU): symmetric evaluation around the midpoint
+void linspace_f32(float start, float end, int steps, std::vector<float>& out)
+{
+    out.resize(steps);
+    if (steps == 1) { out[0] = start; return; }
+    const float step = (end - start) / (float)(steps - 1);
+    const int half = steps / 2;
+    for (int i = 0; i < steps; ++i)
+        out[i] = i < half ? start + step * (float)i : end - step * (float)(steps - i - 1);
+}
+
+struct NfftTables {
+    int n_fft = 0, F = 0, KS = 0, NT = 0, groups = 0;
+    int n_entries = 0, n_dense = 0;
+    float2* tw1 = nullptr;
+    float2* tw2 = nullptr;
+    int* ent_meta = nullptr;
+    float* ent_b = nullptr;
+    int* ent_range = nullptr;
+    int* wave_tiles = nullptr;
+    float* fb_dense = nullptr;   // (F, M) for the direct-DFT kernel
+    void release()
+    {
+        void* ptrs[] = {tw1, tw2, ent_meta, ent_b, ent_range, wave_tiles, fb_dense};
+        for (void* q : ptrs) (void)hipFree(q);
+        *this = NfftTables();
+    }
+};
+
+}  // namespace
+
+struct dmel_plan {
+    dmel_config cfg{};
+    int device = 0;
+    int T = 0;
+    int nchunks = 1, chunk = 0;
+    double f_max = 0;
+    std::map<int, NfftTables> tables;
+    std::map<int, std::vector<float>> custom_fb;
+    float* psum = nullptr;
+    int psum_clips = 0;
+    float* win = nullptr;          // 2 * kMaxNfft floats
+    double* partials = nullptr;    // kMaxPartials doubles
+    std::mutex mu;
+    dmel_plan_info info{};
+    // optional event timing
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    struct Span { size_t a, b; int kind; };
+    std::vector<Span> spans;
+};
+
+namespace {
+
+constexpr int kMaxPartials = 1024;
+constexpr size_t kMaxSpans = 16384;
+
+// returns an event index recorded on s, or (size_t)-1 when profiling is off / full
+size_t prof_mark(dmel_plan* pl, hipStream_t s)
+{
+    if (!pl->profiling || pl->spans.size() >= kMaxSpans) return (size_t)-1;
+    if (pl->ev_used == pl->ev_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return (size_t)-1;
+        pl->ev_pool.push_back(e);
+    }
+    const size_t i = pl->ev_used++;
+    if (hipEventRecord(pl->ev_pool[i], s) != hipSuccess) return (size_t)-1;
+    return i;
+}
+void prof_span(dmel_plan* pl, size_t a, size_t b, int kind)
+{
+    if (a != (size_t)-1 && b != (size_t)-1) pl->spans.push_back({a, b, kind});
+}
+
+dmel_status build_tables(dmel_plan* pl, int N, NfftTables** out)
+{
+    auto it = pl->tables.find(N);
+    if (it != pl->tables.end()) { *out = &it->second; return DMEL_OK; }
+    NfftTables tb;
+    tb.n_fft = N;
+    tb.F = N / 2 + 1;
+    const int M = pl->cfg.n_mels;
+    std::vector<float> fb((size_t)tb.F * M);
+    auto cit = pl->custom_fb.find(N);
+    if (cit != pl->custom_fb.end()) {
+        fb = cit->second;
+    } else {
+        dmel_status st = dmel_mel_fbanks_host(tb.F, pl->cfg.f_min, pl->f_max, M, pl->cfg.sample_rate, fb.data());
+        if (st != DMEL_OK) return st;
+    }
+    DMEL_HIP(hipMalloc(&tb.fb_dense, fb.size() * sizeof(float)));
+    DMEL_HIP(hipMemcpy(tb.fb_dense, fb.data(), fb.size() * sizeof(float), hipMemcpyHostToDevice));
+
+    if (N >= dmel::kMinFastNfft) {
+        int R = 0, C = 0;
+        switch (N) {
+            case 32: R = 4; C = 2; break;   case 64: R = 8; C = 1; break;
+            case 128: R = 8; C = 2; break;  case 256: R = 16; C = 1; break;
+            case 512: R = 16; C = 2; break; case 1024: R = 16; C = 4; break;
+            case 2048: R = 32; C = 2; break; case 4096: R = 64; C = 1; break;
+            default: return fail(DMEL_ERR_UNSUPPORTED, "n_fft has no FFT plan");
+        }
+        const int G = N / R;
+        std::vector<float2> tw1((size_t)R * G), tw2((size_t)R * C);
+        for (int q = 0; q < R; ++q)
+            for (int lg = 0; lg < G; ++lg) {
+                const double th = -2.0 * M_PI * (double)((long long)lg * q % N) / (double)N;
+                tw1[(size_t)q * G + lg] = make_float2((float)std::cos(th), (float)std::sin(th));
+            }
+        for (int p1 = 0; p1 < R; ++p1)
+            for (int r = 0; r < C; ++r) {
+                const double th = -2.0 * M_PI * (double)(r * p1 % G) / (double)G;
+                tw2[(size_t)p1 * C + r] = make_float2((float)std::cos(th), (float)std::sin(th));
+            }
+        DMEL_HIP(hipMalloc(&tb.tw1, tw1.size() * sizeof(float2)));
+        DMEL_HIP(hipMemcpy(tb.tw1, tw1.data(), tw1.size() * sizeof(float2), hipMemcpyHostToDevice));
+        DMEL_HIP(hipMalloc(&tb.tw2, tw2.size() * sizeof(float2)));
+        DMEL_HIP(hipMemcpy(tb.tw2, tw2.data(), tw2.size() * sizeof(float2), hipMemcpyHostToDevice));
+
+        // Non-zero 4 x 16 blocks of the filterbank as MFMA B-fragments.  Mel tiles are handled in
+        // groups of 8 (128 mel bands); inside a group wave w owns tiles w and 7-w (the HTK bands
+        // widen with frequency, so pairing a narrow and a wide tile balances the four waves).
+        tb.KS = (tb.F + 3) / 4;
+        tb.NT = (M + 15) / 16;
+        tb.groups = (tb.NT + 7) / 8;
+        tb.n_dense = tb.KS * tb.NT;
+        std::vector<int> meta, range((size_t)tb.groups * 8), wtiles((size_t)tb.groups * 8);
+        std::vector<float> bfr;
+        for (int g = 0; g < tb.groups; ++g) {
+            const int ntg = std::min(8, tb.NT - 8 * g);
+            for (int w = 0; w < dmel::kWaves; ++w) {
+                int tiles[2] = {-1, -1};
+                if (w < ntg) tiles[0] = 8 * g + w;
+                if (7 - w >= 4 && 7 - w < ntg) tiles[1] = 8 * g + 7 - w;
+                wtiles[(size_t)(g * 4 + w) * 2 + 0] = tiles[0];
+                wtiles[(size_t)(g * 4 + w) * 2 + 1] = tiles[1];
+                range[(size_t)(g * 4 + w) * 2 + 0] = (int)meta.size();
+                for (int ks = 0; ks < tb.KS; ++ks)
+                    for (int loc = 0; loc < 2; ++loc) {
+                        if (tiles[loc] < 0) continue;
+                        float blk[64];
+                        bool any = false;
+                        for (int l = 0; l < 64; ++l) {
+                            const int f = 4 * ks + (l >> 4), m = 16 * tiles[loc] + (l & 15);
+                            const float v = (f < tb.F && m < M) ? fb[(size_t)f * M + m] : 0.f;
+                            blk[l] = v;
+                            any |= (v != 0.f);
+                        }
+                        if (!any) continue;
+                        meta.push_back(ks | (loc << 16));
+                        bfr.insert(bfr.end(), blk, blk + 64);
+                    }
+                range[(size_t)(g * 4 + w) * 2 + 1] = (int)meta.size();
+            }
+        }
+        tb.n_entries = (int)meta.size();
+        const size_t ne = std::max<size_t>(meta.size(), 1);
+        DMEL_HIP(hipMalloc(&tb.ent_meta, ne * sizeof(int)));
+        DMEL_HIP(hipMalloc(&tb.ent_b, ne * 64 * sizeof(float)));
+        if (!meta.empty()) {
+            DMEL_HIP(hipMemcpy(tb.ent_meta, meta.data(), meta.size() * sizeof(int), hipMemcpyHostToDevice));
+            DMEL_HIP(hipMemcpy(tb.ent_b, bfr.data(), bfr.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
+        DMEL_HIP(hipMalloc(&tb.ent_range, range.size() * sizeof(int)));
+        DMEL_HIP(hipMemcpy(tb.ent_range, range.data(), range.size() * sizeof(int), hipMemcpyHostToDevice));
+        DMEL_HIP(hipMalloc(&tb.wave_tiles, wtiles.size() * sizeof(int)));
+        DMEL_HIP(hipMemcpy(tb.wave_tiles, wtiles.data(), wtiles.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    auto ins = pl->tables.emplace(N, tb);
+    *out = &ins.first->second;
+    return DMEL_OK;
+}
+
+dmel_status ensure_psum(dmel_plan* pl, int batch)
+{
+    if (batch <= pl->psum_clips) return DMEL_OK;
+    if (pl->psum) { (void)hipFree(pl->psum); pl->psum = nullptr; pl->psum_clips = 0; }
+    const int clips = std::max(batch, pl->cfg.max_batch);
+    DMEL_HIP(hipMalloc(&pl->psum, (size_t)clips * pl->nchunks * sizeof(float)));
+    pl->psum_clips = clips;
+    return DMEL_OK;
+}
+
+// shared body of dmel_forward / dmel_spectrogram
+dmel_status run_forward(dmel_plan* pl, const float* x, int batch, float lambd, unsigned flags, double eps,
+                        float* out, float* tangent, int mode, int remove_dc, void* stream)
+{
+    if (!pl) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
+    if (batch < 0) return fail(DMEL_ERR_INVALID_ARGUMENT, "batch < 0");
+    if (batch == 0) return DMEL_OK;
+    if (!x || !out) return fail(DMEL_ERR_INVALID_ARGUMENT, "x / out is NULL");
+    if (batch > 65534) return fail(DMEL_ERR_INVALID_ARGUMENT, "batch > 65534 (split the call)");
+    if (!std::isfinite(lambd)) return fail(DMEL_ERR_INVALID_ARGUMENT, "lambd is not finite");
+    std::lock_guard<std::mutex> lock(pl->mu);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int N = dmel_n_fft(lambd);
+    if (N > dmel::kMaxNfft)
+        return fail(DMEL_ERR_UNSUPPORTED, "n_fft = " + std::to_string(N) + " > 4096 (|lambd| > 682.6) is not supported by the HIP kernels");
+    NfftTables* tb = nullptr;
+    dmel_status st = build_tables(pl, N, &tb);
+    if (st != DMEL_OK) return st;
+    if ((st = ensure_psum(pl, batch)) != DMEL_OK) return st;
+
+    dmel::PrepParams pp{};
+    pp.x = x; pp.psum = pl->psum; pp.win = pl->win;
+    pp.B = batch; pp.L = pl->cfg.n_points; pp.nchunks = pl->nchunks; pp.chunk = pl->chunk;
+    pp.N = N; pp.normalize = pl->cfg.normalize_window; pp.lambd_abs = std::fabs(lambd);
+    // x~*w and x~*dw/dlambd share one complex FFT; dw/dlambd is ~1/|lambd| times smaller than w, and the
+    // even/odd split that separates the two spectra leaves an error of eps * (the larger one) in each.
+    // Pre-multiplying dw by a power of two ~|lambd| (exact) keeps both at the same scale; the
+    // epilogue divides it out again through `sign` (also exact).
+    int ex = 0;
+    (void)std::frexp(std::fabs(lambd) > 1e-30f ? std::fabs(lambd) : 1.0f, &ex);
+    ex = std::max(-60, std::min(60, ex));
+    pp.dw_scale = std::ldexp(1.0f, ex);
+    const size_t m0 = prof_mark(pl, s);
+    DMEL_HIP(dmel::launch_prep(pp, s));
+    const size_t m1 = prof_mark(pl, s);
+    prof_span(pl, m0, m1, 0);
+
+    const float sign = (lambd > 0.f ? 1.f : (lambd < 0.f ? -1.f : 0.f)) / pp.dw_scale;
+    pl->info.n_fft = N; pl->info.n_freqs = tb->F; pl->info.n_time = pl->T;
+    if (N < dmel::kMinFastNfft) {
+        dmel::NaiveParams np{};
+        np.x = x; np.out = out; np.tangent = tangent; np.psum = pl->psum; np.win = pl->win; np.fb = tb->fb_dense;
+        np.B = batch; np.L = pl->cfg.n_points; np.T = pl->T; np.hop = pl->cfg.hop_length; np.M = pl->cfg.n_mels;
+        np.nchunks = pl->nchunks; np.N = N; np.F = tb->F; np.mode = mode;
+        np.inv_L = 1.0f / (float)pl->cfg.n_points; np.sign = sign; np.eps = (float)eps; np.flags = flags;
+        np.remove_dc = remove_dc;
+        DMEL_HIP(dmel::launch_naive(np, s));
+        prof_span(pl, m1, prof_mark(pl, s), 1);
+        pl->info.kernel_path = 1; pl->info.frames_per_tile = 1; pl->info.grid_fwd = batch * pl->T;
+        pl->info.fb_blocks = 0; pl->info.fb_blocks_dense = 0; pl->info.lds_bytes = (2 * N + 2 * tb->F) * 4;
+        return DMEL_OK;
+    }
+    dmel::FwdParams fp{};
+    fp.x = x; fp.out = out; fp.tangent = tangent; fp.psum = pl->psum; fp.win = pl->win;
+    fp.tw1 = tb->tw1; fp.tw2 = tb->tw2; fp.ent_meta = tb->ent_meta; fp.ent_b = tb->ent_b;
+    fp.ent_range = tb->ent_range; fp.wave_tiles = tb->wave_tiles;
+    fp.B = batch; fp.L = pl->cfg.n_points; fp.T = pl->T; fp.hop = pl->cfg.hop_length; fp.M = pl->cfg.n_mels;
+    fp.nchunks = pl->nchunks; fp.groups = tb->groups;
+    const int fpt = dmel::forward_frames_per_tile(N, mode);
+    fp.tiles_per_clip = (pl->T + fpt - 1) / fpt;
+    fp.inv_L = 1.0f / (float)pl->cfg.n_points; fp.sign = sign; fp.eps = (float)eps; fp.flags = flags;
+    fp.remove_dc = remove_dc;
+    const long long grid = (long long)batch * fp.tiles_per_clip;
+    if (grid > 0x7fffffffLL) return fail(DMEL_ERR_INVALID_ARGUMENT, "too many tiles for one launch");
+    DMEL_HIP(dmel::launch_forward(N, mode, fp, (int)grid, s));
+    prof_span(pl, m1, prof_mark(pl, s), 1);
+    pl->info.kernel_path = 0; pl->info.frames_per_tile = fpt; pl->info.grid_fwd = (int)grid;
+    pl->info.fb_blocks = tb->n_entries; pl->info.fb_blocks_dense = tb->n_dense;
+    pl->info.lds_bytes = dmel::forward_lds_bytes(N);
+    return DMEL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t dmel_abi_version(void) { return DMEL_ABI_VERSION; }
+
+const char* dmel_last_error(void) { return g_err.c_str(); }
+
+int32_t dmel_n_fft(float lambd)
+{
+    const float a = std::fabs(lambd);       // models.py:38
+    const float prod = a * 6.0f;            // time_frequency.py:39, fp32 tensor product
+    if (!(prod < 9.0e15f)) return 0x40000000;
+    long long x = (long long)prod;          // time_frequency.py:61 int(): truncation
+    long long v = x - 1;
+    int bits = 0;
+    if (v < 0) bits = 1;                    // python: (-1).bit_length() == 1
+    else while (v > 0) { ++bits; v >>= 1; }
+    if (bits > 30) return 0x40000000;
+    return (int32_t)(1LL << bits);          // time_frequency.py:62
+}
+
+dmel_status dmel_window_host(float lambd, int32_t n_fft, int32_t normalize, float* window, float* dwindow)
+{
+    if (n_fft < 1 || !window) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_window_host: bad arguments");
+    const float denom = std::fabs(lambd) + 1e-15f;
+    const double den = (double)denom;
+    std::vector<double> dw(n_fft);
+    double ww = 0.0, wd = 0.0;
+    for (int n = 0; n < n_fft; ++n) {
+        const float d = (float)n - (float)n_fft / 2.0f;
+        const float t = d / denom;
+        window[n] = std::exp(-0.5f * (t * t));
+        dw[n] = (double)window[n] * (double)d * (double)d / (den * den * den);
+        ww += (double)window[n] * (double)window[n];
+        wd += (double)window[n] * dw[n];
+    }
+    if (normalize) {
+        const double nrm = std::sqrt(ww);
+        for (int n = 0; n < n_fft; ++n) {
+            const double w = (double)window[n];
+            dw[n] = dw[n] / nrm - w * wd / (nrm * nrm * nrm);
+            window[n] = (float)(w / nrm);
+        }
+    }
+    if (dwindow) for (int n = 0; n < n_fft; ++n) dwindow[n] = (float)dw[n];
+    return DMEL_OK;
+}
+
+dmel_status dmel_mel_fbanks_host(int32_t n_freqs, double f_min, double f_max, int32_t n_mels,
+                                 int32_t sample_rate, float* fb)
+{
+    if (n_freqs < 1 || n_mels < 1 || sample_rate < 2 || !fb)
+        return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_mel_fbanks_host: bad arguments");
+    std::vector<float> all_freqs, m_pts, f_pts(n_mels + 2);
+    linspace_f32(0.0f, (float)(sample_rate / 2), n_freqs, all_freqs);
+    const double m_min = 2595.0 * std::log10(1.0 + f_min / 700.0);
+    const double m_max = 2595.0 * std::log10(1.0 + f_max / 700.0);
+    linspace_f32((float)m_min, (float)m_max, n_mels + 2, m_pts);
+    for (int i = 0; i < n_mels + 2; ++i) f_pts[i] = 700.0f * (std::pow(10.0f, m_pts[i] / 2595.0f) - 1.0f);
+    for (int f = 0; f < n_freqs; ++f)
+        for (int m = 0; m < n_mels; ++m) {
+            const float down = (-1.0f * (f_pts[m] - all_freqs[f])) / (f_pts[m + 1] - f_pts[m]);
+            const float up = (f_pts[m + 2] - all_freqs[f]) / (f_pts[m + 2] - f_pts[m + 1]);
+            fb[(size_t)f * n_mels + m] = std::max(0.0f, std::min(down, up));
+        }
+    return DMEL_OK;
+}
+
+int32_t dmel_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    int ok = 0;
+    for (int d = 0; d < n; ++d) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) != hipSuccess) continue;
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++ok;
+    }
+    return ok;
+}
+
+dmel_status dmel_plan_create(const dmel_config* cfg, dmel_plan** plan)
+{
+    if (!cfg || !plan) return fail(DMEL_ERR_INVALID_ARGUMENT, "cfg / plan is NULL");
+    *plan = nullptr;
+    if (cfg->n_points < 1 || cfg->hop_length < 1 || cfg->n_mels < 1 || cfg->sample_rate < 2)
+        return fail(DMEL_ERR_INVALID_ARGUMENT, "n_points, hop_length, n_mels must be >= 1 and sample_rate >= 2");
+    if (cfg->n_mels > 65535) return fail(DMEL_ERR_INVALID_ARGUMENT, "n_mels too large");
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return fail(DMEL_ERR_NO_DEVICE, "no HIP device"); }
+    hipDeviceProp_t prop;
+    DMEL_HIP(hipGetDeviceProperties(&prop, dev));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(DMEL_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", libdmel_hip is built for gfx950 only");
+    DMEL_HIP(dmel::forward_prepare_attributes());
+    dmel_plan* pl = new (std::nothrow) dmel_plan();
+    if (!pl) return fail(DMEL_ERR_OUT_OF_MEMORY, "host allocation failed");
+    pl->cfg = *cfg;
+    pl->device = dev;
+    pl->T = cfg->n_points / cfg->hop_length + 1;                      // models.py:30
+    pl->f_max = cfg->f_max < 0 ? (double)(cfg->sample_rate / 2) : cfg->f_max;   // models.py:25
+    int nch = (cfg->n_points + 4095) / 4096;
+    nch = std::max(1, std::min(nch, dmel::kMaxChunks));
+    pl->nchunks = nch;
+    pl->chunk = (cfg->n_points + nch - 1) / nch;
+    hipError_t e = hipMalloc(&pl->win, 2 * dmel::kMaxNfft * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&pl->partials, kMaxPartials * sizeof(double));
+    if (e != hipSuccess) { dmel_plan_destroy(pl); return fail(DMEL_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    if (cfg->max_batch > 0) {
+        dmel_status st = ensure_psum(pl, cfg->max_batch);
+        if (st != DMEL_OK) { dmel_plan_destroy(pl); return st; }
+    }
+    *plan = pl;
+    return DMEL_OK;
+}
+
+dmel_status dmel_plan_destroy(dmel_plan* plan)
+{
+    if (!plan) return DMEL_OK;
+    for (auto& kv : plan->tables) kv.second.release();
+    for (hipEvent_t e : plan->ev_pool) (void)hipEventDestroy(e);
+    (void)hipFree(plan->psum); (void)hipFree(plan->win); (void)hipFree(plan->partials);
+    delete plan;
+    return DMEL_OK;
+}
+
+dmel_status dmel_plan_set_filterbank(dmel_plan* plan, int32_t n_fft, const float* fb)
+{
+    if (!plan) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
+    if (n_fft < 1 || n_fft > dmel::kMaxNfft || (n_fft & (n_fft - 1)))
+        return fail(DMEL_ERR_INVALID_ARGUMENT, "n_fft must be a power of two in [1, 4096]");
+    std::lock_guard<std::mutex> lock(plan->mu);
+    DMEL_HIP(hipDeviceSynchronize());     // tables of this n_fft may be in use by queued kernels
+    auto it = plan->tables.find(n_fft);
+    if (it != plan->tables.end()) { it->second.release(); plan->tables.erase(it); }
+    if (fb) {
+        const size_t n = (size_t)(n_fft / 2 + 1) * plan->cfg.n_mels;
+        plan->custom_fb[n_fft] = std::vector<float>(fb, fb + n);
+    } else {
+        plan->custom_fb.erase(n_fft);
+    }
+    return DMEL_OK;
+}
+
+dmel_status dmel_forward(dmel_plan* plan, const float* x, int32_t batch, float lambd, uint32_t flags,
+                         double eps, float* out, float* tangent, void* stream)
+{
+    return run_forward(plan, x, batch, lambd, flags, eps, out, tangent,
+                       tangent ? dmel::kTrain : dmel::kInfer, /*remove_dc=*/1, stream);
+}
+
+dmel_status dmel_spectrogram(dmel_plan* plan, const float* x, int32_t batch, float lambd,
+                             int32_t remove_dc, float* spec, void* stream)
+{
+    return run_forward(plan, x, batch, lambd, 0u, 0.0, spec, nullptr, dmel::kSpec, remove_dc ? 1 : 0, stream);
+}
+
+dmel_status dmel_backward(dmel_plan* plan, const float* grad_out, const float* tangent, int64_t count,
+                          int32_t accumulate, float* dlambd, void* stream)
+{
+    if (!plan) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
+    if (count < 0 || !dlambd || (count > 0 && (!grad_out || !tangent)))
+        return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_backward: bad arguments");
+    std::lock_guard<std::mutex> lock(plan->mu);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const size_t m0 = prof_mark(plan, s);
+    DMEL_HIP(dmel::launch_dot(grad_out, tangent, (long long)count, accumulate, plan->partials, kMaxPartials, dlambd, s));
+    prof_span(plan, m0, prof_mark(plan, s), 2);
+    return DMEL_OK;
+}
+
+dmel_status dmel_plan_set_profiling(dmel_plan* plan, int32_t enable)
+{
+    if (!plan) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
+    std::lock_guard<std::mutex> lock(plan->mu);
+    plan->profiling = enable != 0;
+    return DMEL_OK;
+}
+
+dmel_status dmel_plan_get_profile(dmel_plan* plan, dmel_profile* profile)
+{
+    if (!plan || !profile) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan / profile is NULL");
+    std::lock_guard<std::mutex> lock(plan->mu);
+    dmel_profile pr{};
+    for (const auto& sp : plan->spans) {
+        DMEL_HIP(hipEventSynchronize(plan->ev_pool[sp.b]));
+        float ms = 0.f;
+        DMEL_HIP(hipEventElapsedTime(&ms, plan->ev_pool[sp.a], plan->ev_pool[sp.b]));
+        if (sp.kind == 0) { pr.prep_ms += ms; ++pr.prep_launches; }
+        else if (sp.kind == 1) { pr.fwd_ms += ms; ++pr.fwd_launches; }
+        else { pr.bwd_ms += ms; ++pr.bwd_launches; }
+    }
+    plan->spans.clear();
+    plan->ev_used = 0;
+    *profile = pr;
+    return DMEL_OK;
+}
+
+dmel_status dmel_plan_get_info(const dmel_plan* plan, dmel_plan_info* info)
+{
+    if (!plan || !info) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan / info is NULL");
+    *info = plan->info;
+    return DMEL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,462 @@
+// dmel_fwd.hip -- fused forward of the DMEL layer for gfx950 (MI355X).
+//
+// One workgroup (4 waves) produces a tile of consecutive STFT frames of one clip, from waveform
+// samples to log-mel values, without touching HBM in between:
+//
+//   phase 1 (VALU + LDS, per wave): DC-removed, Gaussian-windowed frame -> complex FFT.  A wave
+//            holds R points per lane and transforms 64/G frames at a time: radix-R butterflies in
+//            registers, one transposition through LDS, radix-R again, and a radix-C stage across
+//            adjacent lanes with DPP quad permutes (tools/wavefft_sim.py is the index model).
+//            Two real sequences ride in one complex FFT: (x~ w, x~ dw/dlambd) when the tangent is
+//            wanted (training), two neighbouring frames otherwise.  The spectrum Z stays in LDS.
+//   phase 2 (MFMA): the mel contraction of models.py:53.  A-fragments are formed on the fly from
+//            Z (|X|^2 and d|X|^2/dlambd rows), B-fragments are the non-zero 4x16 blocks of the
+//            filterbank, v_mfma_f32_16x16x4_f32 accumulates exact fp32.  Each wave owns two mel
+//            tiles, so no cross-wave reduction is needed.
+//   epilogue: scale, log(mel + eps) (models.py:73), tangent d out / d lambd, straight from the
+//            accumulators into the (B,1,M,T) layout of models.py:36.
+//
+// Reference semantics restated here: models.py:33-56 (layer forward), time_frequency.py:21-30
+// (window), :32-58 (STFT, |.|^2), models.py:73 (log).
+#include "dmel_kernels.h"
+
+namespace dmel {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+// ---- compile-time helpers -------------------------------------------------------------------
+template <int I> struct IC { static constexpr int value = I; };
+template <int B, int E, class F> __device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (B < E) { f(IC<B>{}); static_for<B + 1, E>(f); }
+}
+constexpr int ilog2(int v) { int r = 0; while (v > 1) { v >>= 1; ++r; } return r; }
+constexpr int bitrev(int i, int bits) { int r = 0; for (int b = 0; b < bits; ++b) { r = (r << 1) | (i & 1); i >>= 1; } return r; }
+
+// cos(2 pi j / 64), j = 0..16
+constexpr float kCos64[17] = {
+    1.0f, 0.99518472667219688624f, 0.98078528040323044913f, 0.95694033573220886494f,
+    0.92387953251128675613f, 0.88192126434835502971f, 0.83146961230254523708f, 0.77301045336273696081f,
+    0.70710678118654752440f, 0.63439328416364549822f, 0.55557023301960222474f, 0.47139673682599764856f,
+    0.38268343236508977173f, 0.29028467725446236764f, 0.19509032201612826785f, 0.09801714032956060199f,
+    0.0f};
+constexpr float cos64(int j)   // j in [0, 32]
+{
+    return j <= 16 ? kCos64[j] : -kCos64[32 - j];
+}
+constexpr float sin64(int j)   // j in [0, 32]
+{
+    return j <= 16 ? kCos64[16 - j] : kCos64[j - 16];
+}
+
+// a * exp(-2 pi i TW / 64), TW in [0, 32)
+template <int TW> __device__ __forceinline__ float2 cmul_tw(float2 a)
+{
+    if constexpr (TW == 0) return a;
+    else if constexpr (TW == 16) return make_float2(a.y, -a.x);
+    else if constexpr (TW == 8) { constexpr float c = 0.70710678118654752440f; return make_float2(c * (a.x + a.y), c * (a.y - a.x)); }
+    else if constexpr (TW == 24) { constexpr float c = 0.70710678118654752440f; return make_float2(c * (a.y - a.x), -c * (a.x + a.y)); }
+    else {
+        constexpr float c = cos64(TW), s = sin64(TW);
+        return make_float2(fmaf(a.y, s, a.x * c), fmaf(-a.x, s, a.y * c));
+    }
+}
+
+// Radix-2 decimation-in-frequency FFT of R points held in registers; logical output q ends up in
+// v[bitrev(q)].  Fully unrolled: every index and twiddle is a compile-time constant.
+template <int R, int SPAN = R / 2> __device__ __forceinline__ void fft_reg(float2 (&v)[R])
+{
+    if constexpr (SPAN >= 1) {
+        static_for<0, R / (2 * SPAN)>([&](auto blk) {
+            constexpr int base = decltype(blk)::value * 2 * SPAN;
+            static_for<0, SPAN>([&](auto jj) {
+                constexpr int j = decltype(jj)::value;
+                const float2 a = v[base + j], b = v[base + j + SPAN];
+                v[base + j] = make_float2(a.x + b.x, a.y + b.y);
+                v[base + j + SPAN] = cmul_tw<j * 32 / SPAN>(make_float2(a.x - b.x, a.y - b.y));
+            });
+        });
+        fft_reg<R, SPAN / 2>(v);
+    }
+}
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 w)
+{
+    return make_float2(fmaf(-a.y, w.y, a.x * w.x), fmaf(a.y, w.x, a.x * w.y));
+}
+
+// value of lane (l ^ 1) / (l ^ 2) inside each quad: DPP quad_perm, no LDS traffic
+__device__ __forceinline__ float quad_xor1(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_xor2(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+}
+
+template <int R, int C> __device__ __forceinline__ int z_index(int k)
+{
+    if constexpr (C == 1) return k;
+    else return k + (k / (R * R)) * 4;
+}
+
+// ---- prep kernel: per-clip partial sums (DC removal, models.py:38) + window tables -----------
+__global__ void __launch_bounds__(kThreads) dmel_prep_kernel(PrepParams p)
+{
+    __shared__ double red[kThreads];
+    const int tid = threadIdx.x;
+    if (blockIdx.y == (unsigned)p.B) {
+        // window block: time_frequency.py:21-30 in fp32, derivative in fp64
+        if (blockIdx.x != 0) return;
+        const float denom = p.lambd_abs + 1e-15f;
+        const double den = (double)denom;
+        double s_ww = 0.0, s_wd = 0.0;
+        for (int n = tid; n < p.N; n += kThreads) {
+            const float d = (float)n - (float)p.N / 2.0f;
+            const float t = d / denom;
+            const float w = expf(-0.5f * (t * t));
+            const double dw = (double)w * (double)d * (double)d / (den * den * den);
+            p.win[n] = w;
+            p.win[p.N + n] = (float)(dw * (double)p.dw_scale);
+            s_ww += (double)w * (double)w;
+            s_wd += (double)w * dw;
+        }
+        if (!p.normalize) return;
+        // time_frequency.py:25: w / sqrt(sum w^2); derivative of the quotient
+        red[tid] = s_ww; __syncthreads();
+        for (int o = kThreads / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+        const double ww = red[0]; __syncthreads();
+        red[tid] = s_wd; __syncthreads();
+        for (int o = kThreads / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+        const double wd = red[0];
+        const double nrm = sqrt(ww);
+        for (int n = tid; n < p.N; n += kThreads) {
+            const double w = (double)p.win[n], dw = (double)p.win[p.N + n];
+            // dw was rounded to fp32 above; recompute it in fp64 for the quotient rule
+            const float d = (float)n - (float)p.N / 2.0f;
+            const double dwe = w * (double)d * (double)d / (den * den * den);
+            (void)dw;
+            p.win[n] = (float)(w / nrm);
+            p.win[p.N + n] = (float)((dwe / nrm - w * wd / (nrm * nrm * nrm)) * (double)p.dw_scale);
+        }
+        return;
+    }
+    const int b = blockIdx.y, c = blockIdx.x;
+    const long long lo = (long long)c * p.chunk;
+    long long hi = lo + p.chunk; if (hi > p.L) hi = p.L;
+    const float* xb = p.x + (size_t)b * p.L;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    long long i = lo + tid;
+    for (; i + 3 * kThreads < hi; i += 4 * kThreads) {
+        acc0 += xb[i]; acc1 += xb[i + kThreads]; acc2 += xb[i + 2 * kThreads]; acc3 += xb[i + 3 * kThreads];
+    }
+    for (; i < hi; i += kThreads) acc0 += xb[i];
+    red[tid] = ((double)acc0 + (double)acc1) + ((double)acc2 + (double)acc3);
+    __syncthreads();
+    for (int o = kThreads / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    if (tid == 0) p.psum[(size_t)b * p.nchunks + c] = (float)red[0];
+}
+
+hipError_t launch_prep(const PrepParams& p, hipStream_t s)
+{
+    dim3 grid(p.nchunks, p.B + 1);
+    hipLaunchKernelGGL(dmel_prep_kernel, grid, dim3(kThreads), 0, s, p);
+    return hipGetLastError();
+}
+
+// ---- fused forward --------------------------------------------------------------------------
+template <int N, int MODE>
+__global__ void __launch_bounds__(kThreads) dmel_fwd_kernel(FwdParams p)
+{
+    constexpr FftGeom g = geom<N>();
+    constexpr int R = g.R, C = g.C, G = g.G, FPW = g.FPW, PASSES = g.PASSES, SLOTS = g.SLOTS, MT = g.MT;
+    constexpr int LB = ilog2(R);
+    constexpr int EXS = g.EX_STRIDE, SS = g.SLOT_STRIDE_F2;
+    constexpr int FPT = (MODE == kTrain) ? SLOTS : 2 * SLOTS;   // frames per tile
+    constexpr int F = N / 2 + 1;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* lds = reinterpret_cast<float2*>(smem_raw);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x / p.tiles_per_clip;
+    const int t0 = (blockIdx.x % p.tiles_per_clip) * FPT;
+    const float* xb = p.x + (size_t)b * p.L;
+
+    float mean = 0.f;
+    if (p.remove_dc) {
+        double s = 0.0;
+        for (int c = 0; c < p.nchunks; ++c) s += (double)p.psum[(size_t)b * p.nchunks + c];
+        mean = (float)(s * (double)p.inv_L);
+    }
+
+    // ================= phase 1: FFT of this wave's frames ====================================
+    const int j = lane / G, lg = lane % G;
+    const int qp = lg / C, r = lg % C;
+#pragma unroll 1
+    for (int pass = 0; pass < PASSES; ++pass) {
+        const int slot = pass * (kWaves * FPW) + wave * FPW + j;
+        float2* sl = lds + slot * SS;
+        float2 z[R];
+        {
+            const int tA = (MODE == kTrain) ? (t0 + slot) : (t0 + 2 * slot);
+            const long long sA = (long long)tA * p.hop - N / 2 + lg;
+            const long long sB = sA + p.hop;                       // frame tA + 1 (pair modes)
+            static_for<0, R>([&](auto aa) {
+                constexpr int a = decltype(aa)::value;
+                const int n = lg + G * a;
+                const long long ia = sA + G * a;
+                const float va = (ia >= 0 && ia < p.L) ? (xb[ia] - mean) : 0.f;
+                const float w = p.win[n];
+                if constexpr (MODE == kTrain) {
+                    const float dw = p.win[N + n];
+                    z[a] = make_float2(va * w, va * dw);
+                } else {
+                    const long long ib = sB + G * a;
+                    const float vb = (ib >= 0 && ib < p.L) ? (xb[ib] - mean) : 0.f;
+                    z[a] = make_float2(va * w, vb * w);
+                }
+            });
+        }
+        fft_reg<R>(z);
+        // twiddle w_N^(lg*q), transposition through LDS: S[q][lg]
+        static_for<0, R>([&](auto qq) {
+            constexpr int q = decltype(qq)::value;
+            float2 v = z[bitrev(q, LB)];
+            if constexpr (q != 0) v = cmul(v, p.tw1[q * G + lg]);
+            sl[q * EXS + lg] = v;
+        });
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float2 u[R];
+        static_for<0, R>([&](auto bb) {
+            constexpr int bi = decltype(bb)::value;
+            u[bi] = sl[qp * EXS + r + C * bi];
+        });
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        fft_reg<R>(u);
+        // twiddle w_G^(r*p1), radix-C across adjacent lanes, spectrum to LDS in natural order
+        static_for<0, R>([&](auto pp) {
+            constexpr int p1 = decltype(pp)::value;
+            float2 v = u[bitrev(p1, LB)];
+            int p2 = 0;
+            if constexpr (C > 1) {
+                if constexpr (p1 != 0) v = cmul(v, p.tw2[p1 * C + r]);
+            }
+            if constexpr (C == 2) {
+                const float ox = quad_xor1(v.x), oy = quad_xor1(v.y);
+                const float sg = (r == 0) ? 1.f : -1.f;
+                v = make_float2(fmaf(sg, v.x, ox), fmaf(sg, v.y, oy));
+                p2 = r;
+            } else if constexpr (C == 4) {
+                float ox = quad_xor2(v.x), oy = quad_xor2(v.y);
+                float sg = (r < 2) ? 1.f : -1.f;
+                float2 t = make_float2(fmaf(sg, v.x, ox), fmaf(sg, v.y, oy));
+                if (r == 3) t = make_float2(t.y, -t.x);
+                ox = quad_xor1(t.x); oy = quad_xor1(t.y);
+                sg = ((r & 1) == 0) ? 1.f : -1.f;
+                v = make_float2(fmaf(sg, t.x, ox), fmaf(sg, t.y, oy));
+                p2 = ((r & 1) << 1) | (r >> 1);
+            }
+            const int k = qp + R * p1 + R * R * p2;
+            sl[z_index<R, C>(k)] = v;
+        });
+    }
+    __syncthreads();
+
+    if constexpr (MODE == kSpec) {
+        // power spectrogram (time_frequency.py:53), layout (B, F, T)
+        for (int idx = tid; idx < SLOTS * F; idx += kThreads) {
+            const int k = idx / SLOTS, slot = idx % SLOTS;
+            const float2* sl = lds + slot * SS;
+            const float2 zk = sl[z_index<R, C>(k)], zn = sl[z_index<R, C>((N - k) & (N - 1))];
+            const float sx = zk.x + zn.x, sy = zk.y - zn.y, dx = zk.x - zn.x, dy = zk.y + zn.y;
+            const int t = t0 + 2 * slot;
+            float* o = p.out + ((size_t)b * F + k) * p.T;
+            if (t < p.T) o[t] = 0.25f * (sx * sx + sy * sy);
+            if (t + 1 < p.T) o[t + 1] = 0.25f * (dx * dx + dy * dy);
+        }
+        return;
+    } else {
+        // ================= phase 2: mel contraction on the matrix cores ======================
+        const int row16 = lane & 15;
+        const int slot8 = 2 * (row16 >> 2) + (row16 & 1);
+        const int type = (row16 >> 1) & 1;
+        const int kofs = lane >> 4;
+        const int cg = lane >> 4;      // accumulator row group of this lane (C/D layout)
+        const int col = lane & 15;
+
+        for (int grp = 0; grp < p.groups; ++grp) {
+            floatx4 acc[2][MT];
+            static_for<0, 2>([&](auto l) { static_for<0, MT>([&](auto m) {
+                acc[decltype(l)::value][decltype(m)::value] = floatx4{0.f, 0.f, 0.f, 0.f}; }); });
+            const int eb = p.ent_range[(grp * kWaves + wave) * 2 + 0];
+            const int ee = p.ent_range[(grp * kWaves + wave) * 2 + 1];
+            for (int e = eb; e < ee; ++e) {
+                const int meta = __builtin_amdgcn_readfirstlane(p.ent_meta[e]);
+                const int ks = meta & 0xFFFF, loc = meta >> 16;
+                const float bf = p.ent_b[(size_t)e * 64 + lane];
+                const int kk = 4 * ks + kofs;
+                const int zi_k = z_index<R, C>(kk & (N - 1));
+                const int zi_n = z_index<R, C>((N - kk) & (N - 1));
+                float av[MT];
+                static_for<0, MT>([&](auto m) {
+                    constexpr int mt = decltype(m)::value;
+                    const int slot = mt * 8 + slot8;
+                    const bool valid = slot < SLOTS;
+                    const float2* sl = lds + (valid ? slot : 0) * SS;
+                    const float2 zk = sl[zi_k], zn = sl[zi_n];
+                    const float sx = zk.x + zn.x, sy = zk.y - zn.y, dx = zk.x - zn.x, dy = zk.y + zn.y;
+                    float val;
+                    if constexpr (MODE == kTrain) val = type ? fmaf(sx, dy, -(sy * dx)) : fmaf(sx, sx, sy * sy);
+                    else val = type ? fmaf(dx, dx, dy * dy) : fmaf(sx, sx, sy * sy);
+                    av[mt] = valid ? val : 0.f;
+                });
+                if (loc == 0) {
+                    static_for<0, MT>([&](auto m) { constexpr int mt = decltype(m)::value;
+                        acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bf, acc[0][mt], 0, 0, 0); });
+                } else {
+                    static_for<0, MT>([&](auto m) { constexpr int mt = decltype(m)::value;
+                        acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bf, acc[1][mt], 0, 0, 0); });
+                }
+            }
+            // ---- epilogue: accumulators -> (B,1,M,T) ------------------------------------------
+            const bool do_log = (p.flags & 1u) != 0;
+            static_for<0, 2>([&](auto l) {
+                constexpr int loc = decltype(l)::value;
+                const int nt = p.wave_tiles[(grp * kWaves + wave) * 2 + loc];
+                if (nt < 0) return;
+                const int m = 16 * nt + col;
+                if (m >= p.M) return;
+                float* orow = p.out + ((size_t)b * p.M + m) * p.T;
+                float* trow = p.tangent ? p.tangent + ((size_t)b * p.M + m) * p.T : nullptr;
+                static_for<0, MT>([&](auto mm) {
+                    constexpr int mt = decltype(mm)::value;
+                    const floatx4 a = acc[loc][mt];
+                    if constexpr (MODE == kTrain) {
+                        // rows 4cg+i: i=0,1 -> |X|^2 of slots 2cg, 2cg+1; i=2,3 -> d|X|^2 of the same slots
+                        static_for<0, 2>([&](auto ss) {
+                            constexpr int s = decltype(ss)::value;
+                            const int slot = mt * 8 + 2 * cg + s;
+                            const int t = t0 + slot;
+                            if (slot < SLOTS && t < p.T) {
+                                const float mel = 0.25f * a[s];
+                                const float dmel = 0.5f * p.sign * a[2 + s];
+                                if (do_log) {
+                                    const float me = mel + p.eps;
+                                    orow[t] = logf(me);
+                                    if (trow) trow[t] = dmel / me;
+                                } else {
+                                    orow[t] = mel;
+                                    if (trow) trow[t] = dmel;
+                                }
+                            }
+                        });
+                    } else {
+                        // slot holds frames (2*slot, 2*slot+1) as (type 0, type 1)
+                        static_for<0, 4>([&](auto ii) {
+                            constexpr int i = decltype(ii)::value;
+                            const int slot = mt * 8 + 2 * cg + (i & 1);
+                            const int t = t0 + 2 * slot + (i >> 1);
+                            if (slot < SLOTS && t < p.T) {
+                                const float mel = 0.25f * a[i];
+                                orow[t] = do_log ? logf(mel + p.eps) : mel;
+                            }
+                        });
+                    }
+                });
+            });
+        }
+    }
+}
+
+template <int N, int MODE> static hipError_t launch_one(const FwdParams& p, int grid, hipStream_t s)
+{
+    constexpr FftGeom g = geom<N>();
+    constexpr int lds = g.SLOTS * g.SLOT_STRIDE_F2 * 8;
+    hipLaunchKernelGGL((dmel_fwd_kernel<N, MODE>), dim3(grid), dim3(kThreads), lds, s, p);
+    return hipGetLastError();
+}
+
+template <int N> static hipError_t launch_n(int mode, const FwdParams& p, int grid, hipStream_t s)
+{
+    switch (mode) {
+        case kTrain: return launch_one<N, kTrain>(p, grid, s);
+        case kInfer: return launch_one<N, kInfer>(p, grid, s);
+        case kSpec: return launch_one<N, kSpec>(p, grid, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_forward(int n_fft, int mode, const FwdParams& p, int grid, hipStream_t s)
+{
+    switch (n_fft) {
+        case 32: return launch_n<32>(mode, p, grid, s);
+        case 64: return launch_n<64>(mode, p, grid, s);
+        case 128: return launch_n<128>(mode, p, grid, s);
+        case 256: return launch_n<256>(mode, p, grid, s);
+        case 512: return launch_n<512>(mode, p, grid, s);
+        case 1024: return launch_n<1024>(mode, p, grid, s);
+        case 2048: return launch_n<2048>(mode, p, grid, s);
+        case 4096: return launch_n<4096>(mode, p, grid, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+template <int N> static constexpr int lds_of() { return geom<N>().SLOTS * geom<N>().SLOT_STRIDE_F2 * 8; }
+
+int forward_lds_bytes(int n_fft)
+{
+    switch (n_fft) {
+        case 32: return lds_of<32>(); case 64: return lds_of<64>(); case 128: return lds_of<128>();
+        case 256: return lds_of<256>(); case 512: return lds_of<512>(); case 1024: return lds_of<1024>();
+        case 2048: return lds_of<2048>(); case 4096: return lds_of<4096>();
+    }
+    return -1;
+}
+
+int forward_frames_per_tile(int n_fft, int mode)
+{
+    int slots = -1;
+    switch (n_fft) {
+        case 32: slots = geom<32>().SLOTS; break; case 64: slots = geom<64>().SLOTS; break;
+        case 128: slots = geom<128>().SLOTS; break; case 256: slots = geom<256>().SLOTS; break;
+        case 512: slots = geom<512>().SLOTS; break; case 1024: slots = geom<1024>().SLOTS; break;
+        case 2048: slots = geom<2048>().SLOTS; break; case 4096: slots = geom<4096>().SLOTS; break;
+    }
+    if (slots < 0) return -1;
+    return mode == kTrain ? slots : 2 * slots;
+}
+
+template <int N, int MODE> static hipError_t set_attr()
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&dmel_fwd_kernel<N, MODE>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_of<N>());
+}
+template <int N> static hipError_t set_attr_n()
+{
+    hipError_t e;
+    if ((e = set_attr<N, kTrain>()) != hipSuccess) return e;
+    if ((e = set_attr<N, kInfer>()) != hipSuccess) return e;
+    return set_attr<N, kSpec>();
+}
+
+hipError_t forward_prepare_attributes()
+{
+    hipError_t e;
+    if ((e = set_attr_n<32>()) != hipSuccess) return e;
+    if ((e = set_attr_n<64>()) != hipSuccess) return e;
+    if ((e = set_attr_n<128>()) != hipSuccess) return e;
+    if ((e = set_attr_n<256>()) != hipSuccess) return e;
+    if ((e = set_attr_n<512>()) != hipSuccess) return e;
+    if ((e = set_attr_n<1024>()) != hipSuccess) return e;
+    if ((e = set_attr_n<2048>()) != hipSuccess) return e;
+    return set_attr_n<4096>();
+}
+
+}  // namespace dmel

@@ -1,0 +1,100 @@
+// dmel_kernels.h -- shared between the host API (dmel_api.cpp) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dmel {
+
+constexpr int kWave = 64;
+constexpr int kThreads = 256;          // 4 waves per workgroup
+constexpr int kWaves = 4;
+constexpr int kMaxChunks = 64;         // partial sums per clip for the DC removal
+constexpr int kMaxNfft = 4096;
+constexpr int kMinFastNfft = 32;       // below this the direct-DFT kernel runs
+
+enum Mode : int { kTrain = 0, kInfer = 1, kSpec = 2 };
+
+// Compile-time FFT plan for one wave: N = R * R * C, R points per lane (tools/wavefft_sim.py).
+template <int N> struct FftPlan;
+template <> struct FftPlan<32>   { static constexpr int R = 4,  C = 2, PASSES = 1; };
+template <> struct FftPlan<64>   { static constexpr int R = 8,  C = 1, PASSES = 1; };
+template <> struct FftPlan<128>  { static constexpr int R = 8,  C = 2, PASSES = 1; };
+template <> struct FftPlan<256>  { static constexpr int R = 16, C = 1, PASSES = 1; };
+template <> struct FftPlan<512>  { static constexpr int R = 16, C = 2, PASSES = 1; };
+template <> struct FftPlan<1024> { static constexpr int R = 16, C = 4, PASSES = 2; };
+template <> struct FftPlan<2048> { static constexpr int R = 32, C = 2, PASSES = 2; };
+template <> struct FftPlan<4096> { static constexpr int R = 64, C = 1, PASSES = 1; };
+
+struct FftGeom {
+    int N, R, C, G, FPW, PASSES, SLOTS, MT, EX_STRIDE, SLOT_STRIDE_F2;
+};
+
+constexpr int ex_stride(int G, int C) { return G + (G >= 32 ? C : 1); }
+constexpr int z_index_host(int k, int R, int C) { return C == 1 ? k : k + (k / (R * R)) * 4; }
+constexpr int slot_stride_f2(int N, int R, int C)
+{
+    const int G = N / R;
+    const int a = R * ex_stride(G, C);
+    const int b = z_index_host(N - 1, R, C) + 1;
+    const int need = (a > b ? a : b) * 8;
+    return ((need + 255) / 256 * 256 + 32) / 8;     // = 32 bytes (mod 256): A-fragment reads of 8 slots
+}
+
+template <int N> constexpr FftGeom geom()
+{
+    using P = FftPlan<N>;
+    FftGeom g{};
+    g.N = N; g.R = P::R; g.C = P::C; g.G = N / P::R; g.FPW = kWave / g.G; g.PASSES = P::PASSES;
+    g.SLOTS = kWaves * g.FPW * g.PASSES;
+    g.MT = g.SLOTS >= 8 ? g.SLOTS / 8 : 1;
+    g.EX_STRIDE = ex_stride(g.G, g.C);
+    g.SLOT_STRIDE_F2 = slot_stride_f2(N, P::R, P::C);
+    return g;
+}
+
+// One non-zero 4(k) x 16(mel) block of the filterbank, pre-arranged as the B operand of
+// v_mfma_f32_16x16x4_f32: lane l holds fb[4*ks + (l >> 4)][16*tile + (l & 15)].
+// meta = ks | (loc << 16): loc selects which of the wave's two mel tiles the block belongs to.
+struct FwdParams {
+    const float* x;            // (B, L)
+    float* out;                // (B, 1, M, T) or spec (B, F, T) in kSpec mode
+    float* tangent;            // same shape as out or nullptr
+    const float* psum;         // (B, nchunks) partial sums of x
+    const float* win;          // [0..N): w, [N..2N): dw/d|lambd|
+    const float2* tw1;         // (R, G): w_N^(lg*q)
+    const float2* tw2;         // (R, C): w_G^(r*p1)
+    const int* ent_meta;       // entries of all (group, wave) lists, concatenated
+    const float* ent_b;        // 64 floats per entry
+    const int* ent_range;      // (groups, 4, 2): [begin, end) into the entry arrays
+    const int* wave_tiles;     // (groups, 4, 2): global mel-tile index of loc 0 / 1, or -1
+    int B, L, T, hop, M, nchunks, groups, tiles_per_clip;
+    float inv_L, sign, eps;
+    unsigned flags;
+    int remove_dc;
+};
+
+struct PrepParams {
+    const float* x; float* psum; float* win;
+    int B, L, nchunks, chunk, N, normalize;
+    float lambd_abs;
+    float dw_scale;   // power of two ~ |lambd|: the dw table is stored pre-multiplied by it (see dmel_api.cpp)
+};
+
+hipError_t launch_prep(const PrepParams& p, hipStream_t s);
+hipError_t launch_forward(int n_fft, int mode, const FwdParams& p, int grid, hipStream_t s);
+int forward_lds_bytes(int n_fft);
+int forward_frames_per_tile(int n_fft, int mode);
+hipError_t forward_prepare_attributes();   // raises the dynamic-LDS limit of every instantiation once
+
+// direct-DFT kernel for n_fft < 32 (and as an on-device cross-check of the fast path)
+struct NaiveParams {
+    const float* x; float* out; float* tangent; const float* psum; const float* win; const float* fb;
+    int B, L, T, hop, M, nchunks, N, F, mode;
+    float inv_L, sign, eps; unsigned flags; int remove_dc;
+};
+hipError_t launch_naive(const NaiveParams& p, hipStream_t s);
+
+hipError_t launch_dot(const float* g, const float* t, long long count, int accumulate, double* partials,
+                      int max_partials, float* result, hipStream_t s);
+
+}  // namespace dmel

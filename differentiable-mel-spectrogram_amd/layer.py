@@ -1,0 +1,150 @@
+"""Host-side mirror of the reference's layer interface, running on libdmel_hip.so.
+
+``MelSpectrogramLayer`` keeps the constructor, attributes, parameter name (``lambd``), output
+shape/dtype and error behaviour of the reference's ``models.MelSpectrogramLayer``
+(models.py:14-56) so that the wrapping nets (models.py:58-166), the two-LR-group optimizer keyed
+on ``"spectrogram_layer.lambd"`` (main.py:36-48) and ``load_state_dict(strict=True)``
+(utils.py:270) work unchanged.  The arithmetic runs in the HIP kernels behind the C ABI
+(``capi.py`` -> ``include/dmel.h``); torch is used for device memory, streams and autograd
+plumbing only.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import capi
+
+
+def _stream_ptr(device) -> int:
+    return int(torch.cuda.current_stream(device).cuda_stream)
+
+
+class _DmelFunction(torch.autograd.Function):
+    """forward: dmel_forward (carries d out / d lambd); backward: dmel_backward (one dot product)."""
+
+    @staticmethod
+    def forward(ctx, x, lambd, plan, lam_host, log, eps):
+        B = x.shape[0]
+        out = torch.empty((B, 1, plan.n_mels, plan.n_time), dtype=torch.float32, device=x.device)  # models.py:36
+        want_tangent = ctx.needs_input_grad[1]
+        tangent = torch.empty_like(out) if want_tangent else None
+        with torch.cuda.device(x.device):
+            plan.forward(x.data_ptr(), B, lam_host, out.data_ptr(), tangent.data_ptr() if want_tangent else None,
+                         log, eps, _stream_ptr(x.device))
+        ctx.plan = plan
+        ctx.lambd_shape = lambd.shape
+        ctx.lambd_dtype = lambd.dtype
+        if want_tangent:
+            ctx.save_for_backward(tangent)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        if not ctx.needs_input_grad[1]:
+            return None, None, None, None, None, None
+        (tangent,) = ctx.saved_tensors
+        g = grad_out.to(torch.float32).contiguous()
+        dl = torch.empty((1,), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            ctx.plan.backward(g.data_ptr(), tangent.data_ptr(), g.numel(), dl.data_ptr(), _stream_ptr(g.device))
+        return None, dl.reshape(ctx.lambd_shape).to(ctx.lambd_dtype), None, None, None, None
+
+
+class MelSpectrogramLayer(nn.Module):
+    """Differentiable (log-)Mel spectrogram with a trainable Gaussian window width.
+
+    Signature-compatible with the reference (models.py:15):
+        MelSpectrogramLayer(init_lambd, n_mels, n_points, sample_rate, f_min=0, f_max=None,
+                            hop_length=1, device='cpu', optimized=False, normalize_window=False)
+    Extra keyword-only options: ``log=True`` fuses ``torch.log(s + eps)`` (models.py:73) into the
+    kernel epilogue (default False = linear mel power, exactly what the reference layer returns).
+
+    forward(x: (B, n_points)) -> (B, 1, n_mels, n_points // hop_length + 1) float32.
+    """
+
+    def __init__(self, init_lambd, n_mels, n_points, sample_rate, f_min=0, f_max=None, hop_length=1,
+                 device="cpu", optimized=False, normalize_window=False, *, log=False, eps=1e-10):
+        super().__init__()
+        if not torch.is_tensor(init_lambd):
+            init_lambd = torch.tensor(float(init_lambd), dtype=torch.float32)
+        self.hop_length = hop_length
+        self.lambd = nn.Parameter(init_lambd)                        # models.py:19
+        self.device = device
+        self.optimized = optimized
+        self.normalize_window = normalize_window
+        self.f_min = f_min
+        self.f_max = f_max if f_max is not None else sample_rate // 2   # models.py:25
+        self.n_mels = n_mels
+        self.sample_rate = sample_rate
+        self.n_freq = n_mels                                          # models.py:29
+        self.n_time = n_points // hop_length + 1                      # models.py:30
+        self.n_points = n_points
+        self.log = bool(log)
+        self.eps = float(eps)
+        self._plans = {}                                              # device index -> capi.Plan (not state)
+
+    # -- plumbing -----------------------------------------------------------------------------
+    def _plan_for(self, dev: torch.device) -> capi.Plan:
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        plan = self._plans.get(idx)
+        if plan is None:
+            with torch.cuda.device(idx):
+                plan = capi.Plan(self.n_points, self.hop_length, self.n_mels, self.sample_rate, float(self.f_min),
+                                 float(self.f_max), bool(self.normalize_window))
+            self._plans[idx] = plan
+        return plan
+
+    def plan_info(self, device=None) -> dict:
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        return self._plan_for(dev).info()
+
+    def n_fft(self) -> int:
+        """n_fft the next forward will use: next_pow2(int(6*|lambd|)) (time_frequency.py:39,60-65)."""
+        return capi.n_fft(float(self.lambd.detach()))
+
+    # -- forward ------------------------------------------------------------------------------
+    def forward(self, x):
+        if x.dim() != 2:
+            raise ValueError(f"expected x of shape (batch, n_points), got {tuple(x.shape)}")
+        batch_size, n_points = x.shape
+        if n_points != self.n_points:
+            # the reference fails here too (RuntimeError from the slice-assign at models.py:54)
+            raise RuntimeError(f"input has {n_points} points, the layer was built for n_points={self.n_points}")
+        if not self.optimized:
+            raise NotImplementedError(
+                "optimized=False (window = whole signal, n_fft = 2*n_points; time_frequency.py:41,51) is not on the "
+                "HIP hot path; construct the layer with optimized=True as all mel experiments do (search_spaces.py:11,44)")
+        if not x.is_cuda:
+            raise RuntimeError("dmel_amd runs on MI355X only: x must be a CUDA/HIP tensor (no CPU fallback)")
+        if x.requires_grad:
+            raise NotImplementedError("gradient w.r.t. the waveform is not implemented (the reference never uses it)")
+        if self.lambd.device != x.device:
+            raise RuntimeError(f"lambd is on {self.lambd.device} but x is on {x.device}; call layer.to(x.device)")
+        xf = x.detach().to(torch.float32).contiguous()
+        # one host read of the parameter per forward (the reference does one per sample, time_frequency.py:39)
+        lam_host = float(self.lambd.detach())
+        plan = self._plan_for(x.device)
+        return _DmelFunction.apply(xf, self.lambd, plan, lam_host, self.log, self.eps)
+
+    def extra_repr(self):
+        return (f"n_mels={self.n_mels}, n_points={self.n_points}, sample_rate={self.sample_rate}, "
+                f"hop_length={self.hop_length}, f_min={self.f_min}, f_max={self.f_max}, "
+                f"normalize_window={self.normalize_window}, log={self.log}")
+
+
+# BASELINE.json's north_star calls the layer by this name; the reference has no such symbol.
+DifferentiableMelSpectrogram = MelSpectrogramLayer
+
+
+def dmel_log_mel(x, lambd, n_mels, sample_rate, hop_length, f_min=0.0, f_max=None, normalize_window=False,
+                 log=True, eps=1e-10, _plan_cache={}):
+    """Functional form: log-mel (or mel) of x with window width ``lambd`` (a tensor that may require grad)."""
+    key = (x.device.index, x.shape[1], hop_length, n_mels, sample_rate, float(f_min), f_max, bool(normalize_window))
+    plan = _plan_cache.get(key)
+    if plan is None:
+        with torch.cuda.device(x.device):
+            plan = capi.Plan(x.shape[1], hop_length, n_mels, sample_rate, float(f_min),
+                             None if f_max is None else float(f_max), bool(normalize_window))
+        _plan_cache[key] = plan
+    return _DmelFunction.apply(x.detach().to(torch.float32).contiguous(), lambd, plan, float(lambd.detach()), log, eps)

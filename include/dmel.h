@@ -1,0 +1,149 @@
+/*
+ * dmel.h -- C ABI of libdmel_hip.so: the MI355X (gfx950) implementation of the DMEL hot path.
+ *
+ * The reference (johnmartinsson/differentiable-mel-spectrogram) is pure Python and has no FFI;
+ * its boundary for this path is the nn.Module `MelSpectrogramLayer` (models.py:14-56) plus the
+ * `torch.log(s + 1e-10)` line of the nets that wrap it (models.py:73).  Each entry point below
+ * names the reference code it replaces.  Signatures carry plain pointers and sizes only (device
+ * pointers are HIP device addresses, `stream` is a hipStream_t passed as void*); no torch types.
+ *
+ * Conventions
+ *   - every function returns a dmel_status (0 = DMEL_OK); dmel_last_error() gives the message of
+ *     the calling thread's last failure.
+ *   - waveforms  x        : (batch, n_points) fp32, row-major, device      models.py:33
+ *   - outputs    out      : (batch, 1, n_mels, n_points / hop + 1) fp32    models.py:30,36
+ *   - tangent             : same shape as out, d out / d lambd (raw, signed parameter)
+ *   - lambd is the trainable window std-dev in samples (models.py:19); the kernels use |lambd|
+ *     (models.py:38) and n_fft = next_pow2(int(6*|lambd|)) (time_frequency.py:39,60-65).
+ *   - a plan owns its device tables/workspace; one stream may use a plan at a time.
+ */
+#ifndef DMEL_H
+#define DMEL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMEL_ABI_VERSION 1
+
+typedef enum dmel_status {
+    DMEL_OK = 0,
+    DMEL_ERR_INVALID_ARGUMENT = 1,  /* bad shape / null pointer / negative size          */
+    DMEL_ERR_UNSUPPORTED = 2,       /* n_fft outside [1, 4096] for the HIP kernels        */
+    DMEL_ERR_HIP = 3,               /* a HIP runtime call failed (message has the detail) */
+    DMEL_ERR_NO_DEVICE = 4,         /* no gfx950 device visible                           */
+    DMEL_ERR_OUT_OF_MEMORY = 5
+} dmel_status;
+
+/* Constructor arguments of the layer: models.py:15-30 (MelSpectrogramLayer.__init__). */
+typedef struct dmel_config {
+    int32_t n_points;          /* clip length L                                   models.py:30 */
+    int32_t hop_length;        /*                                                 models.py:18 */
+    int32_t n_mels;            /*                                                 models.py:26 */
+    int32_t sample_rate;       /*                                                 models.py:27 */
+    double f_min;              /*                                                 models.py:24 */
+    double f_max;              /* < 0: sample_rate / 2 (integer division)         models.py:25 */
+    int32_t normalize_window;  /* time_frequency.py:25-28 (norm=True branch)                   */
+    int32_t max_batch;         /* workspace is sized for this many clips (grown on demand)     */
+} dmel_config;
+
+typedef struct dmel_plan dmel_plan;
+
+/* Flags for dmel_forward */
+#define DMEL_FLAG_LOG 1u       /* fuse out = log(mel + eps)                        models.py:73 */
+
+/* ---- host-side helpers (no device needed) ------------------------------------------------- */
+
+int32_t dmel_abi_version(void);
+
+/* time_frequency.py:60-65 applied as at :39 -- fp32 product 6*|lambd|, int() truncation,
+ * 1 << (x-1).bit_length().  Returns n_fft (>= 1). */
+int32_t dmel_n_fft(float lambd);
+
+/* time_frequency.py:21-30: Gaussian window of length n_fft centred at n_fft/2 (fp32 arithmetic as
+ * the reference), optional L2 normalisation; dwindow (may be NULL) receives d window / d |lambd|. */
+dmel_status dmel_window_host(float lambd, int32_t n_fft, int32_t normalize, float* window, float* dwindow);
+
+/* models.py:42-48: torchaudio.functional.melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate)
+ * with norm=None, mel_scale="htk".  fb is (n_freqs, n_mels) row-major fp32, host memory. */
+dmel_status dmel_mel_fbanks_host(int32_t n_freqs, double f_min, double f_max, int32_t n_mels,
+                                 int32_t sample_rate, float* fb);
+
+const char* dmel_last_error(void);
+
+/* ---- device path --------------------------------------------------------------------------- */
+
+/* Number of visible HIP devices whose architecture is gfx950 (0 when none / no driver). */
+int32_t dmel_device_count(void);
+
+/* MelSpectrogramLayer.__init__ (models.py:15-30).  Binds to the current HIP device. */
+dmel_status dmel_plan_create(const dmel_config* cfg, dmel_plan** plan);
+dmel_status dmel_plan_destroy(dmel_plan* plan);
+
+/* Replace the mel filterbank of the plan by a caller-supplied (n_freqs, n_mels) fp32 HOST matrix for
+ * the given n_fft (n_freqs = n_fft/2+1): the contraction of models.py:53 then uses it instead of the
+ * HTK table.  Pass fb = NULL to return to the built-in table. */
+dmel_status dmel_plan_set_filterbank(dmel_plan* plan, int32_t n_fft, const float* fb);
+
+/*
+ * MelSpectrogramLayer.forward (models.py:33-56) [+ models.py:73 when DMEL_FLAG_LOG]:
+ * DC removal, Gaussian-windowed STFT (center=True, zero padding), |.|^2, mel contraction.
+ *   x        device, (batch, n_points) fp32
+ *   lambd    host value of the parameter (the reference reads it to the host too,
+ *            time_frequency.py:39); may be negative or zero
+ *   out      device, (batch, 1, n_mels, n_time) fp32
+ *   tangent  device, same shape, or NULL for inference: receives d out / d lambd so that
+ *            the backward is a single dot product (one trainable scalar -> forward mode)
+ *   eps      the 1e-10 of models.py:73 (ignored without DMEL_FLAG_LOG)
+ * Asynchronous on `stream`.
+ */
+dmel_status dmel_forward(dmel_plan* plan, const float* x, int32_t batch, float lambd, uint32_t flags,
+                         double eps, float* out, float* tangent, void* stream);
+
+/*
+ * Backward to lambd.grad (what loss.backward() reaches through the layer, train.py:47):
+ *   dlambd[0] = sum_i grad_out[i] * tangent[i]        (accumulate != 0: += instead of =)
+ * grad_out, tangent: device fp32, `count` elements; dlambd: device fp32 scalar.
+ * Deterministic (fixed-order two-stage reduction, fp64 accumulation).  Asynchronous on `stream`.
+ */
+dmel_status dmel_backward(dmel_plan* plan, const float* grad_out, const float* tangent, int64_t count,
+                          int32_t accumulate, float* dlambd, void* stream);
+
+/* Power spectrogram only, (batch, n_fft/2+1, n_time) fp32 = time_frequency.differentiable_spectrogram
+ * (time_frequency.py:32-58, optimized branch) applied per clip; remove_dc != 0 adds models.py:38. */
+dmel_status dmel_spectrogram(dmel_plan* plan, const float* x, int32_t batch, float lambd,
+                             int32_t remove_dc, float* spec, void* stream);
+
+/* Introspection for tests / benchmarks */
+typedef struct dmel_plan_info {
+    int32_t n_fft;             /* of the most recent forward                                */
+    int32_t n_freqs;
+    int32_t n_time;
+    int32_t frames_per_tile;   /* frames one workgroup of the fused kernel produces         */
+    int32_t grid_fwd;          /* workgroups of the fused forward kernel                    */
+    int32_t fb_blocks;         /* non-zero 4x16 filterbank blocks fed to the MFMA loop      */
+    int32_t fb_blocks_dense;   /* the same count for a dense matrix                         */
+    int32_t lds_bytes;         /* dynamic LDS of the fused kernel                           */
+    int32_t kernel_path;       /* 0 = wave-FFT + MFMA kernel, 1 = direct-DFT kernel (n_fft < 32) */
+} dmel_plan_info;
+dmel_status dmel_plan_get_info(const dmel_plan* plan, dmel_plan_info* info);
+
+/* Per-kernel device timing with HIP events recorded on the caller's stream around each launch
+ * (bench.py's roofline line).  Off by default; recording stops silently after 16384 launches. */
+typedef struct dmel_profile {
+    double prep_ms;            /* sum over launches: partial sums + window tables kernel    */
+    double fwd_ms;             /* fused forward kernel                                      */
+    double bwd_ms;             /* both kernels of dmel_backward                             */
+    int32_t prep_launches, fwd_launches, bwd_launches;
+} dmel_profile;
+dmel_status dmel_plan_set_profiling(dmel_plan* plan, int32_t enable);
+/* Waits for the recorded events, returns the sums since the last call and resets them. */
+dmel_status dmel_plan_get_profile(dmel_plan* plan, dmel_profile* profile);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMEL_H */

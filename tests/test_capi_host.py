@@ -1,0 +1,84 @@
+"""CPU-side checks of the C-ABI library: it loads without a GPU, exports every symbol of include/dmel.h,
+its host-side functions agree with the oracle, and device entry points fail loudly without a device."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import cases as C
+from oracle import dmel_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from dmel_amd import capi
+    L = capi.load()
+    header = open(os.path.join(ROOT, "include", "dmel.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", header, flags=re.S)          # strip comments
+    declared = sorted(set(re.findall(r"\b(dmel_[a-z_0-9]+)\s*\(", code)))
+    assert declared, "no declarations found"
+    assert sorted(capi.SYMBOLS) == declared
+    for name in declared:
+        assert hasattr(L, name), f"libdmel_hip.so does not export {name}"
+    assert L.dmel_abi_version() == 1
+
+
+def test_n_fft_rule_matches_oracle_and_fixtures():
+    from dmel_amd import capi
+    for case in C.CASES:
+        assert capi.n_fft(case["lambd"]) == int(C.load(case)["n_fft"]) == O.n_fft(case["lambd"])
+    rng = np.random.default_rng(0)
+    for lam in np.concatenate([rng.uniform(0, 700, 500), [0.0, 1 / 6, 1 / 3, 0.5, 85.33333, 85.5, 682.6, 682.7]]):
+        assert capi.n_fft(float(lam)) == O.n_fft(float(lam))
+        assert capi.n_fft(-float(lam)) == O.n_fft(float(lam))
+
+
+@pytest.mark.parametrize("F,M,sr,fmin,fmax", [(257, 64, 16000, 0, 8000), (513, 128, 16000, 0, 8000), (1025, 128, 16000, 0, 8000),
+                                             (1025, 128, 44100, 0, 22050), (65, 64, 8000, 0, 4000), (2049, 64, 8000, 0, 4000),
+                                             (129, 40, 16000, 125.0, 7000.0)])
+def test_filterbank_tables(F, M, sr, fmin, fmax):
+    """SURVEY.md 8(c) G8 table shapes.  torchaudio is absent, so these are formula-vs-formula (parity unpinned):
+    the product's C++ table against the oracle's C table, plus the structural properties of an HTK bank."""
+    from dmel_amd import capi
+    fb = capi.mel_fbanks_host(F, fmin, fmax, M, sr)
+    assert np.array_equal(fb, O.mel_fbanks(F, fmin, fmax, M, sr))
+    assert fb.min() >= 0.0 and fb.max() <= 1.0
+    assert ((fb > 0).sum(axis=1) <= 2).all()            # triangles overlap pairwise only
+    nz = [np.flatnonzero(fb[:, m]) for m in range(M)]
+    assert all(len(i) == 0 or (np.diff(i) == 1).all() for i in nz)   # each band is one contiguous run
+
+
+def test_window_host_matches_oracle():
+    from dmel_amd import capi
+    for lam, n, norm in ((64.0, 512, False), (128.0, 1024, True), (13.3333, 128, False), (400.0, 4096, True)):
+        w, dw = capi.window_host(lam, n, norm)
+        wo, dwo = O.window(lam, n, norm)
+        assert np.array_equal(w, wo)
+        assert np.abs(dw - dwo).max() <= 1e-6 * np.abs(dwo).max()
+
+
+def test_no_device_fails_loudly():
+    import torch
+    from dmel_amd import MelSpectrogramLayer, capi
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    assert capi.device_count() == 0
+    with pytest.raises(capi.DmelError):
+        capi.Plan(16000, 256, 64, 16000)
+    layer = MelSpectrogramLayer(torch.tensor(64.0), 64, 16000, 16000, hop_length=256, optimized=True)
+    assert list(layer.state_dict().keys()) == ["lambd"]
+    with pytest.raises(RuntimeError):
+        layer(torch.zeros(1, 16000))          # CPU tensor: there is no CPU fallback
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "differentiable-mel-spectrogram_amd")
+    for dirpath, _, files in os.walk(pkg):
+        if "build" in dirpath.split(os.sep):
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "dmel_oracle" not in text and "import oracle" not in text and "from oracle" not in text, f

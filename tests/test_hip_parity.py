@@ -1,0 +1,277 @@
+"""GPU parity tests: the HIP path (through the C ABI / nn.Module) against
+  (1) the golden vectors captured from the reference (tests/golden/*.npz), and
+  (2) the CPU oracle on the same seeded inputs.
+Tolerances (BASELINE.json north_star): rel <= 1e-4 on mel, abs <= 1e-4 on log-mel,
+rel <= 1e-4 on d lambd.
+"""
+import numpy as np
+import pytest
+import torch
+
+import cases as C
+from oracle import dmel_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _layer(case, log=False, trainable=True):
+    from dmel_amd import MelSpectrogramLayer
+    layer = MelSpectrogramLayer(torch.tensor(float(case["lambd"]), dtype=torch.float32), n_mels=case["n_mels"],
+                                n_points=case["L"], sample_rate=case["sr"], f_min=case["f_min"], f_max=case["f_max"],
+                                hop_length=case["hop"], device="cuda:0", optimized=True,
+                                normalize_window=case["normalize_window"], log=log).to("cuda:0")
+    layer.requires_grad_(trainable)
+    return layer
+
+
+def _rel_err(got, exp):
+    # rel error on mel; bins more than 120 dB below the loudest one are fp32 noise in the reference
+    # itself (its own floor), so they are measured against that floor
+    scale = np.maximum(np.abs(exp), 1e-6 * np.abs(exp).max() + 1e-30)
+    return float((np.abs(got.astype(np.float64) - exp.astype(np.float64)) / scale).max())
+
+
+def _log_err(got_y, exp_y, eps=1e-10):
+    """abs error on log-mel == rel error on (mel + eps), with the same 120 dB floor as _rel_err."""
+    return _rel_err(np.exp(got_y.astype(np.float64)), np.exp(exp_y.astype(np.float64)))
+
+
+def _dlam_tol(exp_d, g_np, t_ref):
+    """rel 1e-4 on d lambd, plus the fp32 floor of the sum itself: d lambd = sum g*t cancels heavily
+    (sum|g*t| / |d lambd| reaches 2.5e4 in the fixtures), and the reference's own fp32 autograd value
+    carries ~1e-8 * sum|g*t| of rounding noise."""
+    return TOL * abs(exp_d) + 2e-8 * float(np.abs(g_np.astype(np.float64) * t_ref.astype(np.float64)).sum()) + 1e-7
+
+
+@pytest.mark.parametrize("case", C.CASES, ids=[c["name"] for c in C.CASES])
+def test_matches_reference_golden(case):
+    gold = C.load(case)
+    x = torch.from_numpy(C.make_input(case)).to("cuda:0")
+    g = torch.from_numpy(C.make_cotangent(case)).to("cuda:0")
+    idx = C.sample_index(case)
+    exp = gold["mel"].reshape(-1) if idx is None else gold["mel_sampled"]
+
+    lin = _layer(case, log=False)
+    assert lin.n_fft() == int(gold["n_fft"])
+    mel = lin(x)
+    assert mel.shape == C.out_shape(case) and mel.dtype == torch.float32
+    (mel * g).sum().backward()
+    mel_np = mel.detach().cpu().numpy()
+    got = mel_np.reshape(-1) if idx is None else mel_np.reshape(-1)[idx]
+    assert _rel_err(got, exp) <= TOL
+    np.testing.assert_allclose(mel_np.astype(np.float64).reshape(case["B"], -1).sum(1), gold["mel_sum"], rtol=TOL, atol=1e-12)
+    dl_lin = float(lin.lambd.grad)
+
+    lg = _layer(case, log=True)
+    y = lg(x)
+    (y * g).sum().backward()
+    y_np = y.detach().cpu().numpy()
+    goty = y_np.reshape(-1) if idx is None else y_np.reshape(-1)[idx]
+    expy = np.log(exp.astype(np.float32) + np.float32(1e-10))
+    assert _log_err(goty, expy) <= TOL
+    dl_log = float(lg.lambd.grad)
+
+    x32 = C.make_input(case).astype(np.float32)
+    g_np = C.make_cotangent(case)
+    for got_d, exp_d, log in ((dl_lin, float(gold["dlam_lin"]), False), (dl_log, float(gold["dlam_log"]), True)):
+        if case["kind"] == "zero":
+            assert got_d == 0.0 and np.isfinite(got_d)
+        else:
+            _, t_ref = O.forward(x32, case["lambd"], case["hop"], case["n_mels"], case["sr"], case["f_min"], case["f_max"],
+                                 case["normalize_window"], apply_log=log)
+            assert abs(got_d - exp_d) <= _dlam_tol(exp_d, g_np, t_ref), (got_d, exp_d)
+
+
+@pytest.mark.parametrize("name", ["g1_c1", "g2_c2", "g5_n128", "g5_n4096", "g6_n256_ragged", "g6_n64", "g6_n32",
+                                  "g6_n2048_short", "g6_normwin", "g6_tone_dc"])
+def test_matches_oracle_elementwise(name):
+    """Every element (not just the stored sample) against the fp64-accumulating oracle, and the
+    tangent d out / d lambd itself, which the golden fixtures only pin through its dot product."""
+    case = C.BY_NAME[name]
+    x_np = C.make_input(case).astype(np.float32)
+    x = torch.from_numpy(x_np).to("cuda:0")
+    from dmel_amd import capi
+    plan = capi.Plan(case["L"], case["hop"], case["n_mels"], case["sr"], case["f_min"], case["f_max"], case["normalize_window"])
+    for log in (False, True):
+        out = torch.empty(C.out_shape(case), dtype=torch.float32, device="cuda:0")
+        tan = torch.empty_like(out)
+        plan.forward(x.data_ptr(), case["B"], case["lambd"], out.data_ptr(), tan.data_ptr(), log, 1e-10,
+                     torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        o_ref, t_ref = O.forward(x_np, case["lambd"], case["hop"], case["n_mels"], case["sr"], case["f_min"], case["f_max"],
+                                 case["normalize_window"], apply_log=log)
+        o, t = out.cpu().numpy(), tan.cpu().numpy()
+        if log:
+            assert _log_err(o, o_ref) <= TOL
+        else:
+            assert _rel_err(o, o_ref) <= TOL
+        # tangent: signed sums cancel, so measure against the frame's own scale
+        tscale = np.abs(t_ref).max() + 1e-30
+        assert float(np.abs(t - t_ref).max()) / tscale <= TOL
+
+
+@pytest.mark.parametrize("name", ["g1_c1", "g2_c2", "g6_n256_ragged", "g5_n128", "g6_n32"])
+def test_inference_path_equals_training_path(name):
+    """Without a trainable lambd two frames share one FFT; results must agree with the tangent-carrying kernel."""
+    case = C.BY_NAME[name]
+    x = torch.from_numpy(C.make_input(case).astype(np.float32)).to("cuda:0")
+    a = _layer(case, log=True, trainable=True)(x)
+    with torch.no_grad():
+        b = _layer(case, log=True, trainable=False)(x)
+    assert not b.requires_grad
+    assert float((a.detach() - b).abs().max()) <= 2e-5
+
+
+@pytest.mark.parametrize("name", ["g1_c1", "g2_c2", "g5_n128", "g6_n256_ragged", "g6_n2048_short"])
+def test_spectrogram_stage(name):
+    """Framing + window + FFT + |.|^2 alone (time_frequency.py:32-58) against the oracle."""
+    case = C.BY_NAME[name]
+    x_np = C.make_input(case).astype(np.float32)
+    from dmel_amd import capi
+    plan = capi.Plan(case["L"], case["hop"], case["n_mels"], case["sr"])
+    n = capi.n_fft(case["lambd"])
+    spec = torch.empty((case["B"], n // 2 + 1, case["L"] // case["hop"] + 1), dtype=torch.float32, device="cuda:0")
+    x = torch.from_numpy(x_np).to("cuda:0")
+    for dc in (False, True):
+        plan.spectrogram(x.data_ptr(), case["B"], case["lambd"], spec.data_ptr(), torch.cuda.current_stream().cuda_stream, remove_dc=dc)
+        torch.cuda.synchronize()
+        ref = O.spectrogram(x_np, case["lambd"], case["hop"], remove_dc=dc)
+        assert _rel_err(spec.cpu().numpy(), ref) <= TOL
+
+
+def test_tiny_nfft_uses_direct_dft_kernel():
+    for lam, n in ((2.0, 16), (0.7, 4), (0.0, 2), (0.2, 1)):
+        case = dict(C.BY_NAME["g6_n32"], lambd=lam)
+        x_np = C.make_input(case).astype(np.float32)
+        layer = _layer(case, log=True)
+        assert layer.n_fft() == n
+        y = layer(torch.from_numpy(x_np).to("cuda:0"))
+        assert layer.plan_info()["kernel_path"] == 1
+        y_ref, t_ref = O.forward(x_np, lam, case["hop"], case["n_mels"], case["sr"], apply_log=True)
+        assert float(np.abs(y.detach().cpu().numpy() - y_ref).max()) <= TOL
+        g = torch.from_numpy(C.make_cotangent(case)).to("cuda:0")
+        (y * g).sum().backward()
+        ref = O.backward(C.make_cotangent(case), t_ref)
+        assert abs(float(layer.lambd.grad) - ref) <= TOL * abs(ref) + 1e-6
+
+
+def test_dense_custom_filterbank():
+    """A dense (non-banded) matrix exercises every MFMA block: mel = fb^T P with P from the spectrogram stage."""
+    case = C.BY_NAME["g6_n256_ragged"]
+    from dmel_amd import capi
+    x_np = C.make_input(case).astype(np.float32)
+    x = torch.from_numpy(x_np).to("cuda:0")
+    n = capi.n_fft(case["lambd"])
+    F, M, T, B = n // 2 + 1, case["n_mels"], case["L"] // case["hop"] + 1, case["B"]
+    rng = np.random.default_rng(5)
+    fb = rng.uniform(-1.0, 1.0, size=(F, M)).astype(np.float32)
+    plan = capi.Plan(case["L"], case["hop"], M, case["sr"])
+    plan.set_filterbank(n, fb)
+    out = torch.empty((B, 1, M, T), dtype=torch.float32, device="cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    plan.forward(x.data_ptr(), B, case["lambd"], out.data_ptr(), None, False, 1e-10, s)
+    torch.cuda.synchronize()
+    info = plan.info()
+    assert info["fb_blocks"] == info["fb_blocks_dense"]
+    P = O.spectrogram(x_np, case["lambd"], case["hop"], remove_dc=True).astype(np.float64)      # (B,F,T)
+    ref = np.einsum("fm,bft->bmt", fb.astype(np.float64), P)[:, None]
+    err = np.abs(out.cpu().numpy() - ref).max() / np.abs(ref).max()
+    assert err <= 2e-5
+    plan.set_filterbank(n, None)
+    plan.forward(x.data_ptr(), B, case["lambd"], out.data_ptr(), None, False, 1e-10, s)
+    torch.cuda.synchronize()
+    o_ref, _ = O.forward(x_np, case["lambd"], case["hop"], M, case["sr"], want_tangent=False)
+    assert _rel_err(out.cpu().numpy(), o_ref) <= TOL
+
+
+def test_error_behaviour():
+    from dmel_amd import MelSpectrogramLayer, capi
+    case = C.BY_NAME["g1_c1"]
+    layer = _layer(case)
+    with pytest.raises(RuntimeError):       # the reference raises RuntimeError on a length mismatch too
+        layer(torch.zeros(2, case["L"] + 1, device="cuda:0"))
+    with pytest.raises(ValueError):
+        layer(torch.zeros(case["L"], device="cuda:0"))
+    with pytest.raises(RuntimeError):
+        layer(torch.zeros(2, case["L"]))      # CPU tensor: no fallback
+    big = _layer(dict(case, lambd=700.0))     # n_fft 8192 > 4096
+    with pytest.raises(capi.DmelError):
+        big(torch.zeros(1, case["L"], device="cuda:0"))
+    slow = MelSpectrogramLayer(torch.tensor(64.0), 64, case["L"], 16000, hop_length=256, optimized=False).to("cuda:0")
+    with pytest.raises(NotImplementedError):
+        slow(torch.zeros(1, case["L"], device="cuda:0"))
+    # empty batch and non-contiguous / fp64 input are fine
+    assert layer(torch.zeros(0, case["L"], device="cuda:0")).shape == (0, 1, case["n_mels"], case["L"] // case["hop"] + 1)
+    x = torch.from_numpy(C.make_input(case)).to("cuda:0")
+    xt = torch.stack([x, x], dim=2)[:, :, 0]
+    assert not xt.is_contiguous()
+    assert torch.equal(layer(xt), layer(x))
+    assert float((layer(x.double()) - layer(x)).abs().max()) == 0.0
+
+
+def test_state_dict_and_param_groups():
+    case = C.BY_NAME["g1_c1"]
+    layer = _layer(case)
+    assert list(layer.state_dict().keys()) == ["lambd"]                  # utils.py:270 strict load
+    other = _layer(dict(case, lambd=10.0))
+    other.load_state_dict(layer.state_dict(), strict=True)
+    assert float(other.lambd) == case["lambd"]
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.spectrogram_layer = layer
+            self.fc = torch.nn.Linear(4, 2)
+    names = [n for n, _ in Net().named_parameters()]
+    assert "spectrogram_layer.lambd" in names                            # main.py:39
+
+
+# ---- full BASELINE size (config 2): properties that need no oracle at that size ----------------
+def _c2_layer(log=True):
+    case = dict(C.BY_NAME["g2_c2"])
+    return _layer(case, log=log), case
+
+
+def test_c2_full_size_properties():
+    from dmel_amd import synth
+    layer, case = _c2_layer(log=False)
+    B = 256
+    x_np = synth.waveforms(B, case["L"], seed=0)
+    x = torch.from_numpy(x_np).to("cuda:0")
+    g = torch.from_numpy(synth.cotangent((B, 1, case["n_mels"], case["L"] // case["hop"] + 1), seed=1)).to("cuda:0")
+    mel = layer(x)
+    (mel * g).sum().backward()
+    d_full = float(layer.lambd.grad)
+    # (1) |.|^2 is homogeneous of degree 2 and every step scales exactly by powers of two
+    mel2 = layer(2.0 * x)
+    assert torch.equal(mel2, 4.0 * mel)
+    # (2) clips are independent: permuting the batch permutes the output bit for bit
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(3)).to("cuda:0")
+    assert torch.equal(layer(x[perm]), mel[perm])
+    # (3) the gradient is additive over batch shards (what the multi-GPU all-reduce relies on)
+    parts = 0.0
+    for sl in (slice(0, 96), slice(96, 256)):
+        layer.lambd.grad = None
+        (layer(x[sl]) * g[sl]).sum().backward()
+        parts += float(layer.lambd.grad)
+    assert abs(parts - d_full) <= 1e-5 * abs(d_full) + 1e-6
+    # (4) eight clips spread over the batch against the oracle
+    pick = [0, 1, 37, 100, 128, 200, 254, 255]
+    ref, tref = O.forward(x_np[pick], case["lambd"], case["hop"], case["n_mels"], case["sr"])
+    assert _rel_err(mel.detach().cpu().numpy()[pick], ref) <= TOL
+    # (5) run-to-run determinism, forward and backward
+    layer.lambd.grad = None
+    m3 = layer(x)
+    (m3 * g).sum().backward()
+    assert torch.equal(m3, mel) and float(layer.lambd.grad) == d_full
+    # (6) finite-difference check of d lambd in fp32 (loose: the loss is fp32)
+    lg, _ = _c2_layer(log=True)
+    y = lg(x[:32]); (y * g[:32]).sum().backward()
+    ana = float(lg.lambd.grad)
+    h = 0.25
+    with torch.no_grad():
+        lp, _ = _c2_layer(log=True); lp.lambd += h
+        lm, _ = _c2_layer(log=True); lm.lambd -= h
+        num = float(((lp(x[:32]).double() - lm(x[:32]).double()) * g[:32].double()).sum()) / (2 * h)
+    assert abs(num - ana) <= 2e-2 * abs(ana) + 1e-3

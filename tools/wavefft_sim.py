@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""Lane-level numpy model of the wave-cooperative FFT used by csrc/dmel_fwd.hip.
+
+One 64-lane wave transforms FPW = 64/G frames of N = R*R*C complex points, R points per lane:
+  stage 1  radix-R DFT in registers over a   (lane lg holds n = lg + G*a)
+  twiddle  w_N^(lg*q)
+  exchange through LDS (row q, column lg; padded rows)
+  stage 2  radix-R DFT in registers over b   (lane C*q'+r holds element r + C*b of sub-problem q')
+  twiddle  w_G^(r*p1)
+  stage 3  radix-C butterflies across C adjacent lanes (DPP quad permutes on the GPU)
+  result   Z[q' + R*p1 + R*R*p2] at lane C*q' + rho(p2), register p1
+This file mirrors the kernel's index arithmetic one to one so that it can be checked against
+numpy.fft without a GPU; tests/test_wavefft_model.py runs it for every supported N.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# N -> (R, C)
+PLAN = {32: (4, 2), 64: (8, 1), 128: (8, 2), 256: (16, 1), 512: (16, 2), 1024: (16, 4), 2048: (32, 2), 4096: (64, 1)}
+WAVE = 64
+
+
+def bitrev(i: int, bits: int) -> int:
+    r = 0
+    for _ in range(bits):
+        r = (r << 1) | (i & 1)
+        i >>= 1
+    return r
+
+
+def fft_inreg(v: np.ndarray) -> np.ndarray:
+    """Radix-2 DIF on axis -1 (length R), output left in bit-reversed positions, like the
+    unrolled register butterflies in the kernel.  v: (..., R) complex."""
+    v = v.copy()
+    R = v.shape[-1]
+    span = R // 2
+    while span >= 1:
+        for base in range(0, R, 2 * span):
+            for j in range(span):
+                a, b = v[..., base + j].copy(), v[..., base + j + span].copy()
+                tw = np.exp(-2j * np.pi * j / (2 * span))
+                v[..., base + j] = a + b
+                v[..., base + j + span] = (a - b) * tw
+        span //= 2
+    return v
+
+
+def z_index(k: int, R: int, C: int) -> int:
+    """Padded position of bin k inside a slot (complex units): +4 per R*R block keeps the final
+    ds_write_b64 conflict-free."""
+    if C == 1:
+        return k
+    return k + (k // (R * R)) * 4
+
+
+def wave_fft(frames: np.ndarray, N: int) -> np.ndarray:
+    """frames: (FPW, N) complex -> (FPW, N) complex spectrum, computed the way one wave does."""
+    R, C = PLAN[N]
+    G = N // R
+    FPW = WAVE // G
+    assert frames.shape == (FPW, N)
+    lb = int(np.log2(R))
+    lane = np.arange(WAVE)
+    j, lg = lane // G, lane % G
+
+    # stage 0/1: registers z[lane, a] = x[j, lg + G*a]
+    z = np.stack([frames[j, lg + G * a] for a in range(R)], axis=1)
+    y = fft_inreg(z)                                  # logical q at register bitrev(q)
+    # twiddle w_N^(lg*q) and exchange: S[j][q][lg]
+    stride = G + (C if G >= 32 else 1)
+    lds = np.zeros((FPW, R * stride), complex)
+    for q in range(R):
+        val = y[:, bitrev(q, lb)] * np.exp(-2j * np.pi * lg * q / N)
+        lds[j, q * stride + lg] = val
+    # stage 2: lane lg = C*q' + r reads element r + C*b of sub-problem q'
+    qp, r = lg // C, lg % C
+    u = np.stack([lds[j, qp * stride + r + C * b] for b in range(R)], axis=1)
+    U = fft_inreg(u)                                  # logical p1 at register bitrev(p1)
+    out = np.zeros((FPW, N), complex)
+    V = np.zeros((WAVE, R), complex)
+    for p1 in range(R):
+        val = U[:, bitrev(p1, lb)] * np.exp(-2j * np.pi * r * p1 / G)
+        # stage 3: radix-C across the C adjacent lanes
+        if C == 1:
+            res, p2 = val, np.zeros(WAVE, int)
+        elif C == 2:
+            partner = val[lane ^ 1]
+            res = np.where(r == 0, val + partner, partner - val)
+            p2 = r
+        else:  # C == 4, DIF: xor 2 then xor 1; lane r ends with p2 = bitrev2(r)
+            partner = val[lane ^ 2]
+            t = np.where(r < 2, val + partner, partner - val)
+            t = np.where(r == 3, t * (-1j), t)
+            partner = t[lane ^ 1]
+            res = np.where((r & 1) == 0, t + partner, partner - t)
+            p2 = np.array([0, 2, 1, 3])[r]
+        V[:, p1] = res
+        k = qp + R * p1 + R * R * p2
+        out[j, k] = res
+    return out
+
+
+def bank_conflicts_exchange(N: int) -> dict:
+    """Worst-case LDS conflict degree of the exchange reads/writes (8-byte elements)."""
+    R, C = PLAN[N]
+    G = N // R
+    FPW = WAVE // G
+    stride = G + (C if G >= 32 else 1)
+    slot = slot_stride_bytes(N) // 8
+    lane = np.arange(WAVE)
+    j, lg = lane // G, lane % G
+    qp, r = lg // C, lg % C
+
+    def degree(addr_words8, group, banks64):
+        worst = 1
+        for g0 in range(0, WAVE, group):
+            a = addr_words8[g0:g0 + group]
+            bank = (a * 2) % (64 if banks64 else 32)
+            uniq = {}
+            for ad, bk in zip(a, bank):
+                uniq.setdefault(bk, set()).add(ad)
+            worst = max(worst, max(len(s) for s in uniq.values()))
+        return worst
+
+    wr = max(degree(j * slot + q * stride + lg, 16, False) for q in range(R))
+    rd = max(degree(j * slot + qp * stride + r + C * b, 32, True) for b in range(R))
+    p2 = (np.array([0, 2, 1, 3])[r] if C == 4 else r) if C > 1 else np.zeros(WAVE, int)
+    zw = max(degree(j * slot + np.array([z_index(int(kk), R, C) for kk in qp + R * p1 + R * R * p2]), 16, False)
+             for p1 in range(R))
+    return dict(exchange_write=wr, exchange_read=rd, z_write=zw)
+
+
+def slot_stride_bytes(N: int) -> int:
+    """Bytes between consecutive FFT slots in LDS: room for the padded exchange image and the
+    padded spectrum, rounded so that stride = 32 (mod 256) (A-fragment reads, 8 slots x 32 B)."""
+    R, C = PLAN[N]
+    G = N // R
+    stride = G + (C if G >= 32 else 1)
+    need = max(R * stride, z_index(N - 1, R, C) + 1) * 8
+    s = (need + 255) // 256 * 256 + 32
+    return s
+
+
+if __name__ == "__main__":
+    rng = np.random.default_rng(0)
+    for N in sorted(PLAN):
+        R, C = PLAN[N]
+        FPW = WAVE // (N // R)
+        x = rng.standard_normal((FPW, N)) + 1j * rng.standard_normal((FPW, N))
+        got = wave_fft(x, N)
+        ref = np.fft.fft(x, axis=1)
+        print(N, (R, C), "FPW", FPW, "err", np.abs(got - ref).max(), bank_conflicts_exchange(N),
+              "slot", slot_stride_bytes(N))
