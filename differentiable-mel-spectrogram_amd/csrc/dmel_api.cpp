@@ -48,14 +48,12 @@ struct NfftTables {
     int n_entries = 0, n_dense = 0;
     float2* tw1 = nullptr;
     float2* tw2 = nullptr;
-    int* ent_meta = nullptr;
     float* ent_b = nullptr;
-    int* ent_range = nullptr;
-    int* wave_tiles = nullptr;
+    int4* tile_ranges = nullptr;
     float* fb_dense = nullptr;   // (F, M) for the direct-DFT kernel
     void release()
     {
-        void* ptrs[] = {tw1, tw2, ent_meta, ent_b, ent_range, wave_tiles, fb_dense};
+        void* ptrs[] = {tw1, tw2, ent_b, tile_ranges, fb_dense};
         for (void* q : ptrs) (void)hipFree(q);
         *this = NfftTables();
     }
@@ -160,47 +158,46 @@ dmel_status build_tables(dmel_plan* pl, int N, NfftTables** out)
         tb.NT = (M + 15) / 16;
         tb.groups = (tb.NT + 7) / 8;
         tb.n_dense = tb.KS * tb.NT;
-        std::vector<int> meta, range((size_t)tb.groups * 8), wtiles((size_t)tb.groups * 8);
+        std::vector<int4> ranges((size_t)tb.groups * 8);
         std::vector<float> bfr;
+        tb.n_entries = 0;
         for (int g = 0; g < tb.groups; ++g) {
             const int ntg = std::min(8, tb.NT - 8 * g);
             for (int w = 0; w < dmel::kWaves; ++w) {
                 int tiles[2] = {-1, -1};
                 if (w < ntg) tiles[0] = 8 * g + w;
                 if (7 - w >= 4 && 7 - w < ntg) tiles[1] = 8 * g + 7 - w;
-                wtiles[(size_t)(g * 4 + w) * 2 + 0] = tiles[0];
-                wtiles[(size_t)(g * 4 + w) * 2 + 1] = tiles[1];
-                range[(size_t)(g * 4 + w) * 2 + 0] = (int)meta.size();
-                for (int ks = 0; ks < tb.KS; ++ks)
-                    for (int loc = 0; loc < 2; ++loc) {
-                        if (tiles[loc] < 0) continue;
-                        float blk[64];
-                        bool any = false;
-                        for (int l = 0; l < 64; ++l) {
-                            const int f = 4 * ks + (l >> 4), m = 16 * tiles[loc] + (l & 15);
-                            const float v = (f < tb.F && m < M) ? fb[(size_t)f * M + m] : 0.f;
-                            blk[l] = v;
-                            any |= (v != 0.f);
+                for (int loc = 0; loc < 2; ++loc) {
+                    int4 tr = make_int4(0, 0, 0, tiles[loc]);
+                    if (tiles[loc] >= 0) {
+                        // the band of a mel tile is one contiguous run of k-steps: [first, last] with a non-zero block
+                        int first = tb.KS, last = -1;
+                        for (int ks = 0; ks < tb.KS; ++ks)
+                            for (int l = 0; l < 64; ++l) {
+                                const int f = 4 * ks + (l >> 4), m = 16 * tiles[loc] + (l & 15);
+                                if (f < tb.F && m < M && fb[(size_t)f * M + m] != 0.f) { first = std::min(first, ks); last = std::max(last, ks); }
+                            }
+                        if (last >= first) {
+                            const int nks = (last - first + 1 + 3) / 4 * 4;
+                            tr.x = first; tr.y = nks; tr.z = (int)bfr.size();
+                            tb.n_entries += last - first + 1;
+                            for (int i = 0; i < nks; ++i)
+                                for (int l = 0; l < 64; ++l) {
+                                    const int ks = first + i, f = 4 * ks + (l >> 4), m = 16 * tiles[loc] + (l & 15);
+                                    bfr.push_back((ks <= last && f < tb.F && m < M) ? fb[(size_t)f * M + m] : 0.f);
+                                }
                         }
-                        if (!any) continue;
-                        meta.push_back(ks | (loc << 16));
-                        bfr.insert(bfr.end(), blk, blk + 64);
                     }
-                range[(size_t)(g * 4 + w) * 2 + 1] = (int)meta.size();
+                    ranges[(size_t)(g * 4 + w) * 2 + loc] = tr;
+                }
             }
         }
-        tb.n_entries = (int)meta.size();
-        const size_t ne = std::max<size_t>(meta.size(), 1);
-        DMEL_HIP(hipMalloc(&tb.ent_meta, ne * sizeof(int)));
-        DMEL_HIP(hipMalloc(&tb.ent_b, ne * 64 * sizeof(float)));
-        if (!meta.empty()) {
-            DMEL_HIP(hipMemcpy(tb.ent_meta, meta.data(), meta.size() * sizeof(int), hipMemcpyHostToDevice));
+        const size_t nb = std::max<size_t>(bfr.size(), 64);
+        DMEL_HIP(hipMalloc(&tb.ent_b, nb * sizeof(float)));
+        if (!bfr.empty())
             DMEL_HIP(hipMemcpy(tb.ent_b, bfr.data(), bfr.size() * sizeof(float), hipMemcpyHostToDevice));
-        }
-        DMEL_HIP(hipMalloc(&tb.ent_range, range.size() * sizeof(int)));
-        DMEL_HIP(hipMemcpy(tb.ent_range, range.data(), range.size() * sizeof(int), hipMemcpyHostToDevice));
-        DMEL_HIP(hipMalloc(&tb.wave_tiles, wtiles.size() * sizeof(int)));
-        DMEL_HIP(hipMemcpy(tb.wave_tiles, wtiles.data(), wtiles.size() * sizeof(int), hipMemcpyHostToDevice));
+        DMEL_HIP(hipMalloc(&tb.tile_ranges, ranges.size() * sizeof(int4)));
+        DMEL_HIP(hipMemcpy(tb.tile_ranges, ranges.data(), ranges.size() * sizeof(int4), hipMemcpyHostToDevice));
     }
     auto ins = pl->tables.emplace(N, tb);
     *out = &ins.first->second;
@@ -271,8 +268,7 @@ dmel_status run_forward(dmel_plan* pl, const float* x, int batch, float lambd, u
     }
     dmel::FwdParams fp{};
     fp.x = x; fp.out = out; fp.tangent = tangent; fp.psum = pl->psum; fp.win = pl->win;
-    fp.tw1 = tb->tw1; fp.tw2 = tb->tw2; fp.ent_meta = tb->ent_meta; fp.ent_b = tb->ent_b;
-    fp.ent_range = tb->ent_range; fp.wave_tiles = tb->wave_tiles;
+    fp.tw1 = tb->tw1; fp.tw2 = tb->tw2; fp.ent_b = tb->ent_b; fp.tile_ranges = tb->tile_ranges;
     fp.B = batch; fp.L = pl->cfg.n_points; fp.T = pl->T; fp.hop = pl->cfg.hop_length; fp.M = pl->cfg.n_mels;
     fp.nchunks = pl->nchunks; fp.groups = tb->groups;
     const int fpt = dmel::forward_frames_per_tile(N, mode);

@@ -186,41 +186,66 @@ __global__ void __launch_bounds__(kThreads) dmel_fwd_kernel(FwdParams p)
     const int t0 = (blockIdx.x % p.tiles_per_clip) * FPT;
     const float* xb = p.x + (size_t)b * p.L;
 
-    float mean = 0.f;
-    if (p.remove_dc) {
-        double s = 0.0;
-        for (int c = 0; c < p.nchunks; ++c) s += (double)p.psum[(size_t)b * p.nchunks + c];
-        mean = (float)(s * (double)p.inv_L);
-    }
-
     // ================= phase 1: FFT of this wave's frames ====================================
     const int j = lane / G, lg = lane % G;
     const int qp = lg / C, r = lg % C;
-#pragma unroll 1
-    for (int pass = 0; pass < PASSES; ++pass) {
+    constexpr bool PAIR = (MODE != kTrain);
+    // Samples of every pass are requested up front with clamped (always valid) addresses and zeroed by
+    // a select afterwards: a conditional load would make hipcc branch around each one and wait for it
+    // separately (cdna_hip_programming.md section 5, trap (c)).
+    float xa[PASSES][R];
+    float xb2[PAIR ? PASSES : 1][PAIR ? R : 1];
+    static_for<0, PASSES>([&](auto pp) {
+        constexpr int pass = decltype(pp)::value;
+        const int slot = pass * (kWaves * FPW) + wave * FPW + j;
+        const int tA = PAIR ? (t0 + 2 * slot) : (t0 + slot);
+        const int sA = tA * p.hop - N / 2 + lg;                    // |t*hop| < 2^31 is checked on the host
+        static_for<0, R>([&](auto aa) {
+            constexpr int a = decltype(aa)::value;
+            const int ia = sA + G * a;
+            const bool in = (ia >= 0) && (ia < p.L);
+            int ca = in ? ia : 0;
+            asm volatile("" : "+v"(ca));                            // keep the load unconditional (see above)
+            const float v = xb[ca];
+            xa[pass][a] = v;
+            if constexpr (PAIR) {
+                const int ib = ia + p.hop;
+                const bool inb = (ib >= 0) && (ib < p.L);
+                int cb = inb ? ib : 0;
+                asm volatile("" : "+v"(cb));
+                const float vb = xb[cb];
+                xb2[pass][a] = vb;
+            }
+        });
+    });
+    // clip mean (models.py:38): the <= 64 partial sums of the prep kernel, one per lane, one round trip,
+    // added in a fixed butterfly order (deterministic)
+    float mean = 0.f;
+    if (p.remove_dc) {
+        float ps = (lane < p.nchunks) ? p.psum[(size_t)b * p.nchunks + lane] : 0.f;
+        static_for<0, 6>([&](auto st) { ps += __shfl_xor(ps, 1 << decltype(st)::value, 64); });
+        mean = ps * p.inv_L;
+    }
+    static_for<0, PASSES>([&](auto pp) {
+        constexpr int pass = decltype(pp)::value;
         const int slot = pass * (kWaves * FPW) + wave * FPW + j;
         float2* sl = lds + slot * SS;
+        const int tA = PAIR ? (t0 + 2 * slot) : (t0 + slot);
+        const int sA = tA * p.hop - N / 2 + lg;
         float2 z[R];
-        {
-            const int tA = (MODE == kTrain) ? (t0 + slot) : (t0 + 2 * slot);
-            const long long sA = (long long)tA * p.hop - N / 2 + lg;
-            const long long sB = sA + p.hop;                       // frame tA + 1 (pair modes)
-            static_for<0, R>([&](auto aa) {
-                constexpr int a = decltype(aa)::value;
-                const int n = lg + G * a;
-                const long long ia = sA + G * a;
-                const float va = (ia >= 0 && ia < p.L) ? (xb[ia] - mean) : 0.f;
-                const float w = p.win[n];
-                if constexpr (MODE == kTrain) {
-                    const float dw = p.win[N + n];
-                    z[a] = make_float2(va * w, va * dw);
-                } else {
-                    const long long ib = sB + G * a;
-                    const float vb = (ib >= 0 && ib < p.L) ? (xb[ib] - mean) : 0.f;
-                    z[a] = make_float2(va * w, vb * w);
-                }
-            });
-        }
+        static_for<0, R>([&](auto aa) {
+            constexpr int a = decltype(aa)::value;
+            const int n = lg + G * a;
+            const float w = p.win[n];
+            const int ia = sA + G * a;
+            // zero padding of torch.stft(center=True, pad_mode='constant') applies AFTER the DC removal
+            const float va = ((ia >= 0) && (ia < p.L)) ? xa[pass][a] - mean : 0.f;
+            if constexpr (MODE == kTrain) z[a] = make_float2(va * w, va * p.win[N + n]);
+            else {
+                const int ib = ia + p.hop;
+                z[a] = make_float2(va * w, (((ib >= 0) && (ib < p.L)) ? xb2[pass][a] - mean : 0.f) * w);
+            }
+        });
         fft_reg<R>(z);
         // twiddle w_N^(lg*q), transposition through LDS: S[q][lg]
         static_for<0, R>([&](auto qq) {
@@ -266,7 +291,7 @@ __global__ void __launch_bounds__(kThreads) dmel_fwd_kernel(FwdParams p)
             const int k = qp + R * p1 + R * R * p2;
             sl[z_index<R, C>(k)] = v;
         });
-    }
+    });
     __syncthreads();
 
     if constexpr (MODE == kSpec) {
@@ -292,44 +317,54 @@ __global__ void __launch_bounds__(kThreads) dmel_fwd_kernel(FwdParams p)
         const int col = lane & 15;
 
         for (int grp = 0; grp < p.groups; ++grp) {
-            floatx4 acc[2][MT];
-            static_for<0, 2>([&](auto l) { static_for<0, MT>([&](auto m) {
-                acc[decltype(l)::value][decltype(m)::value] = floatx4{0.f, 0.f, 0.f, 0.f}; }); });
-            const int eb = p.ent_range[(grp * kWaves + wave) * 2 + 0];
-            const int ee = p.ent_range[(grp * kWaves + wave) * 2 + 1];
-            for (int e = eb; e < ee; ++e) {
-                const int meta = __builtin_amdgcn_readfirstlane(p.ent_meta[e]);
-                const int ks = meta & 0xFFFF, loc = meta >> 16;
-                const float bf = p.ent_b[(size_t)e * 64 + lane];
-                const int kk = 4 * ks + kofs;
-                const int zi_k = z_index<R, C>(kk & (N - 1));
-                const int zi_n = z_index<R, C>((N - kk) & (N - 1));
-                float av[MT];
-                static_for<0, MT>([&](auto m) {
-                    constexpr int mt = decltype(m)::value;
-                    const int slot = mt * 8 + slot8;
-                    const bool valid = slot < SLOTS;
-                    const float2* sl = lds + (valid ? slot : 0) * SS;
-                    const float2 zk = sl[zi_k], zn = sl[zi_n];
-                    const float sx = zk.x + zn.x, sy = zk.y - zn.y, dx = zk.x - zn.x, dy = zk.y + zn.y;
-                    float val;
-                    if constexpr (MODE == kTrain) val = type ? fmaf(sx, dy, -(sy * dx)) : fmaf(sx, sx, sy * sy);
-                    else val = type ? fmaf(dx, dx, dy * dy) : fmaf(sx, sx, sy * sy);
-                    av[mt] = valid ? val : 0.f;
-                });
-                if (loc == 0) {
-                    static_for<0, MT>([&](auto m) { constexpr int mt = decltype(m)::value;
-                        acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bf, acc[0][mt], 0, 0, 0); });
-                } else {
-                    static_for<0, MT>([&](auto m) { constexpr int mt = decltype(m)::value;
-                        acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bf, acc[1][mt], 0, 0, 0); });
+            // acc[loc][mt][parity]: two accumulators per tile so that consecutive MFMAs never wait on each other
+            floatx4 acc[2][MT][2];
+            static_for<0, 2>([&](auto l) { static_for<0, MT>([&](auto m) { static_for<0, 2>([&](auto e) {
+                acc[decltype(l)::value][decltype(m)::value][decltype(e)::value] = floatx4{0.f, 0.f, 0.f, 0.f}; }); }); });
+            int tile_of[2];
+            static_for<0, 2>([&](auto l) {
+                constexpr int loc = decltype(l)::value;
+                // (ks0, nks, boff, tile): the filterbank is banded, so the non-zero 4x16 blocks of one mel tile
+                // form ONE contiguous run of k-steps; nks is padded to a multiple of 4 with zero blocks
+                const int4 tr = p.tile_ranges[(grp * kWaves + wave) * 2 + loc];
+                const int ks0 = __builtin_amdgcn_readfirstlane(tr.x), nks = __builtin_amdgcn_readfirstlane(tr.y);
+                const int boff = __builtin_amdgcn_readfirstlane(tr.z);
+                tile_of[loc] = __builtin_amdgcn_readfirstlane(tr.w);
+                if (nks <= 0) return;
+                const float* bp = p.ent_b + (size_t)boff + lane;
+                float bc[4], bn[4];
+                static_for<0, 4>([&](auto u) { bc[decltype(u)::value] = bp[decltype(u)::value * 64]; });
+                for (int i = 0; i < nks; i += 4) {
+                    // B fragments of the next four k-steps are in flight while this group is consumed
+                    const int inext = (i + 4 < nks) ? (i + 4) : i;
+                    static_for<0, 4>([&](auto u) { bn[decltype(u)::value] = bp[(size_t)(inext + decltype(u)::value) * 64]; });
+                    static_for<0, 4>([&](auto uu) {
+                        constexpr int u = decltype(uu)::value;
+                        const int kk = 4 * (ks0 + i + u) + kofs;
+                        const int zi_k = z_index<R, C>(kk & (N - 1));
+                        const int zi_n = z_index<R, C>((N - kk) & (N - 1));
+                        static_for<0, MT>([&](auto m) {
+                            constexpr int mt = decltype(m)::value;
+                            const int slot = mt * 8 + slot8;
+                            const bool valid = slot < SLOTS;
+                            const float2* sl = lds + (valid ? slot : 0) * SS;
+                            const float2 zk = sl[zi_k], zn = sl[zi_n];
+                            const float sx = zk.x + zn.x, sy = zk.y - zn.y, dx = zk.x - zn.x, dy = zk.y + zn.y;
+                            float val;
+                            if constexpr (MODE == kTrain) val = type ? fmaf(sx, dy, -(sy * dx)) : fmaf(sx, sx, sy * sy);
+                            else val = type ? fmaf(dx, dx, dy * dy) : fmaf(sx, sx, sy * sy);
+                            if constexpr (SLOTS < 8) val = valid ? val : 0.f;
+                            acc[loc][mt][u & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(val, bc[u], acc[loc][mt][u & 1], 0, 0, 0);
+                        });
+                    });
+                    static_for<0, 4>([&](auto u) { bc[decltype(u)::value] = bn[decltype(u)::value]; });
                 }
-            }
+            });
             // ---- epilogue: accumulators -> (B,1,M,T) ------------------------------------------
             const bool do_log = (p.flags & 1u) != 0;
             static_for<0, 2>([&](auto l) {
                 constexpr int loc = decltype(l)::value;
-                const int nt = p.wave_tiles[(grp * kWaves + wave) * 2 + loc];
+                const int nt = tile_of[loc];
                 if (nt < 0) return;
                 const int m = 16 * nt + col;
                 if (m >= p.M) return;
@@ -337,7 +372,7 @@ __global__ void __launch_bounds__(kThreads) dmel_fwd_kernel(FwdParams p)
                 float* trow = p.tangent ? p.tangent + ((size_t)b * p.M + m) * p.T : nullptr;
                 static_for<0, MT>([&](auto mm) {
                     constexpr int mt = decltype(mm)::value;
-                    const floatx4 a = acc[loc][mt];
+                    const floatx4 a = acc[loc][mt][0] + acc[loc][mt][1];
                     if constexpr (MODE == kTrain) {
                         // rows 4cg+i: i=0,1 -> |X|^2 of slots 2cg, 2cg+1; i=2,3 -> d|X|^2 of the same slots
                         static_for<0, 2>([&](auto ss) {

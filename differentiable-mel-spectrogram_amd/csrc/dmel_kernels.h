@@ -52,9 +52,8 @@ template <int N> constexpr FftGeom geom()
     return g;
 }
 
-// One non-zero 4(k) x 16(mel) block of the filterbank, pre-arranged as the B operand of
+// One 4(k) x 16(mel) block of the filterbank, pre-arranged as the B operand of
 // v_mfma_f32_16x16x4_f32: lane l holds fb[4*ks + (l >> 4)][16*tile + (l & 15)].
-// meta = ks | (loc << 16): loc selects which of the wave's two mel tiles the block belongs to.
 struct FwdParams {
     const float* x;            // (B, L)
     float* out;                // (B, 1, M, T) or spec (B, F, T) in kSpec mode
@@ -63,10 +62,8 @@ struct FwdParams {
     const float* win;          // [0..N): w, [N..2N): dw/d|lambd|
     const float2* tw1;         // (R, G): w_N^(lg*q)
     const float2* tw2;         // (R, C): w_G^(r*p1)
-    const int* ent_meta;       // entries of all (group, wave) lists, concatenated
-    const float* ent_b;        // 64 floats per entry
-    const int* ent_range;      // (groups, 4, 2): [begin, end) into the entry arrays
-    const int* wave_tiles;     // (groups, 4, 2): global mel-tile index of loc 0 / 1, or -1
+    const float* ent_b;        // 64 floats per 4x16 block, blocks of one mel tile contiguous in k
+    const int4* tile_ranges;   // (groups, 4 waves, 2): {first k-step, #k-steps (multiple of 4), offset into ent_b, mel tile or -1}
     int B, L, T, hop, M, nchunks, groups, tiles_per_clip;
     float inv_L, sign, eps;
     unsigned flags;
