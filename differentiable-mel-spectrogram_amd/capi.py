@@ -156,9 +156,9 @@ class Plan:
             pass
 
     def forward(self, x_ptr: int, batch: int, lambd: float, out_ptr: int, tangent_ptr: int | None,
-                log: bool, eps: float, stream: int):
-        _check(load().dmel_forward(self._h, x_ptr, batch, C.c_float(float(lambd)), DMEL_FLAG_LOG if log else 0,
-                                   float(eps), out_ptr, tangent_ptr, stream))
+                log: bool, eps: float, stream: int, extra_flags: int = 0):
+        _check(load().dmel_forward(self._h, x_ptr, batch, C.c_float(float(lambd)),
+                                   (DMEL_FLAG_LOG if log else 0) | int(extra_flags), float(eps), out_ptr, tangent_ptr, stream))
 
     def backward(self, grad_ptr: int, tangent_ptr: int, count: int, dlambd_ptr: int, stream: int, accumulate: bool = False):
         _check(load().dmel_backward(self._h, grad_ptr, tangent_ptr, int(count), int(accumulate), dlambd_ptr, stream))

@@ -49,6 +49,7 @@ struct NfftTables {
     float2* tw1 = nullptr;
     float2* tw2 = nullptr;
     float* ent_b = nullptr;
+    int ent_b_floats = 0;
     int4* tile_ranges = nullptr;
     float* fb_dense = nullptr;   // (F, M) for the direct-DFT kernel
     void release()
@@ -158,16 +159,17 @@ dmel_status build_tables(dmel_plan* pl, int N, NfftTables** out)
         tb.NT = (M + 15) / 16;
         tb.groups = (tb.NT + 7) / 8;
         tb.n_dense = tb.KS * tb.NT;
+        const int waves = dmel::forward_waves(N), nloc = 8 / waves;
         std::vector<int4> ranges((size_t)tb.groups * 8);
         std::vector<float> bfr;
         tb.n_entries = 0;
         for (int g = 0; g < tb.groups; ++g) {
             const int ntg = std::min(8, tb.NT - 8 * g);
-            for (int w = 0; w < dmel::kWaves; ++w) {
+            for (int w = 0; w < waves; ++w) {
                 int tiles[2] = {-1, -1};
                 if (w < ntg) tiles[0] = 8 * g + w;
-                if (7 - w >= 4 && 7 - w < ntg) tiles[1] = 8 * g + 7 - w;
-                for (int loc = 0; loc < 2; ++loc) {
+                if (nloc == 2 && 7 - w >= 4 && 7 - w < ntg) tiles[1] = 8 * g + 7 - w;
+                for (int loc = 0; loc < nloc; ++loc) {
                     int4 tr = make_int4(0, 0, 0, tiles[loc]);
                     if (tiles[loc] >= 0) {
                         // the band of a mel tile is one contiguous run of k-steps: [first, last] with a non-zero block
@@ -188,10 +190,11 @@ dmel_status build_tables(dmel_plan* pl, int N, NfftTables** out)
                                 }
                         }
                     }
-                    ranges[(size_t)(g * 4 + w) * 2 + loc] = tr;
+                    ranges[(size_t)(g * waves + w) * nloc + loc] = tr;
                 }
             }
         }
+        tb.ent_b_floats = (int)bfr.size();
         const size_t nb = std::max<size_t>(bfr.size(), 64);
         DMEL_HIP(hipMalloc(&tb.ent_b, nb * sizeof(float)));
         if (!bfr.empty())
@@ -268,7 +271,7 @@ dmel_status run_forward(dmel_plan* pl, const float* x, int batch, float lambd, u
     }
     dmel::FwdParams fp{};
     fp.x = x; fp.out = out; fp.tangent = tangent; fp.psum = pl->psum; fp.win = pl->win;
-    fp.tw1 = tb->tw1; fp.tw2 = tb->tw2; fp.ent_b = tb->ent_b; fp.tile_ranges = tb->tile_ranges;
+    fp.tw1 = tb->tw1; fp.tw2 = tb->tw2; fp.ent_b = tb->ent_b; fp.tile_ranges = tb->tile_ranges; fp.ent_b_floats = tb->ent_b_floats;
     fp.B = batch; fp.L = pl->cfg.n_points; fp.T = pl->T; fp.hop = pl->cfg.hop_length; fp.M = pl->cfg.n_mels;
     fp.nchunks = pl->nchunks; fp.groups = tb->groups;
     const int fpt = dmel::forward_frames_per_tile(N, mode);

@@ -166,15 +166,31 @@ hipError_t launch_prep(const PrepParams& p, hipStream_t s)
 }
 
 // ---- fused forward --------------------------------------------------------------------------
+// Raw buffer loads: 32-bit offsets from an SGPR descriptor, and the hardware range check returns 0
+// for offsets outside [0, bytes) -- a negative sample index wraps to a huge unsigned offset.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ptr, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_f32(__amdgpu_buffer_rsrc_t r, int byte_off)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ int clampi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }   // v_med3_i32
+// (the 64-bit form __builtin_amdgcn_raw_buffer_load_b64 is mis-lowered to a single dword load by hipcc 7.2:
+// twiddle tables are therefore read with ordinary float2 loads)
+
 template <int N, int MODE>
-__global__ void __launch_bounds__(kThreads) dmel_fwd_kernel(FwdParams p)
+__global__ void __launch_bounds__(geom<N>().THREADS) dmel_fwd_kernel(FwdParams p)
 {
     constexpr FftGeom g = geom<N>();
     constexpr int R = g.R, C = g.C, G = g.G, FPW = g.FPW, PASSES = g.PASSES, SLOTS = g.SLOTS, MT = g.MT;
+    constexpr int WAVES = g.WAVES, NLOC = g.NLOC, THREADS = g.THREADS;
     constexpr int LB = ilog2(R);
     constexpr int EXS = g.EX_STRIDE, SS = g.SLOT_STRIDE_F2;
     constexpr int FPT = (MODE == kTrain) ? SLOTS : 2 * SLOTS;   // frames per tile
     constexpr int F = N / 2 + 1;
+    constexpr bool PAIR = (MODE != kTrain);
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* lds = reinterpret_cast<float2*>(smem_raw);
@@ -184,119 +200,147 @@ __global__ void __launch_bounds__(kThreads) dmel_fwd_kernel(FwdParams p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x / p.tiles_per_clip;
     const int t0 = (blockIdx.x % p.tiles_per_clip) * FPT;
-    const float* xb = p.x + (size_t)b * p.L;
+    const bool dbg_skip_fft = (p.flags & 0x200u) != 0;     // timing ablations only (tools/ablate.py)
+    const bool dbg_skip_gemm = (p.flags & 0x100u) != 0;
+
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (size_t)b * p.L, (unsigned)p.L * 4u);
+    const __amdgpu_buffer_rsrc_t rwin = make_rsrc(p.win, 2u * N * 4u);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.ent_b, (unsigned)p.ent_b_floats * 4u);
+
+    // ---- requests that phase 2 will need, issued before anything else --------------------------
+    // (ks0, nks, boff, tile) of this wave's mel tiles in group 0 and their first four B fragments
+    int4 tr0[NLOC];
+    float bfirst[NLOC][4];
+    if constexpr (MODE != kSpec) {
+        static_for<0, NLOC>([&](auto l) {
+            constexpr int loc = decltype(l)::value;
+            tr0[loc] = p.tile_ranges[wave * NLOC + loc];
+        });
+        static_for<0, NLOC>([&](auto l) {
+            constexpr int loc = decltype(l)::value;
+            static_for<0, 4>([&](auto u) {
+                bfirst[loc][decltype(u)::value] = buf_f32(rb, (tr0[loc].z + decltype(u)::value * 64 + lane) * 4);
+            });
+        });
+    }
 
     // ================= phase 1: FFT of this wave's frames ====================================
     const int j = lane / G, lg = lane % G;
     const int qp = lg / C, r = lg % C;
-    constexpr bool PAIR = (MODE != kTrain);
-    // Samples of every pass are requested up front with clamped (always valid) addresses and zeroed by
-    // a select afterwards: a conditional load would make hipcc branch around each one and wait for it
-    // separately (cdna_hip_programming.md section 5, trap (c)).
-    float xa[PASSES][R];
-    float xb2[PAIR ? PASSES : 1][PAIR ? R : 1];
-    static_for<0, PASSES>([&](auto pp) {
-        constexpr int pass = decltype(pp)::value;
-        const int slot = pass * (kWaves * FPW) + wave * FPW + j;
-        const int tA = PAIR ? (t0 + 2 * slot) : (t0 + slot);
-        const int sA = tA * p.hop - N / 2 + lg;                    // |t*hop| < 2^31 is checked on the host
-        static_for<0, R>([&](auto aa) {
-            constexpr int a = decltype(aa)::value;
-            const int ia = sA + G * a;
-            const bool in = (ia >= 0) && (ia < p.L);
-            int ca = in ? ia : 0;
-            asm volatile("" : "+v"(ca));                            // keep the load unconditional (see above)
-            const float v = xb[ca];
-            xa[pass][a] = v;
-            if constexpr (PAIR) {
-                const int ib = ia + p.hop;
-                const bool inb = (ib >= 0) && (ib < p.L);
-                int cb = inb ? ib : 0;
-                asm volatile("" : "+v"(cb));
-                const float vb = xb[cb];
-                xb2[pass][a] = vb;
+    if (!dbg_skip_fft) {
+        // Samples of every pass are requested up front.  Frames that lie wholly inside the clip (all but
+        // the first/last few) use plain offsets; the others clamp every index into the clip and are
+        // zeroed by a select below.  (The hardware range check of buffer loads is not relied upon: it
+        // covers voffset + immediate but not soffset, and hipcc chooses that split.)
+        float xa[PASSES][R];
+        float xb2[PAIR ? PASSES : 1][PAIR ? R : 1];
+        bool inside[PASSES];
+        static_for<0, PASSES>([&](auto pp) {
+            constexpr int pass = decltype(pp)::value;
+            const int slot = pass * (WAVES * FPW) + wave * FPW + j;
+            const int tA = PAIR ? (t0 + 2 * slot) : (t0 + slot);
+            const int f0 = tA * p.hop - N / 2;                       // first sample of frame tA
+            const int f1 = PAIR ? f0 + p.hop : f0;
+            inside[pass] = __all((f0 >= 0) && (f1 + N <= p.L));
+            const int sA = f0 + lg;
+            if (inside[pass]) {
+                static_for<0, R>([&](auto aa) {
+                    constexpr int a = decltype(aa)::value;
+                    xa[pass][a] = buf_f32(rx, (sA + G * a) * 4);
+                    if constexpr (PAIR) xb2[pass][a] = buf_f32(rx, (sA + p.hop + G * a) * 4);
+                });
+            } else {
+                static_for<0, R>([&](auto aa) {
+                    constexpr int a = decltype(aa)::value;
+                    xa[pass][a] = buf_f32(rx, clampi(sA + G * a, p.L - 1) * 4);
+                    if constexpr (PAIR) xb2[pass][a] = buf_f32(rx, clampi(sA + p.hop + G * a, p.L - 1) * 4);
+                });
             }
         });
-    });
-    // clip mean (models.py:38): the <= 64 partial sums of the prep kernel, one per lane, one round trip,
-    // added in a fixed butterfly order (deterministic)
-    float mean = 0.f;
-    if (p.remove_dc) {
-        float ps = (lane < p.nchunks) ? p.psum[(size_t)b * p.nchunks + lane] : 0.f;
-        static_for<0, 6>([&](auto st) { ps += __shfl_xor(ps, 1 << decltype(st)::value, 64); });
-        mean = ps * p.inv_L;
-    }
-    static_for<0, PASSES>([&](auto pp) {
-        constexpr int pass = decltype(pp)::value;
-        const int slot = pass * (kWaves * FPW) + wave * FPW + j;
-        float2* sl = lds + slot * SS;
-        const int tA = PAIR ? (t0 + 2 * slot) : (t0 + slot);
-        const int sA = tA * p.hop - N / 2 + lg;
-        float2 z[R];
-        static_for<0, R>([&](auto aa) {
-            constexpr int a = decltype(aa)::value;
-            const int n = lg + G * a;
-            const float w = p.win[n];
-            const int ia = sA + G * a;
+        // clip mean (models.py:38): the <= 64 partial sums of the prep kernel, one per lane, one round
+        // trip, added in a fixed butterfly order (deterministic)
+        float mean = 0.f;
+        if (p.remove_dc) {
+            float ps = (lane < p.nchunks) ? p.psum[(size_t)b * p.nchunks + lane] : 0.f;
+            static_for<0, 6>([&](auto st) { ps += __shfl_xor(ps, 1 << decltype(st)::value, 64); });
+            mean = ps * p.inv_L;
+        }
+        static_for<0, PASSES>([&](auto pp) {
+            constexpr int pass = decltype(pp)::value;
+            const int slot = pass * (WAVES * FPW) + wave * FPW + j;
+            float2* sl = lds + slot * SS;
+            const int tA = PAIR ? (t0 + 2 * slot) : (t0 + slot);
+            const int f0 = tA * p.hop - N / 2;                       // first sample of frame tA
+            const int f1 = PAIR ? f0 + p.hop : f0;
             // zero padding of torch.stft(center=True, pad_mode='constant') applies AFTER the DC removal
-            const float va = ((ia >= 0) && (ia < p.L)) ? xa[pass][a] - mean : 0.f;
-            if constexpr (MODE == kTrain) z[a] = make_float2(va * w, va * p.win[N + n]);
-            else {
-                const int ib = ia + p.hop;
-                z[a] = make_float2(va * w, (((ib >= 0) && (ib < p.L)) ? xb2[pass][a] - mean : 0.f) * w);
-            }
+            const bool inside_w = inside[pass];
+            float2 z[R];
+            static_for<0, R>([&](auto aa) {
+                constexpr int a = decltype(aa)::value;
+                const int n = lg + G * a;
+                const float w = buf_f32(rwin, n * 4);
+                float va = xa[pass][a] - mean;
+                if (!inside_w) { const int ia = f0 + n; va = ((ia >= 0) && (ia < p.L)) ? va : 0.f; }
+                if constexpr (MODE == kTrain) z[a] = make_float2(va * w, va * buf_f32(rwin, (N + n) * 4));
+                else {
+                    float vb = xb2[pass][a] - mean;
+                    if (!inside_w) { const int ib = f1 + n; vb = ((ib >= 0) && (ib < p.L)) ? vb : 0.f; }
+                    z[a] = make_float2(va * w, vb * w);
+                }
+            });
+            fft_reg<R>(z);
+            // twiddle w_N^(lg*q), transposition through LDS: S[q][lg]
+            static_for<0, R>([&](auto qq) {
+                constexpr int q = decltype(qq)::value;
+                float2 v = z[bitrev(q, LB)];
+                if constexpr (q != 0) v = cmul(v, p.tw1[q * G + lg]);
+                sl[q * EXS + lg] = v;
+            });
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float2 u[R];
+            static_for<0, R>([&](auto bb) {
+                constexpr int bi = decltype(bb)::value;
+                u[bi] = sl[qp * EXS + r + C * bi];
+            });
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            fft_reg<R>(u);
+            // twiddle w_G^(r*p1), radix-C across adjacent lanes, spectrum to LDS in natural order
+            static_for<0, R>([&](auto pp1) {
+                constexpr int p1 = decltype(pp1)::value;
+                float2 v = u[bitrev(p1, LB)];
+                int p2 = 0;
+                if constexpr (C > 1) {
+                    if constexpr (p1 != 0) v = cmul(v, p.tw2[p1 * C + r]);
+                }
+                if constexpr (C == 2) {
+                    const float ox = quad_xor1(v.x), oy = quad_xor1(v.y);
+                    const float sg = (r == 0) ? 1.f : -1.f;
+                    v = make_float2(fmaf(sg, v.x, ox), fmaf(sg, v.y, oy));
+                    p2 = r;
+                } else if constexpr (C == 4) {
+                    float ox = quad_xor2(v.x), oy = quad_xor2(v.y);
+                    float sg = (r < 2) ? 1.f : -1.f;
+                    float2 t = make_float2(fmaf(sg, v.x, ox), fmaf(sg, v.y, oy));
+                    if (r == 3) t = make_float2(t.y, -t.x);
+                    ox = quad_xor1(t.x); oy = quad_xor1(t.y);
+                    sg = ((r & 1) == 0) ? 1.f : -1.f;
+                    v = make_float2(fmaf(sg, t.x, ox), fmaf(sg, t.y, oy));
+                    p2 = ((r & 1) << 1) | (r >> 1);
+                }
+                const int k = qp + R * p1 + R * R * p2;
+                sl[z_index<R, C>(k)] = v;
+            });
         });
-        fft_reg<R>(z);
-        // twiddle w_N^(lg*q), transposition through LDS: S[q][lg]
-        static_for<0, R>([&](auto qq) {
-            constexpr int q = decltype(qq)::value;
-            float2 v = z[bitrev(q, LB)];
-            if constexpr (q != 0) v = cmul(v, p.tw1[q * G + lg]);
-            sl[q * EXS + lg] = v;
-        });
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        float2 u[R];
-        static_for<0, R>([&](auto bb) {
-            constexpr int bi = decltype(bb)::value;
-            u[bi] = sl[qp * EXS + r + C * bi];
-        });
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        fft_reg<R>(u);
-        // twiddle w_G^(r*p1), radix-C across adjacent lanes, spectrum to LDS in natural order
-        static_for<0, R>([&](auto pp) {
-            constexpr int p1 = decltype(pp)::value;
-            float2 v = u[bitrev(p1, LB)];
-            int p2 = 0;
-            if constexpr (C > 1) {
-                if constexpr (p1 != 0) v = cmul(v, p.tw2[p1 * C + r]);
-            }
-            if constexpr (C == 2) {
-                const float ox = quad_xor1(v.x), oy = quad_xor1(v.y);
-                const float sg = (r == 0) ? 1.f : -1.f;
-                v = make_float2(fmaf(sg, v.x, ox), fmaf(sg, v.y, oy));
-                p2 = r;
-            } else if constexpr (C == 4) {
-                float ox = quad_xor2(v.x), oy = quad_xor2(v.y);
-                float sg = (r < 2) ? 1.f : -1.f;
-                float2 t = make_float2(fmaf(sg, v.x, ox), fmaf(sg, v.y, oy));
-                if (r == 3) t = make_float2(t.y, -t.x);
-                ox = quad_xor1(t.x); oy = quad_xor1(t.y);
-                sg = ((r & 1) == 0) ? 1.f : -1.f;
-                v = make_float2(fmaf(sg, t.x, ox), fmaf(sg, t.y, oy));
-                p2 = ((r & 1) << 1) | (r >> 1);
-            }
-            const int k = qp + R * p1 + R * R * p2;
-            sl[z_index<R, C>(k)] = v;
-        });
-    });
+    }
     __syncthreads();
+    if (dbg_skip_gemm) { if (tid == 0 && lds[0].x == 12345.678f) p.out[0] = 0.f; return; }
 
     if constexpr (MODE == kSpec) {
         // power spectrogram (time_frequency.py:53), layout (B, F, T)
-        for (int idx = tid; idx < SLOTS * F; idx += kThreads) {
+        for (int idx = tid; idx < SLOTS * F; idx += THREADS) {
             const int k = idx / SLOTS, slot = idx % SLOTS;
             const float2* sl = lds + slot * SS;
             const float2 zk = sl[z_index<R, C>(k)], zn = sl[z_index<R, C>((N - k) & (N - 1))];
@@ -318,26 +362,30 @@ __global__ void __launch_bounds__(kThreads) dmel_fwd_kernel(FwdParams p)
 
         for (int grp = 0; grp < p.groups; ++grp) {
             // acc[loc][mt][parity]: two accumulators per tile so that consecutive MFMAs never wait on each other
-            floatx4 acc[2][MT][2];
-            static_for<0, 2>([&](auto l) { static_for<0, MT>([&](auto m) { static_for<0, 2>([&](auto e) {
+            floatx4 acc[NLOC][MT][2];
+            static_for<0, NLOC>([&](auto l) { static_for<0, MT>([&](auto m) { static_for<0, 2>([&](auto e) {
                 acc[decltype(l)::value][decltype(m)::value][decltype(e)::value] = floatx4{0.f, 0.f, 0.f, 0.f}; }); }); });
-            int tile_of[2];
-            static_for<0, 2>([&](auto l) {
+            int tile_of[NLOC];
+            static_for<0, NLOC>([&](auto l) {
                 constexpr int loc = decltype(l)::value;
                 // (ks0, nks, boff, tile): the filterbank is banded, so the non-zero 4x16 blocks of one mel tile
                 // form ONE contiguous run of k-steps; nks is padded to a multiple of 4 with zero blocks
-                const int4 tr = p.tile_ranges[(grp * kWaves + wave) * 2 + loc];
+                int4 tr = tr0[loc];
+                if (grp > 0) tr = p.tile_ranges[(grp * WAVES + wave) * NLOC + loc];
                 const int ks0 = __builtin_amdgcn_readfirstlane(tr.x), nks = __builtin_amdgcn_readfirstlane(tr.y);
                 const int boff = __builtin_amdgcn_readfirstlane(tr.z);
                 tile_of[loc] = __builtin_amdgcn_readfirstlane(tr.w);
                 if (nks <= 0) return;
-                const float* bp = p.ent_b + (size_t)boff + lane;
+                const int bbase = (boff + lane) * 4;
                 float bc[4], bn[4];
-                static_for<0, 4>([&](auto u) { bc[decltype(u)::value] = bp[decltype(u)::value * 64]; });
+                static_for<0, 4>([&](auto u) {
+                    bc[decltype(u)::value] = (grp == 0) ? bfirst[loc][decltype(u)::value]
+                                                        : buf_f32(rb, bbase + decltype(u)::value * 256);
+                });
                 for (int i = 0; i < nks; i += 4) {
                     // B fragments of the next four k-steps are in flight while this group is consumed
-                    const int inext = (i + 4 < nks) ? (i + 4) : i;
-                    static_for<0, 4>([&](auto u) { bn[decltype(u)::value] = bp[(size_t)(inext + decltype(u)::value) * 64]; });
+                    // (past the end the offsets fall outside the buffer and read as 0, unused)
+                    static_for<0, 4>([&](auto u) { bn[decltype(u)::value] = buf_f32(rb, bbase + (i + 4 + decltype(u)::value) * 256); });
                     static_for<0, 4>([&](auto uu) {
                         constexpr int u = decltype(uu)::value;
                         const int kk = 4 * (ks0 + i + u) + kofs;
@@ -362,7 +410,7 @@ __global__ void __launch_bounds__(kThreads) dmel_fwd_kernel(FwdParams p)
             });
             // ---- epilogue: accumulators -> (B,1,M,T) ------------------------------------------
             const bool do_log = (p.flags & 1u) != 0;
-            static_for<0, 2>([&](auto l) {
+            static_for<0, NLOC>([&](auto l) {
                 constexpr int loc = decltype(l)::value;
                 const int nt = tile_of[loc];
                 if (nt < 0) return;
@@ -414,7 +462,7 @@ template <int N, int MODE> static hipError_t launch_one(const FwdParams& p, int 
 {
     constexpr FftGeom g = geom<N>();
     constexpr int lds = g.SLOTS * g.SLOT_STRIDE_F2 * 8;
-    hipLaunchKernelGGL((dmel_fwd_kernel<N, MODE>), dim3(grid), dim3(kThreads), lds, s, p);
+    hipLaunchKernelGGL((dmel_fwd_kernel<N, MODE>), dim3(grid), dim3(g.THREADS), lds, s, p);
     return hipGetLastError();
 }
 
@@ -466,6 +514,16 @@ int forward_frames_per_tile(int n_fft, int mode)
     }
     if (slots < 0) return -1;
     return mode == kTrain ? slots : 2 * slots;
+}
+
+int forward_waves(int n_fft)
+{
+    switch (n_fft) {
+        case 32: return geom<32>().WAVES; case 64: return geom<64>().WAVES; case 128: return geom<128>().WAVES;
+        case 256: return geom<256>().WAVES; case 512: return geom<512>().WAVES; case 1024: return geom<1024>().WAVES;
+        case 2048: return geom<2048>().WAVES; case 4096: return geom<4096>().WAVES;
+    }
+    return -1;
 }
 
 template <int N, int MODE> static hipError_t set_attr()

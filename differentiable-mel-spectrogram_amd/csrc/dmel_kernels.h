@@ -6,8 +6,7 @@
 namespace dmel {
 
 constexpr int kWave = 64;
-constexpr int kThreads = 256;          // 4 waves per workgroup
-constexpr int kWaves = 4;
+constexpr int kThreads = 256;          // prep / dot kernels
 constexpr int kMaxChunks = 64;         // partial sums per clip for the DC removal
 constexpr int kMaxNfft = 4096;
 constexpr int kMinFastNfft = 32;       // below this the direct-DFT kernel runs
@@ -15,18 +14,20 @@ constexpr int kMinFastNfft = 32;       // below this the direct-DFT kernel runs
 enum Mode : int { kTrain = 0, kInfer = 1, kSpec = 2 };
 
 // Compile-time FFT plan for one wave: N = R * R * C, R points per lane (tools/wavefft_sim.py).
+// WAVES waves per workgroup; each wave runs PASSES rounds of FPW = 64/G frames.  In the contraction
+// phase a wave owns NLOC = 8 / WAVES of the 8 mel tiles of a group.
 template <int N> struct FftPlan;
-template <> struct FftPlan<32>   { static constexpr int R = 4,  C = 2, PASSES = 1; };
-template <> struct FftPlan<64>   { static constexpr int R = 8,  C = 1, PASSES = 1; };
-template <> struct FftPlan<128>  { static constexpr int R = 8,  C = 2, PASSES = 1; };
-template <> struct FftPlan<256>  { static constexpr int R = 16, C = 1, PASSES = 1; };
-template <> struct FftPlan<512>  { static constexpr int R = 16, C = 2, PASSES = 1; };
-template <> struct FftPlan<1024> { static constexpr int R = 16, C = 4, PASSES = 2; };
-template <> struct FftPlan<2048> { static constexpr int R = 32, C = 2, PASSES = 2; };
-template <> struct FftPlan<4096> { static constexpr int R = 64, C = 1, PASSES = 1; };
+template <> struct FftPlan<32>   { static constexpr int R = 4,  C = 2, PASSES = 1, WAVES = 4; };
+template <> struct FftPlan<64>   { static constexpr int R = 8,  C = 1, PASSES = 1, WAVES = 4; };
+template <> struct FftPlan<128>  { static constexpr int R = 8,  C = 2, PASSES = 1, WAVES = 4; };
+template <> struct FftPlan<256>  { static constexpr int R = 16, C = 1, PASSES = 1, WAVES = 4; };
+template <> struct FftPlan<512>  { static constexpr int R = 16, C = 2, PASSES = 1, WAVES = 4; };
+template <> struct FftPlan<1024> { static constexpr int R = 16, C = 4, PASSES = 1, WAVES = 8; };
+template <> struct FftPlan<2048> { static constexpr int R = 32, C = 2, PASSES = 1, WAVES = 8; };
+template <> struct FftPlan<4096> { static constexpr int R = 64, C = 1, PASSES = 1, WAVES = 4; };
 
 struct FftGeom {
-    int N, R, C, G, FPW, PASSES, SLOTS, MT, EX_STRIDE, SLOT_STRIDE_F2;
+    int N, R, C, G, FPW, PASSES, WAVES, NLOC, THREADS, SLOTS, MT, EX_STRIDE, SLOT_STRIDE_F2;
 };
 
 constexpr int ex_stride(int G, int C) { return G + (G >= 32 ? C : 1); }
@@ -45,7 +46,8 @@ template <int N> constexpr FftGeom geom()
     using P = FftPlan<N>;
     FftGeom g{};
     g.N = N; g.R = P::R; g.C = P::C; g.G = N / P::R; g.FPW = kWave / g.G; g.PASSES = P::PASSES;
-    g.SLOTS = kWaves * g.FPW * g.PASSES;
+    g.WAVES = P::WAVES; g.NLOC = 8 / P::WAVES; g.THREADS = kWave * P::WAVES;
+    g.SLOTS = g.WAVES * g.FPW * g.PASSES;
     g.MT = g.SLOTS >= 8 ? g.SLOTS / 8 : 1;
     g.EX_STRIDE = ex_stride(g.G, g.C);
     g.SLOT_STRIDE_F2 = slot_stride_f2(N, P::R, P::C);
@@ -63,7 +65,8 @@ struct FwdParams {
     const float2* tw1;         // (R, G): w_N^(lg*q)
     const float2* tw2;         // (R, C): w_G^(r*p1)
     const float* ent_b;        // 64 floats per 4x16 block, blocks of one mel tile contiguous in k
-    const int4* tile_ranges;   // (groups, 4 waves, 2): {first k-step, #k-steps (multiple of 4), offset into ent_b, mel tile or -1}
+    const int4* tile_ranges;   // (groups, WAVES, NLOC): {first k-step, #k-steps (multiple of 4), offset into ent_b, mel tile or -1}
+    int ent_b_floats;          // size of ent_b (buffer bounds)
     int B, L, T, hop, M, nchunks, groups, tiles_per_clip;
     float inv_L, sign, eps;
     unsigned flags;
@@ -81,6 +84,7 @@ hipError_t launch_prep(const PrepParams& p, hipStream_t s);
 hipError_t launch_forward(int n_fft, int mode, const FwdParams& p, int grid, hipStream_t s);
 int forward_lds_bytes(int n_fft);
 int forward_frames_per_tile(int n_fft, int mode);
+int forward_waves(int n_fft);              // waves per workgroup of the fused kernel for this n_fft
 hipError_t forward_prepare_attributes();   // raises the dynamic-LDS limit of every instantiation once
 
 // direct-DFT kernel for n_fft < 32 (and as an on-device cross-check of the fast path)
