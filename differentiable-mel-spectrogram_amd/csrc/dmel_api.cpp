@@ -159,38 +159,48 @@ dmel_status build_tables(dmel_plan* pl, int N, NfftTables** out)
         tb.NT = (M + 15) / 16;
         tb.groups = (tb.NT + 7) / 8;
         tb.n_dense = tb.KS * tb.NT;
-        const int waves = dmel::forward_waves(N), nloc = 8 / waves;
-        std::vector<int4> ranges((size_t)tb.groups * 8);
+        const int waves = dmel::forward_waves(N);
+        std::vector<int4> ranges((size_t)tb.groups * waves * 2, make_int4(0, 0, 0, -1));
         std::vector<float> bfr;
         tb.n_entries = 0;
+        // run of k-steps [ks_a, ks_b) of mel tile `tile` appended to the B-fragment stream
+        auto emit = [&](int tile, int ks_a, int ks_b) {
+            int4 tr = make_int4(ks_a, ks_b - ks_a, (int)bfr.size(), tile);
+            for (int ks = ks_a; ks < ks_b; ++ks)
+                for (int l = 0; l < 64; ++l) {
+                    const int f = 4 * ks + (l >> 4), m = 16 * tile + (l & 15);
+                    bfr.push_back((f < tb.F && m < M) ? fb[(size_t)f * M + m] : 0.f);
+                }
+            return tr;
+        };
         for (int g = 0; g < tb.groups; ++g) {
             const int ntg = std::min(8, tb.NT - 8 * g);
-            for (int w = 0; w < waves; ++w) {
-                int tiles[2] = {-1, -1};
-                if (w < ntg) tiles[0] = 8 * g + w;
-                if (nloc == 2 && 7 - w >= 4 && 7 - w < ntg) tiles[1] = 8 * g + 7 - w;
-                for (int loc = 0; loc < nloc; ++loc) {
-                    int4 tr = make_int4(0, 0, 0, tiles[loc]);
-                    if (tiles[loc] >= 0) {
-                        // the band of a mel tile is one contiguous run of k-steps: [first, last] with a non-zero block
-                        int first = tb.KS, last = -1;
-                        for (int ks = 0; ks < tb.KS; ++ks)
-                            for (int l = 0; l < 64; ++l) {
-                                const int f = 4 * ks + (l >> 4), m = 16 * tiles[loc] + (l & 15);
-                                if (f < tb.F && m < M && fb[(size_t)f * M + m] != 0.f) { first = std::min(first, ks); last = std::max(last, ks); }
-                            }
-                        if (last >= first) {
-                            const int nks = (last - first + 1 + 3) / 4 * 4;
-                            tr.x = first; tr.y = nks; tr.z = (int)bfr.size();
-                            tb.n_entries += last - first + 1;
-                            for (int i = 0; i < nks; ++i)
-                                for (int l = 0; l < 64; ++l) {
-                                    const int ks = first + i, f = 4 * ks + (l >> 4), m = 16 * tiles[loc] + (l & 15);
-                                    bfr.push_back((ks <= last && f < tb.F && m < M) ? fb[(size_t)f * M + m] : 0.f);
-                                }
-                        }
+            for (int tl = 0; tl < ntg; ++tl) {
+                const int tile = 8 * g + tl;
+                // the band of a mel tile is one contiguous run of k-steps: [first, last] with a non-zero block
+                int first = tb.KS, last = -1;
+                for (int ks = 0; ks < tb.KS; ++ks)
+                    for (int l = 0; l < 64; ++l) {
+                        const int f = 4 * ks + (l >> 4), m = 16 * tile + (l & 15);
+                        if (f < tb.F && m < M && fb[(size_t)f * M + m] != 0.f) { first = std::min(first, ks); last = std::max(last, ks); }
                     }
-                    ranges[(size_t)(g * waves + w) * nloc + loc] = tr;
+                if (last < first) {     // an all-zero tile still needs its outputs written
+                    if (waves == 8) ranges[(size_t)(g * 8 + tl) * 2] = make_int4(0, 0, 0, tile);
+                    else ranges[(size_t)(g * 4 + (tl < 4 ? tl : 7 - tl)) * 2 + (tl < 4 ? 0 : 1)] = make_int4(0, 0, 0, tile);
+                    continue;
+                }
+                tb.n_entries += last - first + 1;
+                first = first / 4 * 4;                       // groups of 4 k-steps start at multiples of 16 bins
+                const int nks = (last - first + 1 + 3) / 4 * 4;
+                if (waves == 8) {
+                    // owner wave tl takes the first half, wave 7-tl the second (its partial goes through LDS)
+                    const int h = (nks / 4 + 1) / 2 * 4;
+                    ranges[(size_t)(g * 8 + tl) * 2 + 0] = emit(tile, first, first + h);
+                    if (nks > h) ranges[(size_t)(g * 8 + (7 - tl)) * 2 + 1] = emit(tile, first + h, first + nks);
+                } else {
+                    // 4 waves: wave w owns tiles w and 7-w whole
+                    const int w = tl < 4 ? tl : 7 - tl, loc = tl < 4 ? 0 : 1;
+                    ranges[(size_t)(g * 4 + w) * 2 + loc] = emit(tile, first, first + nks);
                 }
             }
         }

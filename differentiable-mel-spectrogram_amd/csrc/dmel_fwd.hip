@@ -181,7 +181,7 @@ __device__ __forceinline__ int clampi(int v, int hi) { return v < 0 ? 0 : (v > h
 // twiddle tables are therefore read with ordinary float2 loads)
 
 template <int N, int MODE>
-__global__ void __launch_bounds__(geom<N>().THREADS) dmel_fwd_kernel(FwdParams p)
+__global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_kernel(FwdParams p)
 {
     constexpr FftGeom g = geom<N>();
     constexpr int R = g.R, C = g.C, G = g.G, FPW = g.FPW, PASSES = g.PASSES, SLOTS = g.SLOTS, MT = g.MT;
@@ -198,8 +198,17 @@ __global__ void __launch_bounds__(geom<N>().THREADS) dmel_fwd_kernel(FwdParams p
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x / p.tiles_per_clip;
-    const int t0 = (blockIdx.x % p.tiles_per_clip) * FPT;
+    // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an L2).  Re-labelling them so
+    // that each XCD gets a CONTIGUOUS range of tiles puts the tiles of one clip on one L2: their
+    // overlapping sample reads hit, and the 32-byte output pieces that together make up whole lines
+    // of out/tangent merge there before going to HBM.  Speed only; any placement is correct.
+    int wg = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7, xcd = wg & 7;
+        wg = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (wg >> 3);
+    }
+    const int b = wg / p.tiles_per_clip;
+    const int t0 = (wg % p.tiles_per_clip) * FPT;
     const bool dbg_skip_fft = (p.flags & 0x200u) != 0;     // timing ablations only (tools/ablate.py)
     const bool dbg_skip_gemm = (p.flags & 0x100u) != 0;
 
@@ -209,8 +218,11 @@ __global__ void __launch_bounds__(geom<N>().THREADS) dmel_fwd_kernel(FwdParams p
 
     // ---- requests that phase 2 will need, issued before anything else --------------------------
     // (ks0, nks, boff, tile) of this wave's mel tiles in group 0 and their first four B fragments
+    // The first NBPRE k-steps of every tile (all of them for the HTK bank at the usual sizes) sit in
+    // registers from here on: nothing in phase 2 then waits on global memory.
+    constexpr int NBPRE = g.NBPRE;
     int4 tr0[NLOC];
-    float bfirst[NLOC][4];
+    float bpre[NLOC][NBPRE];
     if constexpr (MODE != kSpec) {
         static_for<0, NLOC>([&](auto l) {
             constexpr int loc = decltype(l)::value;
@@ -218,8 +230,9 @@ __global__ void __launch_bounds__(geom<N>().THREADS) dmel_fwd_kernel(FwdParams p
         });
         static_for<0, NLOC>([&](auto l) {
             constexpr int loc = decltype(l)::value;
-            static_for<0, 4>([&](auto u) {
-                bfirst[loc][decltype(u)::value] = buf_f32(rb, (tr0[loc].z + decltype(u)::value * 64 + lane) * 4);
+            static_for<0, NBPRE>([&](auto u) {
+                // offsets past this tile's run read the next tile's blocks or, past the buffer, 0: never used
+                bpre[loc][decltype(u)::value] = buf_f32(rb, (tr0[loc].z + decltype(u)::value * 64 + lane) * 4);
             });
         });
     }
@@ -375,41 +388,78 @@ __global__ void __launch_bounds__(geom<N>().THREADS) dmel_fwd_kernel(FwdParams p
                 const int ks0 = __builtin_amdgcn_readfirstlane(tr.x), nks = __builtin_amdgcn_readfirstlane(tr.y);
                 const int boff = __builtin_amdgcn_readfirstlane(tr.z);
                 tile_of[loc] = __builtin_amdgcn_readfirstlane(tr.w);
-                if (nks <= 0) return;
+                if (nks <= 0 || (p.flags & 0x800u)) return;       // 0x800: timing ablation, skip the MFMA loop
                 const int bbase = (boff + lane) * 4;
-                float bc[4], bn[4];
-                static_for<0, 4>([&](auto u) {
-                    bc[decltype(u)::value] = (grp == 0) ? bfirst[loc][decltype(u)::value]
-                                                        : buf_f32(rb, bbase + decltype(u)::value * 256);
-                });
-                for (int i = 0; i < nks; i += 4) {
-                    // B fragments of the next four k-steps are in flight while this group is consumed
-                    // (past the end the offsets fall outside the buffer and read as 0, unused)
-                    static_for<0, 4>([&](auto u) { bn[decltype(u)::value] = buf_f32(rb, bbase + (i + 4 + decltype(u)::value) * 256); });
-                    static_for<0, 4>([&](auto uu) {
-                        constexpr int u = decltype(uu)::value;
-                        const int kk = 4 * (ks0 + i + u) + kofs;
-                        const int zi_k = z_index<R, C>(kk & (N - 1));
-                        const int zi_n = z_index<R, C>((N - kk) & (N - 1));
-                        static_for<0, MT>([&](auto m) {
-                            constexpr int mt = decltype(m)::value;
-                            const int slot = mt * 8 + slot8;
-                            const bool valid = slot < SLOTS;
-                            const float2* sl = lds + (valid ? slot : 0) * SS;
-                            const float2 zk = sl[zi_k], zn = sl[zi_n];
-                            const float sx = zk.x + zn.x, sy = zk.y - zn.y, dx = zk.x - zn.x, dy = zk.y + zn.y;
-                            float val;
-                            if constexpr (MODE == kTrain) val = type ? fmaf(sx, dy, -(sy * dx)) : fmaf(sx, sx, sy * sy);
-                            else val = type ? fmaf(dx, dx, dy * dy) : fmaf(sx, sx, sy * sy);
+                // One group = 4 consecutive k-steps = 16 consecutive bins starting at a multiple of 16 (the host
+                // aligns every run to 4 k-steps), so the 4 reads of Z[k] share one base address and, except at one
+                // bin per 256, so do the 4 reads of the mirrored Z[N-k].
+                auto group4 = [&](int ksg, float b0, float b1, float b2, float b3) {
+                    const float bq[4] = {b0, b1, b2, b3};
+                    const int k0 = 4 * ksg + kofs;                               // bin of k-step 0 for this lane
+                    const int m0 = (N - k0) & (N - 1);
+                    const int zk0 = z_index<R, C>(k0 & (N - 1));
+                    const int zn0 = z_index<R, C>(m0);
+                    const int zn1 = z_index<R, C>((m0 - 4) & (N - 1));
+                    static_for<0, MT>([&](auto m) {
+                        constexpr int mt = decltype(m)::value;
+                        const int slot = mt * 8 + slot8;
+                        const bool valid = slot < SLOTS;
+                        const float2* sl = lds + (valid ? slot : 0) * SS;
+                        float2 zk[4], zn[4];
+                        static_for<0, 4>([&](auto uu) {
+                            constexpr int u = decltype(uu)::value;
+                            zk[u] = sl[zk0 + 4 * u];
+                            zn[u] = (u == 0) ? sl[zn0] : sl[zn1 - 4 * (u - 1)];
+                        });
+                        static_for<0, 4>([&](auto uu) {
+                            constexpr int u = decltype(uu)::value;
+                            const float sx = zk[u].x + zn[u].x, sy = zk[u].y - zn[u].y;
+                            const float dx = zk[u].x - zn[u].x, dy = zk[u].y + zn[u].y;
+                            // rows of type 0 carry |S|^2, rows of type 1 carry Im(conj(S) D) (train) or |D|^2 (pairs)
+                            float px, py, qx, qy;
+                            if constexpr (MODE == kTrain) { px = type ? dy : sx; py = type ? -dx : sy; qx = sx; qy = sy; }
+                            else { px = type ? dx : sx; py = type ? dy : sy; qx = px; qy = py; }
+                            float val = fmaf(qx, px, qy * py);
                             if constexpr (SLOTS < 8) val = valid ? val : 0.f;
-                            acc[loc][mt][u & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(val, bc[u], acc[loc][mt][u & 1], 0, 0, 0);
+                            acc[loc][mt][u & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(val, bq[u], acc[loc][mt][u & 1], 0, 0, 0);
                         });
                     });
-                    static_for<0, 4>([&](auto u) { bc[decltype(u)::value] = bn[decltype(u)::value]; });
+                };
+                if (grp == 0) {
+                    // k-steps whose B fragments are already in registers
+                    static_for<0, NBPRE / 4>([&](auto qq) {
+                        constexpr int i = decltype(qq)::value * 4;
+                        if (i < nks) group4(ks0 + i, bpre[loc][i], bpre[loc][i + 1], bpre[loc][i + 2], bpre[loc][i + 3]);
+                    });
+                }
+                // the rest (long runs: dense custom filterbanks, further mel groups) streams with a 4-step prefetch
+                const int istart = (grp == 0) ? NBPRE : 0;
+                if (istart < nks) {
+                    float bc[4], bn[4];
+                    static_for<0, 4>([&](auto u) { bc[decltype(u)::value] = buf_f32(rb, bbase + (istart + decltype(u)::value) * 256); });
+                    for (int i = istart; i < nks; i += 4) {
+                        static_for<0, 4>([&](auto u) { bn[decltype(u)::value] = buf_f32(rb, bbase + (i + 4 + decltype(u)::value) * 256); });
+                        group4(ks0 + i, bc[0], bc[1], bc[2], bc[3]);
+                        static_for<0, 4>([&](auto u) { bc[decltype(u)::value] = bn[decltype(u)::value]; });
+                    }
                 }
             });
             // ---- epilogue: accumulators -> (B,1,M,T) ------------------------------------------
             const bool do_log = (p.flags & 1u) != 0;
+            floatx4 tot[NLOC][MT];
+            static_for<0, NLOC>([&](auto l) { static_for<0, MT>([&](auto m) {
+                tot[decltype(l)::value][decltype(m)::value] = acc[decltype(l)::value][decltype(m)::value][0] + acc[decltype(l)::value][decltype(m)::value][1]; }); });
+            if constexpr (WAVES == 8) {
+                // run 1 of this wave is the second half of tile 7-wave: hand it to its owner through LDS
+                static_assert(MT == 1, "the half-tile exchange assumes one M-tile");
+                floatx4* xch = reinterpret_cast<floatx4*>(smem_raw + SLOTS * SS * 8);
+                xch[(7 - wave) * 64 + lane] = tot[1][0];
+                __syncthreads();
+                tot[0][0] += xch[wave * 64 + lane];
+                if (p.groups > 1) __syncthreads();
+                tile_of[1] = -1;
+            }
+            if (p.flags & 0x400u) continue;                        // 0x400: timing ablation, skip the epilogue
             static_for<0, NLOC>([&](auto l) {
                 constexpr int loc = decltype(l)::value;
                 const int nt = tile_of[loc];
@@ -420,9 +470,24 @@ __global__ void __launch_bounds__(geom<N>().THREADS) dmel_fwd_kernel(FwdParams p
                 float* trow = p.tangent ? p.tangent + ((size_t)b * p.M + m) * p.T : nullptr;
                 static_for<0, MT>([&](auto mm) {
                     constexpr int mt = decltype(mm)::value;
-                    const floatx4 a = acc[loc][mt][0] + acc[loc][mt][1];
+                    const floatx4 a = tot[loc][mt];
                     if constexpr (MODE == kTrain) {
                         // rows 4cg+i: i=0,1 -> |X|^2 of slots 2cg, 2cg+1; i=2,3 -> d|X|^2 of the same slots
+                        const int tp = t0 + mt * 8 + 2 * cg;
+                        if (((p.T | t0) & 1) == 0 && mt * 8 + 2 * cg + 1 < SLOTS && tp + 1 < p.T) {
+                            // even T: both frames of this lane form one aligned 8-byte store per tensor
+                            float2 o2, t2;
+                            static_for<0, 2>([&](auto ss) {
+                                constexpr int s = decltype(ss)::value;
+                                const float mel = 0.25f * a[s];
+                                const float dmel = 0.5f * p.sign * a[2 + s];
+                                const float me = mel + p.eps;
+                                (s == 0 ? o2.x : o2.y) = do_log ? logf(me) : mel;
+                                (s == 0 ? t2.x : t2.y) = do_log ? dmel / me : dmel;
+                            });
+                            *reinterpret_cast<float2*>(orow + tp) = o2;
+                            if (trow) *reinterpret_cast<float2*>(trow + tp) = t2;
+                        } else
                         static_for<0, 2>([&](auto ss) {
                             constexpr int s = decltype(ss)::value;
                             const int slot = mt * 8 + 2 * cg + s;
@@ -461,7 +526,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS) dmel_fwd_kernel(FwdParams p
 template <int N, int MODE> static hipError_t launch_one(const FwdParams& p, int grid, hipStream_t s)
 {
     constexpr FftGeom g = geom<N>();
-    constexpr int lds = g.SLOTS * g.SLOT_STRIDE_F2 * 8;
+    constexpr int lds = g.LDS_BYTES;
     hipLaunchKernelGGL((dmel_fwd_kernel<N, MODE>), dim3(grid), dim3(g.THREADS), lds, s, p);
     return hipGetLastError();
 }
@@ -491,7 +556,7 @@ hipError_t launch_forward(int n_fft, int mode, const FwdParams& p, int grid, hip
     return hipErrorInvalidValue;
 }
 
-template <int N> static constexpr int lds_of() { return geom<N>().SLOTS * geom<N>().SLOT_STRIDE_F2 * 8; }
+template <int N> static constexpr int lds_of() { return geom<N>().LDS_BYTES; }
 
 int forward_lds_bytes(int n_fft)
 {

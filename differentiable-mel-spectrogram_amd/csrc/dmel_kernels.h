@@ -14,20 +14,23 @@ constexpr int kMinFastNfft = 32;       // below this the direct-DFT kernel runs
 enum Mode : int { kTrain = 0, kInfer = 1, kSpec = 2 };
 
 // Compile-time FFT plan for one wave: N = R * R * C, R points per lane (tools/wavefft_sim.py).
-// WAVES waves per workgroup; each wave runs PASSES rounds of FPW = 64/G frames.  In the contraction
-// phase a wave owns NLOC = 8 / WAVES of the 8 mel tiles of a group.
+// MINW: waves per SIMD the register allocation must allow (what the LDS footprint admits).
+// WAVES waves per workgroup; each wave runs PASSES rounds of FPW = 64/G frames.  In the contraction phase
+// every wave works on NLOC = 2 runs of k-steps: with 4 waves, the whole mel tiles w and 7-w; with 8 waves,
+// the first half of tile w and the second half of tile 7-w (exchanged through 8 KB of LDS), which
+// evens out the HTK bands that widen with frequency.
 template <int N> struct FftPlan;
-template <> struct FftPlan<32>   { static constexpr int R = 4,  C = 2, PASSES = 1, WAVES = 4; };
-template <> struct FftPlan<64>   { static constexpr int R = 8,  C = 1, PASSES = 1, WAVES = 4; };
-template <> struct FftPlan<128>  { static constexpr int R = 8,  C = 2, PASSES = 1, WAVES = 4; };
-template <> struct FftPlan<256>  { static constexpr int R = 16, C = 1, PASSES = 1, WAVES = 4; };
-template <> struct FftPlan<512>  { static constexpr int R = 16, C = 2, PASSES = 1, WAVES = 4; };
-template <> struct FftPlan<1024> { static constexpr int R = 16, C = 4, PASSES = 1, WAVES = 8; };
-template <> struct FftPlan<2048> { static constexpr int R = 32, C = 2, PASSES = 1, WAVES = 8; };
-template <> struct FftPlan<4096> { static constexpr int R = 64, C = 1, PASSES = 1, WAVES = 4; };
+template <> struct FftPlan<32>   { static constexpr int R = 4,  C = 2, PASSES = 1, WAVES = 4, NBPRE = 4, MINW = 4; };
+template <> struct FftPlan<64>   { static constexpr int R = 8,  C = 1, PASSES = 1, WAVES = 4, NBPRE = 4, MINW = 4; };
+template <> struct FftPlan<128>  { static constexpr int R = 8,  C = 2, PASSES = 1, WAVES = 4, NBPRE = 8, MINW = 4; };
+template <> struct FftPlan<256>  { static constexpr int R = 16, C = 1, PASSES = 1, WAVES = 4, NBPRE = 12, MINW = 4; };
+template <> struct FftPlan<512>  { static constexpr int R = 16, C = 2, PASSES = 1, WAVES = 4, NBPRE = 20, MINW = 4; };
+template <> struct FftPlan<1024> { static constexpr int R = 16, C = 4, PASSES = 1, WAVES = 8, NBPRE = 20, MINW = 4; };
+template <> struct FftPlan<2048> { static constexpr int R = 32, C = 2, PASSES = 1, WAVES = 8, NBPRE = 40, MINW = 2; };
+template <> struct FftPlan<4096> { static constexpr int R = 64, C = 1, PASSES = 1, WAVES = 4, NBPRE = 8, MINW = 1; };
 
 struct FftGeom {
-    int N, R, C, G, FPW, PASSES, WAVES, NLOC, THREADS, SLOTS, MT, EX_STRIDE, SLOT_STRIDE_F2;
+    int N, R, C, G, FPW, PASSES, WAVES, NLOC, THREADS, SLOTS, MT, EX_STRIDE, SLOT_STRIDE_F2, NBPRE, MINW, LDS_BYTES;
 };
 
 constexpr int ex_stride(int G, int C) { return G + (G >= 32 ? C : 1); }
@@ -46,11 +49,12 @@ template <int N> constexpr FftGeom geom()
     using P = FftPlan<N>;
     FftGeom g{};
     g.N = N; g.R = P::R; g.C = P::C; g.G = N / P::R; g.FPW = kWave / g.G; g.PASSES = P::PASSES;
-    g.WAVES = P::WAVES; g.NLOC = 8 / P::WAVES; g.THREADS = kWave * P::WAVES;
+    g.WAVES = P::WAVES; g.NLOC = 2; g.THREADS = kWave * P::WAVES; g.NBPRE = P::NBPRE; g.MINW = P::MINW;
     g.SLOTS = g.WAVES * g.FPW * g.PASSES;
     g.MT = g.SLOTS >= 8 ? g.SLOTS / 8 : 1;
     g.EX_STRIDE = ex_stride(g.G, g.C);
     g.SLOT_STRIDE_F2 = slot_stride_f2(N, P::R, P::C);
+    g.LDS_BYTES = g.SLOTS * g.SLOT_STRIDE_F2 * 8 + (g.WAVES == 8 ? 8 * 64 * 16 : 0);   // + partial-tile exchange
     return g;
 }
 
@@ -65,7 +69,7 @@ struct FwdParams {
     const float2* tw1;         // (R, G): w_N^(lg*q)
     const float2* tw2;         // (R, C): w_G^(r*p1)
     const float* ent_b;        // 64 floats per 4x16 block, blocks of one mel tile contiguous in k
-    const int4* tile_ranges;   // (groups, WAVES, NLOC): {first k-step, #k-steps (multiple of 4), offset into ent_b, mel tile or -1}
+    const int4* tile_ranges;   // (groups, WAVES, 2): {first k-step, #k-steps (multiple of 4), offset into ent_b, mel tile or -1}
     int ent_b_floats;          // size of ent_b (buffer bounds)
     int B, L, T, hop, M, nchunks, groups, tiles_per_clip;
     float inv_L, sign, eps;
