@@ -248,7 +248,7 @@ dmel_status run_forward(dmel_plan* pl, const float* x, int batch, float lambd, u
     if ((st = ensure_psum(pl, batch)) != DMEL_OK) return st;
 
     dmel::PrepParams pp{};
-    pp.x = x; pp.psum = pl->psum; pp.win = pl->win;
+    pp.x = x; pp.psum = pl->psum; pp.win2 = reinterpret_cast<float2*>(pl->win);
     pp.B = batch; pp.L = pl->cfg.n_points; pp.nchunks = pl->nchunks; pp.chunk = pl->chunk;
     pp.N = N; pp.normalize = pl->cfg.normalize_window; pp.lambd_abs = std::fabs(lambd);
     // x~*w and x~*dw/dlambd share one complex FFT; dw/dlambd is ~1/|lambd| times smaller than w, and the
@@ -268,7 +268,7 @@ dmel_status run_forward(dmel_plan* pl, const float* x, int batch, float lambd, u
     pl->info.n_fft = N; pl->info.n_freqs = tb->F; pl->info.n_time = pl->T;
     if (N < dmel::kMinFastNfft) {
         dmel::NaiveParams np{};
-        np.x = x; np.out = out; np.tangent = tangent; np.psum = pl->psum; np.win = pl->win; np.fb = tb->fb_dense;
+        np.x = x; np.out = out; np.tangent = tangent; np.psum = pl->psum; np.win2 = reinterpret_cast<const float2*>(pl->win); np.fb = tb->fb_dense;
         np.B = batch; np.L = pl->cfg.n_points; np.T = pl->T; np.hop = pl->cfg.hop_length; np.M = pl->cfg.n_mels;
         np.nchunks = pl->nchunks; np.N = N; np.F = tb->F; np.mode = mode;
         np.inv_L = 1.0f / (float)pl->cfg.n_points; np.sign = sign; np.eps = (float)eps; np.flags = flags;
@@ -280,7 +280,7 @@ dmel_status run_forward(dmel_plan* pl, const float* x, int batch, float lambd, u
         return DMEL_OK;
     }
     dmel::FwdParams fp{};
-    fp.x = x; fp.out = out; fp.tangent = tangent; fp.psum = pl->psum; fp.win = pl->win;
+    fp.x = x; fp.out = out; fp.tangent = tangent; fp.psum = pl->psum; fp.win2 = reinterpret_cast<const float2*>(pl->win);
     fp.tw1 = tb->tw1; fp.tw2 = tb->tw2; fp.ent_b = tb->ent_b; fp.tile_ranges = tb->tile_ranges; fp.ent_b_floats = tb->ent_b_floats;
     fp.B = batch; fp.L = pl->cfg.n_points; fp.T = pl->T; fp.hop = pl->cfg.hop_length; fp.M = pl->cfg.n_mels;
     fp.nchunks = pl->nchunks; fp.groups = tb->groups;

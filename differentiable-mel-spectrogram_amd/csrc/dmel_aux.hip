@@ -76,8 +76,9 @@ __global__ void __launch_bounds__(128) dmel_naive_kernel(NaiveParams p)
     for (int n = tid; n < p.N; n += blockDim.x) {
         const long long i = (long long)t * p.hop - p.N / 2 + n;
         const float v = (i >= 0 && i < p.L) ? (xb[i] - mean) : 0.f;
-        fa[n] = v * p.win[n];
-        fb_[n] = v * p.win[p.N + n];
+        const float2 wd = p.win2[n];
+        fa[n] = v * wd.x;
+        fb_[n] = v * wd.y;
     }
     __syncthreads();
     for (int f = tid; f < p.F; f += blockDim.x) {

@@ -49,40 +49,49 @@ constexpr float sin64(int j)   // j in [0, 32]
     return j <= 16 ? kCos64[16 - j] : kCos64[j - 16];
 }
 
+// Complex numbers live in one 64-bit register pair (re, im) through every stage, so that each complex
+// add / multiply is one or two packed VALU instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 with
+// op_sel / neg modifiers for the swaps and sign flips) and no register shuffling is needed between stages.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f rot_mi(v2f a) { return v2f{a.y, -a.x}; }          // a * (-i)
+__device__ __forceinline__ v2f splat(float c) { return v2f{c, c}; }
+
 // a * exp(-2 pi i TW / 64), TW in [0, 32)
-template <int TW> __device__ __forceinline__ float2 cmul_tw(float2 a)
+template <int TW> __device__ __forceinline__ v2f cmul_tw(v2f a)
 {
     if constexpr (TW == 0) return a;
-    else if constexpr (TW == 16) return make_float2(a.y, -a.x);
-    else if constexpr (TW == 8) { constexpr float c = 0.70710678118654752440f; return make_float2(c * (a.x + a.y), c * (a.y - a.x)); }
-    else if constexpr (TW == 24) { constexpr float c = 0.70710678118654752440f; return make_float2(c * (a.y - a.x), -c * (a.x + a.y)); }
+    else if constexpr (TW == 16) return rot_mi(a);
     else {
-        constexpr float c = cos64(TW), s = sin64(TW);
-        return make_float2(fmaf(a.y, s, a.x * c), fmaf(-a.x, s, a.y * c));
+        // (a.x c + a.y s, a.y c - a.x s) = a * (c, c) + a.yx * (s, -s): two packed ops, signs in the constant
+        constexpr float c = (TW == 8) ? 0.70710678118654752440f : (TW == 24) ? -0.70710678118654752440f : cos64(TW);
+        constexpr float sn = (TW == 8 || TW == 24) ? 0.70710678118654752440f : sin64(TW);
+        return __builtin_elementwise_fma(a.yx, v2f{sn, -sn}, a * splat(c));
     }
 }
 
 // Radix-2 decimation-in-frequency FFT of R points held in registers; logical output q ends up in
 // v[bitrev(q)].  Fully unrolled: every index and twiddle is a compile-time constant.
-template <int R, int SPAN = R / 2> __device__ __forceinline__ void fft_reg(float2 (&v)[R])
+template <int R, int SPAN = R / 2> __device__ __forceinline__ void fft_reg(v2f (&v)[R])
 {
     if constexpr (SPAN >= 1) {
         static_for<0, R / (2 * SPAN)>([&](auto blk) {
             constexpr int base = decltype(blk)::value * 2 * SPAN;
             static_for<0, SPAN>([&](auto jj) {
                 constexpr int j = decltype(jj)::value;
-                const float2 a = v[base + j], b = v[base + j + SPAN];
-                v[base + j] = make_float2(a.x + b.x, a.y + b.y);
-                v[base + j + SPAN] = cmul_tw<j * 32 / SPAN>(make_float2(a.x - b.x, a.y - b.y));
+                const v2f a = v[base + j], b = v[base + j + SPAN];
+                v[base + j] = a + b;
+                v[base + j + SPAN] = cmul_tw<j * 32 / SPAN>(a - b);
             });
         });
         fft_reg<R, SPAN / 2>(v);
     }
 }
 
-__device__ __forceinline__ float2 cmul(float2 a, float2 w)
+// a * w for a table twiddle w = (re, im): a * (re, re) + a.yx * (-im, im)
+__device__ __forceinline__ v2f cmul(v2f a, float2 w)
 {
-    return make_float2(fmaf(-a.y, w.y, a.x * w.x), fmaf(a.y, w.x, a.x * w.y));
+    return __builtin_elementwise_fma(a.yx, v2f{-w.y, w.y}, a * splat(w.x));
 }
 
 // value of lane (l ^ 1) / (l ^ 2) inside each quad: DPP quad_perm, no LDS traffic
@@ -117,8 +126,7 @@ __global__ void __launch_bounds__(kThreads) dmel_prep_kernel(PrepParams p)
             const float t = d / denom;
             const float w = expf(-0.5f * (t * t));
             const double dw = (double)w * (double)d * (double)d / (den * den * den);
-            p.win[n] = w;
-            p.win[p.N + n] = (float)(dw * (double)p.dw_scale);
+            p.win2[n] = make_float2(w, (float)(dw * (double)p.dw_scale));
             s_ww += (double)w * (double)w;
             s_wd += (double)w * dw;
         }
@@ -132,13 +140,12 @@ __global__ void __launch_bounds__(kThreads) dmel_prep_kernel(PrepParams p)
         const double wd = red[0];
         const double nrm = sqrt(ww);
         for (int n = tid; n < p.N; n += kThreads) {
-            const double w = (double)p.win[n], dw = (double)p.win[p.N + n];
+            const double w = (double)p.win2[n].x, dw = (double)p.win2[n].y;
             // dw was rounded to fp32 above; recompute it in fp64 for the quotient rule
             const float d = (float)n - (float)p.N / 2.0f;
             const double dwe = w * (double)d * (double)d / (den * den * den);
             (void)dw;
-            p.win[n] = (float)(w / nrm);
-            p.win[p.N + n] = (float)((dwe / nrm - w * wd / (nrm * nrm * nrm)) * (double)p.dw_scale);
+            p.win2[n] = make_float2((float)(w / nrm), (float)((dwe / nrm - w * wd / (nrm * nrm * nrm)) * (double)p.dw_scale));
         }
         return;
     }
@@ -193,7 +200,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
     constexpr bool PAIR = (MODE != kTrain);
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float2* lds = reinterpret_cast<float2*>(smem_raw);
+    v2f* lds = reinterpret_cast<v2f*>(smem_raw);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -213,7 +220,6 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
     const bool dbg_skip_gemm = (p.flags & 0x100u) != 0;
 
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (size_t)b * p.L, (unsigned)p.L * 4u);
-    const __amdgpu_buffer_rsrc_t rwin = make_rsrc(p.win, 2u * N * 4u);
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.ent_b, (unsigned)p.ent_b_floats * 4u);
 
     // ---- requests that phase 2 will need, issued before anything else --------------------------
@@ -281,38 +287,39 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
         static_for<0, PASSES>([&](auto pp) {
             constexpr int pass = decltype(pp)::value;
             const int slot = pass * (WAVES * FPW) + wave * FPW + j;
-            float2* sl = lds + slot * SS;
+            v2f* sl = lds + slot * SS;
             const int tA = PAIR ? (t0 + 2 * slot) : (t0 + slot);
             const int f0 = tA * p.hop - N / 2;                       // first sample of frame tA
             const int f1 = PAIR ? f0 + p.hop : f0;
             // zero padding of torch.stft(center=True, pad_mode='constant') applies AFTER the DC removal
             const bool inside_w = inside[pass];
-            float2 z[R];
+            v2f z[R];
             static_for<0, R>([&](auto aa) {
                 constexpr int a = decltype(aa)::value;
                 const int n = lg + G * a;
-                const float w = buf_f32(rwin, n * 4);
+                const float2 wd2 = p.win2[n];                       // (w[n], dw[n] / d|lambd| * scale)
+                const v2f wd = v2f{wd2.x, wd2.y};
                 float va = xa[pass][a] - mean;
                 if (!inside_w) { const int ia = f0 + n; va = ((ia >= 0) && (ia < p.L)) ? va : 0.f; }
-                if constexpr (MODE == kTrain) z[a] = make_float2(va * w, va * buf_f32(rwin, (N + n) * 4));
+                if constexpr (MODE == kTrain) z[a] = splat(va) * wd;
                 else {
                     float vb = xb2[pass][a] - mean;
                     if (!inside_w) { const int ib = f1 + n; vb = ((ib >= 0) && (ib < p.L)) ? vb : 0.f; }
-                    z[a] = make_float2(va * w, vb * w);
+                    z[a] = v2f{va, vb} * wd.xx;
                 }
             });
             fft_reg<R>(z);
             // twiddle w_N^(lg*q), transposition through LDS: S[q][lg]
             static_for<0, R>([&](auto qq) {
                 constexpr int q = decltype(qq)::value;
-                float2 v = z[bitrev(q, LB)];
+                v2f v = z[bitrev(q, LB)];
                 if constexpr (q != 0) v = cmul(v, p.tw1[q * G + lg]);
                 sl[q * EXS + lg] = v;
             });
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            float2 u[R];
+            v2f u[R];
             static_for<0, R>([&](auto bb) {
                 constexpr int bi = decltype(bb)::value;
                 u[bi] = sl[qp * EXS + r + C * bi];
@@ -323,24 +330,21 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
             // twiddle w_G^(r*p1), radix-C across adjacent lanes, spectrum to LDS in natural order
             static_for<0, R>([&](auto pp1) {
                 constexpr int p1 = decltype(pp1)::value;
-                float2 v = u[bitrev(p1, LB)];
+                v2f v = u[bitrev(p1, LB)];
                 int p2 = 0;
                 if constexpr (C > 1) {
                     if constexpr (p1 != 0) v = cmul(v, p.tw2[p1 * C + r]);
                 }
                 if constexpr (C == 2) {
-                    const float ox = quad_xor1(v.x), oy = quad_xor1(v.y);
-                    const float sg = (r == 0) ? 1.f : -1.f;
-                    v = make_float2(fmaf(sg, v.x, ox), fmaf(sg, v.y, oy));
+                    const v2f o = v2f{quad_xor1(v.x), quad_xor1(v.y)};
+                    v = __builtin_elementwise_fma(splat((r == 0) ? 1.f : -1.f), v, o);
                     p2 = r;
                 } else if constexpr (C == 4) {
-                    float ox = quad_xor2(v.x), oy = quad_xor2(v.y);
-                    float sg = (r < 2) ? 1.f : -1.f;
-                    float2 t = make_float2(fmaf(sg, v.x, ox), fmaf(sg, v.y, oy));
-                    if (r == 3) t = make_float2(t.y, -t.x);
-                    ox = quad_xor1(t.x); oy = quad_xor1(t.y);
-                    sg = ((r & 1) == 0) ? 1.f : -1.f;
-                    v = make_float2(fmaf(sg, t.x, ox), fmaf(sg, t.y, oy));
+                    v2f o = v2f{quad_xor2(v.x), quad_xor2(v.y)};
+                    v2f t = __builtin_elementwise_fma(splat((r < 2) ? 1.f : -1.f), v, o);
+                    if (r == 3) t = rot_mi(t);
+                    o = v2f{quad_xor1(t.x), quad_xor1(t.y)};
+                    v = __builtin_elementwise_fma(splat(((r & 1) == 0) ? 1.f : -1.f), t, o);
                     p2 = ((r & 1) << 1) | (r >> 1);
                 }
                 const int k = qp + R * p1 + R * R * p2;
@@ -355,8 +359,8 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
         // power spectrogram (time_frequency.py:53), layout (B, F, T)
         for (int idx = tid; idx < SLOTS * F; idx += THREADS) {
             const int k = idx / SLOTS, slot = idx % SLOTS;
-            const float2* sl = lds + slot * SS;
-            const float2 zk = sl[z_index<R, C>(k)], zn = sl[z_index<R, C>((N - k) & (N - 1))];
+            const v2f* sl = lds + slot * SS;
+            const v2f zk = sl[z_index<R, C>(k)], zn = sl[z_index<R, C>((N - k) & (N - 1))];
             const float sx = zk.x + zn.x, sy = zk.y - zn.y, dx = zk.x - zn.x, dy = zk.y + zn.y;
             const int t = t0 + 2 * slot;
             float* o = p.out + ((size_t)b * F + k) * p.T;
@@ -404,8 +408,8 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                         constexpr int mt = decltype(m)::value;
                         const int slot = mt * 8 + slot8;
                         const bool valid = slot < SLOTS;
-                        const float2* sl = lds + (valid ? slot : 0) * SS;
-                        float2 zk[4], zn[4];
+                        const v2f* sl = lds + (valid ? slot : 0) * SS;
+                        v2f zk[4], zn[4];
                         static_for<0, 4>([&](auto uu) {
                             constexpr int u = decltype(uu)::value;
                             zk[u] = sl[zk0 + 4 * u];

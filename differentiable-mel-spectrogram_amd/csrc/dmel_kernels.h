@@ -65,7 +65,7 @@ struct FwdParams {
     float* out;                // (B, 1, M, T) or spec (B, F, T) in kSpec mode
     float* tangent;            // same shape as out or nullptr
     const float* psum;         // (B, nchunks) partial sums of x
-    const float* win;          // [0..N): w, [N..2N): dw/d|lambd|
+    const float2* win2;        // [n] = (w[n], dw[n]/d|lambd| * dw_scale)
     const float2* tw1;         // (R, G): w_N^(lg*q)
     const float2* tw2;         // (R, C): w_G^(r*p1)
     const float* ent_b;        // 64 floats per 4x16 block, blocks of one mel tile contiguous in k
@@ -78,7 +78,7 @@ struct FwdParams {
 };
 
 struct PrepParams {
-    const float* x; float* psum; float* win;
+    const float* x; float* psum; float2* win2;
     int B, L, nchunks, chunk, N, normalize;
     float lambd_abs;
     float dw_scale;   // power of two ~ |lambd|: the dw table is stored pre-multiplied by it (see dmel_api.cpp)
@@ -93,7 +93,7 @@ hipError_t forward_prepare_attributes();   // raises the dynamic-LDS limit of ev
 
 // direct-DFT kernel for n_fft < 32 (and as an on-device cross-check of the fast path)
 struct NaiveParams {
-    const float* x; float* out; float* tangent; const float* psum; const float* win; const float* fb;
+    const float* x; float* out; float* tangent; const float* psum; const float2* win2; const float* fb;
     int B, L, T, hop, M, nchunks, N, F, mode;
     float inv_L, sign, eps; unsigned flags; int remove_dc;
 };
