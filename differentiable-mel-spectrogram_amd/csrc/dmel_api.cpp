@@ -73,7 +73,8 @@ struct dmel_plan {
     float* psum = nullptr;
     int psum_clips = 0;
     float* win = nullptr;          // 2 * kMaxNfft floats
-    double* partials = nullptr;    // kMaxPartials doubles
+    double* partials = nullptr;    // kMaxPartials doubles, followed by the ticket counter of the dot kernel
+    unsigned* dot_counter = nullptr;
     std::mutex mu;
     dmel_plan_info info{};
     // optional event timing
@@ -86,7 +87,7 @@ struct dmel_plan {
 
 namespace {
 
-constexpr int kMaxPartials = 1024;
+constexpr int kMaxPartials = 512;
 constexpr size_t kMaxSpans = 16384;
 
 // returns an event index recorded on s, or (size_t)-1 when profiling is off / full
@@ -403,9 +404,11 @@ dmel_status dmel_plan_create(const dmel_config* cfg, dmel_plan** plan)
     int nch = (cfg->n_points + 4095) / 4096;
     nch = std::max(1, std::min(nch, dmel::kMaxChunks));
     pl->nchunks = nch;
-    pl->chunk = (cfg->n_points + nch - 1) / nch;
+    pl->chunk = ((cfg->n_points + nch - 1) / nch + 3) / 4 * 4;   // multiple of 4 samples: chunks keep 16-byte alignment
     hipError_t e = hipMalloc(&pl->win, 2 * dmel::kMaxNfft * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc(&pl->partials, kMaxPartials * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&pl->partials, (kMaxPartials + 2) * sizeof(double));
+    if (e == hipSuccess) e = hipMemset(pl->partials, 0, (kMaxPartials + 2) * sizeof(double));
+    if (e == hipSuccess) pl->dot_counter = reinterpret_cast<unsigned*>(pl->partials + kMaxPartials);
     if (e != hipSuccess) { dmel_plan_destroy(pl); return fail(DMEL_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     if (cfg->max_batch > 0) {
         dmel_status st = ensure_psum(pl, cfg->max_batch);
@@ -465,7 +468,7 @@ dmel_status dmel_backward(dmel_plan* plan, const float* grad_out, const float* t
     std::lock_guard<std::mutex> lock(plan->mu);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const size_t m0 = prof_mark(plan, s);
-    DMEL_HIP(dmel::launch_dot(grad_out, tangent, (long long)count, accumulate, plan->partials, kMaxPartials, dlambd, s));
+    DMEL_HIP(dmel::launch_dot(grad_out, tangent, (long long)count, accumulate, plan->partials, plan->dot_counter, kMaxPartials, dlambd, s));
     prof_span(plan, m0, prof_mark(plan, s), 2);
     return DMEL_OK;
 }

@@ -7,51 +7,75 @@
 
 namespace dmel {
 
-// ---- deterministic two-stage dot product ------------------------------------------------------
-__global__ void __launch_bounds__(kThreads) dmel_dot_partial_kernel(const float* __restrict__ g,
-                                                                    const float* __restrict__ t,
-                                                                    long long count, double* partials)
+// ---- deterministic dot product, one launch ----------------------------------------------------
+// Every workgroup reduces its slice in fp64 and publishes ONE partial with a write-through (sc1) store;
+// the workgroup that draws the last ticket adds the partials in index order (fixed order => the same
+// bits every run) and writes the scalar.  Hand-off = cdna_hip_programming.md Guideline 16, R1 in its
+// counter form: sc1 payload, the storing lane drains vmcnt, relaxed agent-scope ticket; the reader uses
+// sc1 loads only, so no acquire fence is needed.  The counter is left at 0 for the next launch.
+// fixed-order reduction of one fp64 value per thread: butterfly inside each wave (shuffles, no LDS),
+// then the four wave sums in index order.  Result valid in thread 0.
+__device__ __forceinline__ double block_sum(double v, double* red4)
 {
-    __shared__ double red[kThreads];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int tid = threadIdx.x;
+    if ((tid & 63) == 0) red4[tid >> 6] = v;
+    __syncthreads();
+    return ((red4[0] + red4[1]) + (red4[2] + red4[3]));
+}
+
+__global__ void __launch_bounds__(kThreads) dmel_dot_kernel(const float* __restrict__ g, const float* __restrict__ t,
+                                                            long long count, double* partials, unsigned* counter,
+                                                            int accumulate, float* result)
+{
+    __shared__ double red4[4], red4b[4];
+    __shared__ int is_last;
     const int tid = threadIdx.x;
     const long long stride = (long long)gridDim.x * kThreads;
     double acc = 0.0;
     const long long n4 = ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(t)) & 15) == 0 ? count / 4 : 0;
     const float4* g4 = reinterpret_cast<const float4*>(g);
     const float4* t4 = reinterpret_cast<const float4*>(t);
-    for (long long i = (long long)blockIdx.x * kThreads + tid; i < n4; i += stride) {
+    long long i = (long long)blockIdx.x * kThreads + tid;
+    for (; i + 3 * stride < n4; i += 4 * stride) {        // four independent 16-byte loads per tensor in flight
+        const float4 a0 = g4[i], a1 = g4[i + stride], a2 = g4[i + 2 * stride], a3 = g4[i + 3 * stride];
+        const float4 b0 = t4[i], b1 = t4[i + stride], b2 = t4[i + 2 * stride], b3 = t4[i + 3 * stride];
+        acc += ((double)a0.x * (double)b0.x + (double)a0.y * (double)b0.y) + ((double)a0.z * (double)b0.z + (double)a0.w * (double)b0.w);
+        acc += ((double)a1.x * (double)b1.x + (double)a1.y * (double)b1.y) + ((double)a1.z * (double)b1.z + (double)a1.w * (double)b1.w);
+        acc += ((double)a2.x * (double)b2.x + (double)a2.y * (double)b2.y) + ((double)a2.z * (double)b2.z + (double)a2.w * (double)b2.w);
+        acc += ((double)a3.x * (double)b3.x + (double)a3.y * (double)b3.y) + ((double)a3.z * (double)b3.z + (double)a3.w * (double)b3.w);
+    }
+    for (; i < n4; i += stride) {
         const float4 a = g4[i], b = t4[i];
         acc += ((double)a.x * (double)b.x + (double)a.y * (double)b.y) + ((double)a.z * (double)b.z + (double)a.w * (double)b.w);
     }
-    for (long long i = n4 * 4 + (long long)blockIdx.x * kThreads + tid; i < count; i += stride)
-        acc += (double)g[i] * (double)t[i];
-    red[tid] = acc;
+    for (long long k = n4 * 4 + (long long)blockIdx.x * kThreads + tid; k < count; k += stride)
+        acc += (double)g[k] * (double)t[k];
+    const double bsum = block_sum(acc, red4);
+    if (tid == 0) {
+        __hip_atomic_store(&partials[blockIdx.x], bsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (ticket == gridDim.x - 1);
+    }
     __syncthreads();
-    for (int o = kThreads / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
-    if (tid == 0) partials[blockIdx.x] = red[0];
-}
-
-__global__ void __launch_bounds__(kThreads) dmel_dot_final_kernel(const double* partials, int n, int accumulate, float* result)
-{
-    __shared__ double red[kThreads];
-    const int tid = threadIdx.x;
-    double acc = 0.0;
-    for (int i = tid; i < n; i += kThreads) acc += partials[i];
-    red[tid] = acc;
-    __syncthreads();
-    for (int o = kThreads / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
-    if (tid == 0) result[0] = accumulate ? (float)((double)result[0] + red[0]) : (float)red[0];
+    if (!is_last) return;
+    double sum = 0.0;
+    for (int q = tid; q < (int)gridDim.x; q += kThreads)
+        sum += __hip_atomic_load(&partials[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double total = block_sum(sum, red4b);
+    if (tid == 0) {
+        result[0] = accumulate ? (float)((double)result[0] + total) : (float)total;
+        __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 hipError_t launch_dot(const float* g, const float* t, long long count, int accumulate, double* partials,
-                      int max_partials, float* result, hipStream_t s)
+                      unsigned* counter, int max_partials, float* result, hipStream_t s)
 {
-    long long want = (count + (long long)kThreads * 8 - 1) / ((long long)kThreads * 8);
+    long long want = (count + (long long)kThreads * 16 - 1) / ((long long)kThreads * 16);
     int blocks = (int)(want < 1 ? 1 : (want > max_partials ? max_partials : want));
-    hipLaunchKernelGGL(dmel_dot_partial_kernel, dim3(blocks), dim3(kThreads), 0, s, g, t, count, partials);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(dmel_dot_final_kernel, dim3(1), dim3(kThreads), 0, s, partials, blocks, accumulate, result);
+    hipLaunchKernelGGL(dmel_dot_kernel, dim3(blocks), dim3(kThreads), 0, s, g, t, count, partials, counter, accumulate, result);
     return hipGetLastError();
 }
 

@@ -155,8 +155,16 @@ __global__ void __launch_bounds__(kThreads) dmel_prep_kernel(PrepParams p)
     const float* xb = p.x + (size_t)b * p.L;
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
     long long i = lo + tid;
-    for (; i + 3 * kThreads < hi; i += 4 * kThreads) {
-        acc0 += xb[i]; acc1 += xb[i + kThreads]; acc2 += xb[i + 2 * kThreads]; acc3 += xb[i + 3 * kThreads];
+    if (((reinterpret_cast<uintptr_t>(xb + lo)) & 15) == 0) {
+        // 16-byte aligned chunk: stream it with dwordx4 loads
+        const float4* x4 = reinterpret_cast<const float4*>(xb + lo);
+        const long long n4 = (hi - lo) / 4;
+        for (long long q = tid; q < n4; q += kThreads) { const float4 v = x4[q]; acc0 += v.x; acc1 += v.y; acc2 += v.z; acc3 += v.w; }
+        i = lo + n4 * 4 + tid;
+    } else {
+        for (; i + 3 * kThreads < hi; i += 4 * kThreads) {
+            acc0 += xb[i]; acc1 += xb[i + kThreads]; acc2 += xb[i + 2 * kThreads]; acc3 += xb[i + 3 * kThreads];
+        }
     }
     for (; i < hi; i += kThreads) acc0 += xb[i];
     red[tid] = ((double)acc0 + (double)acc1) + ((double)acc2 + (double)acc3);

@@ -100,6 +100,6 @@ struct NaiveParams {
 hipError_t launch_naive(const NaiveParams& p, hipStream_t s);
 
 hipError_t launch_dot(const float* g, const float* t, long long count, int accumulate, double* partials,
-                      int max_partials, float* result, hipStream_t s);
+                      unsigned* counter, int max_partials, float* result, hipStream_t s);
 
 }  // namespace dmel
