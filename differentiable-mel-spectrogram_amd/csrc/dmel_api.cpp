@@ -248,10 +248,6 @@ dmel_status run_forward(dmel_plan* pl, const float* x, int batch, float lambd, u
     if (st != DMEL_OK) return st;
     if ((st = ensure_psum(pl, batch)) != DMEL_OK) return st;
 
-    dmel::PrepParams pp{};
-    pp.x = x; pp.psum = pl->psum; pp.win2 = reinterpret_cast<float2*>(pl->win);
-    pp.B = batch; pp.L = pl->cfg.n_points; pp.nchunks = pl->nchunks; pp.chunk = pl->chunk;
-    pp.N = N; pp.normalize = pl->cfg.normalize_window; pp.lambd_abs = std::fabs(lambd);
     // x~*w and x~*dw/dlambd share one complex FFT; dw/dlambd is ~1/|lambd| times smaller than w, and the
     // even/odd split that separates the two spectra leaves an error of eps * (the larger one) in each.
     // Pre-multiplying dw by a power of two ~|lambd| (exact) keeps both at the same scale; the
@@ -259,13 +255,27 @@ dmel_status run_forward(dmel_plan* pl, const float* x, int batch, float lambd, u
     int ex = 0;
     (void)std::frexp(std::fabs(lambd) > 1e-30f ? std::fabs(lambd) : 1.0f, &ex);
     ex = std::max(-60, std::min(60, ex));
-    pp.dw_scale = std::ldexp(1.0f, ex);
-    const size_t m0 = prof_mark(pl, s);
-    DMEL_HIP(dmel::launch_prep(pp, s));
-    const size_t m1 = prof_mark(pl, s);
-    prof_span(pl, m0, m1, 0);
+    const float dw_scale = std::ldexp(1.0f, ex);
 
-    const float sign = (lambd > 0.f ? 1.f : (lambd < 0.f ? -1.f : 0.f)) / pp.dw_scale;
+    // The fused kernel builds its own window table (n_fft <= 2048) and, for clips up to 32768 samples, its
+    // own clip mean; the prep kernel only runs for what is left: partial sums of long clips, the window
+    // table of n_fft 4096, and everything the direct-DFT kernel (n_fft < 32) needs.
+    const bool fast = N >= dmel::kMinFastNfft;
+    const bool kernel_mean = fast && pl->cfg.n_points <= 32768;
+    const bool need_sums = remove_dc && !kernel_mean;
+    const bool need_window = !fast || N > 2048;
+    const size_t m0 = prof_mark(pl, s);
+    if (need_sums || need_window) {
+        dmel::PrepParams pp{};
+        pp.x = x; pp.psum = pl->psum; pp.win2 = reinterpret_cast<float2*>(pl->win);
+        pp.B = need_sums ? batch : 0; pp.L = pl->cfg.n_points; pp.nchunks = pl->nchunks; pp.chunk = pl->chunk;
+        pp.N = N; pp.normalize = pl->cfg.normalize_window; pp.lambd_abs = std::fabs(lambd); pp.dw_scale = dw_scale;
+        DMEL_HIP(dmel::launch_prep(pp, s));
+    }
+    const size_t m1 = prof_mark(pl, s);
+    if (need_sums || need_window) prof_span(pl, m0, m1, 0);
+
+    const float sign = (lambd > 0.f ? 1.f : (lambd < 0.f ? -1.f : 0.f)) / dw_scale;
     pl->info.n_fft = N; pl->info.n_freqs = tb->F; pl->info.n_time = pl->T;
     if (N < dmel::kMinFastNfft) {
         dmel::NaiveParams np{};
@@ -281,14 +291,15 @@ dmel_status run_forward(dmel_plan* pl, const float* x, int batch, float lambd, u
         return DMEL_OK;
     }
     dmel::FwdParams fp{};
-    fp.x = x; fp.out = out; fp.tangent = tangent; fp.psum = pl->psum; fp.win2 = reinterpret_cast<const float2*>(pl->win);
+    fp.x = x; fp.out = out; fp.tangent = tangent; fp.psum = need_sums ? pl->psum : nullptr; fp.win2 = reinterpret_cast<const float2*>(pl->win);
     fp.tw1 = tb->tw1; fp.tw2 = tb->tw2; fp.ent_b = tb->ent_b; fp.tile_ranges = tb->tile_ranges; fp.ent_b_floats = tb->ent_b_floats;
     fp.B = batch; fp.L = pl->cfg.n_points; fp.T = pl->T; fp.hop = pl->cfg.hop_length; fp.M = pl->cfg.n_mels;
     fp.nchunks = pl->nchunks; fp.groups = tb->groups;
     const int fpt = dmel::forward_frames_per_tile(N, mode);
     fp.tiles_per_clip = (pl->T + fpt - 1) / fpt;
     fp.inv_L = 1.0f / (float)pl->cfg.n_points; fp.sign = sign; fp.eps = (float)eps; fp.flags = flags;
-    fp.remove_dc = remove_dc;
+    fp.remove_dc = remove_dc; fp.normalize = pl->cfg.normalize_window;
+    fp.lambd_abs = std::fabs(lambd); fp.dw_scale = dw_scale;
     const long long grid = (long long)batch * fp.tiles_per_clip;
     if (grid > 0x7fffffffLL) return fail(DMEL_ERR_INVALID_ARGUMENT, "too many tiles for one launch");
     DMEL_HIP(dmel::launch_forward(N, mode, fp, (int)grid, s));

@@ -209,6 +209,9 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     v2f* lds = reinterpret_cast<v2f*>(smem_raw);
+    float2* wtab = reinterpret_cast<float2*>(smem_raw + g.AUX_OFF);   // window table (phase 1 only)
+    float* red = reinterpret_cast<float*>(smem_raw + g.RED_OFF);
+    constexpr bool WIN_LDS = g.WIN_LDS != 0;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -284,13 +287,68 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                 });
             }
         });
-        // clip mean (models.py:38): the <= 64 partial sums of the prep kernel, one per lane, one round
-        // trip, added in a fixed butterfly order (deterministic)
+        // ---- window table into LDS (time_frequency.py:21-30): every workgroup evaluates the same fp32
+        // expression, so the table is identical everywhere; this replaces a separate kernel launch
+        if constexpr (WIN_LDS) {
+            const float denom = p.lambd_abs + 1e-15f;
+            const double den = (double)denom, den3 = den * den * den;
+            float s_ww = 0.f, s_wd = 0.f;
+            for (int n = tid; n < N; n += THREADS) {
+                const float d = (float)n - (float)N / 2.0f;
+                const float t = d / denom;
+                const float w = expf(-0.5f * (t * t));
+                const float dw = (float)((double)w * (double)d * (double)d / den3 * (double)p.dw_scale);
+                wtab[n] = make_float2(w, dw);
+                s_ww += w * w; s_wd += w * dw;
+            }
+            if (p.normalize) {
+                // time_frequency.py:25: w / sqrt(sum w^2) and the derivative of the quotient (fixed-order sums)
+                static_for<0, 6>([&](auto st) { s_ww += __shfl_xor(s_ww, 1 << decltype(st)::value, 64);
+                                                s_wd += __shfl_xor(s_wd, 1 << decltype(st)::value, 64); });
+                __syncthreads();
+                if (lane == 0) { red[wave] = s_ww; red[8 + wave] = s_wd; }
+                __syncthreads();
+                float ww = 0.f, wd = 0.f;
+                for (int q = 0; q < WAVES; ++q) { ww += red[q]; wd += red[8 + q]; }
+                __syncthreads();
+                const float inv = 1.0f / sqrtf(ww);
+                for (int n = tid; n < N; n += THREADS) {
+                    const float2 e = wtab[n];
+                    wtab[n] = make_float2(e.x * inv, e.y * inv - e.x * wd * inv * inv * inv);
+                }
+            }
+        }
+        // ---- clip mean (models.py:38) --------------------------------------------------------------
         float mean = 0.f;
-        if (p.remove_dc) {
-            float ps = (lane < p.nchunks) ? p.psum[(size_t)b * p.nchunks + lane] : 0.f;
+        if (p.remove_dc && p.psum == nullptr) {
+            // short clips: every workgroup adds up its clip itself (L2 hits after the first toucher), in a
+            // fixed order, instead of a separate pass over x
+            const float* xc = p.x + (size_t)b * p.L;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            int i = 0;
+            if ((reinterpret_cast<uintptr_t>(xc) & 15) == 0) {
+                const float4* x4 = reinterpret_cast<const float4*>(xc);
+                const int n4 = p.L / 4;
+                for (int q = tid; q < n4; q += THREADS) { const float4 v = x4[q]; a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w; }
+                i = n4 * 4;
+            }
+            for (int q = i + tid; q < p.L; q += THREADS) a0 += xc[q];
+            float ps = (a0 + a1) + (a2 + a3);
             static_for<0, 6>([&](auto st) { ps += __shfl_xor(ps, 1 << decltype(st)::value, 64); });
-            mean = ps * p.inv_L;
+            if (lane == 0) red[wave] = ps;
+            __syncthreads();
+            float tot = 0.f;
+            for (int q = 0; q < WAVES; ++q) tot += red[q];
+            mean = tot * p.inv_L;
+        } else {
+            if constexpr (WIN_LDS) __syncthreads();              // window table complete
+            if (p.remove_dc) {
+                // long clips: the <= 64 partial sums of the prep kernel, one per lane, one round trip, added
+                // in a fixed butterfly order (deterministic)
+                float ps = (lane < p.nchunks) ? p.psum[(size_t)b * p.nchunks + lane] : 0.f;
+                static_for<0, 6>([&](auto st) { ps += __shfl_xor(ps, 1 << decltype(st)::value, 64); });
+                mean = ps * p.inv_L;
+            }
         }
         static_for<0, PASSES>([&](auto pp) {
             constexpr int pass = decltype(pp)::value;
@@ -305,7 +363,8 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
             static_for<0, R>([&](auto aa) {
                 constexpr int a = decltype(aa)::value;
                 const int n = lg + G * a;
-                const float2 wd2 = p.win2[n];                       // (w[n], dw[n] / d|lambd| * scale)
+                float2 wd2;                                          // (w[n], dw[n] / d|lambd| * scale)
+                if constexpr (WIN_LDS) wd2 = wtab[n]; else wd2 = p.win2[n];
                 const v2f wd = v2f{wd2.x, wd2.y};
                 float va = xa[pass][a] - mean;
                 if (!inside_w) { const int ia = f0 + n; va = ((ia >= 0) && (ia < p.L)) ? va : 0.f; }

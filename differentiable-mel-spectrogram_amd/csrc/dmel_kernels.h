@@ -30,7 +30,7 @@ template <> struct FftPlan<2048> { static constexpr int R = 32, C = 2, PASSES = 
 template <> struct FftPlan<4096> { static constexpr int R = 64, C = 1, PASSES = 1, WAVES = 4, NBPRE = 8, MINW = 1; };
 
 struct FftGeom {
-    int N, R, C, G, FPW, PASSES, WAVES, NLOC, THREADS, SLOTS, MT, EX_STRIDE, SLOT_STRIDE_F2, NBPRE, MINW, LDS_BYTES;
+    int N, R, C, G, FPW, PASSES, WAVES, NLOC, THREADS, SLOTS, MT, EX_STRIDE, SLOT_STRIDE_F2, NBPRE, MINW, LDS_BYTES, AUX_OFF, RED_OFF, WIN_LDS;
 };
 
 constexpr int ex_stride(int G, int C) { return G + (G >= 32 ? C : 1); }
@@ -54,7 +54,13 @@ template <int N> constexpr FftGeom geom()
     g.MT = g.SLOTS >= 8 ? g.SLOTS / 8 : 1;
     g.EX_STRIDE = ex_stride(g.G, g.C);
     g.SLOT_STRIDE_F2 = slot_stride_f2(N, P::R, P::C);
-    g.LDS_BYTES = g.SLOTS * g.SLOT_STRIDE_F2 * 8 + (g.WAVES == 8 ? 8 * 64 * 16 : 0);   // + partial-tile exchange
+    // LDS map: [FFT slots][aux: window table (phase 1) aliased with the half-tile exchange (phase 2)][8 sums]
+    g.WIN_LDS = (N <= 2048) ? 1 : 0;                      // n_fft 4096 has no room: its window stays in global memory
+    const int xch = (g.WAVES == 8) ? 8 * 64 * 16 : 0;
+    const int win = g.WIN_LDS ? N * 8 : 0;
+    g.AUX_OFF = g.SLOTS * g.SLOT_STRIDE_F2 * 8;
+    g.RED_OFF = g.AUX_OFF + (xch > win ? xch : win);
+    g.LDS_BYTES = g.RED_OFF + 64;
     return g;
 }
 
@@ -64,7 +70,7 @@ struct FwdParams {
     const float* x;            // (B, L)
     float* out;                // (B, 1, M, T) or spec (B, F, T) in kSpec mode
     float* tangent;            // same shape as out or nullptr
-    const float* psum;         // (B, nchunks) partial sums of x
+    const float* psum;         // (B, nchunks) partial sums of x, or nullptr: the kernel sums the clip itself (short clips)
     const float2* win2;        // [n] = (w[n], dw[n]/d|lambd| * dw_scale)
     const float2* tw1;         // (R, G): w_N^(lg*q)
     const float2* tw2;         // (R, C): w_G^(r*p1)
@@ -73,8 +79,9 @@ struct FwdParams {
     int ent_b_floats;          // size of ent_b (buffer bounds)
     int B, L, T, hop, M, nchunks, groups, tiles_per_clip;
     float inv_L, sign, eps;
+    float lambd_abs, dw_scale;  // for the in-kernel window table (time_frequency.py:21-30)
     unsigned flags;
-    int remove_dc;
+    int remove_dc, normalize;
 };
 
 struct PrepParams {
