@@ -29,4 +29,4 @@ for name in names:
             plan.forward(x.data_ptr(), B, lam, out.data_ptr(), tan.data_ptr() if tg else None, True, 1e-10, s, extra_flags=fl)
         torch.cuda.synchronize()
         pr = plan.get_profile(); plan.set_profiling(False)
-        print(f"{name} {label:22s} fwd {1e3*pr['fwd_ms']/pr['fwd_launches']:8.2f} us   prep {1e3*pr['prep_ms']/pr['prep_launches']:6.2f} us   info {plan.info()}")
+        print(f"{name} {label:22s} fwd {1e3*pr['fwd_ms']/pr['fwd_launches']:8.2f} us   prep {1e3*pr['prep_ms']/max(1,pr['prep_launches']):6.2f} us   info {plan.info()}")
