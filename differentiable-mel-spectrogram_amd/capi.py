@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "libdmel_hip.so")
+LIB_PATH = os.environ.get("DMEL_LIB") or os.path.join(_PKG_DIR, "libdmel_hip.so")   # DMEL_LIB: diagnostic builds (tools/stamps.py)
 
 DMEL_OK = 0
 DMEL_ERR_INVALID_ARGUMENT = 1

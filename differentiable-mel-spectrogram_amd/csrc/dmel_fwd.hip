@@ -195,6 +195,24 @@ __device__ __forceinline__ int clampi(int v, int hi) { return v < 0 ? 0 : (v > h
 // (the 64-bit form __builtin_amdgcn_raw_buffer_load_b64 is mis-lowered to a single dword load by hipcc 7.2:
 // twiddle tables are therefore read with ordinary float2 loads)
 
+#ifdef DMEL_STAMPS
+// Diagnostic build only (tools/stamps.py): s_memtime stamps of every wave at the phase boundaries of the
+// fused kernel, kept in a buffer nothing else reads.  Never compiled into libdmel_hip.so.
+constexpr int kStampSlots = 16;
+__device__ unsigned long long g_stamps[4096 * 8 * kStampSlots];
+__device__ __forceinline__ void stamp(int wgid, int wave, int lane, int idx)
+{
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (lane == 0 && wgid < 4096) g_stamps[((size_t)wgid * 8 + wave) * kStampSlots + idx] = t;
+}
+#define STAMP(i) stamp(blockIdx.x, wave, lane, i)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
 template <int N, int MODE>
 __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_kernel(FwdParams p)
 {
@@ -227,6 +245,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
     }
     const int b = wg / p.tiles_per_clip;
     const int t0 = (wg % p.tiles_per_clip) * FPT;
+    STAMP(0);
     const bool dbg_skip_fft = (p.flags & 0x200u) != 0;     // timing ablations only (tools/ablate.py)
     const bool dbg_skip_gemm = (p.flags & 0x100u) != 0;
 
@@ -287,6 +306,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                 });
             }
         });
+        STAMP(1);   // loads issued
         // ---- window table into LDS (time_frequency.py:21-30): every workgroup evaluates the same fp32
         // expression, so the table is identical everywhere; this replaces a separate kernel launch
         if constexpr (WIN_LDS) {
@@ -350,6 +370,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                 mean = ps * p.inv_L;
             }
         }
+        STAMP(2);   // window table + clip mean done
         static_for<0, PASSES>([&](auto pp) {
             constexpr int pass = decltype(pp)::value;
             const int slot = pass * (WAVES * FPW) + wave * FPW + j;
@@ -375,7 +396,9 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                     z[a] = v2f{va, vb} * wd.xx;
                 }
             });
+            STAMP(3);   // samples arrived, windowed
             fft_reg<R>(z);
+            STAMP(4);   // radix-R #1
             // twiddle w_N^(lg*q), transposition through LDS: S[q][lg]
             static_for<0, R>([&](auto qq) {
                 constexpr int q = decltype(qq)::value;
@@ -393,7 +416,9 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
             });
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            STAMP(5);   // twiddle + LDS transposition
             fft_reg<R>(u);
+            STAMP(6);   // radix-R #2
             // twiddle w_G^(r*p1), radix-C across adjacent lanes, spectrum to LDS in natural order
             static_for<0, R>([&](auto pp1) {
                 constexpr int p1 = decltype(pp1)::value;
@@ -419,7 +444,9 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
             });
         });
     }
+    STAMP(7);   // twiddle + cross-lane radix-C + spectrum to LDS
     __syncthreads();
+    STAMP(8);   // barrier
     if (dbg_skip_gemm) { if (tid == 0 && lds[0].x == 12345.678f) p.out[0] = 0.f; return; }
 
     if constexpr (MODE == kSpec) {
@@ -515,6 +542,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                     }
                 }
             });
+            STAMP(9);   // MFMA loops
             // ---- epilogue: accumulators -> (B,1,M,T) ------------------------------------------
             const bool do_log = (p.flags & 1u) != 0;
             floatx4 tot[NLOC][MT];
@@ -530,6 +558,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                 if (p.groups > 1) __syncthreads();
                 tile_of[1] = -1;
             }
+            STAMP(10);  // half-tile exchange
             if (p.flags & 0x400u) continue;                        // 0x400: timing ablation, skip the epilogue
             static_for<0, NLOC>([&](auto l) {
                 constexpr int loc = decltype(l)::value;
@@ -590,6 +619,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                     }
                 });
             });
+            STAMP(11);  // epilogue stores issued
         }
     }
 }
@@ -689,3 +719,10 @@ hipError_t forward_prepare_attributes()
 }
 
 }  // namespace dmel
+
+#ifdef DMEL_STAMPS
+extern "C" int dmel_debug_read_stamps(unsigned long long* host, int count)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dmel::g_stamps), sizeof(unsigned long long) * (size_t)count);
+}
+#endif

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Where does a workgroup of the fused forward kernel spend its cycles?  (GPU box; diagnostic build.)
+
+Builds libdmel_hip_stamps.so with -DDMEL_STAMPS (s_memtime stamps at the phase boundaries, written to a
+buffer nothing else reads), runs config 2 once and prints, per phase, the median / max wave time in
+shader cycles (100 MHz s_memtime ticks are NOT used: s_memtime counts shader clocks on gfx950).
+Read the SHARES, not the total: the stamps fence overlaps the real kernel has.
+
+  python tools/stamps.py build      (dev container: cross-compiles)
+  python tools/stamps.py run [c2]   (GPU box)
+"""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "differentiable-mel-spectrogram_amd")
+LIB = os.path.join(PKG, "build", "libdmel_hip_stamps.so")
+NAMES = ["start->loads issued", "window table + clip mean", "samples arrive, window", "radix-R #1", "twiddle + LDS transposition",
+         "radix-R #2", "twiddle + radix-C + Z store", "barrier wait", "MFMA loops", "half-tile exchange", "epilogue"]
+
+if sys.argv[1] == "build":
+    srcs = [os.path.join(PKG, "csrc", f) for f in ("dmel_fwd.hip", "dmel_aux.hip", "dmel_api.cpp")]
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-DDMEL_STAMPS", "-shared", "-o", LIB]
+    for s in srcs:
+        cmd += ["-x", "hip", s]
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    subprocess.check_call(cmd)
+    print(LIB)
+    sys.exit(0)
+
+os.environ["DMEL_LIB"] = LIB
+sys.path.insert(0, ROOT)
+import ctypes as C
+import numpy as np
+import torch
+import dmel_amd
+from dmel_amd import capi, synth
+from bench import CONFIGS
+
+name = sys.argv[2] if len(sys.argv) > 2 else "c2"
+B, L, sr, lam, hop, M = CONFIGS[name]
+T = L // hop + 1
+x = torch.from_numpy(synth.waveforms(B, L, seed=0)).cuda()
+out = torch.empty((B, 1, M, T), device="cuda"); tan = torch.empty_like(out)
+plan = capi.Plan(L, hop, M, sr, max_batch=B)
+s = torch.cuda.current_stream().cuda_stream
+for _ in range(3):
+    plan.forward(x.data_ptr(), B, lam, out.data_ptr(), tan.data_ptr(), True, 1e-10, s)
+torch.cuda.synchronize()
+info = plan.info()
+nwg = min(info["grid_fwd"], 4096)
+waves = 8 if info["n_fft"] in (1024, 2048) else 4
+SL = 16
+buf = np.zeros(4096 * 8 * SL, dtype=np.uint64)
+L_ = capi.load()
+L_.dmel_debug_read_stamps.argtypes = [C.c_void_p, C.c_int]
+rc = L_.dmel_debug_read_stamps(buf.ctypes.data, buf.size)
+assert rc == 0, rc
+st = buf.reshape(4096, 8, SL)[:nwg, :waves, :12].astype(np.int64)
+t_first = st[:, :, 0].min()
+print(f"{name}: n_fft {info['n_fft']}, {nwg} workgroups x {waves} waves; kernel span (first start -> last end) "
+      f"{(st[:, :, 11].max() - t_first)} cycles")
+d = np.diff(st, axis=2)          # (wg, wave, 11)
+tot = (st[:, :, 11] - st[:, :, 0])
+print(f"per-wave lifetime: median {np.median(tot):.0f}  max {tot.max()} cycles")
+for i, nm in enumerate(NAMES):
+    v = d[:, :, i]
+    print(f"  {nm:32s} median {np.median(v):8.0f}   p90 {np.percentile(v, 90):8.0f}   max {v.max():8d}   share {100 * np.median(v) / np.median(tot):5.1f} %")
+start = st[:, 0, 0] - t_first
+print("workgroup start times (cycles after the first): p10 %d  median %d  p90 %d  max %d" %
+      (np.percentile(start, 10), np.median(start), np.percentile(start, 90), start.max()))
