@@ -49,12 +49,13 @@ struct NfftTables {
     float2* tw1 = nullptr;
     float2* tw2 = nullptr;
     float* ent_b = nullptr;
+    float* ent_pre = nullptr;
     int ent_b_floats = 0;
     int4* tile_ranges = nullptr;
     float* fb_dense = nullptr;   // (F, M) for the direct-DFT kernel
     void release()
     {
-        void* ptrs[] = {tw1, tw2, ent_b, tile_ranges, fb_dense};
+        void* ptrs[] = {tw1, tw2, ent_b, ent_pre, tile_ranges, fb_dense};
         for (void* q : ptrs) (void)hipFree(q);
         *this = NfftTables();
     }
@@ -206,6 +207,19 @@ dmel_status build_tables(dmel_plan* pl, int N, NfftTables** out)
             }
         }
         tb.ent_b_floats = (int)bfr.size();
+        {   // register-resident prefix of every run of group 0, at a fixed position per (wave, run)
+            const int nbpre = dmel::forward_nbpre(N);
+            std::vector<float> pre((size_t)waves * 2 * nbpre * 64, 0.f);
+            for (int w = 0; w < waves; ++w)
+                for (int loc = 0; loc < 2; ++loc) {
+                    const int4 tr = ranges[(size_t)w * 2 + loc];
+                    const int n = std::min(tr.y, nbpre);
+                    if (n > 0)
+                        std::copy(bfr.begin() + tr.z, bfr.begin() + tr.z + (size_t)n * 64, pre.begin() + ((size_t)(w * 2 + loc) * nbpre) * 64);
+                }
+            DMEL_HIP(hipMalloc(&tb.ent_pre, pre.size() * sizeof(float)));
+            DMEL_HIP(hipMemcpy(tb.ent_pre, pre.data(), pre.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
         const size_t nb = std::max<size_t>(bfr.size(), 64);
         DMEL_HIP(hipMalloc(&tb.ent_b, nb * sizeof(float)));
         if (!bfr.empty())
@@ -292,7 +306,7 @@ dmel_status run_forward(dmel_plan* pl, const float* x, int batch, float lambd, u
     }
     dmel::FwdParams fp{};
     fp.x = x; fp.out = out; fp.tangent = tangent; fp.psum = need_sums ? pl->psum : nullptr; fp.win2 = reinterpret_cast<const float2*>(pl->win);
-    fp.tw1 = tb->tw1; fp.tw2 = tb->tw2; fp.ent_b = tb->ent_b; fp.tile_ranges = tb->tile_ranges; fp.ent_b_floats = tb->ent_b_floats;
+    fp.tw1 = tb->tw1; fp.tw2 = tb->tw2; fp.ent_b = tb->ent_b; fp.tile_ranges = tb->tile_ranges; fp.ent_b_floats = tb->ent_b_floats; fp.ent_pre = tb->ent_pre;
     fp.B = batch; fp.L = pl->cfg.n_points; fp.T = pl->T; fp.hop = pl->cfg.hop_length; fp.M = pl->cfg.n_mels;
     fp.nchunks = pl->nchunks; fp.groups = tb->groups;
     const int fpt = dmel::forward_frames_per_tile(N, mode);

@@ -104,6 +104,27 @@ __device__ __forceinline__ float quad_xor2(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
 }
 
+// Sum over the 64 lanes in a fixed order, same value in every lane: four DPP steps inside each row of 16
+// (xor 1, xor 2, half-mirror, mirror: no LDS round trips, unlike __shfl_xor = ds_bpermute), then the four
+// row sums through scalar registers.
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wave_sum(float v)
+{
+    v += dpp_f<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);     // row_half_mirror
+    v += dpp_f<0x140>(v);     // row_mirror
+    const int vi = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
 template <int R, int C> __device__ __forceinline__ int z_index(int k)
 {
     if constexpr (C == 1) return k;
@@ -267,8 +288,8 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
         static_for<0, NLOC>([&](auto l) {
             constexpr int loc = decltype(l)::value;
             static_for<0, NBPRE>([&](auto u) {
-                // offsets past this tile's run read the next tile's blocks or, past the buffer, 0: never used
-                bpre[loc][decltype(u)::value] = buf_f32(rb, (tr0[loc].z + decltype(u)::value * 64 + lane) * 4);
+                // fixed layout (wave, run, k-step, lane): the address does not wait for tile_ranges
+                bpre[loc][decltype(u)::value] = p.ent_pre[((wave * NLOC + loc) * NBPRE + decltype(u)::value) * 64 + lane];
             });
         });
     }
@@ -323,8 +344,8 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
             }
             if (p.normalize) {
                 // time_frequency.py:25: w / sqrt(sum w^2) and the derivative of the quotient (fixed-order sums)
-                static_for<0, 6>([&](auto st) { s_ww += __shfl_xor(s_ww, 1 << decltype(st)::value, 64);
-                                                s_wd += __shfl_xor(s_wd, 1 << decltype(st)::value, 64); });
+                s_ww = wave_sum(s_ww);
+                s_wd = wave_sum(s_wd);
                 __syncthreads();
                 if (lane == 0) { red[wave] = s_ww; red[8 + wave] = s_wd; }
                 __syncthreads();
@@ -354,7 +375,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
             }
             for (int q = i + tid; q < p.L; q += THREADS) a0 += xc[q];
             float ps = (a0 + a1) + (a2 + a3);
-            static_for<0, 6>([&](auto st) { ps += __shfl_xor(ps, 1 << decltype(st)::value, 64); });
+            ps = wave_sum(ps);
             if (lane == 0) red[wave] = ps;
             __syncthreads();
             float tot = 0.f;
@@ -366,8 +387,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                 // long clips: the <= 64 partial sums of the prep kernel, one per lane, one round trip, added
                 // in a fixed butterfly order (deterministic)
                 float ps = (lane < p.nchunks) ? p.psum[(size_t)b * p.nchunks + lane] : 0.f;
-                static_for<0, 6>([&](auto st) { ps += __shfl_xor(ps, 1 << decltype(st)::value, 64); });
-                mean = ps * p.inv_L;
+                mean = wave_sum(ps) * p.inv_L;
             }
         }
         STAMP(2);   // window table + clip mean done
@@ -688,6 +708,16 @@ int forward_waves(int n_fft)
         case 32: return geom<32>().WAVES; case 64: return geom<64>().WAVES; case 128: return geom<128>().WAVES;
         case 256: return geom<256>().WAVES; case 512: return geom<512>().WAVES; case 1024: return geom<1024>().WAVES;
         case 2048: return geom<2048>().WAVES; case 4096: return geom<4096>().WAVES;
+    }
+    return -1;
+}
+
+int forward_nbpre(int n_fft)
+{
+    switch (n_fft) {
+        case 32: return geom<32>().NBPRE; case 64: return geom<64>().NBPRE; case 128: return geom<128>().NBPRE;
+        case 256: return geom<256>().NBPRE; case 512: return geom<512>().NBPRE; case 1024: return geom<1024>().NBPRE;
+        case 2048: return geom<2048>().NBPRE; case 4096: return geom<4096>().NBPRE;
     }
     return -1;
 }

@@ -77,6 +77,7 @@ struct FwdParams {
     const float* ent_b;        // 64 floats per 4x16 block, blocks of one mel tile contiguous in k
     const int4* tile_ranges;   // (groups, WAVES, 2): {first k-step, #k-steps (multiple of 4), offset into ent_b, mel tile or -1}
     int ent_b_floats;          // size of ent_b (buffer bounds)
+    const float* ent_pre;      // (WAVES, 2, NBPRE, 64): the first NBPRE k-steps of every run of mel group 0, zero padded
     int B, L, T, hop, M, nchunks, groups, tiles_per_clip;
     float inv_L, sign, eps;
     float lambd_abs, dw_scale;  // for the in-kernel window table (time_frequency.py:21-30)
@@ -96,6 +97,7 @@ hipError_t launch_forward(int n_fft, int mode, const FwdParams& p, int grid, hip
 int forward_lds_bytes(int n_fft);
 int forward_frames_per_tile(int n_fft, int mode);
 int forward_waves(int n_fft);              // waves per workgroup of the fused kernel for this n_fft
+int forward_nbpre(int n_fft);              // k-steps per run kept in registers (layout of FwdParams::ent_pre)
 hipError_t forward_prepare_attributes();   // raises the dynamic-LDS limit of every instantiation once
 
 // direct-DFT kernel for n_fft < 32 (and as an on-device cross-check of the fast path)
