@@ -5,13 +5,13 @@ Drop-in for the reference's ``models.MelSpectrogramLayer`` (models.py:14-56) and
 HIP kernels for gfx950 behind a C-ABI shared library (``include/dmel.h``).
 
 Heavy pieces (torch, the HIP library) are imported lazily so that ``dmel_amd.synth``
-and ``dmel_amd.hostmath`` stay usable from tooling that has neither.
+stays usable from tooling that has neither.
 """
 from __future__ import annotations
 
 import importlib
 
-__all__ = ["MelSpectrogramLayer", "DifferentiableMelSpectrogram", "dmel_log_mel", "capi", "hostmath", "synth"]
+__all__ = ["MelSpectrogramLayer", "DifferentiableMelSpectrogram", "dmel_log_mel", "capi", "synth", "dist", "nets"]
 
 _LAZY = {
     "MelSpectrogramLayer": ("layer", "MelSpectrogramLayer"),
@@ -24,6 +24,6 @@ def __getattr__(name):
     if name in _LAZY:
         mod, attr = _LAZY[name]
         return getattr(importlib.import_module(f"dmel_amd.{mod}"), attr)
-    if name in ("capi", "hostmath", "synth", "layer", "dist"):
+    if name in ("capi", "synth", "layer", "dist", "nets"):
         return importlib.import_module(f"dmel_amd.{name}")
     raise AttributeError(name)

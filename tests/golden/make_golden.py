@@ -119,8 +119,25 @@ def run_dspec(models, tf):
     return dict(spec=s.detach().numpy().astype(np.float32), dlam_lin=np.float32(dl.item()))
 
 
+def run_net_keys(models):
+    """state_dict keys + shapes of the reference's wrapping nets (models.py:58-136): the checkpoint contract."""
+    import json
+    out = {}
+    for name in ("MelLinearNet", "MelMlpNet", "MelConvNet"):
+        net = getattr(models, name)(10, torch.tensor(8000 * 0.035 / 6), "cpu", 64, 8000, 8000, hop_length=80, optimized=True,
+                                    energy_normalize=True)
+        out[name] = {k: list(v.shape) for k, v in net.state_dict().items()}
+    json.dump(out, open(os.path.join(HERE, "net_state_keys.json"), "w"), indent=1)
+    print("net_state_keys.json:", {k: list(v) for k, v in out.items()})
+
+
 def main(argv):
     models, tf = import_reference()
+    if len(argv) == 1 or "net_keys" in argv:
+        run_net_keys(models)
+        argv = [a for a in argv if a != "net_keys"]
+        if len(argv) == 1 and "net_keys" in sys.argv:
+            return
     names = argv[1:] or [c["name"] for c in C.CASES] + ["g7_dspec"]
     for name in names:
         if name == "g7_dspec":

@@ -275,3 +275,37 @@ def test_c2_full_size_properties():
         lm, _ = _c2_layer(log=True); lm.lambd -= h
         num = float(((lp(x[:32]).double() - lm(x[:32]).double()) * g[:32].double()).sum()) / (2 * h)
     assert abs(num - ana) <= 2e-2 * abs(ana) + 1e-3
+
+
+# ---- the nets that call the layer, and the two-LR-group training step ---------------
+@pytest.mark.parametrize("net_name", ["MelLinearNet", "MelMlpNet", "MelConvNet"])
+def test_caller_nets_train_step(net_name):
+    from dmel_amd import nets
+    torch.manual_seed(0)
+    B, L, sr, hop, M, ncls = 6, 8000, 8000, 80, 64, 10
+    net = getattr(nets, net_name)(ncls, torch.tensor(8000 * 0.035 / 6), "cuda:0", M, sr, L, hop_length=hop, optimized=True,
+                                  energy_normalize=True).to("cuda:0")
+    names = [n for n, _ in net.named_parameters()]
+    assert names[0] == "spectrogram_layer.lambd"
+    opt = nets.make_optimizer(net, lr_model=1e-4, lr_tf=1.0)
+    assert [g["lr"] for g in opt.param_groups][0] == 1.0 and all(g["lr"] == 1e-4 for g in opt.param_groups[1:])
+    from dmel_amd import synth
+    x = torch.from_numpy(synth.waveforms(B, L, seed=5)).to("cuda:0")
+    y = torch.arange(B, device="cuda:0") % ncls
+    lam0 = float(net.spectrogram_layer.lambd)
+    logits, s = net(x)
+    assert logits.shape == (B, ncls) and s.shape == (B, 1, M, L // hop + 1)
+    ref, _ = O.forward(x.cpu().numpy(), lam0, hop, M, sr, apply_log=True, want_tangent=False)
+    assert float(np.abs(s.detach().cpu().numpy() - ref).max()) <= TOL          # s is log(mel + 1e-10), models.py:73
+    loss = torch.nn.CrossEntropyLoss()(logits, y)
+    loss.backward()
+    g = net.spectrogram_layer.lambd.grad
+    assert g is not None and torch.isfinite(g) and float(g) != 0.0
+    opt.step()
+    assert float(net.spectrogram_layer.lambd) != lam0
+    # frozen front end (main.py:27): no tangent is produced and no gradient reaches lambd
+    net.spectrogram_layer.requires_grad_(False)
+    net.zero_grad(set_to_none=True)
+    logits, s = net(x)
+    torch.nn.CrossEntropyLoss()(logits, y).backward()
+    assert net.spectrogram_layer.lambd.grad is None
