@@ -11,12 +11,13 @@ from __future__ import annotations
 
 import importlib
 
-__all__ = ["MelSpectrogramLayer", "DifferentiableMelSpectrogram", "dmel_log_mel", "capi", "synth", "dist", "nets"]
+__all__ = ["MelSpectrogramLayer", "DifferentiableMelSpectrogram", "SpectrogramLayer", "dmel_log_mel", "capi", "synth", "dist", "nets"]
 
 _LAZY = {
     "MelSpectrogramLayer": ("layer", "MelSpectrogramLayer"),
     "DifferentiableMelSpectrogram": ("layer", "DifferentiableMelSpectrogram"),
     "dmel_log_mel": ("layer", "dmel_log_mel"),
+    "SpectrogramLayer": ("layer", "SpectrogramLayer"),
 }
 
 

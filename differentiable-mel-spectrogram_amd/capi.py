@@ -25,7 +25,7 @@ SYMBOLS = (
     "dmel_abi_version", "dmel_n_fft", "dmel_window_host", "dmel_mel_fbanks_host", "dmel_last_error",
     "dmel_device_count", "dmel_plan_create", "dmel_plan_destroy", "dmel_plan_set_filterbank",
     "dmel_forward", "dmel_backward", "dmel_spectrogram", "dmel_plan_get_info",
-    "dmel_plan_set_profiling", "dmel_plan_get_profile",
+    "dmel_plan_set_profiling", "dmel_plan_get_profile", "dmel_spectrogram_ex",
 )
 
 
@@ -91,6 +91,8 @@ def load():
     L.dmel_backward.restype = C.c_int
     L.dmel_spectrogram.argtypes = [vp, vp, C.c_int32, C.c_float, C.c_int32, vp, vp]
     L.dmel_spectrogram.restype = C.c_int
+    L.dmel_spectrogram_ex.argtypes = [vp, vp, C.c_int32, C.c_float, C.c_int32, C.c_uint32, vp, vp, vp]
+    L.dmel_spectrogram_ex.restype = C.c_int
     L.dmel_plan_get_info.argtypes = [vp, C.POINTER(DmelPlanInfo)]
     L.dmel_plan_get_info.restype = C.c_int
     L.dmel_plan_set_profiling.argtypes = [vp, C.c_int32]
@@ -165,6 +167,12 @@ class Plan:
 
     def spectrogram(self, x_ptr: int, batch: int, lambd: float, spec_ptr: int, stream: int, remove_dc: bool = False):
         _check(load().dmel_spectrogram(self._h, x_ptr, batch, C.c_float(float(lambd)), int(remove_dc), spec_ptr, stream))
+
+    def spectrogram_ex(self, x_ptr: int, batch: int, lambd: float, n_fft_: int, spec_ptr: int, tangent_ptr, stream: int,
+                       remove_dc: bool = True, half_window: bool = False):
+        flags = (1 if remove_dc else 0) | (2 if half_window else 0)
+        _check(load().dmel_spectrogram_ex(self._h, x_ptr, batch, C.c_float(float(lambd)), int(n_fft_), flags, spec_ptr,
+                                          tangent_ptr, stream))
 
     def set_filterbank(self, n_fft_: int, fb):
         import numpy as np

@@ -244,7 +244,8 @@ dmel_status ensure_psum(dmel_plan* pl, int batch)
 
 // shared body of dmel_forward / dmel_spectrogram
 dmel_status run_forward(dmel_plan* pl, const float* x, int batch, float lambd, unsigned flags, double eps,
-                        float* out, float* tangent, int mode, int remove_dc, void* stream)
+                        float* out, float* tangent, int mode, int remove_dc, void* stream,
+                        int n_fft_override = 0, int win_half = 0)
 {
     if (!pl) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
     if (batch < 0) return fail(DMEL_ERR_INVALID_ARGUMENT, "batch < 0");
@@ -254,7 +255,9 @@ dmel_status run_forward(dmel_plan* pl, const float* x, int batch, float lambd, u
     if (!std::isfinite(lambd)) return fail(DMEL_ERR_INVALID_ARGUMENT, "lambd is not finite");
     std::lock_guard<std::mutex> lock(pl->mu);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int N = dmel_n_fft(lambd);
+    const int N = n_fft_override > 0 ? n_fft_override : dmel_n_fft(lambd);
+    if (n_fft_override > 0 && (N & (N - 1)))
+        return fail(DMEL_ERR_UNSUPPORTED, "n_fft = " + std::to_string(N) + " is not a power of two");
     if (N > dmel::kMaxNfft)
         return fail(DMEL_ERR_UNSUPPORTED, "n_fft = " + std::to_string(N) + " > 4096 (|lambd| > 682.6) is not supported by the HIP kernels");
     NfftTables* tb = nullptr;
@@ -283,7 +286,7 @@ dmel_status run_forward(dmel_plan* pl, const float* x, int batch, float lambd, u
         dmel::PrepParams pp{};
         pp.x = x; pp.psum = pl->psum; pp.win2 = reinterpret_cast<float2*>(pl->win);
         pp.B = need_sums ? batch : 0; pp.L = pl->cfg.n_points; pp.nchunks = pl->nchunks; pp.chunk = pl->chunk;
-        pp.N = N; pp.normalize = pl->cfg.normalize_window; pp.lambd_abs = std::fabs(lambd); pp.dw_scale = dw_scale;
+        pp.N = N; pp.normalize = pl->cfg.normalize_window; pp.lambd_abs = std::fabs(lambd); pp.dw_scale = dw_scale; pp.win_half = win_half;
         DMEL_HIP(dmel::launch_prep(pp, s));
     }
     const size_t m1 = prof_mark(pl, s);
@@ -313,7 +316,7 @@ dmel_status run_forward(dmel_plan* pl, const float* x, int batch, float lambd, u
     fp.tiles_per_clip = (pl->T + fpt - 1) / fpt;
     fp.inv_L = 1.0f / (float)pl->cfg.n_points; fp.sign = sign; fp.eps = (float)eps; fp.flags = flags;
     fp.remove_dc = remove_dc; fp.normalize = pl->cfg.normalize_window;
-    fp.lambd_abs = std::fabs(lambd); fp.dw_scale = dw_scale;
+    fp.lambd_abs = std::fabs(lambd); fp.dw_scale = dw_scale; fp.win_half = win_half;
     const long long grid = (long long)batch * fp.tiles_per_clip;
     if (grid > 0x7fffffffLL) return fail(DMEL_ERR_INVALID_ARGUMENT, "too many tiles for one launch");
     DMEL_HIP(dmel::launch_forward(N, mode, fp, (int)grid, s));
@@ -482,6 +485,14 @@ dmel_status dmel_spectrogram(dmel_plan* plan, const float* x, int32_t batch, flo
                              int32_t remove_dc, float* spec, void* stream)
 {
     return run_forward(plan, x, batch, lambd, 0u, 0.0, spec, nullptr, dmel::kSpec, remove_dc ? 1 : 0, stream);
+}
+
+dmel_status dmel_spectrogram_ex(dmel_plan* plan, const float* x, int32_t batch, float lambd, int32_t n_fft,
+                                uint32_t flags, float* spec, float* tangent, void* stream)
+{
+    if (n_fft < 0) return fail(DMEL_ERR_INVALID_ARGUMENT, "n_fft < 0");
+    return run_forward(plan, x, batch, lambd, 0u, 0.0, spec, tangent, tangent ? dmel::kSpecTrain : dmel::kSpec,
+                       (flags & DMEL_SPEC_REMOVE_DC) ? 1 : 0, stream, n_fft, (flags & DMEL_SPEC_HALF_WINDOW) ? 1 : 0);
 }
 
 dmel_status dmel_backward(dmel_plan* plan, const float* grad_out, const float* tangent, int64_t count,

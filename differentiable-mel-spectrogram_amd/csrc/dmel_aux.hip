@@ -118,8 +118,12 @@ __global__ void __launch_bounds__(128) dmel_naive_kernel(NaiveParams p)
         D[f] = 2.f * (xr * yr + xi * yi);
     }
     __syncthreads();
-    if (p.mode == kSpec) {
-        for (int f = tid; f < p.F; f += blockDim.x) p.out[((size_t)b * p.F + f) * p.T + t] = P[f];
+    if (p.mode == kSpec || p.mode == kSpecTrain) {
+        for (int f = tid; f < p.F; f += blockDim.x) {
+            const size_t o = ((size_t)b * p.F + f) * p.T + t;
+            p.out[o] = P[f];
+            if (p.tangent) p.tangent[o] = p.sign * D[f];
+        }
         return;
     }
     const bool do_log = (p.flags & 1u) != 0;

@@ -145,7 +145,8 @@ __global__ void __launch_bounds__(kThreads) dmel_prep_kernel(PrepParams p)
         for (int n = tid; n < p.N; n += kThreads) {
             const float d = (float)n - (float)p.N / 2.0f;
             const float t = d / denom;
-            const float w = expf(-0.5f * (t * t));
+            float w = expf(-0.5f * (t * t));
+            if (p.win_half && (n < p.N / 4 || n >= 3 * p.N / 4)) w = 0.f;
             const double dw = (double)w * (double)d * (double)d / (den * den * den);
             p.win2[n] = make_float2(w, (float)(dw * (double)p.dw_scale));
             s_ww += (double)w * (double)w;
@@ -242,9 +243,10 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
     constexpr int WAVES = g.WAVES, NLOC = g.NLOC, THREADS = g.THREADS;
     constexpr int LB = ilog2(R);
     constexpr int EXS = g.EX_STRIDE, SS = g.SLOT_STRIDE_F2;
-    constexpr int FPT = (MODE == kTrain) ? SLOTS : 2 * SLOTS;   // frames per tile
+    constexpr bool PAIR = (MODE == kInfer || MODE == kSpec);    // two frames share one complex FFT
+    constexpr bool IS_SPEC = (MODE == kSpec || MODE == kSpecTrain);
+    constexpr int FPT = PAIR ? 2 * SLOTS : SLOTS;               // frames per tile
     constexpr int F = N / 2 + 1;
-    constexpr bool PAIR = (MODE != kTrain);
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     v2f* lds = reinterpret_cast<v2f*>(smem_raw);
@@ -280,7 +282,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
     constexpr int NBPRE = g.NBPRE;
     int4 tr0[NLOC];
     float bpre[NLOC][NBPRE];
-    if constexpr (MODE != kSpec) {
+    if constexpr (!IS_SPEC) {
         static_for<0, NLOC>([&](auto l) {
             constexpr int loc = decltype(l)::value;
             tr0[loc] = p.tile_ranges[wave * NLOC + loc];
@@ -337,7 +339,8 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
             for (int n = tid; n < N; n += THREADS) {
                 const float d = (float)n - (float)N / 2.0f;
                 const float t = d / denom;
-                const float w = expf(-0.5f * (t * t));
+                float w = expf(-0.5f * (t * t));
+                if (p.win_half && (n < N / 4 || n >= 3 * N / 4)) w = 0.f;     // torch.stft pads a win_length = N/2 window
                 const float dw = (float)((double)w * (double)d * (double)d / den3 * (double)p.dw_scale);
                 wtab[n] = make_float2(w, dw);
                 s_ww += w * w; s_wd += w * dw;
@@ -409,7 +412,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                 const v2f wd = v2f{wd2.x, wd2.y};
                 float va = xa[pass][a] - mean;
                 if (!inside_w) { const int ia = f0 + n; va = ((ia >= 0) && (ia < p.L)) ? va : 0.f; }
-                if constexpr (MODE == kTrain) z[a] = splat(va) * wd;
+                if constexpr (!PAIR) z[a] = splat(va) * wd;
                 else {
                     float vb = xb2[pass][a] - mean;
                     if (!inside_w) { const int ib = f1 + n; vb = ((ib >= 0) && (ib < p.L)) ? vb : 0.f; }
@@ -469,17 +472,26 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
     STAMP(8);   // barrier
     if (dbg_skip_gemm) { if (tid == 0 && lds[0].x == 12345.678f) p.out[0] = 0.f; return; }
 
-    if constexpr (MODE == kSpec) {
-        // power spectrogram (time_frequency.py:53), layout (B, F, T)
+    if constexpr (IS_SPEC) {
+        // power spectrogram (time_frequency.py:53), layout (B, F, T); kSpecTrain also writes d P / d lambd
         for (int idx = tid; idx < SLOTS * F; idx += THREADS) {
             const int k = idx / SLOTS, slot = idx % SLOTS;
             const v2f* sl = lds + slot * SS;
             const v2f zk = sl[z_index<R, C>(k)], zn = sl[z_index<R, C>((N - k) & (N - 1))];
             const float sx = zk.x + zn.x, sy = zk.y - zn.y, dx = zk.x - zn.x, dy = zk.y + zn.y;
-            const int t = t0 + 2 * slot;
-            float* o = p.out + ((size_t)b * F + k) * p.T;
-            if (t < p.T) o[t] = 0.25f * (sx * sx + sy * sy);
-            if (t + 1 < p.T) o[t + 1] = 0.25f * (dx * dx + dy * dy);
+            if constexpr (MODE == kSpec) {
+                const int t = t0 + 2 * slot;
+                float* o = p.out + ((size_t)b * F + k) * p.T;
+                if (t < p.T) o[t] = 0.25f * (sx * sx + sy * sy);
+                if (t + 1 < p.T) o[t + 1] = 0.25f * (dx * dx + dy * dy);
+            } else {
+                const int t = t0 + slot;
+                if (t < p.T) {
+                    const size_t o = ((size_t)b * F + k) * p.T + t;
+                    p.out[o] = 0.25f * (sx * sx + sy * sy);
+                    if (p.tangent) p.tangent[o] = 0.5f * p.sign * fmaf(sx, dy, -(sy * dx));
+                }
+            }
         }
         return;
     } else {
@@ -658,6 +670,7 @@ template <int N> static hipError_t launch_n(int mode, const FwdParams& p, int gr
         case kTrain: return launch_one<N, kTrain>(p, grid, s);
         case kInfer: return launch_one<N, kInfer>(p, grid, s);
         case kSpec: return launch_one<N, kSpec>(p, grid, s);
+        case kSpecTrain: return launch_one<N, kSpecTrain>(p, grid, s);
     }
     return hipErrorInvalidValue;
 }
@@ -699,7 +712,7 @@ int forward_frames_per_tile(int n_fft, int mode)
         case 2048: slots = geom<2048>().SLOTS; break; case 4096: slots = geom<4096>().SLOTS; break;
     }
     if (slots < 0) return -1;
-    return mode == kTrain ? slots : 2 * slots;
+    return (mode == kTrain || mode == kSpecTrain) ? slots : 2 * slots;
 }
 
 int forward_waves(int n_fft)
@@ -732,7 +745,8 @@ template <int N> static hipError_t set_attr_n()
     hipError_t e;
     if ((e = set_attr<N, kTrain>()) != hipSuccess) return e;
     if ((e = set_attr<N, kInfer>()) != hipSuccess) return e;
-    return set_attr<N, kSpec>();
+    if ((e = set_attr<N, kSpec>()) != hipSuccess) return e;
+    return set_attr<N, kSpecTrain>();
 }
 
 hipError_t forward_prepare_attributes()

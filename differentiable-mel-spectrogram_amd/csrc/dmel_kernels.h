@@ -11,7 +11,7 @@ constexpr int kMaxChunks = 64;         // partial sums per clip for the DC remov
 constexpr int kMaxNfft = 4096;
 constexpr int kMinFastNfft = 32;       // below this the direct-DFT kernel runs
 
-enum Mode : int { kTrain = 0, kInfer = 1, kSpec = 2 };
+enum Mode : int { kTrain = 0, kInfer = 1, kSpec = 2, kSpecTrain = 3 };   // kSpec*: power spectrogram (B,F,T), no mel stage
 
 // Compile-time FFT plan for one wave: N = R * R * C, R points per lane (tools/wavefft_sim.py).
 // MINW: waves per SIMD the register allocation must allow (what the LDS footprint admits).
@@ -83,6 +83,7 @@ struct FwdParams {
     float lambd_abs, dw_scale;  // for the in-kernel window table (time_frequency.py:21-30)
     unsigned flags;
     int remove_dc, normalize;
+    int win_half;               // window support = middle half of n_fft (DSPEC: win_length = n_fft / 2)
 };
 
 struct PrepParams {
@@ -90,6 +91,7 @@ struct PrepParams {
     int B, L, nchunks, chunk, N, normalize;
     float lambd_abs;
     float dw_scale;   // power of two ~ |lambd|: the dw table is stored pre-multiplied by it (see dmel_api.cpp)
+    int win_half;
 };
 
 hipError_t launch_prep(const PrepParams& p, hipStream_t s);

@@ -133,6 +133,84 @@ class MelSpectrogramLayer(nn.Module):
                 f"normalize_window={self.normalize_window}, log={self.log}")
 
 
+class _DspecFunction(torch.autograd.Function):
+    """forward: dmel_spectrogram_ex (carries d spec / d lambd); backward: dmel_backward."""
+
+    @staticmethod
+    def forward(ctx, x, lambd, plan, lam_host, n_fft, half_window):
+        B = x.shape[0]
+        out = torch.empty((B, 1, n_fft // 2 + 1, plan.n_time), dtype=torch.float32, device=x.device)
+        want_tangent = ctx.needs_input_grad[1]
+        tangent = torch.empty_like(out) if want_tangent else None
+        with torch.cuda.device(x.device):
+            plan.spectrogram_ex(x.data_ptr(), B, lam_host, n_fft, out.data_ptr(), tangent.data_ptr() if want_tangent else None,
+                                _stream_ptr(x.device), remove_dc=True, half_window=half_window)
+        ctx.plan, ctx.lambd_shape, ctx.lambd_dtype = plan, lambd.shape, lambd.dtype
+        if want_tangent:
+            ctx.save_for_backward(tangent)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        if not ctx.needs_input_grad[1]:
+            return None, None, None, None, None, None
+        (tangent,) = ctx.saved_tensors
+        g = grad_out.to(torch.float32).contiguous()
+        dl = torch.empty((1,), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            ctx.plan.backward(g.data_ptr(), tangent.data_ptr(), g.numel(), dl.data_ptr(), _stream_ptr(g.device))
+        return None, dl.reshape(ctx.lambd_shape).to(ctx.lambd_dtype), None, None, None, None
+
+
+class SpectrogramLayer(nn.Module):
+    """DSPEC: differentiable spectrogram with a trainable Gaussian window width.
+
+    Signature-compatible with the reference (models.py:171-200):
+        SpectrogramLayer(init_lambd, device='cpu', optimized=False, size=(512, 1024), hop_length=1, normalize_window=False)
+    ``optimized=False``: window = whole signal, n_fft = 2*n_points (time_frequency.py:41,51), output
+    ``(B, 1, n_points + 1, n_points // hop_length + 1)``; n_points must be a power of two <= 2048.
+    ``optimized=True``: n_fft = next_pow2(int(6*|lambd|)) and the output must have the shape ``size``.
+    """
+
+    def __init__(self, init_lambd, device="cpu", optimized=False, size=(512, 1024), hop_length=1, normalize_window=False):
+        super().__init__()
+        if not torch.is_tensor(init_lambd):
+            init_lambd = torch.tensor(float(init_lambd), dtype=torch.float32)
+        self.hop_length = hop_length
+        self.lambd = nn.Parameter(init_lambd)                        # models.py:176
+        self.device = device
+        self.size = size
+        self.optimized = optimized
+        self.normalize_window = normalize_window
+        self._plans = {}
+
+    def forward(self, x):
+        if x.dim() != 2:
+            raise ValueError(f"expected x of shape (batch, n_points), got {tuple(x.shape)}")
+        if not x.is_cuda:
+            raise RuntimeError("dmel_amd runs on MI355X only: x must be a CUDA/HIP tensor (no CPU fallback)")
+        if x.requires_grad:
+            raise NotImplementedError("gradient w.r.t. the waveform is not implemented (the reference never uses it)")
+        batch_size, n_points = x.shape
+        lam_host = float(self.lambd.detach())
+        if self.optimized:
+            n_fft, half = capi.n_fft(lam_host), False
+            expect = (n_fft // 2 + 1, n_points // self.hop_length + 1)
+            if tuple(self.size) != expect:     # the reference's slice-assign at models.py:198 fails the same way
+                raise RuntimeError(f"size={tuple(self.size)} but the spectrogram is {expect}")
+        else:
+            n_fft, half = 2 * n_points, True
+            if n_fft & (n_fft - 1) or n_fft > 4096 or n_fft < 2:
+                raise NotImplementedError(f"optimized=False needs n_points to be a power of two <= 2048 on the HIP path, got {n_points}")
+        key = (x.device.index, n_points)
+        plan = self._plans.get(key)
+        if plan is None:
+            with torch.cuda.device(x.device):
+                plan = capi.Plan(n_points, self.hop_length, 1, 2, 0.0, 1.0, bool(self.normalize_window))
+            self._plans[key] = plan
+        return _DspecFunction.apply(x.detach().to(torch.float32).contiguous(), self.lambd, plan, lam_host, n_fft, half)
+
+
 # BASELINE.json's north_star calls the layer by this name; the reference has no such symbol.
 DifferentiableMelSpectrogram = MelSpectrogramLayer
 

@@ -117,6 +117,20 @@ dmel_status dmel_backward(dmel_plan* plan, const float* grad_out, const float* t
 dmel_status dmel_spectrogram(dmel_plan* plan, const float* x, int32_t batch, float lambd,
                              int32_t remove_dc, float* spec, void* stream);
 
+/*
+ * SpectrogramLayer.forward (models.py:171-200) = time_frequency.differentiable_spectrogram per clip
+ * (time_frequency.py:32-58) with the tangent d spec / d lambd for its backward.
+ *   n_fft   0: derive from lambd (optimized branch, :39); otherwise the transform length to use --
+ *           the non-optimized branch (:41,:51) is n_fft = 2 * n_points with DMEL_SPEC_HALF_WINDOW
+ *           (torch.stft zero-pads the win_length = n_points window to n_fft on both sides).
+ *           Must be a power of two <= 4096.
+ *   spec, tangent   device, (batch, n_fft/2+1, n_time) fp32; tangent may be NULL.
+ */
+#define DMEL_SPEC_REMOVE_DC 1u      /* models.py:187: x[idx] - mean(x[idx])                          */
+#define DMEL_SPEC_HALF_WINDOW 2u    /* window support = middle half of n_fft                          */
+dmel_status dmel_spectrogram_ex(dmel_plan* plan, const float* x, int32_t batch, float lambd, int32_t n_fft,
+                                uint32_t flags, float* spec, float* tangent, void* stream);
+
 /* Introspection for tests / benchmarks */
 typedef struct dmel_plan_info {
     int32_t n_fft;             /* of the most recent forward                                */

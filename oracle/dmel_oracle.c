@@ -339,3 +339,79 @@ int dmel_oracle_spectrogram(const float* x, int B, int L, float lambd_raw, int h
     free(w); free(cs); free(sn);
     return DMEL_ORACLE_OK;
 }
+
+/* naive DFT for transform lengths that are not powers of two (non-optimized DSPEC with arbitrary n_points) */
+static void dft_c2c(const double* re, const double* im, int n, double* ore, double* oim)
+{
+    for (int k = 0; k < n; ++k) {
+        double sr = 0.0, si = 0.0;
+        for (int t = 0; t < n; ++t) {
+            double a = -2.0 * M_PI * (double)(((long long)k * t) % n) / (double)n;
+            double c = cos(a), s = sin(a);
+            sr += re[t] * c - im[t] * s;
+            si += re[t] * s + im[t] * c;
+        }
+        ore[k] = sr; oim[k] = si;
+    }
+}
+
+/*
+ * DSPEC: models.SpectrogramLayer.forward (models.py:171-200) with optimized=False:
+ *   window_length = len(x) = L (time_frequency.py:41), window centred at L/2 (:24), n_fft = 2L (:51),
+ *   torch.stft(center=True, pad_mode='constant', win_length=L) zero-pads the window to n_fft on both
+ *   sides; |.|^2 (:53); DC removal and abs(lambd) at models.py:187.
+ * spec, tangent: (B, L+1, L/hop+1) fp32; tangent = d spec / d lambd (may be NULL).
+ */
+int dmel_oracle_dspec(const float* x, int B, int L, float lambd_raw, int hop, int normalize_window,
+                      float* spec, float* tangent)
+{
+    if (!x || !spec || B < 0 || L < 1 || hop < 1) return DMEL_ORACLE_EINVAL;
+    const int N = 2 * L, F = L + 1, T = L / hop + 1, padw = (N - L) / 2;
+    const int pow2 = (N & (N - 1)) == 0;
+    const double sgn = (lambd_raw > 0) - (lambd_raw < 0);
+    float* g = (float*)malloc(sizeof(float) * (size_t)L);
+    double* dg = (double*)malloc(sizeof(double) * (size_t)L);
+    double* cs = (double*)malloc(sizeof(double) * (size_t)N);
+    double* sn = (double*)malloc(sizeof(double) * (size_t)N);
+    if (!g || !dg || !cs || !sn) { free(g); free(dg); free(cs); free(sn); return DMEL_ORACLE_ENOMEM; }
+    dmel_oracle_window(lambd_raw, L, normalize_window, g, dg);
+    for (int k = 0; k < N; ++k) { cs[k] = cos(2.0 * M_PI * k / N); sn[k] = sin(2.0 * M_PI * k / N); }
+#pragma omp parallel
+    {
+        double* re = (double*)malloc(sizeof(double) * (size_t)N);
+        double* im = (double*)malloc(sizeof(double) * (size_t)N);
+        double* ore = (double*)malloc(sizeof(double) * (size_t)N);
+        double* oim = (double*)malloc(sizeof(double) * (size_t)N);
+#pragma omp for schedule(static)
+        for (int b = 0; b < B; ++b) {
+            const float* xb = x + (size_t)b * L;
+            double s = 0.0;
+            for (int i = 0; i < L; ++i) s += (double)xb[i];
+            const float mean = (float)(s / (double)L);
+            for (int t = 0; t < T && re && im && ore && oim; ++t) {
+                for (int n = 0; n < N; ++n) {
+                    long long si = (long long)t * hop - N / 2 + n;
+                    float v = (si >= 0 && si < L) ? (xb[si] - mean) : 0.0f;
+                    int m = n - padw;
+                    if (m >= 0 && m < L) { re[n] = (double)(v * g[m]); im[n] = (double)v * dg[m]; }
+                    else { re[n] = 0.0; im[n] = 0.0; }
+                }
+                double *zr = re, *zi = im;
+                if (pow2) fft_c2c(re, im, N, cs, sn);
+                else { dft_c2c(re, im, N, ore, oim); zr = ore; zi = oim; }
+                for (int k = 0; k < F; ++k) {
+                    int nk = (N - k) % N;
+                    double sr = zr[k] + zr[nk], sim = zi[k] - zi[nk];
+                    double dr = zr[k] - zr[nk], di = zi[k] + zi[nk];
+                    double xr = 0.5 * sr, xi = 0.5 * sim, yr = 0.5 * di, yi = -0.5 * dr;
+                    size_t o = ((size_t)b * F + k) * T + t;
+                    spec[o] = (float)(xr * xr + xi * xi);
+                    if (tangent) tangent[o] = (float)(sgn * 2.0 * (xr * yr + xi * yi));
+                }
+            }
+        }
+        free(re); free(im); free(ore); free(oim);
+    }
+    free(g); free(dg); free(cs); free(sn);
+    return DMEL_ORACLE_OK;
+}

@@ -45,6 +45,8 @@ def lib():
         L.dmel_oracle_backward.restype = C.c_double
         L.dmel_oracle_spectrogram.argtypes = [fp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, fp]
         L.dmel_oracle_spectrogram.restype = C.c_int
+        L.dmel_oracle_dspec.argtypes = [fp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, fp, fp]
+        L.dmel_oracle_dspec.restype = C.c_int
         _lib = L
     return _lib
 
@@ -112,3 +114,14 @@ def spectrogram(x: np.ndarray, lambd: float, hop: int, normalize_window: bool = 
     rc = lib().dmel_oracle_spectrogram(_fp(x), B, L, np.float32(lambd), hop, int(normalize_window), int(remove_dc), _fp(spec))
     assert rc == 0
     return spec
+
+
+def dspec(x: np.ndarray, lambd: float, hop: int = 1, normalize_window: bool = False):
+    """Non-optimized SpectrogramLayer (models.py:171-200): returns (spec, tangent), each (B, 1, L+1, L//hop+1)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    B, L = x.shape
+    spec = np.empty((B, 1, L + 1, L // hop + 1), np.float32)
+    tan = np.empty_like(spec)
+    rc = lib().dmel_oracle_dspec(_fp(x), B, L, np.float32(lambd), hop, int(normalize_window), _fp(spec), _fp(tan))
+    assert rc == 0
+    return spec, tan

@@ -86,3 +86,18 @@ def test_window_centre_is_n_over_2():
     wm, _ = O.window(64.0 - h, 512)
     num = (wp.astype(np.float64) - wm.astype(np.float64)) / (2 * h)
     assert np.abs(num - dw).max() < 5e-5
+
+
+def test_dspec_oracle_matches_reference():
+    """G7: the reference's non-optimized SpectrogramLayer (models.py:171-200), L = 128, hop = 1, lambd = 6.38."""
+    import os
+    from dmel_amd import synth
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "g7_dspec.npz"))
+    x = synth.waveforms(2, 128, seed=77, scale=1.0)
+    spec, tan = O.dspec(x, 6.38, hop=1)
+    assert spec.shape == gold["spec"].shape == (2, 1, 129, 129)
+    scale = np.maximum(np.abs(gold["spec"]), 1e-6 * gold["spec"].max())
+    assert float((np.abs(spec - gold["spec"]) / scale).max()) <= TOL
+    g = synth.cotangent(spec.shape, seed=78)
+    d = O.backward(g, tan)
+    assert abs(d - float(gold["dlam_lin"])) <= TOL * abs(float(gold["dlam_lin"]))
