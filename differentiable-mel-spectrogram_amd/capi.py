@@ -19,6 +19,7 @@ DMEL_ERR_HIP = 3
 DMEL_ERR_NO_DEVICE = 4
 DMEL_ERR_OUT_OF_MEMORY = 5
 DMEL_FLAG_LOG = 1
+DMEL_FLAG_FULL_WINDOW = 2
 
 # every symbol include/dmel.h declares (tests check the library exports exactly these)
 SYMBOLS = (

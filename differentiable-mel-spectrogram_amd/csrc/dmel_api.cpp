@@ -477,6 +477,14 @@ dmel_status dmel_plan_set_filterbank(dmel_plan* plan, int32_t n_fft, const float
 dmel_status dmel_forward(dmel_plan* plan, const float* x, int32_t batch, float lambd, uint32_t flags,
                          double eps, float* out, float* tangent, void* stream)
 {
+    if (flags & DMEL_FLAG_FULL_WINDOW) {
+        if (!plan) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
+        const int L = plan->cfg.n_points;
+        if ((L & (L - 1)) || 2 * L > dmel::kMaxNfft)
+            return fail(DMEL_ERR_UNSUPPORTED, "DMEL_FLAG_FULL_WINDOW needs n_points to be a power of two <= 2048");
+        return run_forward(plan, x, batch, lambd, flags & ~DMEL_FLAG_FULL_WINDOW, eps, out, tangent,
+                           tangent ? dmel::kTrain : dmel::kInfer, 1, stream, 2 * L, 1);
+    }
     return run_forward(plan, x, batch, lambd, flags, eps, out, tangent,
                        tangent ? dmel::kTrain : dmel::kInfer, /*remove_dc=*/1, stream);
 }

@@ -24,14 +24,14 @@ class _DmelFunction(torch.autograd.Function):
     """forward: dmel_forward (carries d out / d lambd); backward: dmel_backward (one dot product)."""
 
     @staticmethod
-    def forward(ctx, x, lambd, plan, lam_host, log, eps):
+    def forward(ctx, x, lambd, plan, lam_host, log, eps, full_window=False):
         B = x.shape[0]
         out = torch.empty((B, 1, plan.n_mels, plan.n_time), dtype=torch.float32, device=x.device)  # models.py:36
         want_tangent = ctx.needs_input_grad[1]
         tangent = torch.empty_like(out) if want_tangent else None
         with torch.cuda.device(x.device):
             plan.forward(x.data_ptr(), B, lam_host, out.data_ptr(), tangent.data_ptr() if want_tangent else None,
-                         log, eps, _stream_ptr(x.device))
+                         log, eps, _stream_ptr(x.device), extra_flags=capi.DMEL_FLAG_FULL_WINDOW if full_window else 0)
         ctx.plan = plan
         ctx.lambd_shape = lambd.shape
         ctx.lambd_dtype = lambd.dtype
@@ -42,13 +42,13 @@ class _DmelFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         if not ctx.needs_input_grad[1]:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         (tangent,) = ctx.saved_tensors
         g = grad_out.to(torch.float32).contiguous()
         dl = torch.empty((1,), dtype=torch.float32, device=g.device)
         with torch.cuda.device(g.device):
             ctx.plan.backward(g.data_ptr(), tangent.data_ptr(), g.numel(), dl.data_ptr(), _stream_ptr(g.device))
-        return None, dl.reshape(ctx.lambd_shape).to(ctx.lambd_dtype), None, None, None, None
+        return None, dl.reshape(ctx.lambd_shape).to(ctx.lambd_dtype), None, None, None, None, None
 
 
 class MelSpectrogramLayer(nn.Module):
@@ -100,8 +100,9 @@ class MelSpectrogramLayer(nn.Module):
         return self._plan_for(dev).info()
 
     def n_fft(self) -> int:
-        """n_fft the next forward will use: next_pow2(int(6*|lambd|)) (time_frequency.py:39,60-65)."""
-        return capi.n_fft(float(self.lambd.detach()))
+        """n_fft the next forward will use: next_pow2(int(6*|lambd|)) (time_frequency.py:39,60-65), or 2*n_points
+        in the optimized=False branch (time_frequency.py:51)."""
+        return capi.n_fft(float(self.lambd.detach())) if self.optimized else 2 * self.n_points
 
     # -- forward ------------------------------------------------------------------------------
     def forward(self, x):
@@ -111,10 +112,11 @@ class MelSpectrogramLayer(nn.Module):
         if n_points != self.n_points:
             # the reference fails here too (RuntimeError from the slice-assign at models.py:54)
             raise RuntimeError(f"input has {n_points} points, the layer was built for n_points={self.n_points}")
-        if not self.optimized:
+        if not self.optimized and (n_points & (n_points - 1) or n_points > 2048):
             raise NotImplementedError(
-                "optimized=False (window = whole signal, n_fft = 2*n_points; time_frequency.py:41,51) is not on the "
-                "HIP hot path; construct the layer with optimized=True as all mel experiments do (search_spaces.py:11,44)")
+                "optimized=False (window = whole signal, n_fft = 2*n_points; time_frequency.py:41,51) runs on the HIP path "
+                "only for power-of-two n_points <= 2048; construct the layer with optimized=True as all mel experiments "
+                "do (search_spaces.py:11,44)")
         if not x.is_cuda:
             raise RuntimeError("dmel_amd runs on MI355X only: x must be a CUDA/HIP tensor (no CPU fallback)")
         if x.requires_grad:
@@ -125,7 +127,7 @@ class MelSpectrogramLayer(nn.Module):
         # one host read of the parameter per forward (the reference does one per sample, time_frequency.py:39)
         lam_host = float(self.lambd.detach())
         plan = self._plan_for(x.device)
-        return _DmelFunction.apply(xf, self.lambd, plan, lam_host, self.log, self.eps)
+        return _DmelFunction.apply(xf, self.lambd, plan, lam_host, self.log, self.eps, not self.optimized)
 
     def extra_repr(self):
         return (f"n_mels={self.n_mels}, n_points={self.n_points}, sample_rate={self.sample_rate}, "

@@ -54,6 +54,8 @@ typedef struct dmel_plan dmel_plan;
 
 /* Flags for dmel_forward */
 #define DMEL_FLAG_LOG 1u       /* fuse out = log(mel + eps)                        models.py:73 */
+#define DMEL_FLAG_FULL_WINDOW 2u /* the layer's optimized=False branch: window = whole clip, n_fft = 2*n_points
+                                  (time_frequency.py:41,51); n_points must be a power of two <= 2048     */
 
 /* ---- host-side helpers (no device needed) ------------------------------------------------- */
 

@@ -193,12 +193,28 @@ static void fft_c2c(double* re, double* im, int n, const double* cs, const doubl
  * n_fft is derived from lambd exactly as the reference does (power of two, so radix-2 is exact
  * in structure).  Returns 0 on success.
  */
+int dmel_oracle_forward_ex(const float* x, int B, int L, float lambd_raw, int hop, int n_mels,
+                           int sample_rate, double f_min, double f_max, int normalize_window,
+                           int apply_log, double eps, int optimized, float* out, float* tangent);
+
 int dmel_oracle_forward(const float* x, int B, int L, float lambd_raw, int hop, int n_mels,
                         int sample_rate, double f_min, double f_max, int normalize_window,
                         int apply_log, double eps, float* out, float* tangent)
 {
+    return dmel_oracle_forward_ex(x, B, L, lambd_raw, hop, n_mels, sample_rate, f_min, f_max, normalize_window,
+                                  apply_log, eps, 1, out, tangent);
+}
+
+/* optimized = 0: the layer's default branch (models.py:15 optimized=False -> time_frequency.py:41,51):
+ * window length = L (normalised over L), n_fft = 2L, window zero-padded to n_fft by torch.stft.
+ * L must be a power of two here (radix-2 FFT). */
+int dmel_oracle_forward_ex(const float* x, int B, int L, float lambd_raw, int hop, int n_mels,
+                           int sample_rate, double f_min, double f_max, int normalize_window,
+                           int apply_log, double eps, int optimized, float* out, float* tangent)
+{
     if (!x || !out || B < 0 || L < 1 || hop < 1 || n_mels < 1 || sample_rate < 2) return DMEL_ORACLE_EINVAL;
-    const int N = dmel_oracle_n_fft(lambd_raw);
+    if (!optimized && (L & (L - 1))) return DMEL_ORACLE_EINVAL;
+    const int N = optimized ? dmel_oracle_n_fft(lambd_raw) : 2 * L;
     const int F = N / 2 + 1;
     const int T = L / hop + 1;
     const int pad = N / 2;
@@ -216,7 +232,13 @@ int dmel_oracle_forward(const float* x, int B, int L, float lambd_raw, int hop, 
     int rc = DMEL_ORACLE_OK;
     if (!w || !dw || !fb || !cs || !sn || !flo || !fhi || !mean) { rc = DMEL_ORACLE_ENOMEM; goto done; }
 
-    dmel_oracle_window(lambd_raw, N, normalize_window, w, dw);
+    if (optimized) {
+        dmel_oracle_window(lambd_raw, N, normalize_window, w, dw);
+    } else {
+        /* Gaussian of length L centred at L/2, placed in the middle of the n_fft = 2L frame */
+        for (int n = 0; n < N; ++n) { w[n] = 0.0f; dw[n] = 0.0; }
+        dmel_oracle_window(lambd_raw, L, normalize_window, w + L / 2, dw + L / 2);
+    }
     rc = dmel_oracle_mel_fbanks(F, f_min, f_max, n_mels, sample_rate, fb);
     if (rc) goto done;
     for (int k = 0; k < N; ++k) { cs[k] = cos(2.0 * M_PI * k / N); sn[k] = sin(2.0 * M_PI * k / N); }

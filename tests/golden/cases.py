@@ -24,9 +24,9 @@ N_SAMPLED = 16384       # otherwise this many fixed pseudo-random positions
 
 
 def _case(name, B, L, sr, lambd, hop, n_mels, kind="noise", normalize_window=False,
-          dtype="float32", seed=0, f_min=0.0, f_max=None):
+          dtype="float32", seed=0, f_min=0.0, f_max=None, optimized=True):
     return dict(name=name, B=B, L=L, sr=sr, lambd=lambd, hop=hop, n_mels=n_mels, kind=kind,
-                normalize_window=normalize_window, dtype=dtype, seed=seed, f_min=f_min, f_max=f_max)
+                normalize_window=normalize_window, dtype=dtype, seed=seed, f_min=f_min, f_max=f_max, optimized=optimized)
 
 
 CASES = [
@@ -57,6 +57,9 @@ CASES = [
     _case("g6_n2048_short", 2, 3000, 16000, 300.0, 128, 128, seed=19),
     _case("g6_n64", 2, 4000, 8000, 9.0, 40, 20, seed=20),
     _case("g6_n32", 2, 2000, 8000, 5.0, 16, 10, seed=21),
+    # the constructor's default branch optimized=False (models.py:15): window = whole signal, n_fft = 2*n_points
+    _case("g7_mel_nonopt_256", 3, 256, 8000, 12.0, 16, 20, seed=22, optimized=False),
+    _case("g7_mel_nonopt_1024n", 2, 1024, 16000, 70.0, 64, 64, seed=23, optimized=False, normalize_window=True),
 ]
 
 BY_NAME = {c["name"]: c for c in CASES}

@@ -87,8 +87,8 @@ def run_case(models, tf, case):
         init_lambd=torch.tensor(float(case["lambd"]), dtype=torch.float32),
         n_mels=case["n_mels"], n_points=case["L"], sample_rate=case["sr"],
         f_min=case["f_min"], f_max=case["f_max"], hop_length=case["hop"], device="cpu",
-        optimized=True, normalize_window=case["normalize_window"])
-    n_fft = tf.next_power_of_2((torch.abs(layer.lambd) * 6).detach().cpu().numpy())
+        optimized=case["optimized"], normalize_window=case["normalize_window"])
+    n_fft = tf.next_power_of_2((torch.abs(layer.lambd) * 6).detach().cpu().numpy()) if case["optimized"] else 2 * case["L"]
 
     mel = layer(x)                                   # models.py:33-56
     y = torch.log(mel + 1e-10)                       # models.py:73

@@ -33,12 +33,13 @@ def test_oracle_matches_reference(case):
     gold = C.load(case)
     x = C.make_input(case).astype(np.float32)
     g = C.make_cotangent(case)
-    assert O.n_fft(case["lambd"]) == int(gold["n_fft"])
+    if case["optimized"]:
+        assert O.n_fft(case["lambd"]) == int(gold["n_fft"])
 
     mel, dmel = O.forward(x, case["lambd"], case["hop"], case["n_mels"], case["sr"], f_min=case["f_min"],
-                          f_max=case["f_max"], normalize_window=case["normalize_window"], apply_log=False)
+                          f_max=case["f_max"], normalize_window=case["normalize_window"], apply_log=False, optimized=case["optimized"])
     y, dy = O.forward(x, case["lambd"], case["hop"], case["n_mels"], case["sr"], f_min=case["f_min"],
-                      f_max=case["f_max"], normalize_window=case["normalize_window"], apply_log=True)
+                      f_max=case["f_max"], normalize_window=case["normalize_window"], apply_log=True, optimized=case["optimized"])
     assert mel.shape == C.out_shape(case)
     exp, idx = _expected(case, gold)
     got = mel.reshape(-1) if idx is None else mel.reshape(-1)[idx]
