@@ -3,8 +3,8 @@
 
 A step = one pass of the hot path over one batch of synthetic waveforms already resident in HBM:
   forward : DC removal -> Gaussian-window STFT -> |.|^2 -> mel contraction -> log(. + 1e-10)
-            (dmel_forward: a prep kernel + the fused kernel, carrying d out / d lambd)
-  backward: lambd.grad = <grad_out, tangent>   (dmel_backward: two-stage deterministic dot)
+            (dmel_forward: ONE fused kernel at this clip length, carrying d out / d lambd)
+  backward: lambd.grad = <grad_out, tangent>   (dmel_backward: one deterministic fp64 dot kernel)
   N > 1   : + one all-reduce (RCCL) of the scalar gradient, batch sharded over ranks (weak scaling)
 Workload at every N: BASELINE config 2 per GPU (256 x 16000 @16 kHz, n_fft 1024 (lambd 128),
 hop 512, 128 mels; config 4 is exactly 8 of these).  The step is driven through the C ABI
@@ -208,7 +208,7 @@ def main():
     roofline = {"bound": "hbm", "kernel": f"dmel_fwd_kernel<{info['n_fft']},train>", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(fwd_us, 2),
-                "other_kernels_us": {"prep": round(prep_us, 2), "backward_dot_x2": round(bwd_us, 2)}}
+                "other_kernels_us": {"prep": round(prep_us, 2), "backward_dot": round(bwd_us, 2)}}
 
     result = {
         "metric": "spectrogram frames/sec (fwd+bwd)", "value": round(value, 1), "unit": "frames/s",
