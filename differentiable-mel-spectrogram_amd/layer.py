@@ -99,10 +99,21 @@ class MelSpectrogramLayer(nn.Module):
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         return self._plan_for(dev).info()
 
+    def _lambd_host(self) -> float:
+        """Host value of lambd: one device->host read per forward (the reference does one per sample,
+        time_frequency.py:39), skipped while the parameter is unchanged (torch bumps ``_version`` on every in-place
+        update, e.g. optimizer.step()), so inference and frozen front ends never synchronise."""
+        key = (self.lambd._version, self.lambd.data_ptr())
+        cached = getattr(self, "_lam_cache", None)
+        if cached is None or cached[0] != key:
+            cached = (key, float(self.lambd.detach()))
+            self._lam_cache = cached
+        return cached[1]
+
     def n_fft(self) -> int:
         """n_fft the next forward will use: next_pow2(int(6*|lambd|)) (time_frequency.py:39,60-65), or 2*n_points
         in the optimized=False branch (time_frequency.py:51)."""
-        return capi.n_fft(float(self.lambd.detach())) if self.optimized else 2 * self.n_points
+        return capi.n_fft(self._lambd_host()) if self.optimized else 2 * self.n_points
 
     # -- forward ------------------------------------------------------------------------------
     def forward(self, x):
@@ -124,8 +135,7 @@ class MelSpectrogramLayer(nn.Module):
         if self.lambd.device != x.device:
             raise RuntimeError(f"lambd is on {self.lambd.device} but x is on {x.device}; call layer.to(x.device)")
         xf = x.detach().to(torch.float32).contiguous()
-        # one host read of the parameter per forward (the reference does one per sample, time_frequency.py:39)
-        lam_host = float(self.lambd.detach())
+        lam_host = self._lambd_host()
         plan = self._plan_for(x.device)
         return _DmelFunction.apply(xf, self.lambd, plan, lam_host, self.log, self.eps, not self.optimized)
 
