@@ -120,13 +120,14 @@ def main():
     g = torch.from_numpy(synth.cotangent((B, 1, M, T), seed=1 + 100 * rank)).to(dev)
     out = torch.empty((B, 1, M, T), dtype=torch.float32, device=dev)
     tan = torch.empty_like(out)
-    dl = [torch.zeros(1, dtype=torch.float32, device=dev) for _ in range(2)]
+    RING = 32  # gradient buffers: the all-reduce of step k may still be in flight while steps k+1 .. k+15 run
+    dl = [torch.zeros(1, dtype=torch.float32, device=dev) for _ in range(RING)]
     plan = capi.Plan(L, hop, M, sr, max_batch=B)
     count = out.numel()
 
     def step_kernels(stream_ptr, k):
         plan.forward(x.data_ptr(), B, lam, out.data_ptr(), tan.data_ptr(), True, 1e-10, stream_ptr)
-        plan.backward(g.data_ptr(), tan.data_ptr(), count, dl[k & 1].data_ptr(), stream_ptr)
+        plan.backward(g.data_ptr(), tan.data_ptr(), count, dl[k % RING].data_ptr(), stream_ptr)
 
     cur = torch.cuda.current_stream(dev)
     step_kernels(cur.cuda_stream, 0)          # builds the per-n_fft tables (hipMalloc) outside any capture
@@ -136,30 +137,40 @@ def main():
     graphs = None
     if args.graph:
         graphs = []
-        for k in range(2):                    # two graphs: alternate gradient buffers so an all-reduce can lag a step
+        for k in range(RING):                 # one graph per gradient buffer
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr):
                 step_kernels(torch.cuda.current_stream(dev).cuda_stream, k)
             graphs.append(gr)
 
-    pending = [None, None]
+    # one all-reduce of the scalar gradient per step, natively over RCCL on its own stream (dmel_comm_*),
+    # falling back to torch.distributed (stream-ordered, no overlap) if the native communicator is unavailable
+    sar = ddist.ScalarAllReduce() if dist is not None else None
+    main_stream = torch.cuda.current_stream(dev).cuda_stream
+    tick = [None] * 64
+    nstep = [0]
 
-    def one_step(k):
-        if pending[k & 1] is not None:        # the buffer about to be overwritten must have been reduced
-            pending[k & 1].wait()
-            pending[k & 1] = None
+    def one_step(_k):
+        k = nstep[0]
+        nstep[0] += 1
+        i = k % RING
+        # Buffer i was last reduced by the collective of step k-32.  Ordering the compute stream after a collective
+        # costs a barrier packet, so it is done once per 16 steps, on the collective of step k-17: the
+        # communicator's stream runs them in order, hence everything up to k-17 is then complete, which covers the
+        # buffers steps k .. k+15 overwrite.
+        if sar is not None and k % 16 == 0 and k >= 17 and tick[(k - 17) % 64] is not None:
+            sar.wait(tick[(k - 17) % 64], main_stream)
         if graphs is not None:
-            graphs[k & 1].replay()
+            graphs[i].replay()
         else:
-            step_kernels(torch.cuda.current_stream(dev).cuda_stream, k)
-        if dist is not None:
-            pending[k & 1] = ddist.allreduce_grad_(dl[k & 1], async_op=True)
+            step_kernels(main_stream, k)
+        if sar is not None:
+            tick[k % 64] = sar.reduce_async(dl[i], main_stream)
 
     def drain():
-        for i in range(2):
-            if pending[i] is not None:
-                pending[i].wait()
-                pending[i] = None
+        k = nstep[0]
+        if sar is not None and k >= 1 and tick[(k - 1) % 64] is not None:
+            sar.wait(tick[(k - 1) % 64], main_stream)      # the last collective (they complete in order)
 
     def barrier():
         if dist is not None:
@@ -218,7 +229,7 @@ def main():
                                f"(lambd {lam}), hop {hop}, n_mels {M}, log fused, fwd + backward to lambd.grad"
                    if args.config == "c2" else f"{args.config}: batch {B} x {L} @ {sr}, lambd {lam}, hop {hop}, n_mels {M}",
                    "global_batch": B * world, "frames_per_step": frames_per_rank * world,
-                   "parallelism": f"batch-sharded x{world}" + (", async all-reduce of d lambd (RCCL)" if world > 1 else ""),
+                   "parallelism": f"batch-sharded x{world}" + (f", one all-reduce of d lambd per step (RCCL, " + ("native dmel_comm on its own stream, up to 17 in flight" if sar.native else "torch.distributed fallback: " + sar.why) + ")" if sar is not None else ""),
                    "launch": "hip-graph replay" if args.graph else "eager, 2 launches per step (fused forward, dot)"},
         "roofline": roofline,
         "kernel_info": info,

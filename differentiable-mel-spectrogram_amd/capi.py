@@ -27,6 +27,7 @@ SYMBOLS = (
     "dmel_device_count", "dmel_plan_create", "dmel_plan_destroy", "dmel_plan_set_filterbank",
     "dmel_forward", "dmel_backward", "dmel_spectrogram", "dmel_plan_get_info",
     "dmel_plan_set_profiling", "dmel_plan_get_profile", "dmel_spectrogram_ex",
+    "dmel_comm_unique_id", "dmel_comm_create", "dmel_comm_destroy", "dmel_comm_allreduce_async", "dmel_comm_wait",
 )
 
 
@@ -94,6 +95,16 @@ def load():
     L.dmel_spectrogram.restype = C.c_int
     L.dmel_spectrogram_ex.argtypes = [vp, vp, C.c_int32, C.c_float, C.c_int32, C.c_uint32, vp, vp, vp]
     L.dmel_spectrogram_ex.restype = C.c_int
+    L.dmel_comm_unique_id.argtypes = [C.c_char_p]
+    L.dmel_comm_unique_id.restype = C.c_int
+    L.dmel_comm_create.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.dmel_comm_create.restype = C.c_int
+    L.dmel_comm_destroy.argtypes = [vp]
+    L.dmel_comm_destroy.restype = C.c_int
+    L.dmel_comm_allreduce_async.argtypes = [vp, vp, C.c_int32, vp, C.POINTER(C.c_int32)]
+    L.dmel_comm_allreduce_async.restype = C.c_int
+    L.dmel_comm_wait.argtypes = [vp, C.c_int32, vp]
+    L.dmel_comm_wait.restype = C.c_int
     L.dmel_plan_get_info.argtypes = [vp, C.POINTER(DmelPlanInfo)]
     L.dmel_plan_get_info.restype = C.c_int
     L.dmel_plan_set_profiling.argtypes = [vp, C.c_int32]
@@ -197,3 +208,39 @@ class Plan:
         inf = DmelPlanInfo()
         _check(load().dmel_plan_get_info(self._h, C.byref(inf)))
         return inf.as_dict()
+
+
+class Comm:
+    """Owner of a dmel_comm handle: native RCCL all-reduce of the scalar gradient (include/dmel.h)."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(Comm.ID_BYTES)
+        _check(load().dmel_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, unique_id: bytes, rank: int, world: int):
+        assert len(unique_id) == Comm.ID_BYTES
+        self._h = C.c_void_p()
+        _check(load().dmel_comm_create(C.create_string_buffer(unique_id, Comm.ID_BYTES), int(rank), int(world), C.byref(self._h)))
+
+    def allreduce_async(self, buf_ptr: int, count: int, stream: int) -> int:
+        t = C.c_int32(-1)
+        _check(load().dmel_comm_allreduce_async(self._h, buf_ptr, int(count), stream, C.byref(t)))
+        return int(t.value)
+
+    def wait(self, ticket: int, stream: int) -> None:
+        _check(load().dmel_comm_wait(self._h, int(ticket), stream))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            load().dmel_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -24,6 +24,13 @@ dmel_status fail(dmel_status st, const std::string& msg)
     g_err = msg;
     return st;
 }
+}  // namespace
+
+namespace dmel {
+dmel_status set_error(dmel_status st, const std::string& msg) { return fail(st, msg); }   // for dmel_comm.cpp
+}
+
+namespace {
 
 #define DMEL_HIP(expr)                                                                             \
     do {                                                                                           \

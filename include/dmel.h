@@ -133,6 +133,24 @@ dmel_status dmel_spectrogram(dmel_plan* plan, const float* x, int32_t batch, flo
 dmel_status dmel_spectrogram_ex(dmel_plan* plan, const float* x, int32_t batch, float lambd, int32_t n_fft,
                                 uint32_t flags, float* spec, float* tangent, void* stream);
 
+/* ---- the one exchange step: all-reduce of lambd.grad across GPUs (RCCL over xGMI) -------------------
+ * The reference has no distributed code; with the batch sharded over one process per GPU the only cross-GPU
+ * datum of this path is the scalar gradient.  These calls issue ncclAllReduce natively on the
+ * communicator's own stream, ordered against the caller's stream by events (no host blocking, ~5 us of host
+ * time), so that the collective of step k overlaps step k+1.  RCCL is dlopen'ed at first use. */
+#define DMEL_COMM_ID_BYTES 128
+typedef struct dmel_comm dmel_comm;
+/* rank 0 creates the id and ships it to the other ranks by any means (dmel_amd.dist uses torch.distributed) */
+dmel_status dmel_comm_unique_id(uint8_t id[DMEL_COMM_ID_BYTES]);
+/* collective: every rank calls it with the same id; binds to the current HIP device */
+dmel_status dmel_comm_create(const uint8_t id[DMEL_COMM_ID_BYTES], int32_t rank, int32_t world, dmel_comm** comm);
+dmel_status dmel_comm_destroy(dmel_comm* comm);
+/* in-place SUM of `count` fp32 at device address `buf`, after everything already queued on `stream`;
+ * `ticket` (0..63, a ring) names the operation for dmel_comm_wait */
+dmel_status dmel_comm_allreduce_async(dmel_comm* comm, float* buf, int32_t count, void* stream, int32_t* ticket);
+/* make `stream` wait for the all-reduce `ticket`; the host does not block */
+dmel_status dmel_comm_wait(dmel_comm* comm, int32_t ticket, void* stream);
+
 /* Introspection for tests / benchmarks */
 typedef struct dmel_plan_info {
     int32_t n_fft;             /* of the most recent forward                                */

@@ -39,6 +39,15 @@ class Layer(torch.nn.Module):
 lay = Layer(); lay.lambd.grad = torch.tensor(float(rank + 1))
 ddist.allreduce_lambd_grad(lay, average=True)
 assert abs(float(lay.lambd.grad) - sum(range(1, world + 1)) / world) < 1e-6
+# the low-overhead reducer bench.py uses: without a GPU the native RCCL communicator cannot exist, every rank
+# must agree on the torch.distributed fallback, and the result must be the same sum
+sar = ddist.ScalarAllReduce()
+assert sar.native is False and sar.why
+v = torch.tensor([float(rank + 1), 10.0 * (rank + 1)])
+t = sar.reduce_async(v, 0)
+sar.wait(t, 0)
+assert torch.allclose(v, torch.tensor([3.0, 30.0])), v
+sar.close()
 dist.destroy_process_group()
 print("rank", rank, "ok", lo, hi)
 '''

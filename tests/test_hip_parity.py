@@ -396,3 +396,27 @@ def test_c3_full_size_properties():
         (layer(x[sl]) * g[sl]).sum().backward()
         parts += float(layer.lambd.grad)
     assert abs(parts - d_full) <= 1e-5 * abs(d_full) + 1e-5
+
+
+def test_native_scalar_allreduce_world1():
+    """dmel_comm_* (RCCL through the C ABI) on a single-rank communicator: SUM over one rank is the identity, the
+    ticket/wait ordering against the caller's stream must hold.  (Multi-rank RCCL cannot be exercised on one GPU.)"""
+    from dmel_amd import capi
+    try:
+        uid = capi.Comm.unique_id()
+    except capi.DmelError as e:
+        pytest.skip(f"RCCL not loadable: {e}")
+    comm = capi.Comm(uid, 0, 1)
+    s = torch.cuda.current_stream().cuda_stream
+    bufs = [torch.full((4,), float(i + 1), device="cuda:0") for i in range(70)]     # more than the 64-ticket ring
+    tickets = []
+    for i, b in enumerate(bufs):
+        b.mul_(2.0)                                   # queued on the caller's stream BEFORE the collective
+        tickets.append(comm.allreduce_async(b.data_ptr(), b.numel(), s))
+        comm.wait(tickets[-1], s)
+        b.add_(1.0)                                   # queued AFTER the wait
+    torch.cuda.synchronize()
+    for i, b in enumerate(bufs):
+        assert torch.equal(b.cpu(), torch.full((4,), 2.0 * (i + 1) + 1.0))
+    assert all(0 <= t < 64 for t in tickets)
+    comm.close()
