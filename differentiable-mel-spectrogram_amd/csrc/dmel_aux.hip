@@ -15,20 +15,33 @@ namespace dmel {
 // sc1 loads only, so no acquire fence is needed.  The counter is left at 0 for the next launch.
 // fixed-order reduction of one fp64 value per thread: butterfly inside each wave (shuffles, no LDS),
 // then the four wave sums in index order.  Result valid in thread 0.
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double v)
+{
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_mov_dpp((int)b, CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
 __device__ __forceinline__ double block_sum(double v, double* red4)
 {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    // inside each row of 16 lanes with DPP (no LDS round trips), then the 4 rows x 4 waves through LDS
+    v += dpp_f64<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);     // row_half_mirror
+    v += dpp_f64<0x140>(v);     // row_mirror
     const int tid = threadIdx.x;
-    if ((tid & 63) == 0) red4[tid >> 6] = v;
+    if ((tid & 15) == 0) red4[tid >> 4] = v;
     __syncthreads();
-    return ((red4[0] + red4[1]) + (red4[2] + red4[3]));
+    double s = 0.0;
+    for (int q = 0; q < 16; ++q) s += red4[q];
+    return s;
 }
 
 __global__ void __launch_bounds__(kThreads) dmel_dot_kernel(const float* __restrict__ g, const float* __restrict__ t,
                                                             long long count, double* partials, unsigned* counter,
                                                             int accumulate, float* result)
 {
-    __shared__ double red4[4], red4b[4];
+    __shared__ double red4[16], red4b[16];
     __shared__ int is_last;
     const int tid = threadIdx.x;
     const long long stride = (long long)gridDim.x * kThreads;
