@@ -95,7 +95,7 @@ struct dmel_plan {
 
 namespace {
 
-constexpr int kMaxPartials = 512;
+constexpr int kMaxPartials = 1024;
 constexpr size_t kMaxSpans = 16384;
 
 // returns an event index recorded on s, or (size_t)-1 when profiling is off / full

@@ -86,7 +86,9 @@ __global__ void __launch_bounds__(kThreads) dmel_dot_kernel(const float* __restr
 hipError_t launch_dot(const float* g, const float* t, long long count, int accumulate, double* partials,
                       unsigned* counter, int max_partials, float* result, hipStream_t s)
 {
-    long long want = (count + (long long)kThreads * 16 - 1) / ((long long)kThreads * 16);
+    // 32 floats per thread and tensor: few workgroups on purpose -- every workgroup ends with one ticket on a single
+    // counter (~11 ns each, serialised), which cost more than the loads at 256+ workgroups
+    long long want = (count + (long long)kThreads * 32 - 1) / ((long long)kThreads * 32);
     int blocks = (int)(want < 1 ? 1 : (want > max_partials ? max_partials : want));
     hipLaunchKernelGGL(dmel_dot_kernel, dim3(blocks), dim3(kThreads), 0, s, g, t, count, partials, counter, accumulate, result);
     return hipGetLastError();
