@@ -465,9 +465,35 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                 const int k = qp + R * p1 + R * R * p2;
                 sl[z_index<R, C>(k)] = v;
             });
+            // ---- pairing pass: the two real spectra packed in Z are separated ONCE per bin here, by the wave
+            // that owns the slot, instead of by every A-fragment builder in phase 2:
+            //   S = Z[k] + conj Z[N-k], D = Z[k] - conj Z[N-k];  PD[k] = (|S|^2, Im(conj S * D))   (train: 4|X|^2, 2 d|X|^2)
+            //                                                    PD[k] = (|S|^2, |D|^2)           (pairs: 4|Xa|^2, 4|Xb|^2)
+            // stored in place over Z[0 .. N/2] (all reads of the wave precede its writes: LDS is in order per wave)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            constexpr int NPAIR = N / (2 * G) + 1;           // bins lg + G*i <= N/2
+            v2f pd[NPAIR];
+            static_for<0, NPAIR>([&](auto ii) {
+                constexpr int i = decltype(ii)::value;
+                const int k = lg + G * i;
+                const int kc = (k <= N / 2) ? k : 0;          // only lane 0 owns the Nyquist bin of the last round
+                const v2f zk = sl[z_index<R, C>(kc)], zn = sl[z_index<R, C>((N - kc) & (N - 1))];
+                const float sx = zk.x + zn.x, sy = zk.y - zn.y, dx = zk.x - zn.x, dy = zk.y + zn.y;
+                if constexpr (!PAIR) pd[i] = v2f{fmaf(sx, sx, sy * sy), fmaf(sx, dy, -(sy * dx))};
+                else pd[i] = v2f{fmaf(sx, sx, sy * sy), fmaf(dx, dx, dy * dy)};
+            });
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            static_for<0, NPAIR>([&](auto ii) {
+                constexpr int i = decltype(ii)::value;
+                const int k = lg + G * i;
+                if (k <= N / 2) sl[z_index<R, C>(k)] = pd[i];
+            });
         });
     }
-    STAMP(7);   // twiddle + cross-lane radix-C + spectrum to LDS
+    STAMP(7);   // twiddle + cross-lane radix-C + spectrum to LDS + pairing pass
     __syncthreads();
     STAMP(8);   // barrier
     if (dbg_skip_gemm) { if (tid == 0 && lds[0].x == 12345.678f) p.out[0] = 0.f; return; }
@@ -476,20 +502,18 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
         // power spectrogram (time_frequency.py:53), layout (B, F, T); kSpecTrain also writes d P / d lambd
         for (int idx = tid; idx < SLOTS * F; idx += THREADS) {
             const int k = idx / SLOTS, slot = idx % SLOTS;
-            const v2f* sl = lds + slot * SS;
-            const v2f zk = sl[z_index<R, C>(k)], zn = sl[z_index<R, C>((N - k) & (N - 1))];
-            const float sx = zk.x + zn.x, sy = zk.y - zn.y, dx = zk.x - zn.x, dy = zk.y + zn.y;
+            const v2f pdv = (lds + slot * SS)[z_index<R, C>(k)];
             if constexpr (MODE == kSpec) {
                 const int t = t0 + 2 * slot;
                 float* o = p.out + ((size_t)b * F + k) * p.T;
-                if (t < p.T) o[t] = 0.25f * (sx * sx + sy * sy);
-                if (t + 1 < p.T) o[t + 1] = 0.25f * (dx * dx + dy * dy);
+                if (t < p.T) o[t] = 0.25f * pdv.x;
+                if (t + 1 < p.T) o[t + 1] = 0.25f * pdv.y;
             } else {
                 const int t = t0 + slot;
                 if (t < p.T) {
                     const size_t o = ((size_t)b * F + k) * p.T + t;
-                    p.out[o] = 0.25f * (sx * sx + sy * sy);
-                    if (p.tangent) p.tangent[o] = 0.5f * p.sign * fmaf(sx, dy, -(sy * dx));
+                    p.out[o] = 0.25f * pdv.x;
+                    if (p.tangent) p.tangent[o] = 0.5f * p.sign * pdv.y;
                 }
             }
         }
@@ -526,30 +550,18 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                 auto group4 = [&](int ksg, float b0, float b1, float b2, float b3) {
                     const float bq[4] = {b0, b1, b2, b3};
                     const int k0 = 4 * ksg + kofs;                               // bin of k-step 0 for this lane
-                    const int m0 = (N - k0) & (N - 1);
                     const int zk0 = z_index<R, C>(k0 & (N - 1));
-                    const int zn0 = z_index<R, C>(m0);
-                    const int zn1 = z_index<R, C>((m0 - 4) & (N - 1));
                     static_for<0, MT>([&](auto m) {
                         constexpr int mt = decltype(m)::value;
                         const int slot = mt * 8 + slot8;
                         const bool valid = slot < SLOTS;
-                        const v2f* sl = lds + (valid ? slot : 0) * SS;
-                        v2f zk[4], zn[4];
+                        // rows of type 0 read PD.x (|S|^2), rows of type 1 PD.y: the A operand is a plain 4-byte LDS read
+                        const float* slf = reinterpret_cast<const float*>(lds + (valid ? slot : 0) * SS) + type;
+                        float av[4];
+                        static_for<0, 4>([&](auto uu) { constexpr int u = decltype(uu)::value; av[u] = slf[2 * (zk0 + 4 * u)]; });
                         static_for<0, 4>([&](auto uu) {
                             constexpr int u = decltype(uu)::value;
-                            zk[u] = sl[zk0 + 4 * u];
-                            zn[u] = (u == 0) ? sl[zn0] : sl[zn1 - 4 * (u - 1)];
-                        });
-                        static_for<0, 4>([&](auto uu) {
-                            constexpr int u = decltype(uu)::value;
-                            const float sx = zk[u].x + zn[u].x, sy = zk[u].y - zn[u].y;
-                            const float dx = zk[u].x - zn[u].x, dy = zk[u].y + zn[u].y;
-                            // rows of type 0 carry |S|^2, rows of type 1 carry Im(conj(S) D) (train) or |D|^2 (pairs)
-                            float px, py, qx, qy;
-                            if constexpr (MODE == kTrain) { px = type ? dy : sx; py = type ? -dx : sy; qx = sx; qy = sy; }
-                            else { px = type ? dx : sx; py = type ? dy : sy; qx = px; qy = py; }
-                            float val = fmaf(qx, px, qy * py);
+                            float val = av[u];
                             if constexpr (SLOTS < 8) val = valid ? val : 0.f;
                             acc[loc][mt][u & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(val, bq[u], acc[loc][mt][u & 1], 0, 0, 0);
                         });
