@@ -324,6 +324,11 @@ dmel_status run_forward(dmel_plan* pl, const float* x, int batch, float lambd, u
     fp.inv_L = 1.0f / (float)pl->cfg.n_points; fp.sign = sign; fp.eps = (float)eps; fp.flags = flags;
     fp.remove_dc = remove_dc; fp.normalize = pl->cfg.normalize_window;
     fp.lambd_abs = std::fabs(lambd); fp.dw_scale = dw_scale; fp.win_half = win_half;
+    {
+        const double den = (double)(std::fabs(lambd) + 1e-15f);
+        const double k3 = (double)dw_scale / (den * den * den);
+        fp.dw_k3 = std::isfinite(k3) && k3 < 3.0e38 ? (float)k3 : 0.f;     // lambd == 0: w' is 0 wherever w is not
+    }
     const long long grid = (long long)batch * fp.tiles_per_clip;
     if (grid > 0x7fffffffLL) return fail(DMEL_ERR_INVALID_ARGUMENT, "too many tiles for one launch");
     DMEL_HIP(dmel::launch_forward(N, mode, fp, (int)grid, s));

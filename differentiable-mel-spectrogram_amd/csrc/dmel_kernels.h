@@ -81,6 +81,7 @@ struct FwdParams {
     int B, L, T, hop, M, nchunks, groups, tiles_per_clip;
     float inv_L, sign, eps;
     float lambd_abs, dw_scale;  // for the in-kernel window table (time_frequency.py:21-30)
+    float dw_k3;                // dw_scale / (|lambd| + 1e-15)^3, computed on the host in fp64
     unsigned flags;
     int remove_dc, normalize;
     int win_half;               // window support = middle half of n_fft (DSPEC: win_length = n_fft / 2)
