@@ -72,16 +72,27 @@ template <int TW> __device__ __forceinline__ v2f cmul_tw(v2f a)
 
 // Radix-2 decimation-in-frequency FFT of R points held in registers; logical output q ends up in
 // v[bitrev(q)].  Fully unrolled: every index and twiddle is a compile-time constant.
+// The twiddle -i (j == SPAN/2) is never applied where it arises: the element is left unrotated and the
+// rotation is folded into its only consumer, the j == 0 butterfly of the odd block one stage later,
+// as a +- (b.y, -b.x) packed FMA with a constant -- no swap / sign-flip instructions are issued.
 template <int R, int SPAN = R / 2> __device__ __forceinline__ void fft_reg(v2f (&v)[R])
 {
     if constexpr (SPAN >= 1) {
         static_for<0, R / (2 * SPAN)>([&](auto blk) {
-            constexpr int base = decltype(blk)::value * 2 * SPAN;
+            constexpr int bi = decltype(blk)::value;
+            constexpr int base = bi * 2 * SPAN;
             static_for<0, SPAN>([&](auto jj) {
                 constexpr int j = decltype(jj)::value;
                 const v2f a = v[base + j], b = v[base + j + SPAN];
-                v[base + j] = a + b;
-                v[base + j + SPAN] = cmul_tw<j * 32 / SPAN>(a - b);
+                if constexpr (j == 0 && (bi & 1) != 0 && 2 * SPAN < R) {
+                    // b carries a pending factor -i: a +- rot_mi(b)
+                    v[base + j] = __builtin_elementwise_fma(b.yx, v2f{1.f, -1.f}, a);
+                    v[base + j + SPAN] = __builtin_elementwise_fma(b.yx, v2f{-1.f, 1.f}, a);
+                } else {
+                    v[base + j] = a + b;
+                    if constexpr (2 * j == SPAN) v[base + j + SPAN] = a - b;          // -i applied by the consumer
+                    else v[base + j + SPAN] = cmul_tw<j * 32 / SPAN>(a - b);
+                }
             });
         });
         fft_reg<R, SPAN / 2>(v);
@@ -287,11 +298,13 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
             constexpr int loc = decltype(l)::value;
             tr0[loc] = p.tile_ranges[wave * NLOC + loc];
         });
+        // one 64-bit base per lane, compile-time offsets from it
+        const float* pre_lane = p.ent_pre + ((unsigned)(wave * (NLOC * NBPRE * 64)) + (unsigned)lane);
         static_for<0, NLOC>([&](auto l) {
             constexpr int loc = decltype(l)::value;
             static_for<0, NBPRE>([&](auto u) {
                 // fixed layout (wave, run, k-step, lane): the address does not wait for tile_ranges
-                bpre[loc][decltype(u)::value] = p.ent_pre[((wave * NLOC + loc) * NBPRE + decltype(u)::value) * 64 + lane];
+                bpre[loc][decltype(u)::value] = pre_lane[(loc * NBPRE + decltype(u)::value) * 64];
             });
         });
     }
@@ -405,21 +418,38 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
             // zero padding of torch.stft(center=True, pad_mode='constant') applies AFTER the DC removal
             const bool inside_w = inside[pass];
             v2f z[R];
-            static_for<0, R>([&](auto aa) {
-                constexpr int a = decltype(aa)::value;
-                const int n = lg + G * a;
-                float2 wd2;                                          // (w[n], dw[n] / d|lambd| * scale)
-                if constexpr (WIN_LDS) wd2 = wtab[n]; else wd2 = p.win2[n];
-                const v2f wd = v2f{wd2.x, wd2.y};
-                float va = xa[pass][a] - mean;
-                if (!inside_w) { const int ia = f0 + n; va = ((ia >= 0) && (ia < p.L)) ? va : 0.f; }
-                if constexpr (!PAIR) z[a] = splat(va) * wd;
-                else {
-                    float vb = xb2[pass][a] - mean;
-                    if (!inside_w) { const int ib = f1 + n; vb = ((ib >= 0) && (ib < p.L)) ? vb : 0.f; }
-                    z[a] = v2f{va, vb} * wd.xx;
-                }
-            });
+            // window entries of this lane: one base register + compile-time offsets (ds_read_b64 offset:512a)
+            int wbyte = (WIN_LDS ? g.AUX_OFF : 0) + lg * 8;
+            asm volatile("" : "+v"(wbyte));
+            auto wload = [&](int a) -> v2f {
+                float2 wd2;                                              // (w[n], dw[n] / d|lambd| * scale)
+                if constexpr (WIN_LDS) wd2 = *reinterpret_cast<const float2*>(smem_raw + wbyte + G * 8 * a);
+                else wd2 = *reinterpret_cast<const float2*>(reinterpret_cast<const unsigned char*>(p.win2) + wbyte + G * 8 * a);
+                return v2f{wd2.x, wd2.y};
+            };
+            if (inside_w) {
+                static_for<0, R>([&](auto aa) {
+                    constexpr int a = decltype(aa)::value;
+                    const v2f wd = wload(a);
+                    const float va = xa[pass][a] - mean;
+                    if constexpr (!PAIR) z[a] = splat(va) * wd;
+                    else z[a] = v2f{va, xb2[pass][a] - mean} * wd.xx;
+                });
+            } else {
+                static_for<0, R>([&](auto aa) {
+                    constexpr int a = decltype(aa)::value;
+                    const int n = lg + G * a;
+                    const v2f wd = wload(a);
+                    const int ia = f0 + n;
+                    const float va = ((ia >= 0) && (ia < p.L)) ? xa[pass][a] - mean : 0.f;
+                    if constexpr (!PAIR) z[a] = splat(va) * wd;
+                    else {
+                        const int ib = f1 + n;
+                        const float vb = ((ib >= 0) && (ib < p.L)) ? xb2[pass][a] - mean : 0.f;
+                        z[a] = v2f{va, vb} * wd.xx;
+                    }
+                });
+            }
             STAMP(3);   // samples arrived, windowed
             fft_reg<R>(z);
             STAMP(4);   // radix-R #1
@@ -444,6 +474,8 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
             fft_reg<R>(u);
             STAMP(6);   // radix-R #2
             // twiddle w_G^(r*p1), radix-C across adjacent lanes, spectrum to LDS in natural order
+            const v2f rot_f = splat((C == 4 && r == 3) ? 0.f : 1.f);
+            const v2f rot_e = (C == 4 && r == 3) ? v2f{1.f, -1.f} : v2f{0.f, 0.f};
             static_for<0, R>([&](auto pp1) {
                 constexpr int p1 = decltype(pp1)::value;
                 v2f v = u[bitrev(p1, LB)];
@@ -458,7 +490,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                 } else if constexpr (C == 4) {
                     v2f o = v2f{quad_xor2(v.x), quad_xor2(v.y)};
                     v2f t = __builtin_elementwise_fma(splat((r < 2) ? 1.f : -1.f), v, o);
-                    if (r == 3) t = rot_mi(t);
+                    t = __builtin_elementwise_fma(t.yx, rot_e, t * rot_f);      // lane r == 3: t * (-i); others: t
                     o = v2f{quad_xor1(t.x), quad_xor1(t.y)};
                     v = __builtin_elementwise_fma(splat(((r & 1) == 0) ? 1.f : -1.f), t, o);
                     p2 = ((r & 1) << 1) | (r >> 1);
@@ -475,12 +507,26 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             constexpr int NPAIR = N / (2 * G) + 1;           // bins lg + G*i <= N/2
+            // Addresses are one of four per-lane byte bases plus a compile-time offset (ds_read_b64 offset:...):
+            //   Z[k],   k = lg + G i:            zb + 8 (G i + pad(G i))
+            //   Z[N-k], lg >= 1:                 mb + 8 (c_i + pad(c_i)),  mb = slot + 8 (G - lg),  c_i = N - G (i + 1)
+            //   lane 0: N - G i itself; it sits one padding step further when it starts an R*R block (mbA), and
+            //   wraps to bin 0 for i = 0 (mb0).
+            constexpr int PADC = (C > 1) ? 4 : 0, RR = R * R;
+            const int slot_b = slot * (SS * 8);
+            int zb = slot_b + lg * 8;
+            int mb = slot_b + (G - lg) * 8;
+            int mbA = mb + ((lg == 0) ? PADC * 8 : 0);
+            int mb0 = (lg == 0) ? slot_b : mb + (N - G + PADC * ((N - G) / RR)) * 8;       // full address of Z[N-k] for i = 0
+            asm volatile("" : "+v"(zb), "+v"(mb), "+v"(mbA), "+v"(mb0));
             v2f pd[NPAIR];
             static_for<0, NPAIR>([&](auto ii) {
                 constexpr int i = decltype(ii)::value;
-                const int k = lg + G * i;
-                const int kc = (k <= N / 2) ? k : 0;          // only lane 0 owns the Nyquist bin of the last round
-                const v2f zk = sl[z_index<R, C>(kc)], zn = sl[z_index<R, C>((N - kc) & (N - 1))];
+                constexpr int ck = G * i, cm = N - G * (i + 1);
+                constexpr bool crossing = PADC != 0 && ((N - G * i) % RR) == 0;
+                const int mbase = (i == 0) ? mb0 : (crossing ? mbA : mb);
+                const v2f zk = *reinterpret_cast<const v2f*>(smem_raw + zb + (ck + PADC * (ck / RR)) * 8);
+                const v2f zn = *reinterpret_cast<const v2f*>(smem_raw + mbase + ((i == 0) ? 0 : (cm + PADC * (cm / RR)) * 8));
                 const float sx = zk.x + zn.x, sy = zk.y - zn.y, dx = zk.x - zn.x, dy = zk.y + zn.y;
                 if constexpr (!PAIR) pd[i] = v2f{fmaf(sx, sx, sy * sy), fmaf(sx, dy, -(sy * dx))};
                 else pd[i] = v2f{fmaf(sx, sx, sy * sy), fmaf(dx, dx, dy * dy)};
@@ -489,8 +535,9 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
             __builtin_amdgcn_wave_barrier();
             static_for<0, NPAIR>([&](auto ii) {
                 constexpr int i = decltype(ii)::value;
-                const int k = lg + G * i;
-                if (k <= N / 2) sl[z_index<R, C>(k)] = pd[i];
+                constexpr int ck = G * i;
+                v2f* dst = reinterpret_cast<v2f*>(smem_raw + zb + (ck + PADC * (ck / RR)) * 8);
+                if (i < NPAIR - 1 || lg == 0) *dst = pd[i];          // the last round holds only the Nyquist bin
             });
         });
     }

@@ -25,10 +25,10 @@ def _layer(case, log=False, trainable=True):
     return layer
 
 
-def _rel_err(got, exp):
+def _rel_err(got, exp, floor=1e-6):
     # rel error on mel; bins more than 120 dB below the loudest one are fp32 noise in the reference
     # itself (its own floor), so they are measured against that floor
-    scale = np.maximum(np.abs(exp), 1e-6 * np.abs(exp).max() + 1e-30)
+    scale = np.maximum(np.abs(exp), floor * np.abs(exp).max() + 1e-30)
     return float((np.abs(got.astype(np.float64) - exp.astype(np.float64)) / scale).max())
 
 
@@ -137,7 +137,9 @@ def test_spectrogram_stage(name):
         plan.spectrogram(x.data_ptr(), case["B"], case["lambd"], spec.data_ptr(), torch.cuda.current_stream().cuda_stream, remove_dc=dc)
         torch.cuda.synchronize()
         ref = O.spectrogram(x_np, case["lambd"], case["hop"], remove_dc=dc)
-        assert _rel_err(spec.cpu().numpy(), ref) <= TOL
+        # single FFT bins (no mel averaging) sit on the fp32 FFT noise floor earlier than mel bands do: torch's own
+        # CPU fp32 stft is 1.16e-4 off the fp64 oracle on g2_c2 with the 1e-6 floor and 2.4e-5 with 1e-5
+        assert _rel_err(spec.cpu().numpy(), ref, floor=1e-5) <= TOL
 
 
 def test_tiny_nfft_uses_direct_dft_kernel():
