@@ -25,7 +25,7 @@ DMEL_FLAG_FULL_WINDOW = 2
 SYMBOLS = (
     "dmel_abi_version", "dmel_n_fft", "dmel_window_host", "dmel_mel_fbanks_host", "dmel_last_error",
     "dmel_device_count", "dmel_plan_create", "dmel_plan_destroy", "dmel_plan_set_filterbank",
-    "dmel_forward", "dmel_backward", "dmel_spectrogram", "dmel_plan_get_info",
+    "dmel_forward", "dmel_backward", "dmel_backward_fb", "dmel_spectrogram", "dmel_plan_get_info",
     "dmel_plan_set_profiling", "dmel_plan_get_profile", "dmel_spectrogram_ex",
     "dmel_comm_unique_id", "dmel_comm_create", "dmel_comm_destroy", "dmel_comm_allreduce_async", "dmel_comm_wait",
 )
@@ -91,6 +91,8 @@ def load():
     L.dmel_forward.restype = C.c_int
     L.dmel_backward.argtypes = [vp, vp, vp, C.c_int64, C.c_int32, vp, vp]
     L.dmel_backward.restype = C.c_int
+    L.dmel_backward_fb.argtypes = [vp, vp, C.c_int32, C.c_float, C.c_uint32, vp, vp, vp, vp]
+    L.dmel_backward_fb.restype = C.c_int
     L.dmel_spectrogram.argtypes = [vp, vp, C.c_int32, C.c_float, C.c_int32, vp, vp]
     L.dmel_spectrogram.restype = C.c_int
     L.dmel_spectrogram_ex.argtypes = [vp, vp, C.c_int32, C.c_float, C.c_int32, C.c_uint32, vp, vp, vp]
@@ -176,6 +178,13 @@ class Plan:
 
     def backward(self, grad_ptr: int, tangent_ptr: int, count: int, dlambd_ptr: int, stream: int, accumulate: bool = False):
         _check(load().dmel_backward(self._h, grad_ptr, tangent_ptr, int(count), int(accumulate), dlambd_ptr, stream))
+
+    def backward_fb(self, x_ptr: int, batch: int, lambd: float, grad_ptr: int, out_ptr: int | None, grad_fb_ptr: int,
+                    log: bool, stream: int, extra_flags: int = 0):
+        """grad of the loss w.r.t. the (n_fft/2+1, n_mels) filterbank (adjoint of models.py:53)."""
+        _check(load().dmel_backward_fb(self._h, x_ptr, batch, C.c_float(float(lambd)),
+                                       (DMEL_FLAG_LOG if log else 0) | int(extra_flags), grad_ptr, out_ptr if log else None,
+                                       grad_fb_ptr, stream))
 
     def spectrogram(self, x_ptr: int, batch: int, lambd: float, spec_ptr: int, stream: int, remove_dc: bool = False):
         _check(load().dmel_spectrogram(self._h, x_ptr, batch, C.c_float(float(lambd)), int(remove_dc), spec_ptr, stream))

@@ -83,6 +83,8 @@ struct dmel_plan {
     float* win = nullptr;          // 2 * kMaxNfft floats
     double* partials = nullptr;    // kMaxPartials doubles, followed by the ticket counter of the dot kernel
     unsigned* dot_counter = nullptr;
+    float* fbw = nullptr;          // workspace of dmel_backward_fb: spectrogram (B, F, T) followed by the slice partials
+    size_t fbw_floats = 0;
     std::mutex mu;
     dmel_plan_info info{};
     // optional event timing
@@ -250,7 +252,7 @@ dmel_status ensure_psum(dmel_plan* pl, int batch)
 }
 
 // shared body of dmel_forward / dmel_spectrogram
-dmel_status run_forward(dmel_plan* pl, const float* x, int batch, float lambd, unsigned flags, double eps,
+dmel_status run_forward_nolock(dmel_plan* pl, const float* x, int batch, float lambd, unsigned flags, double eps,
                         float* out, float* tangent, int mode, int remove_dc, void* stream,
                         int n_fft_override = 0, int win_half = 0)
 {
@@ -260,7 +262,6 @@ dmel_status run_forward(dmel_plan* pl, const float* x, int batch, float lambd, u
     if (!x || !out) return fail(DMEL_ERR_INVALID_ARGUMENT, "x / out is NULL");
     if (batch > 65534) return fail(DMEL_ERR_INVALID_ARGUMENT, "batch > 65534 (split the call)");
     if (!std::isfinite(lambd)) return fail(DMEL_ERR_INVALID_ARGUMENT, "lambd is not finite");
-    std::lock_guard<std::mutex> lock(pl->mu);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int N = n_fft_override > 0 ? n_fft_override : dmel_n_fft(lambd);
     if (n_fft_override > 0 && (N & (N - 1)))
@@ -337,6 +338,15 @@ dmel_status run_forward(dmel_plan* pl, const float* x, int batch, float lambd, u
     pl->info.fb_blocks = tb->n_entries; pl->info.fb_blocks_dense = tb->n_dense;
     pl->info.lds_bytes = dmel::forward_lds_bytes(N);
     return DMEL_OK;
+}
+
+dmel_status run_forward(dmel_plan* pl, const float* x, int batch, float lambd, unsigned flags, double eps,
+                        float* out, float* tangent, int mode, int remove_dc, void* stream,
+                        int n_fft_override = 0, int win_half = 0)
+{
+    if (!pl) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
+    std::lock_guard<std::mutex> lock(pl->mu);
+    return run_forward_nolock(pl, x, batch, lambd, flags, eps, out, tangent, mode, remove_dc, stream, n_fft_override, win_half);
 }
 
 }  // namespace
@@ -463,7 +473,7 @@ dmel_status dmel_plan_destroy(dmel_plan* plan)
     if (!plan) return DMEL_OK;
     for (auto& kv : plan->tables) kv.second.release();
     for (hipEvent_t e : plan->ev_pool) (void)hipEventDestroy(e);
-    (void)hipFree(plan->psum); (void)hipFree(plan->win); (void)hipFree(plan->partials);
+    (void)hipFree(plan->psum); (void)hipFree(plan->win); (void)hipFree(plan->partials); (void)hipFree(plan->fbw);
     delete plan;
     return DMEL_OK;
 }
@@ -525,6 +535,53 @@ dmel_status dmel_backward(dmel_plan* plan, const float* grad_out, const float* t
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const size_t m0 = prof_mark(plan, s);
     DMEL_HIP(dmel::launch_dot(grad_out, tangent, (long long)count, accumulate, plan->partials, plan->dot_counter, kMaxPartials, dlambd, s));
+    prof_span(plan, m0, prof_mark(plan, s), 2);
+    return DMEL_OK;
+}
+
+dmel_status dmel_backward_fb(dmel_plan* plan, const float* x, int32_t batch, float lambd, uint32_t flags,
+                             const float* grad_out, const float* out, float* grad_fb, void* stream)
+{
+    if (!plan) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
+    if (batch < 0) return fail(DMEL_ERR_INVALID_ARGUMENT, "batch < 0");
+    if (!grad_fb || (batch > 0 && (!x || !grad_out))) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_backward_fb: x / grad_out / grad_fb is NULL");
+    if ((flags & DMEL_FLAG_LOG) && batch > 0 && !out)
+        return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_backward_fb: DMEL_FLAG_LOG needs the saved log output");
+    if (!std::isfinite(lambd)) return fail(DMEL_ERR_INVALID_ARGUMENT, "lambd is not finite");
+    int n_over = 0, win_half = 0;
+    if (flags & DMEL_FLAG_FULL_WINDOW) {
+        const int L = plan->cfg.n_points;
+        if ((L & (L - 1)) || 2 * L > dmel::kMaxNfft)
+            return fail(DMEL_ERR_UNSUPPORTED, "DMEL_FLAG_FULL_WINDOW needs n_points to be a power of two <= 2048");
+        n_over = 2 * L; win_half = 1;
+    }
+    const int N = n_over ? n_over : dmel_n_fft(lambd);
+    if (N > dmel::kMaxNfft)
+        return fail(DMEL_ERR_UNSUPPORTED, "n_fft = " + std::to_string(N) + " > 4096 (|lambd| > 682.6) is not supported by the HIP kernels");
+    const int F = N / 2 + 1, M = plan->cfg.n_mels, T = plan->T;
+    std::lock_guard<std::mutex> lock(plan->mu);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (batch == 0) { DMEL_HIP(hipMemsetAsync(grad_fb, 0, (size_t)F * M * sizeof(float), s)); return DMEL_OK; }
+    // enough batch slices to fill the chip a few times over, never more than clips
+    const int tiles = ((F + 31) / 32) * ((M + 127) / 128);
+    const int splits = std::max(1, std::min(batch, (1024 + tiles - 1) / tiles));
+    const size_t spec_floats = ((size_t)batch * F * T + 63) / 64 * 64;
+    const size_t need = spec_floats + (size_t)splits * F * M;
+    if (need > plan->fbw_floats) {
+        DMEL_HIP(hipStreamSynchronize(s));
+        (void)hipFree(plan->fbw); plan->fbw = nullptr; plan->fbw_floats = 0;
+        DMEL_HIP(hipMalloc(&plan->fbw, need * sizeof(float)));
+        plan->fbw_floats = need;
+    }
+    // the spectrogram the layer contracted at models.py:53 (DC removed, models.py:38): P is recomputed, not saved
+    dmel_status st = run_forward_nolock(plan, x, batch, lambd, 0u, 0.0, plan->fbw, nullptr, dmel::kSpec, 1, stream, n_over, win_half);
+    if (st != DMEL_OK) return st;
+    dmel::FbGradParams fp{};
+    fp.spec = plan->fbw; fp.grad_out = grad_out; fp.out = (flags & DMEL_FLAG_LOG) ? out : nullptr;
+    fp.partials = plan->fbw + spec_floats; fp.grad_fb = grad_fb;
+    fp.B = batch; fp.F = F; fp.M = M; fp.T = T; fp.splits = splits;
+    const size_t m0 = prof_mark(plan, s);
+    DMEL_HIP(dmel::launch_fbgrad(fp, s));
     prof_span(plan, m0, prof_mark(plan, s), 2);
     return DMEL_OK;
 }

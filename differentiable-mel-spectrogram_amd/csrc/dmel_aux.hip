@@ -169,4 +169,119 @@ hipError_t launch_naive(const NaiveParams& p, hipStream_t s)
     return hipGetLastError();
 }
 
+// ---- filterbank gradient ----------------------------------------------------------------------
+// grad_fb = sum over clips of  spec_b (F x T) * gm_b^T (T x M): per clip a small GEMM whose K dimension (time) is
+// contiguous in both operands.  One workgroup owns a 32 (freq) x 128 (mel) tile of grad_fb for one slice of the
+// batch; exact-fp32 MFMA 16x16x4, A = spec rows, B = gm rows, both read straight from global memory as 16-byte
+// pieces along t (lane (row, kq) holds t = 16 j + 4 kq + i for k-step i -- any bijection of t onto (step, k) is
+// a valid K order as long as A and B use the same one).  Slices are summed in index order by a second kernel:
+// deterministic, no atomics.
+typedef float floatx4_t __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(4))) f4u { float v[4]; };       // 16-byte load that only needs 4-byte alignment
+
+template <bool LOG>
+__global__ void __launch_bounds__(256) dmel_fbgrad_kernel(FbGradParams p)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = lane & 15, kq = lane >> 4;
+    const int f0 = blockIdx.x * 32, m0 = blockIdx.z * 128;
+    const int split = blockIdx.y;
+    const int b_lo = (int)((long long)p.B * split / p.splits), b_hi = (int)((long long)p.B * (split + 1) / p.splits);
+    const int F = p.F, M = p.M, T = p.T;
+    // rows of the two freq sub-tiles and of this wave's two mel sub-tiles (clamped: rows past the edge are computed on
+    // valid memory and never stored)
+    int fr[2], mr[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        fr[i] = min(f0 + 16 * i + row, F - 1);
+        mr[i] = min(m0 + 16 * (wave + 4 * i) + row, M - 1);
+    }
+    floatx4_t acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) acc[i][j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+    const int tfull = T / 16 * 16;
+    for (int b = b_lo; b < b_hi; ++b) {
+        const float* pa[2]; const float* pg[2]; const float* py[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            pa[i] = p.spec + ((size_t)b * F + fr[i]) * T;
+            pg[i] = p.grad_out + ((size_t)b * M + mr[i]) * T;
+            py[i] = LOG ? p.out + ((size_t)b * M + mr[i]) * T : nullptr;
+        }
+        for (int t = 0; t < tfull; t += 16) {
+            f4u a[2], g[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *reinterpret_cast<const f4u*>(pa[i] + t + 4 * kq);
+                g[i] = *reinterpret_cast<const f4u*>(pg[i] + t + 4 * kq);
+                if constexpr (LOG) {
+                    const f4u y = *reinterpret_cast<const f4u*>(py[i] + t + 4 * kq);
+                    for (int u = 0; u < 4; ++u) g[i].v[u] *= expf(-y.v[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                for (int i = 0; i < 2; ++i)
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].v[u], g[j].v[u], acc[i][j], 0, 0, 0);
+        }
+        if (tfull < T) {
+            // last partial block of 16: element-wise, zero past the end of the row
+            float a[2][4], g[2][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int tt = tfull + 4 * kq + u;
+                const bool ok = tt < T;
+                const int tc = ok ? tt : T - 1;
+                for (int i = 0; i < 2; ++i) {
+                    const float av = pa[i][tc];
+                    float gv = pg[i][tc];
+                    if constexpr (LOG) gv *= expf(-py[i][tc]);
+                    a[i][u] = ok ? av : 0.f;
+                    g[i][u] = ok ? gv : 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                for (int i = 0; i < 2; ++i)
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][u], g[j][u], acc[i][j], 0, 0, 0);
+        }
+    }
+    // D[4 * (lane >> 4) + r][lane & 15]: rows = freq, columns = mel
+    float* part = p.partials + (size_t)split * F * M;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = m0 + 16 * (wave + 4 * j) + row;
+            if (m >= M) continue;
+            for (int r = 0; r < 4; ++r) {
+                const int f = f0 + 16 * i + 4 * kq + r;
+                if (f < F) part[(size_t)f * M + m] = acc[i][j][r];
+            }
+        }
+}
+
+__global__ void __launch_bounds__(256) dmel_fbgrad_reduce_kernel(FbGradParams p)
+{
+    const size_t n = (size_t)p.F * p.M;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int q = 0; q < p.splits; ++q) s += p.partials[(size_t)q * n + i];     // fixed order
+    p.grad_fb[i] = s;
+}
+
+hipError_t launch_fbgrad(const FbGradParams& p, hipStream_t s)
+{
+    const dim3 grid((p.F + 31) / 32, p.splits, (p.M + 127) / 128);
+    if (p.out) hipLaunchKernelGGL(dmel_fbgrad_kernel<true>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(dmel_fbgrad_kernel<false>, grid, dim3(256), 0, s, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const size_t n = (size_t)p.F * p.M;
+    hipLaunchKernelGGL(dmel_fbgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
 }  // namespace dmel

@@ -111,6 +111,19 @@ struct NaiveParams {
 };
 hipError_t launch_naive(const NaiveParams& p, hipStream_t s);
 
+// gradient w.r.t. the filterbank matrix of models.py:53 (adjoint of  mel = spec^T @ fb):
+//   grad_fb[f][m] = sum_{b,t} spec[b][f][t] * gm[b][m][t],   gm = grad_out            (linear output)
+//                                                            gm = grad_out * exp(-out) (log output: d log(s+eps) = ds / (s+eps))
+struct FbGradParams {
+    const float* spec;       // (B, F, T) power spectrogram of the same clips (kSpec pass)
+    const float* grad_out;   // (B, M, T)
+    const float* out;        // (B, M, T) saved log output, or nullptr for the linear layer
+    float* partials;         // (splits, F, M)
+    float* grad_fb;          // (F, M)
+    int B, F, M, T, splits;
+};
+hipError_t launch_fbgrad(const FbGradParams& p, hipStream_t s);
+
 hipError_t launch_dot(const float* g, const float* t, long long count, int accumulate, double* partials,
                       unsigned* counter, int max_partials, float* result, hipStream_t s);
 

@@ -21,34 +21,55 @@ def _stream_ptr(device) -> int:
 
 
 class _DmelFunction(torch.autograd.Function):
-    """forward: dmel_forward (carries d out / d lambd); backward: dmel_backward (one dot product)."""
+    """forward: dmel_forward (carries d out / d lambd); backward: dmel_backward (one dot product) and, when a
+    filterbank tensor that requires grad was passed, dmel_backward_fb (adjoint of models.py:53)."""
 
     @staticmethod
-    def forward(ctx, x, lambd, plan, lam_host, log, eps, full_window=False):
+    def forward(ctx, x, lambd, plan, lam_host, log, eps, full_window=False, fb=None):
         B = x.shape[0]
         out = torch.empty((B, 1, plan.n_mels, plan.n_time), dtype=torch.float32, device=x.device)  # models.py:36
         want_tangent = ctx.needs_input_grad[1]
+        want_fb = fb is not None and ctx.needs_input_grad[7]
         tangent = torch.empty_like(out) if want_tangent else None
+        flags = capi.DMEL_FLAG_FULL_WINDOW if full_window else 0
         with torch.cuda.device(x.device):
             plan.forward(x.data_ptr(), B, lam_host, out.data_ptr(), tangent.data_ptr() if want_tangent else None,
-                         log, eps, _stream_ptr(x.device), extra_flags=capi.DMEL_FLAG_FULL_WINDOW if full_window else 0)
+                         log, eps, _stream_ptr(x.device), extra_flags=flags)
         ctx.plan = plan
         ctx.lambd_shape = lambd.shape
         ctx.lambd_dtype = lambd.dtype
+        ctx.want_tangent, ctx.want_fb = want_tangent, want_fb
+        ctx.fb_args = (lam_host, bool(log), flags, None if fb is None else (tuple(fb.shape), fb.dtype))
+        saved = []
         if want_tangent:
-            ctx.save_for_backward(tangent)
+            saved.append(tangent)
+        if want_fb:
+            saved.append(x)
+            if log:
+                saved.append(out)
+        ctx.save_for_backward(*saved)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        if not ctx.needs_input_grad[1]:
-            return None, None, None, None, None, None, None
-        (tangent,) = ctx.saved_tensors
+        saved = list(ctx.saved_tensors)
         g = grad_out.to(torch.float32).contiguous()
-        dl = torch.empty((1,), dtype=torch.float32, device=g.device)
+        dl = gfb = None
         with torch.cuda.device(g.device):
-            ctx.plan.backward(g.data_ptr(), tangent.data_ptr(), g.numel(), dl.data_ptr(), _stream_ptr(g.device))
-        return None, dl.reshape(ctx.lambd_shape).to(ctx.lambd_dtype), None, None, None, None, None
+            if ctx.want_tangent:
+                tangent = saved.pop(0)
+                dl = torch.empty((1,), dtype=torch.float32, device=g.device)
+                ctx.plan.backward(g.data_ptr(), tangent.data_ptr(), g.numel(), dl.data_ptr(), _stream_ptr(g.device))
+                dl = dl.reshape(ctx.lambd_shape).to(ctx.lambd_dtype)
+            if ctx.want_fb:
+                lam_host, log, flags, (fb_shape, fb_dtype) = ctx.fb_args
+                x = saved.pop(0)
+                out = saved.pop(0) if log else None
+                gfb = torch.empty(fb_shape, dtype=torch.float32, device=g.device)
+                ctx.plan.backward_fb(x.data_ptr(), x.shape[0], lam_host, g.data_ptr(), out.data_ptr() if log else None,
+                                     gfb.data_ptr(), log, _stream_ptr(g.device), extra_flags=flags)
+                gfb = gfb.to(fb_dtype)
+        return None, dl, None, None, None, None, None, gfb
 
 
 class MelSpectrogramLayer(nn.Module):
@@ -59,12 +80,16 @@ class MelSpectrogramLayer(nn.Module):
                             hop_length=1, device='cpu', optimized=False, normalize_window=False)
     Extra keyword-only options: ``log=True`` fuses ``torch.log(s + eps)`` (models.py:73) into the
     kernel epilogue (default False = linear mel power, exactly what the reference layer returns).
+    ``learnable_fb=True`` registers the (n_fft/2+1, n_mels) filterbank of models.py:42-48 as a second
+    parameter ``mel_fb`` (initialised to the HTK bank) and returns its gradient; the matrix is tied to the
+    n_fft it was built for, so the forward raises once ``lambd`` has moved to another power of two.  Off by
+    default: the reference has no such parameter and its checkpoints have no such key.
 
     forward(x: (B, n_points)) -> (B, 1, n_mels, n_points // hop_length + 1) float32.
     """
 
     def __init__(self, init_lambd, n_mels, n_points, sample_rate, f_min=0, f_max=None, hop_length=1,
-                 device="cpu", optimized=False, normalize_window=False, *, log=False, eps=1e-10):
+                 device="cpu", optimized=False, normalize_window=False, *, log=False, eps=1e-10, learnable_fb=False):
         super().__init__()
         if not torch.is_tensor(init_lambd):
             init_lambd = torch.tensor(float(init_lambd), dtype=torch.float32)
@@ -83,6 +108,13 @@ class MelSpectrogramLayer(nn.Module):
         self.log = bool(log)
         self.eps = float(eps)
         self._plans = {}                                              # device index -> capi.Plan (not state)
+        self._fb_synced = {}                                          # device index -> (version, data_ptr) last sent to the plan
+        if learnable_fb:
+            n0 = capi.n_fft(float(init_lambd)) if optimized else 2 * n_points
+            fb0 = capi.mel_fbanks_host(n0 // 2 + 1, float(self.f_min), float(self.f_max), n_mels, sample_rate)   # models.py:42-48
+            self.mel_fb = nn.Parameter(torch.from_numpy(fb0))
+        else:
+            self.mel_fb = None
 
     # -- plumbing -----------------------------------------------------------------------------
     def _plan_for(self, dev: torch.device) -> capi.Plan:
@@ -137,7 +169,20 @@ class MelSpectrogramLayer(nn.Module):
         xf = x.detach().to(torch.float32).contiguous()
         lam_host = self._lambd_host()
         plan = self._plan_for(x.device)
-        return _DmelFunction.apply(xf, self.lambd, plan, lam_host, self.log, self.eps, not self.optimized)
+        fb = self.mel_fb
+        if fb is not None:
+            n = self.n_fft()
+            if fb.shape[0] != n // 2 + 1:
+                raise RuntimeError(f"mel_fb was built for n_fft={2 * (fb.shape[0] - 1)} but lambd={lam_host} now gives n_fft={n}; "
+                                   "a learnable filterbank is tied to one n_fft")
+            if fb.device != x.device:
+                raise RuntimeError(f"mel_fb is on {fb.device} but x is on {x.device}; call layer.to(x.device)")
+            key = (fb._version, fb.data_ptr(), n)
+            idx = x.device.index if x.device.index is not None else torch.cuda.current_device()
+            if self._fb_synced.get(idx) != key:
+                plan.set_filterbank(n, fb.detach().to(torch.float32).cpu().numpy())      # host rebuild of the block tables
+                self._fb_synced[idx] = key
+        return _DmelFunction.apply(xf, self.lambd, plan, lam_host, self.log, self.eps, not self.optimized, fb)
 
     def extra_repr(self):
         return (f"n_mels={self.n_mels}, n_points={self.n_points}, sample_rate={self.sample_rate}, "

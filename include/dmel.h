@@ -114,6 +114,24 @@ dmel_status dmel_forward(dmel_plan* plan, const float* x, int32_t batch, float l
 dmel_status dmel_backward(dmel_plan* plan, const float* grad_out, const float* tangent, int64_t count,
                           int32_t accumulate, float* dlambd, void* stream);
 
+/*
+ * Backward to the filterbank matrix ("mel params"): the adjoint of the contraction at models.py:53,
+ * `torch.matmul(spectrogram, mel_fb)` with mel_fb (n_freqs, n_mels) from models.py:42-48.  The reference keeps
+ * mel_fb constant; this is what torch autograd returns when it is made a leaf:
+ *   grad_fb[f][m] = sum_{b,t} spec[b][f][t] * gm[b][m][t]
+ *   gm = grad_out                 without DMEL_FLAG_LOG
+ *   gm = grad_out * exp(-out)     with DMEL_FLAG_LOG (out = the saved log output of dmel_forward; models.py:73)
+ * The spectrogram is recomputed from x (same lambd and flags as the forward), not saved.
+ *   x         device, (batch, n_points) fp32       grad_out  device, (batch, 1, n_mels, n_time) fp32
+ *   out       device, same shape as grad_out, or NULL without DMEL_FLAG_LOG
+ *   grad_fb   device, (n_fft/2+1, n_mels) fp32, overwritten
+ * flags: DMEL_FLAG_LOG, DMEL_FLAG_FULL_WINDOW as in dmel_forward.  Deterministic (fixed-order sum over batch
+ * slices, exact-fp32 MFMA).  Asynchronous on `stream`; uses a plan-owned workspace, so calls on one plan must be
+ * issued on one stream at a time.
+ */
+dmel_status dmel_backward_fb(dmel_plan* plan, const float* x, int32_t batch, float lambd, uint32_t flags,
+                             const float* grad_out, const float* out, float* grad_fb, void* stream);
+
 /* Power spectrogram only, (batch, n_fft/2+1, n_time) fp32 = time_frequency.differentiable_spectrogram
  * (time_frequency.py:32-58, optimized branch) applied per clip; remove_dc != 0 adds models.py:38. */
 dmel_status dmel_spectrogram(dmel_plan* plan, const float* x, int32_t batch, float lambd,

@@ -362,6 +362,64 @@ int dmel_oracle_spectrogram(const float* x, int B, int L, float lambd_raw, int h
     return DMEL_ORACLE_OK;
 }
 
+/* Adjoint of the mel contraction at models.py:53 (`torch.matmul(spectrogram, mel_fb)`) w.r.t. mel_fb, i.e. what
+ * autograd returns when the filterbank is a leaf:  grad_fb[f][m] = sum_{b,t} P[b][f][t] * gm[b][m][t], with P the
+ * power spectrogram of the DC-removed clip (models.py:38, time_frequency.py:32-58; fp32 window and products as in
+ * the reference, everything after them in fp64) and gm the gradient w.r.t. the LINEAR mel output, (B, M, T) fp64
+ * (for a log output the caller passes grad_out / (mel + eps), models.py:73).  grad_fb: (F, M) fp64. */
+int dmel_oracle_fbgrad(const float* x, int B, int L, float lambd_raw, int hop, int normalize_window,
+                       const double* gm, int n_mels, double* grad_fb)
+{
+    if (!x || !gm || !grad_fb || B < 0 || L < 1 || hop < 1 || n_mels < 1) return DMEL_ORACLE_EINVAL;
+    const int N = dmel_oracle_n_fft(lambd_raw);
+    const int F = N / 2 + 1, T = L / hop + 1, pad = N / 2, M = n_mels;
+    float* w = (float*)malloc(sizeof(float) * (size_t)N);
+    double* cs = (double*)malloc(sizeof(double) * (size_t)N);
+    double* sn = (double*)malloc(sizeof(double) * (size_t)N);
+    if (!w || !cs || !sn) { free(w); free(cs); free(sn); return DMEL_ORACLE_ENOMEM; }
+    dmel_oracle_window(lambd_raw, N, normalize_window, w, NULL);
+    for (int k = 0; k < N; ++k) { cs[k] = cos(2.0 * M_PI * k / N); sn[k] = sin(2.0 * M_PI * k / N); }
+    for (size_t i = 0; i < (size_t)F * M; ++i) grad_fb[i] = 0.0;
+    int rc = DMEL_ORACLE_OK;
+#pragma omp parallel
+    {
+        double* re = (double*)malloc(sizeof(double) * (size_t)N);
+        double* im = (double*)malloc(sizeof(double) * (size_t)N);
+        double* acc = (double*)calloc((size_t)F * M, sizeof(double));
+        if (!re || !im || !acc) {
+#pragma omp critical
+            rc = DMEL_ORACLE_ENOMEM;
+        }
+#pragma omp for schedule(static)
+        for (int b = 0; b < B; ++b) {
+            if (!re || !im || !acc) continue;
+            const float* xb = x + (size_t)b * L;
+            double s = 0.0;
+            for (int i = 0; i < L; ++i) s += (double)xb[i];
+            const float mean = (float)(s / (double)L);
+            for (int t = 0; t < T; ++t) {
+                for (int n = 0; n < N; ++n) {
+                    long long sidx = (long long)t * hop - pad + n;
+                    float v = (sidx >= 0 && sidx < L) ? (xb[sidx] - mean) : 0.0f;
+                    re[n] = (double)(v * w[n]);
+                    im[n] = 0.0;
+                }
+                fft_c2c(re, im, N, cs, sn);
+                for (int k = 0; k < F; ++k) {
+                    const double pw = re[k] * re[k] + im[k] * im[k];
+                    double* row = acc + (size_t)k * M;
+                    for (int m = 0; m < M; ++m) row[m] += pw * gm[((size_t)b * M + m) * T + t];
+                }
+            }
+        }
+#pragma omp critical
+        if (acc) for (size_t i = 0; i < (size_t)F * M; ++i) grad_fb[i] += acc[i];
+        free(re); free(im); free(acc);
+    }
+    free(w); free(cs); free(sn);
+    return rc;
+}
+
 /* naive DFT for transform lengths that are not powers of two (non-optimized DSPEC with arbitrary n_points) */
 static void dft_c2c(const double* re, const double* im, int n, double* ore, double* oim)
 {

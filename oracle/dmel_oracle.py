@@ -48,6 +48,8 @@ def lib():
         L.dmel_oracle_backward.restype = C.c_double
         L.dmel_oracle_spectrogram.argtypes = [fp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, fp]
         L.dmel_oracle_spectrogram.restype = C.c_int
+        L.dmel_oracle_fbgrad.argtypes = [fp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, dp, C.c_int, dp]
+        L.dmel_oracle_fbgrad.restype = C.c_int
         L.dmel_oracle_dspec.argtypes = [fp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, fp, fp]
         L.dmel_oracle_dspec.restype = C.c_int
         _lib = L
@@ -117,6 +119,27 @@ def spectrogram(x: np.ndarray, lambd: float, hop: int, normalize_window: bool = 
     rc = lib().dmel_oracle_spectrogram(_fp(x), B, L, np.float32(lambd), hop, int(normalize_window), int(remove_dc), _fp(spec))
     assert rc == 0
     return spec
+
+
+def backward_fb(x: np.ndarray, lambd: float, hop: int, grad_out: np.ndarray, out: np.ndarray | None = None,
+                normalize_window: bool = False) -> np.ndarray:
+    """d loss / d mel_fb, (n_fft/2+1, n_mels) fp64: adjoint of models.py:53.  ``out`` = the LOG output (models.py:73)
+    when the loss was taken on log(mel + eps); None for the linear layer."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    B, L = x.shape
+    g = np.asarray(grad_out, dtype=np.float64).reshape(B, -1, L // hop + 1)
+    if out is not None:
+        g = g * np.exp(-np.asarray(out, dtype=np.float64).reshape(g.shape))      # d log(s + eps) = ds / (s + eps)
+    g = np.ascontiguousarray(g)
+    M = g.shape[1]
+    N = n_fft(lambd)
+    gfb = np.empty((N // 2 + 1, M), np.float64)
+    dp = C.POINTER(C.c_double)
+    rc = lib().dmel_oracle_fbgrad(_fp(x), B, L, np.float32(lambd), hop, int(normalize_window), g.ctypes.data_as(dp), M,
+                                  gfb.ctypes.data_as(dp))
+    if rc != 0:
+        raise RuntimeError(f"dmel_oracle_fbgrad failed rc={rc}")
+    return gfb
 
 
 def dspec(x: np.ndarray, lambd: float, hop: int = 1, normalize_window: bool = False):

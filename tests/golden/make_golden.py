@@ -119,6 +119,40 @@ def run_dspec(models, tf):
     return dict(spec=s.detach().numpy().astype(np.float32), dlam_lin=np.float32(dl.item()))
 
 
+FBGRAD_CASES = ("g1_c1", "g2_c2", "g5_n128", "g6_n256_ragged")
+
+
+def run_fbgrad(models, tf, case):
+    """G8b: d loss / d mel_fb out of the reference's own forward + torch autograd, with the filterbank of
+    models.py:42-48 made a leaf (the stand-in hands the same leaf tensor to every per-sample call, so the
+    per-sample gradients accumulate exactly as they would for a shared parameter)."""
+    import torchaudio.functional as taf
+    x = torch.from_numpy(C.make_input(case))
+    g = torch.from_numpy(C.make_cotangent(case))
+    layer = models.MelSpectrogramLayer(
+        init_lambd=torch.tensor(float(case["lambd"]), dtype=torch.float32),
+        n_mels=case["n_mels"], n_points=case["L"], sample_rate=case["sr"],
+        f_min=case["f_min"], f_max=case["f_max"], hop_length=case["hop"], device="cpu",
+        optimized=case["optimized"], normalize_window=case["normalize_window"])
+    leaf = {}
+    orig = taf.melscale_fbanks
+
+    def shared_leaf(*a, **k):
+        if "fb" not in leaf:
+            leaf["fb"] = orig(*a, **k).detach().clone().requires_grad_(True)
+        return leaf["fb"]
+
+    taf.melscale_fbanks = shared_leaf
+    try:
+        mel = layer(x)
+        y = torch.log(mel + 1e-10)
+        (g_log,) = torch.autograd.grad((y * g).sum(), leaf["fb"], retain_graph=True)
+        (g_lin,) = torch.autograd.grad((mel * g).sum(), leaf["fb"])
+    finally:
+        taf.melscale_fbanks = orig
+    return dict(gfb_lin=g_lin.numpy().astype(np.float32), gfb_log=g_log.numpy().astype(np.float32))
+
+
 def run_net_keys(models):
     """state_dict keys + shapes of the reference's wrapping nets (models.py:58-136): the checkpoint contract."""
     import json
@@ -138,10 +172,12 @@ def main(argv):
         argv = [a for a in argv if a != "net_keys"]
         if len(argv) == 1 and "net_keys" in sys.argv:
             return
-    names = argv[1:] or [c["name"] for c in C.CASES] + ["g7_dspec"]
+    names = argv[1:] or [c["name"] for c in C.CASES] + ["g7_dspec"] + ["g8_fbgrad_" + n for n in FBGRAD_CASES]
     for name in names:
         if name == "g7_dspec":
             out = run_dspec(models, tf)
+        elif name.startswith("g8_fbgrad_"):
+            out = run_fbgrad(models, tf, C.BY_NAME[name[len("g8_fbgrad_"):]])
         else:
             out = run_case(models, tf, C.BY_NAME[name])
         path = os.path.join(HERE, name + ".npz")

@@ -422,3 +422,92 @@ def test_native_scalar_allreduce_world1():
         assert torch.equal(b.cpu(), torch.full((4,), 2.0 * (i + 1) + 1.0))
     assert all(0 <= t < 64 for t in tickets)
     comm.close()
+
+
+# ---- gradient w.r.t. the filterbank ("mel params", adjoint of models.py:53) ------------------------------------
+def _gfb_err(got, exp):
+    return float(np.abs(got.astype(np.float64) - exp).max() / (np.abs(exp).max() + 1e-30))
+
+
+@pytest.mark.parametrize("name", ["g1_c1", "g2_c2", "g5_n128", "g6_n256_ragged"])
+def test_fbgrad_matches_reference_golden(name):
+    """dmel_backward_fb against torch autograd through the reference with mel_fb made a leaf (g8_fbgrad_*.npz)
+    and against the fp64 oracle."""
+    import os
+    from dmel_amd import capi
+    case = C.BY_NAME[name]
+    gold = np.load(os.path.join(os.path.dirname(C.__file__), f"g8_fbgrad_{name}.npz"))
+    x_np = C.make_input(case).astype(np.float32)
+    g_np = C.make_cotangent(case)
+    x = torch.from_numpy(x_np).to("cuda:0")
+    g = torch.from_numpy(g_np).to("cuda:0")
+    plan = capi.Plan(case["L"], case["hop"], case["n_mels"], case["sr"], case["f_min"], case["f_max"], case["normalize_window"])
+    st = torch.cuda.current_stream().cuda_stream
+    n = capi.n_fft(case["lambd"])
+    y = torch.empty(C.out_shape(case), dtype=torch.float32, device="cuda:0")
+    plan.forward(x.data_ptr(), case["B"], case["lambd"], y.data_ptr(), None, True, 1e-10, st)
+    for log, key in ((False, "gfb_lin"), (True, "gfb_log")):
+        gfb = torch.full((n // 2 + 1, case["n_mels"]), float("nan"), dtype=torch.float32, device="cuda:0")
+        plan.backward_fb(x.data_ptr(), case["B"], case["lambd"], g.data_ptr(), y.data_ptr() if log else None, gfb.data_ptr(), log, st)
+        torch.cuda.synchronize()
+        got = gfb.cpu().numpy()
+        assert np.isfinite(got).all()
+        assert _gfb_err(got, gold[key].astype(np.float64)) <= TOL
+        ref = O.backward_fb(x_np, case["lambd"], case["hop"], g_np, y.cpu().numpy() if log else None, case["normalize_window"])
+        assert _gfb_err(got, ref) <= TOL
+        # deterministic: same bits on a second call
+        gfb2 = torch.empty_like(gfb)
+        plan.backward_fb(x.data_ptr(), case["B"], case["lambd"], g.data_ptr(), y.data_ptr() if log else None, gfb2.data_ptr(), log, st)
+        assert torch.equal(gfb, gfb2)
+
+
+def test_learnable_filterbank_layer():
+    from dmel_amd import MelSpectrogramLayer, capi
+    case = C.BY_NAME["g1_c1"]
+    x_np = C.make_input(case).astype(np.float32)
+    g_np = C.make_cotangent(case)
+    x = torch.from_numpy(x_np).to("cuda:0")
+    g = torch.from_numpy(g_np).to("cuda:0")
+    base = _layer(case, log=True)
+    lay = MelSpectrogramLayer(torch.tensor(float(case["lambd"])), n_mels=case["n_mels"], n_points=case["L"], sample_rate=case["sr"],
+                              hop_length=case["hop"], device="cuda:0", optimized=True, log=True, learnable_fb=True).to("cuda:0")
+    assert sorted(k for k, _ in lay.named_parameters()) == ["lambd", "mel_fb"]
+    assert sorted(base.state_dict().keys()) == ["lambd"]                      # default layer keeps the reference's checkpoint keys
+    n = capi.n_fft(case["lambd"])
+    assert tuple(lay.mel_fb.shape) == (n // 2 + 1, case["n_mels"])
+    y0, y1 = base(x), lay(x)
+    assert float((y0 - y1).detach().abs().max()) <= 1e-5                       # same bank, dense tables instead of banded ones
+    (y1 * g).sum().backward()
+    (y0 * g).sum().backward()
+    assert abs(float(lay.lambd.grad) - float(base.lambd.grad)) <= 1e-4 * abs(float(base.lambd.grad)) + 1e-6
+    ref = O.backward_fb(x_np, case["lambd"], case["hop"], g_np, y1.detach().cpu().numpy())
+    assert _gfb_err(lay.mel_fb.grad.cpu().numpy(), ref) <= TOL
+    # an optimizer step on the bank is picked up by the next forward: compare with spec^T @ fb done by torch
+    with torch.no_grad():
+        lay.mel_fb.add_(0.01 * torch.rand_like(lay.mel_fb))
+    y2 = lay(x).detach()
+    spec = torch.empty((case["B"], n // 2 + 1, lay.n_time), dtype=torch.float32, device="cuda:0")
+    lay._plan_for(x.device).spectrogram(x.data_ptr(), case["B"], case["lambd"], spec.data_ptr(), torch.cuda.current_stream().cuda_stream, remove_dc=True)
+    ref2 = torch.log(torch.einsum("bft,fm->bmt", spec.double(), lay.mel_fb.detach().double()) + 1e-10).unsqueeze(1)
+    assert float((y2.double() - ref2).abs().max()) <= TOL
+    # the bank is tied to its n_fft
+    with torch.no_grad():
+        lay.lambd.fill_(3.0 * float(case["lambd"]))
+    with pytest.raises(RuntimeError, match="tied to one n_fft"):
+        lay(x)
+
+
+def test_backward_fb_rejects_bad_arguments():
+    from dmel_amd import capi
+    plan = capi.Plan(4000, 40, 20, 8000)
+    x = torch.zeros((2, 4000), device="cuda:0")
+    g = torch.zeros((2, 1, 20, 101), device="cuda:0")
+    gfb = torch.zeros((33, 20), device="cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    with pytest.raises(capi.DmelError):
+        plan.backward_fb(x.data_ptr(), 2, 9.0, g.data_ptr(), None, gfb.data_ptr(), True, st)        # log without the saved output
+    with pytest.raises(capi.DmelError):
+        plan.backward_fb(x.data_ptr(), 2, 1000.0, g.data_ptr(), None, gfb.data_ptr(), False, st)    # n_fft 8192
+    plan.backward_fb(x.data_ptr(), 0, 9.0, g.data_ptr(), None, gfb.fill_(1.0).data_ptr(), False, st)   # empty batch: zeros
+    torch.cuda.synchronize()
+    assert float(gfb.abs().max()) == 0.0

@@ -102,3 +102,29 @@ def test_dspec_oracle_matches_reference():
     g = synth.cotangent(spec.shape, seed=78)
     d = O.backward(g, tan)
     assert abs(d - float(gold["dlam_lin"])) <= TOL * abs(float(gold["dlam_lin"]))
+
+
+FBGRAD_CASES = ("g1_c1", "g2_c2", "g5_n128", "g6_n256_ragged")
+
+
+def _gfb_err(got, exp):
+    # one scale for the whole matrix: rows far above the band edge are sums of tiny, cancelling terms
+    return float(np.abs(got - exp).max() / (np.abs(exp).max() + 1e-30))
+
+
+@pytest.mark.parametrize("name", FBGRAD_CASES)
+def test_oracle_fbgrad_matches_reference(name):
+    """d loss / d mel_fb (the adjoint of models.py:53) against torch autograd through the reference's own forward
+    with the filterbank made a leaf (tests/golden/make_golden.py: run_fbgrad)."""
+    import os
+    case = C.BY_NAME[name]
+    gold = np.load(os.path.join(os.path.dirname(C.__file__), f"g8_fbgrad_{name}.npz"))
+    x = C.make_input(case).astype(np.float32)
+    g = C.make_cotangent(case)
+    got_lin = O.backward_fb(x, case["lambd"], case["hop"], g, None, case["normalize_window"])
+    assert got_lin.shape == gold["gfb_lin"].shape
+    assert _gfb_err(got_lin, gold["gfb_lin"]) <= 1e-4
+    y, _ = O.forward(x, case["lambd"], case["hop"], case["n_mels"], case["sr"], case["f_min"], case["f_max"],
+                     case["normalize_window"], apply_log=True, want_tangent=False)
+    got_log = O.backward_fb(x, case["lambd"], case["hop"], g, y, case["normalize_window"])
+    assert _gfb_err(got_log, gold["gfb_log"]) <= 1e-4
