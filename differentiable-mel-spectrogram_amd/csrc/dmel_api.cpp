@@ -60,9 +60,12 @@ struct NfftTables {
     int ent_b_floats = 0;
     int4* tile_ranges = nullptr;
     float* fb_dense = nullptr;   // (F, M) for the direct-DFT kernel
+    float2* tw_long = nullptr;   // long transforms: (N/2) twiddles, (M, F) transposed bank, (M) bands
+    float* fbT = nullptr;
+    int2* band = nullptr;
     void release()
     {
-        void* ptrs[] = {tw1, tw2, ent_b, ent_pre, tile_ranges, fb_dense};
+        void* ptrs[] = {tw1, tw2, ent_b, ent_pre, tile_ranges, fb_dense, tw_long, fbT, band};
         for (void* q : ptrs) (void)hipFree(q);
         *this = NfftTables();
     }
@@ -137,7 +140,30 @@ dmel_status build_tables(dmel_plan* pl, int N, NfftTables** out)
     DMEL_HIP(hipMalloc(&tb.fb_dense, fb.size() * sizeof(float)));
     DMEL_HIP(hipMemcpy(tb.fb_dense, fb.data(), fb.size() * sizeof(float), hipMemcpyHostToDevice));
 
-    if (N >= dmel::kMinFastNfft) {
+    if (N > dmel::kMaxFastNfft) {
+        std::vector<float2> tw((size_t)N / 2);
+        for (int k = 0; k < N / 2; ++k) {
+            const double th = -2.0 * M_PI * (double)k / (double)N;
+            tw[k] = make_float2((float)std::cos(th), (float)std::sin(th));
+        }
+        std::vector<float> fbT((size_t)M * tb.F);
+        std::vector<int2> band(M);
+        for (int m = 0; m < M; ++m) {
+            int lo = tb.F, hi = 0;
+            for (int f = 0; f < tb.F; ++f) {
+                const float c = fb[(size_t)f * M + m];
+                fbT[(size_t)m * tb.F + f] = c;
+                if (c != 0.f) { lo = std::min(lo, f); hi = f + 1; }
+            }
+            band[m] = make_int2(hi > lo ? lo : 0, hi > lo ? hi : 0);
+        }
+        DMEL_HIP(hipMalloc(&tb.tw_long, tw.size() * sizeof(float2)));
+        DMEL_HIP(hipMemcpy(tb.tw_long, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
+        DMEL_HIP(hipMalloc(&tb.fbT, fbT.size() * sizeof(float)));
+        DMEL_HIP(hipMemcpy(tb.fbT, fbT.data(), fbT.size() * sizeof(float), hipMemcpyHostToDevice));
+        DMEL_HIP(hipMalloc(&tb.band, band.size() * sizeof(int2)));
+        DMEL_HIP(hipMemcpy(tb.band, band.data(), band.size() * sizeof(int2), hipMemcpyHostToDevice));
+    } else if (N >= dmel::kMinFastNfft) {
         int R = 0, C = 0;
         switch (N) {
             case 32: R = 4; C = 2; break;   case 64: R = 8; C = 1; break;
@@ -267,7 +293,7 @@ dmel_status run_forward_nolock(dmel_plan* pl, const float* x, int batch, float l
     if (n_fft_override > 0 && (N & (N - 1)))
         return fail(DMEL_ERR_UNSUPPORTED, "n_fft = " + std::to_string(N) + " is not a power of two");
     if (N > dmel::kMaxNfft)
-        return fail(DMEL_ERR_UNSUPPORTED, "n_fft = " + std::to_string(N) + " > 4096 (|lambd| > 682.6) is not supported by the HIP kernels");
+        return fail(DMEL_ERR_UNSUPPORTED, "n_fft = " + std::to_string(N) + " > 16384 (|lambd| > 2730.6) is not supported by the HIP kernels");
     NfftTables* tb = nullptr;
     dmel_status st = build_tables(pl, N, &tb);
     if (st != DMEL_OK) return st;
@@ -285,7 +311,7 @@ dmel_status run_forward_nolock(dmel_plan* pl, const float* x, int batch, float l
     // The fused kernel builds its own window table (n_fft <= 2048) and, for clips up to 32768 samples, its
     // own clip mean; the prep kernel only runs for what is left: partial sums of long clips, the window
     // table of n_fft 4096, and everything the direct-DFT kernel (n_fft < 32) needs.
-    const bool fast = N >= dmel::kMinFastNfft;
+    const bool fast = N >= dmel::kMinFastNfft && N <= dmel::kMaxFastNfft;
     const bool kernel_mean = fast && pl->cfg.n_points <= 32768;
     const bool need_sums = remove_dc && !kernel_mean;
     const bool need_window = !fast || N > 2048;
@@ -313,6 +339,22 @@ dmel_status run_forward_nolock(dmel_plan* pl, const float* x, int batch, float l
         prof_span(pl, m1, prof_mark(pl, s), 1);
         pl->info.kernel_path = 1; pl->info.frames_per_tile = 1; pl->info.grid_fwd = batch * pl->T;
         pl->info.fb_blocks = 0; pl->info.fb_blocks_dense = 0; pl->info.lds_bytes = (2 * N + 2 * tb->F) * 4;
+        return DMEL_OK;
+    }
+    if (N > dmel::kMaxFastNfft) {
+        dmel::LongParams lp{};
+        lp.x = x; lp.out = out; lp.tangent = tangent; lp.psum = pl->psum; lp.win2 = reinterpret_cast<const float2*>(pl->win);
+        lp.tw = tb->tw_long; lp.fbT = tb->fbT; lp.band = tb->band;
+        lp.B = batch; lp.L = pl->cfg.n_points; lp.T = pl->T; lp.hop = pl->cfg.hop_length; lp.M = pl->cfg.n_mels;
+        lp.nchunks = pl->nchunks; lp.N = N; lp.F = tb->F; lp.mode = mode;
+        lp.logN = 0; while ((1 << lp.logN) < N) ++lp.logN;
+        lp.inv_L = 1.0f / (float)pl->cfg.n_points; lp.sign = sign; lp.eps = (float)eps; lp.flags = flags; lp.remove_dc = remove_dc;
+        DMEL_HIP(dmel::launch_long(lp, s));
+        prof_span(pl, m1, prof_mark(pl, s), 1);
+        const bool pair = (mode == dmel::kInfer || mode == dmel::kSpec);
+        pl->info.kernel_path = 2; pl->info.frames_per_tile = pair ? 2 : 1;
+        pl->info.grid_fwd = batch * (pair ? (pl->T + 1) / 2 : pl->T);
+        pl->info.fb_blocks = 0; pl->info.fb_blocks_dense = 0; pl->info.lds_bytes = N * 8;
         return DMEL_OK;
     }
     dmel::FwdParams fp{};
@@ -445,6 +487,7 @@ dmel_status dmel_plan_create(const dmel_config* cfg, dmel_plan** plan)
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(DMEL_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", libdmel_hip is built for gfx950 only");
     DMEL_HIP(dmel::forward_prepare_attributes());
+    DMEL_HIP(dmel::long_prepare_attributes());
     dmel_plan* pl = new (std::nothrow) dmel_plan();
     if (!pl) return fail(DMEL_ERR_OUT_OF_MEMORY, "host allocation failed");
     pl->cfg = *cfg;
@@ -482,7 +525,7 @@ dmel_status dmel_plan_set_filterbank(dmel_plan* plan, int32_t n_fft, const float
 {
     if (!plan) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
     if (n_fft < 1 || n_fft > dmel::kMaxNfft || (n_fft & (n_fft - 1)))
-        return fail(DMEL_ERR_INVALID_ARGUMENT, "n_fft must be a power of two in [1, 4096]");
+        return fail(DMEL_ERR_INVALID_ARGUMENT, "n_fft must be a power of two in [1, 16384]");
     std::lock_guard<std::mutex> lock(plan->mu);
     DMEL_HIP(hipDeviceSynchronize());     // tables of this n_fft may be in use by queued kernels
     auto it = plan->tables.find(n_fft);
@@ -503,7 +546,7 @@ dmel_status dmel_forward(dmel_plan* plan, const float* x, int32_t batch, float l
         if (!plan) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
         const int L = plan->cfg.n_points;
         if ((L & (L - 1)) || 2 * L > dmel::kMaxNfft)
-            return fail(DMEL_ERR_UNSUPPORTED, "DMEL_FLAG_FULL_WINDOW needs n_points to be a power of two <= 2048");
+            return fail(DMEL_ERR_UNSUPPORTED, "DMEL_FLAG_FULL_WINDOW needs n_points to be a power of two <= 8192");
         return run_forward(plan, x, batch, lambd, flags & ~DMEL_FLAG_FULL_WINDOW, eps, out, tangent,
                            tangent ? dmel::kTrain : dmel::kInfer, 1, stream, 2 * L, 1);
     }
@@ -552,12 +595,12 @@ dmel_status dmel_backward_fb(dmel_plan* plan, const float* x, int32_t batch, flo
     if (flags & DMEL_FLAG_FULL_WINDOW) {
         const int L = plan->cfg.n_points;
         if ((L & (L - 1)) || 2 * L > dmel::kMaxNfft)
-            return fail(DMEL_ERR_UNSUPPORTED, "DMEL_FLAG_FULL_WINDOW needs n_points to be a power of two <= 2048");
+            return fail(DMEL_ERR_UNSUPPORTED, "DMEL_FLAG_FULL_WINDOW needs n_points to be a power of two <= 8192");
         n_over = 2 * L; win_half = 1;
     }
     const int N = n_over ? n_over : dmel_n_fft(lambd);
     if (N > dmel::kMaxNfft)
-        return fail(DMEL_ERR_UNSUPPORTED, "n_fft = " + std::to_string(N) + " > 4096 (|lambd| > 682.6) is not supported by the HIP kernels");
+        return fail(DMEL_ERR_UNSUPPORTED, "n_fft = " + std::to_string(N) + " > 16384 (|lambd| > 2730.6) is not supported by the HIP kernels");
     const int F = N / 2 + 1, M = plan->cfg.n_mels, T = plan->T;
     std::lock_guard<std::mutex> lock(plan->mu);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -169,6 +169,137 @@ hipError_t launch_naive(const NaiveParams& p, hipStream_t s)
     return hipGetLastError();
 }
 
+// ---- long transforms -----------------------------------------------------------------------------
+// n_fft 8192 and 16384 (|lambd| > 682.6 samples: windows of 0.5 s and more) do not fit the register-resident wave FFT.
+// One workgroup of 1024 threads transforms one complex sequence of N points held in LDS (128 KB at N = 16384): in-place
+// radix-2 decimation in frequency, log2 N barrier-separated stages, spectrum left in bit-reversed order and read
+// back through __brev.  Same packing as the fused kernel: training mode transforms x~ w + i x~ w' (one frame and its
+// lambd-tangent), inference / spectrogram modes transform two frames at once; the pairing pass is identical.  The
+// mel stage is a band-limited dot product per mel band (one wave per band, fixed-order reduction).  A correctness
+// path for rarely reached sizes, not a tuned one.
+constexpr int kLongThreads = 1024;
+
+__device__ __forceinline__ float wave_sum_shfl(float v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);       // same tree on every lane and every run
+    return v;
+}
+
+__global__ void __launch_bounds__(kLongThreads) dmel_long_kernel(LongParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* Z = reinterpret_cast<float2*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = p.N, F = p.F, sh = 32 - p.logN;
+    const bool pair = (p.mode == kInfer || p.mode == kSpec);
+    const int tiles = pair ? (p.T + 1) / 2 : p.T;
+    const int b = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const int tA = pair ? 2 * tile : tile, tB = tA + 1;
+    const float* xb = p.x + (size_t)b * p.L;
+    float mean = 0.f;
+    if (p.remove_dc) {
+        double s = 0.0;
+        for (int c = 0; c < p.nchunks; ++c) s += (double)p.psum[(size_t)b * p.nchunks + c];
+        mean = (float)(s * (double)p.inv_L);
+    }
+    for (int n = tid; n < N; n += kLongThreads) {
+        const long long ia = (long long)tA * p.hop - N / 2 + n;
+        const float va = (ia >= 0 && ia < p.L) ? (xb[ia] - mean) : 0.f;      // zero padding after the DC removal
+        const float2 wd = p.win2[n];
+        if (pair) {
+            const long long ib = ia + p.hop;
+            const float vb = (tB < p.T && ib >= 0 && ib < p.L) ? (xb[ib] - mean) : 0.f;
+            Z[n] = make_float2(va * wd.x, vb * wd.x);
+        } else {
+            Z[n] = make_float2(va * wd.x, va * wd.y);
+        }
+    }
+    __syncthreads();
+    for (int span = N >> 1, tstep = 1; span >= 1; span >>= 1, tstep <<= 1) {
+        for (int i = tid; i < (N >> 1); i += kLongThreads) {
+            const int j = i & (span - 1);
+            const int lo = ((i - j) << 1) + j, hi = lo + span;
+            const float2 a = Z[lo], c = Z[hi];
+            const float2 w = p.tw[j * tstep];                                 // exp(-2 pi i j / (2 span))
+            const float dx = a.x - c.x, dy = a.y - c.y;
+            Z[lo] = make_float2(a.x + c.x, a.y + c.y);
+            Z[hi] = make_float2(fmaf(dx, w.x, -(dy * w.y)), fmaf(dx, w.y, dy * w.x));
+        }
+        __syncthreads();
+    }
+    // pairing pass (see dmel_fwd.hip): PD[k] = (|S|^2, Im(conj S * D)) or (|S|^2, |D|^2), in place at Z[brev(k)];
+    // the two addresses a thread touches belong to no other thread
+    for (int k = tid; k <= (N >> 1); k += kLongThreads) {
+        const unsigned ak = __brev((unsigned)k) >> sh, an = __brev((unsigned)((N - k) & (N - 1))) >> sh;
+        const float2 zk = Z[ak], zn = Z[an];
+        const float sx = zk.x + zn.x, sy = zk.y - zn.y, dx = zk.x - zn.x, dy = zk.y + zn.y;
+        Z[ak] = pair ? make_float2(fmaf(sx, sx, sy * sy), fmaf(dx, dx, dy * dy))
+                     : make_float2(fmaf(sx, sx, sy * sy), fmaf(sx, dy, -(sy * dx)));
+    }
+    __syncthreads();
+    if (p.mode == kSpec || p.mode == kSpecTrain) {
+        for (int k = tid; k < F; k += kLongThreads) {
+            const float2 pd = Z[__brev((unsigned)k) >> sh];
+            const size_t o = ((size_t)b * F + k) * p.T;
+            if (p.mode == kSpec) {
+                p.out[o + tA] = 0.25f * pd.x;
+                if (tB < p.T) p.out[o + tB] = 0.25f * pd.y;
+            } else {
+                p.out[o + tA] = 0.25f * pd.x;
+                if (p.tangent) p.tangent[o + tA] = 0.5f * p.sign * pd.y;
+            }
+        }
+        return;
+    }
+    const bool do_log = (p.flags & 1u) != 0;
+    for (int m = wave; m < p.M; m += kLongThreads / 64) {
+        const int2 bd = p.band[m];
+        const float* fr = p.fbT + (size_t)m * F;
+        float s0 = 0.f, s1 = 0.f;
+        for (int k = bd.x + lane; k < bd.y; k += 64) {
+            const float c = fr[k];
+            const float2 pd = Z[__brev((unsigned)k) >> sh];
+            s0 = fmaf(c, pd.x, s0);
+            s1 = fmaf(c, pd.y, s1);
+        }
+        s0 = wave_sum_shfl(s0);
+        s1 = wave_sum_shfl(s1);
+        if (lane != 0) continue;
+        const size_t o = ((size_t)b * p.M + m) * p.T;
+        if (pair) {
+            const float ma = 0.25f * s0, mb = 0.25f * s1;
+            p.out[o + tA] = do_log ? logf(ma + p.eps) : ma;
+            if (tB < p.T) p.out[o + tB] = do_log ? logf(mb + p.eps) : mb;
+        } else {
+            const float mel = 0.25f * s0, dmel = 0.5f * p.sign * s1;
+            if (do_log) {
+                const float me = mel + p.eps;
+                p.out[o + tA] = logf(me);
+                if (p.tangent) p.tangent[o + tA] = dmel / me;
+            } else {
+                p.out[o + tA] = mel;
+                if (p.tangent) p.tangent[o + tA] = dmel;
+            }
+        }
+    }
+}
+
+hipError_t long_prepare_attributes()
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(dmel_long_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               kMaxNfft * (int)sizeof(float2));
+}
+
+hipError_t launch_long(const LongParams& p, hipStream_t s)
+{
+    const bool pair = (p.mode == kInfer || p.mode == kSpec);
+    const long long tiles = pair ? (p.T + 1) / 2 : p.T;
+    const long long grid = tiles * p.B;
+    if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(dmel_long_kernel, dim3((unsigned)grid), dim3(kLongThreads), (size_t)p.N * sizeof(float2), s, p);
+    return hipGetLastError();
+}
+
 // ---- filterbank gradient ----------------------------------------------------------------------
 // grad_fb = sum over clips of  spec_b (F x T) * gm_b^T (T x M): per clip a small GEMM whose K dimension (time) is
 // contiguous in both operands.  One workgroup owns a 32 (freq) x 128 (mel) tile of grad_fb for one slice of the

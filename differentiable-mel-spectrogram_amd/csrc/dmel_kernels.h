@@ -8,7 +8,8 @@ namespace dmel {
 constexpr int kWave = 64;
 constexpr int kThreads = 256;          // prep / dot kernels
 constexpr int kMaxChunks = 64;         // partial sums per clip for the DC removal
-constexpr int kMaxNfft = 4096;
+constexpr int kMaxFastNfft = 4096;     // largest transform of the fused wave-FFT kernel
+constexpr int kMaxNfft = 16384;        // largest transform overall: above kMaxFastNfft the one-frame-per-workgroup LDS FFT runs
 constexpr int kMinFastNfft = 32;       // below this the direct-DFT kernel runs
 
 enum Mode : int { kTrain = 0, kInfer = 1, kSpec = 2, kSpecTrain = 3 };   // kSpec*: power spectrogram (B,F,T), no mel stage
@@ -110,6 +111,18 @@ struct NaiveParams {
     float inv_L, sign, eps; unsigned flags; int remove_dc;
 };
 hipError_t launch_naive(const NaiveParams& p, hipStream_t s);
+
+// long transforms (4096 < n_fft <= 16384, |lambd| up to 2730 samples): one workgroup per frame (pair), radix-2 FFT in LDS
+struct LongParams {
+    const float* x; float* out; float* tangent; const float* psum; const float2* win2;
+    const float2* tw;        // (N/2): exp(-2 pi i k / N)
+    const float* fbT;        // (M, F): filterbank transposed, so that one band is contiguous
+    const int2* band;        // (M): [first, last+1) non-zero rows of every filterbank column
+    int B, L, T, hop, M, nchunks, N, F, mode, logN;
+    float inv_L, sign, eps; unsigned flags; int remove_dc;
+};
+hipError_t launch_long(const LongParams& p, hipStream_t s);
+hipError_t long_prepare_attributes();
 
 // gradient w.r.t. the filterbank matrix of models.py:53 (adjoint of  mel = spec^T @ fb):
 //   grad_fb[f][m] = sum_{b,t} spec[b][f][t] * gm[b][m][t],   gm = grad_out            (linear output)

@@ -155,10 +155,10 @@ class MelSpectrogramLayer(nn.Module):
         if n_points != self.n_points:
             # the reference fails here too (RuntimeError from the slice-assign at models.py:54)
             raise RuntimeError(f"input has {n_points} points, the layer was built for n_points={self.n_points}")
-        if not self.optimized and (n_points & (n_points - 1) or n_points > 2048):
+        if not self.optimized and (n_points & (n_points - 1) or n_points > 8192):
             raise NotImplementedError(
                 "optimized=False (window = whole signal, n_fft = 2*n_points; time_frequency.py:41,51) runs on the HIP path "
-                "only for power-of-two n_points <= 2048; construct the layer with optimized=True as all mel experiments "
+                "only for power-of-two n_points <= 8192; construct the layer with optimized=True as all mel experiments "
                 "do (search_spaces.py:11,44)")
         if not x.is_cuda:
             raise RuntimeError("dmel_amd runs on MI355X only: x must be a CUDA/HIP tensor (no CPU fallback)")
@@ -225,7 +225,7 @@ class SpectrogramLayer(nn.Module):
     Signature-compatible with the reference (models.py:171-200):
         SpectrogramLayer(init_lambd, device='cpu', optimized=False, size=(512, 1024), hop_length=1, normalize_window=False)
     ``optimized=False``: window = whole signal, n_fft = 2*n_points (time_frequency.py:41,51), output
-    ``(B, 1, n_points + 1, n_points // hop_length + 1)``; n_points must be a power of two <= 2048.
+    ``(B, 1, n_points + 1, n_points // hop_length + 1)``; n_points must be a power of two <= 8192.
     ``optimized=True``: n_fft = next_pow2(int(6*|lambd|)) and the output must have the shape ``size``.
     """
 
@@ -257,8 +257,8 @@ class SpectrogramLayer(nn.Module):
                 raise RuntimeError(f"size={tuple(self.size)} but the spectrogram is {expect}")
         else:
             n_fft, half = 2 * n_points, True
-            if n_fft & (n_fft - 1) or n_fft > 4096 or n_fft < 2:
-                raise NotImplementedError(f"optimized=False needs n_points to be a power of two <= 2048 on the HIP path, got {n_points}")
+            if n_fft & (n_fft - 1) or n_fft > 16384 or n_fft < 2:
+                raise NotImplementedError(f"optimized=False needs n_points to be a power of two <= 8192 on the HIP path, got {n_points}")
         key = (x.device.index, n_points)
         plan = self._plans.get(key)
         if plan is None:

@@ -32,7 +32,7 @@ extern "C" {
 typedef enum dmel_status {
     DMEL_OK = 0,
     DMEL_ERR_INVALID_ARGUMENT = 1,  /* bad shape / null pointer / negative size          */
-    DMEL_ERR_UNSUPPORTED = 2,       /* n_fft outside [1, 4096] for the HIP kernels        */
+    DMEL_ERR_UNSUPPORTED = 2,       /* n_fft outside [1, 16384] for the HIP kernels       */
     DMEL_ERR_HIP = 3,               /* a HIP runtime call failed (message has the detail) */
     DMEL_ERR_NO_DEVICE = 4,         /* no gfx950 device visible                           */
     DMEL_ERR_OUT_OF_MEMORY = 5
@@ -55,7 +55,7 @@ typedef struct dmel_plan dmel_plan;
 /* Flags for dmel_forward */
 #define DMEL_FLAG_LOG 1u       /* fuse out = log(mel + eps)                        models.py:73 */
 #define DMEL_FLAG_FULL_WINDOW 2u /* the layer's optimized=False branch: window = whole clip, n_fft = 2*n_points
-                                  (time_frequency.py:41,51); n_points must be a power of two <= 2048     */
+                                  (time_frequency.py:41,51); n_points must be a power of two <= 8192     */
 
 /* ---- host-side helpers (no device needed) ------------------------------------------------- */
 
@@ -143,7 +143,7 @@ dmel_status dmel_spectrogram(dmel_plan* plan, const float* x, int32_t batch, flo
  *   n_fft   0: derive from lambd (optimized branch, :39); otherwise the transform length to use --
  *           the non-optimized branch (:41,:51) is n_fft = 2 * n_points with DMEL_SPEC_HALF_WINDOW
  *           (torch.stft zero-pads the win_length = n_points window to n_fft on both sides).
- *           Must be a power of two <= 4096.
+ *           Must be a power of two <= 16384.
  *   spec, tangent   device, (batch, n_fft/2+1, n_time) fp32; tangent may be NULL.
  */
 #define DMEL_SPEC_REMOVE_DC 1u      /* models.py:187: x[idx] - mean(x[idx])                          */
@@ -179,7 +179,7 @@ typedef struct dmel_plan_info {
     int32_t fb_blocks;         /* non-zero 4x16 filterbank blocks fed to the MFMA loop      */
     int32_t fb_blocks_dense;   /* the same count for a dense matrix                         */
     int32_t lds_bytes;         /* dynamic LDS of the fused kernel                           */
-    int32_t kernel_path;       /* 0 = wave-FFT + MFMA kernel, 1 = direct-DFT kernel (n_fft < 32) */
+    int32_t kernel_path;       /* 0 = wave-FFT + MFMA kernel, 1 = direct-DFT kernel (n_fft < 32), 2 = LDS FFT (n_fft > 4096) */
 } dmel_plan_info;
 dmel_status dmel_plan_get_info(const dmel_plan* plan, dmel_plan_info* info);
 

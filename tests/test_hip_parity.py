@@ -197,11 +197,11 @@ def test_error_behaviour():
         layer(torch.zeros(case["L"], device="cuda:0"))
     with pytest.raises(RuntimeError):
         layer(torch.zeros(2, case["L"]))      # CPU tensor: no fallback
-    big = _layer(dict(case, lambd=700.0))     # n_fft 8192 > 4096
+    big = _layer(dict(case, lambd=2800.0))    # n_fft 32768 > 16384
     with pytest.raises(capi.DmelError):
         big(torch.zeros(1, case["L"], device="cuda:0"))
     slow = MelSpectrogramLayer(torch.tensor(64.0), 64, case["L"], 16000, hop_length=256, optimized=False).to("cuda:0")
-    with pytest.raises(NotImplementedError):     # optimized=False needs a power-of-two clip <= 2048 on the HIP path
+    with pytest.raises(NotImplementedError):     # optimized=False needs a power-of-two clip <= 8192 on the HIP path
         slow(torch.zeros(1, case["L"], device="cuda:0"))
     # empty batch and non-contiguous / fp64 input are fine
     assert layer(torch.zeros(0, case["L"], device="cuda:0")).shape == (0, 1, case["n_mels"], case["L"] // case["hop"] + 1)
@@ -507,7 +507,65 @@ def test_backward_fb_rejects_bad_arguments():
     with pytest.raises(capi.DmelError):
         plan.backward_fb(x.data_ptr(), 2, 9.0, g.data_ptr(), None, gfb.data_ptr(), True, st)        # log without the saved output
     with pytest.raises(capi.DmelError):
-        plan.backward_fb(x.data_ptr(), 2, 1000.0, g.data_ptr(), None, gfb.data_ptr(), False, st)    # n_fft 8192
+        plan.backward_fb(x.data_ptr(), 2, 3000.0, g.data_ptr(), None, gfb.data_ptr(), False, st)    # n_fft 32768
     plan.backward_fb(x.data_ptr(), 0, 9.0, g.data_ptr(), None, gfb.fill_(1.0).data_ptr(), False, st)   # empty batch: zeros
     torch.cuda.synchronize()
     assert float(gfb.abs().max()) == 0.0
+
+
+# ---- long transforms: n_fft 8192 / 16384 (one frame per workgroup, radix-2 FFT in LDS) ---------------------------
+LONG_CASES = [
+    dict(C.BY_NAME["g6_fminmax"], name="long_8192", L=12000, lambd=700.0, hop=600, n_mels=40),
+    dict(C.BY_NAME["g1_c1"], name="long_16384", B=2, L=20001, lambd=-1500.0, hop=997, n_mels=64, normalize_window=True),
+]
+
+
+@pytest.mark.parametrize("case", LONG_CASES, ids=[c["name"] for c in LONG_CASES])
+def test_long_transform_matches_oracle(case):
+    from dmel_amd import capi
+    x_np = C.make_input(case).astype(np.float32)
+    g_np = C.make_cotangent(case)
+    x = torch.from_numpy(x_np).to("cuda:0")
+    n = capi.n_fft(case["lambd"])
+    assert n in (8192, 16384)
+    for log in (False, True):
+        layer = _layer(case, log=log)
+        y = layer(x)
+        assert layer.plan_info()["kernel_path"] == 2 and layer.plan_info()["n_fft"] == n
+        (y * torch.from_numpy(g_np).to("cuda:0")).sum().backward()
+        o_ref, t_ref = O.forward(x_np, case["lambd"], case["hop"], case["n_mels"], case["sr"], case["f_min"], case["f_max"],
+                                 case["normalize_window"], apply_log=log)
+        o = y.detach().cpu().numpy()
+        assert (_log_err(o, o_ref) if log else _rel_err(o, o_ref)) <= TOL
+        exp_d = O.backward(g_np, t_ref)
+        assert abs(float(layer.lambd.grad) - exp_d) <= _dlam_tol(exp_d, g_np, t_ref)
+        # inference path: two frames per transform
+        with torch.no_grad():
+            yi = _layer(case, log=log, trainable=False)(x)
+        oi = yi.cpu().numpy()
+        assert (_log_err(oi, o_ref) if log else _rel_err(oi, o_ref)) <= TOL
+    # spectrogram stage and filterbank gradient run on the same kernel
+    plan = capi.Plan(case["L"], case["hop"], case["n_mels"], case["sr"], case["f_min"], case["f_max"], case["normalize_window"])
+    st = torch.cuda.current_stream().cuda_stream
+    spec = torch.empty((case["B"], n // 2 + 1, case["L"] // case["hop"] + 1), dtype=torch.float32, device="cuda:0")
+    plan.spectrogram(x.data_ptr(), case["B"], case["lambd"], spec.data_ptr(), st, remove_dc=True)
+    torch.cuda.synchronize()
+    ref = O.spectrogram(x_np, case["lambd"], case["hop"], normalize_window=case["normalize_window"], remove_dc=True)
+    assert _rel_err(spec.cpu().numpy(), ref, floor=1e-5) <= TOL
+    g = torch.from_numpy(g_np).to("cuda:0")
+    gfb = torch.empty((n // 2 + 1, case["n_mels"]), dtype=torch.float32, device="cuda:0")
+    plan.backward_fb(x.data_ptr(), case["B"], case["lambd"], g.data_ptr(), None, gfb.data_ptr(), False, st)
+    torch.cuda.synchronize()
+    assert _gfb_err(gfb.cpu().numpy(), O.backward_fb(x_np, case["lambd"], case["hop"], g_np, None, case["normalize_window"])) <= TOL
+
+
+def test_full_window_branch_up_to_8192_points():
+    """optimized=False (window = whole clip, n_fft = 2 * n_points) at n_points 4096: n_fft 8192 takes the long-transform kernel."""
+    case = dict(C.BY_NAME["g7_mel_nonopt_1024n"], name="nonopt_4096", L=4096, lambd=300.0, hop=256, normalize_window=False)
+    x_np = C.make_input(case).astype(np.float32)
+    layer = _layer(case, log=True)
+    y = layer(torch.from_numpy(x_np).to("cuda:0"))
+    assert layer.plan_info()["kernel_path"] == 2 and layer.plan_info()["n_fft"] == 8192
+    y_ref, _ = O.forward(x_np, case["lambd"], case["hop"], case["n_mels"], case["sr"], case["f_min"], case["f_max"],
+                         case["normalize_window"], apply_log=True, optimized=False)
+    assert _log_err(y.detach().cpu().numpy(), y_ref) <= TOL
