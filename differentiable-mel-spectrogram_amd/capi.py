@@ -20,12 +20,14 @@ DMEL_ERR_NO_DEVICE = 4
 DMEL_ERR_OUT_OF_MEMORY = 5
 DMEL_FLAG_LOG = 1
 DMEL_FLAG_FULL_WINDOW = 2
+DMEL_FLAG_OUT_BF16 = 4
+DMEL_DTYPE_F32, DMEL_DTYPE_BF16 = 0, 1
 
 # every symbol include/dmel.h declares (tests check the library exports exactly these)
 SYMBOLS = (
     "dmel_abi_version", "dmel_n_fft", "dmel_window_host", "dmel_mel_fbanks_host", "dmel_last_error",
     "dmel_device_count", "dmel_plan_create", "dmel_plan_destroy", "dmel_plan_set_filterbank",
-    "dmel_forward", "dmel_backward", "dmel_backward_fb", "dmel_spectrogram", "dmel_plan_get_info",
+    "dmel_forward", "dmel_backward", "dmel_backward_ex", "dmel_backward_fb", "dmel_spectrogram", "dmel_plan_get_info",
     "dmel_plan_set_profiling", "dmel_plan_get_profile", "dmel_spectrogram_ex",
     "dmel_comm_unique_id", "dmel_comm_create", "dmel_comm_destroy", "dmel_comm_allreduce_async", "dmel_comm_wait",
 )
@@ -91,6 +93,8 @@ def load():
     L.dmel_forward.restype = C.c_int
     L.dmel_backward.argtypes = [vp, vp, vp, C.c_int64, C.c_int32, vp, vp]
     L.dmel_backward.restype = C.c_int
+    L.dmel_backward_ex.argtypes = [vp, vp, C.c_int32, vp, C.c_int64, C.c_int32, vp, vp]
+    L.dmel_backward_ex.restype = C.c_int
     L.dmel_backward_fb.argtypes = [vp, vp, C.c_int32, C.c_float, C.c_uint32, vp, vp, vp, vp]
     L.dmel_backward_fb.restype = C.c_int
     L.dmel_spectrogram.argtypes = [vp, vp, C.c_int32, C.c_float, C.c_int32, vp, vp]
@@ -176,8 +180,12 @@ class Plan:
         _check(load().dmel_forward(self._h, x_ptr, batch, C.c_float(float(lambd)),
                                    (DMEL_FLAG_LOG if log else 0) | int(extra_flags), float(eps), out_ptr, tangent_ptr, stream))
 
-    def backward(self, grad_ptr: int, tangent_ptr: int, count: int, dlambd_ptr: int, stream: int, accumulate: bool = False):
-        _check(load().dmel_backward(self._h, grad_ptr, tangent_ptr, int(count), int(accumulate), dlambd_ptr, stream))
+    def backward(self, grad_ptr: int, tangent_ptr: int, count: int, dlambd_ptr: int, stream: int, accumulate: bool = False,
+                 grad_bf16: bool = False):
+        if grad_bf16:
+            _check(load().dmel_backward_ex(self._h, grad_ptr, DMEL_DTYPE_BF16, tangent_ptr, int(count), int(accumulate), dlambd_ptr, stream))
+        else:
+            _check(load().dmel_backward(self._h, grad_ptr, tangent_ptr, int(count), int(accumulate), dlambd_ptr, stream))
 
     def backward_fb(self, x_ptr: int, batch: int, lambd: float, grad_ptr: int, out_ptr: int | None, grad_fb_ptr: int,
                     log: bool, stream: int, extra_flags: int = 0):

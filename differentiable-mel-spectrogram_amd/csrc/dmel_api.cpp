@@ -568,18 +568,27 @@ dmel_status dmel_spectrogram_ex(dmel_plan* plan, const float* x, int32_t batch, 
                        (flags & DMEL_SPEC_REMOVE_DC) ? 1 : 0, stream, n_fft, (flags & DMEL_SPEC_HALF_WINDOW) ? 1 : 0);
 }
 
-dmel_status dmel_backward(dmel_plan* plan, const float* grad_out, const float* tangent, int64_t count,
-                          int32_t accumulate, float* dlambd, void* stream)
+dmel_status dmel_backward_ex(dmel_plan* plan, const void* grad_out, int32_t grad_dtype, const float* tangent, int64_t count,
+                             int32_t accumulate, float* dlambd, void* stream)
 {
     if (!plan) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
     if (count < 0 || !dlambd || (count > 0 && (!grad_out || !tangent)))
         return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_backward: bad arguments");
+    if (grad_dtype != DMEL_DTYPE_F32 && grad_dtype != DMEL_DTYPE_BF16)
+        return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_backward_ex: grad_dtype must be DMEL_DTYPE_F32 or DMEL_DTYPE_BF16");
     std::lock_guard<std::mutex> lock(plan->mu);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const size_t m0 = prof_mark(plan, s);
-    DMEL_HIP(dmel::launch_dot(grad_out, tangent, (long long)count, accumulate, plan->partials, plan->dot_counter, kMaxPartials, dlambd, s));
+    DMEL_HIP(dmel::launch_dot(grad_out, grad_dtype == DMEL_DTYPE_BF16, tangent, (long long)count, accumulate, plan->partials,
+                              plan->dot_counter, kMaxPartials, dlambd, s));
     prof_span(plan, m0, prof_mark(plan, s), 2);
     return DMEL_OK;
+}
+
+dmel_status dmel_backward(dmel_plan* plan, const float* grad_out, const float* tangent, int64_t count,
+                          int32_t accumulate, float* dlambd, void* stream)
+{
+    return dmel_backward_ex(plan, grad_out, DMEL_DTYPE_F32, tangent, count, accumulate, dlambd, stream);
 }
 
 dmel_status dmel_backward_fb(dmel_plan* plan, const float* x, int32_t batch, float lambd, uint32_t flags,

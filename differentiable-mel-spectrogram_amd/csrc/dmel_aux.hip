@@ -37,7 +37,24 @@ __device__ __forceinline__ double block_sum(double v, double* red4)
     return s;
 }
 
-__global__ void __launch_bounds__(kThreads) dmel_dot_kernel(const float* __restrict__ g, const float* __restrict__ t,
+// four consecutive gradient elements as fp32: one 16-byte load (fp32) or one 8-byte load (bf16, exact widening)
+template <bool GBF16> __device__ __forceinline__ float4 load_g4(const void* g, long long i)
+{
+    if constexpr (!GBF16) return reinterpret_cast<const float4*>(g)[i];
+    else {
+        const uint2 v = reinterpret_cast<const uint2*>(g)[i];
+        return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u),
+                           __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+    }
+}
+template <bool GBF16> __device__ __forceinline__ float load_g1(const void* g, long long k)
+{
+    if constexpr (!GBF16) return reinterpret_cast<const float*>(g)[k];
+    else return __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(g)[k] << 16);
+}
+
+template <bool GBF16>
+__global__ void __launch_bounds__(kThreads) dmel_dot_kernel(const void* __restrict__ g, const float* __restrict__ t,
                                                             long long count, double* partials, unsigned* counter,
                                                             int accumulate, float* result)
 {
@@ -46,12 +63,12 @@ __global__ void __launch_bounds__(kThreads) dmel_dot_kernel(const float* __restr
     const int tid = threadIdx.x;
     const long long stride = (long long)gridDim.x * kThreads;
     double acc = 0.0;
-    const long long n4 = ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(t)) & 15) == 0 ? count / 4 : 0;
-    const float4* g4 = reinterpret_cast<const float4*>(g);
+    const uintptr_t galign = GBF16 ? 7 : 15;
+    const long long n4 = ((reinterpret_cast<uintptr_t>(g) & galign) | (reinterpret_cast<uintptr_t>(t) & 15)) == 0 ? count / 4 : 0;
     const float4* t4 = reinterpret_cast<const float4*>(t);
     long long i = (long long)blockIdx.x * kThreads + tid;
     for (; i + 3 * stride < n4; i += 4 * stride) {        // four independent 16-byte loads per tensor in flight
-        const float4 a0 = g4[i], a1 = g4[i + stride], a2 = g4[i + 2 * stride], a3 = g4[i + 3 * stride];
+        const float4 a0 = load_g4<GBF16>(g, i), a1 = load_g4<GBF16>(g, i + stride), a2 = load_g4<GBF16>(g, i + 2 * stride), a3 = load_g4<GBF16>(g, i + 3 * stride);
         const float4 b0 = t4[i], b1 = t4[i + stride], b2 = t4[i + 2 * stride], b3 = t4[i + 3 * stride];
         acc += ((double)a0.x * (double)b0.x + (double)a0.y * (double)b0.y) + ((double)a0.z * (double)b0.z + (double)a0.w * (double)b0.w);
         acc += ((double)a1.x * (double)b1.x + (double)a1.y * (double)b1.y) + ((double)a1.z * (double)b1.z + (double)a1.w * (double)b1.w);
@@ -59,11 +76,11 @@ __global__ void __launch_bounds__(kThreads) dmel_dot_kernel(const float* __restr
         acc += ((double)a3.x * (double)b3.x + (double)a3.y * (double)b3.y) + ((double)a3.z * (double)b3.z + (double)a3.w * (double)b3.w);
     }
     for (; i < n4; i += stride) {
-        const float4 a = g4[i], b = t4[i];
+        const float4 a = load_g4<GBF16>(g, i), b = t4[i];
         acc += ((double)a.x * (double)b.x + (double)a.y * (double)b.y) + ((double)a.z * (double)b.z + (double)a.w * (double)b.w);
     }
     for (long long k = n4 * 4 + (long long)blockIdx.x * kThreads + tid; k < count; k += stride)
-        acc += (double)g[k] * (double)t[k];
+        acc += (double)load_g1<GBF16>(g, k) * (double)t[k];
     const double bsum = block_sum(acc, red4);
     if (tid == 0) {
         __hip_atomic_store(&partials[blockIdx.x], bsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -83,14 +100,15 @@ __global__ void __launch_bounds__(kThreads) dmel_dot_kernel(const float* __restr
     }
 }
 
-hipError_t launch_dot(const float* g, const float* t, long long count, int accumulate, double* partials,
+hipError_t launch_dot(const void* g, int g_bf16, const float* t, long long count, int accumulate, double* partials,
                       unsigned* counter, int max_partials, float* result, hipStream_t s)
 {
     // 32 floats per thread and tensor: few workgroups on purpose -- every workgroup ends with one ticket on a single
     // counter (~11 ns each, serialised), which cost more than the loads at 256+ workgroups
     long long want = (count + (long long)kThreads * 32 - 1) / ((long long)kThreads * 32);
     int blocks = (int)(want < 1 ? 1 : (want > max_partials ? max_partials : want));
-    hipLaunchKernelGGL(dmel_dot_kernel, dim3(blocks), dim3(kThreads), 0, s, g, t, count, partials, counter, accumulate, result);
+    if (g_bf16) hipLaunchKernelGGL(dmel_dot_kernel<true>, dim3(blocks), dim3(kThreads), 0, s, g, t, count, partials, counter, accumulate, result);
+    else hipLaunchKernelGGL(dmel_dot_kernel<false>, dim3(blocks), dim3(kThreads), 0, s, g, t, count, partials, counter, accumulate, result);
     return hipGetLastError();
 }
 
@@ -151,12 +169,14 @@ __global__ void __launch_bounds__(128) dmel_naive_kernel(NaiveParams p)
         }
         dmel *= p.sign;
         const size_t o = ((size_t)b * p.M + m) * p.T + t;
+        const bool out_bf16 = (p.flags & 4u) != 0;
+        auto put = [&](float v) { if (out_bf16) reinterpret_cast<unsigned short*>(p.out)[o] = bf16_bits(v); else p.out[o] = v; };
         if (do_log) {
             const float me = mel + p.eps;
-            p.out[o] = logf(me);
+            put(logf(me));
             if (p.tangent) p.tangent[o] = dmel / me;
         } else {
-            p.out[o] = mel;
+            put(mel);
             if (p.tangent) p.tangent[o] = dmel;
         }
     }
@@ -266,18 +286,20 @@ __global__ void __launch_bounds__(kLongThreads) dmel_long_kernel(LongParams p)
         s1 = wave_sum_shfl(s1);
         if (lane != 0) continue;
         const size_t o = ((size_t)b * p.M + m) * p.T;
+        const bool out_bf16 = (p.flags & 4u) != 0;
+        auto put = [&](int t, float v) { if (out_bf16) reinterpret_cast<unsigned short*>(p.out)[o + t] = bf16_bits(v); else p.out[o + t] = v; };
         if (pair) {
             const float ma = 0.25f * s0, mb = 0.25f * s1;
-            p.out[o + tA] = do_log ? logf(ma + p.eps) : ma;
-            if (tB < p.T) p.out[o + tB] = do_log ? logf(mb + p.eps) : mb;
+            put(tA, do_log ? logf(ma + p.eps) : ma);
+            if (tB < p.T) put(tB, do_log ? logf(mb + p.eps) : mb);
         } else {
             const float mel = 0.25f * s0, dmel = 0.5f * p.sign * s1;
             if (do_log) {
                 const float me = mel + p.eps;
-                p.out[o + tA] = logf(me);
+                put(tA, logf(me));
                 if (p.tangent) p.tangent[o + tA] = dmel / me;
             } else {
-                p.out[o + tA] = mel;
+                put(tA, mel);
                 if (p.tangent) p.tangent[o + tA] = dmel;
             }
         }

@@ -637,6 +637,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
             STAMP(9);   // MFMA loops
             // ---- epilogue: accumulators -> (B,1,M,T) ------------------------------------------
             const bool do_log = (p.flags & 1u) != 0;
+            const bool out_bf16 = (p.flags & 4u) != 0;
             floatx4 tot[NLOC][MT];
             static_for<0, NLOC>([&](auto l) { static_for<0, MT>([&](auto m) {
                 tot[decltype(l)::value][decltype(m)::value] = acc[decltype(l)::value][decltype(m)::value][0] + acc[decltype(l)::value][decltype(m)::value][1]; }); });
@@ -658,8 +659,11 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                 if (nt < 0) return;
                 const int m = 16 * nt + col;
                 if (m >= p.M) return;
-                float* orow = p.out + ((size_t)b * p.M + m) * p.T;
-                float* trow = p.tangent ? p.tangent + ((size_t)b * p.M + m) * p.T : nullptr;
+                const size_t rbase = ((size_t)b * p.M + m) * p.T;
+                float* orow = p.out + rbase;
+                unsigned short* orow_h = reinterpret_cast<unsigned short*>(p.out) + rbase;     // DMEL_FLAG_OUT_BF16: out is bf16
+                float* trow = p.tangent ? p.tangent + rbase : nullptr;
+                auto put = [&](int t, float v) { if (out_bf16) orow_h[t] = bf16_bits(v); else orow[t] = v; };
                 static_for<0, MT>([&](auto mm) {
                     constexpr int mt = decltype(mm)::value;
                     const floatx4 a = tot[loc][mt];
@@ -677,7 +681,8 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                                 (s == 0 ? o2.x : o2.y) = do_log ? logf(me) : mel;
                                 (s == 0 ? t2.x : t2.y) = do_log ? dmel / me : dmel;
                             });
-                            *reinterpret_cast<float2*>(orow + tp) = o2;
+                            if (out_bf16) *reinterpret_cast<unsigned*>(orow_h + tp) = (unsigned)bf16_bits(o2.x) | ((unsigned)bf16_bits(o2.y) << 16);
+                            else *reinterpret_cast<float2*>(orow + tp) = o2;
                             if (trow) *reinterpret_cast<float2*>(trow + tp) = t2;
                         } else
                         static_for<0, 2>([&](auto ss) {
@@ -689,10 +694,10 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                                 const float dmel = 0.5f * p.sign * a[2 + s];
                                 if (do_log) {
                                     const float me = mel + p.eps;
-                                    orow[t] = logf(me);
+                                    put(t, logf(me));
                                     if (trow) trow[t] = dmel / me;
                                 } else {
-                                    orow[t] = mel;
+                                    put(t, mel);
                                     if (trow) trow[t] = dmel;
                                 }
                             }
@@ -705,7 +710,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                             const int t = t0 + 2 * slot + (i >> 1);
                             if (slot < SLOTS && t < p.T) {
                                 const float mel = 0.25f * a[i];
-                                orow[t] = do_log ? logf(mel + p.eps) : mel;
+                                put(t, do_log ? logf(mel + p.eps) : mel);
                             }
                         });
                     }

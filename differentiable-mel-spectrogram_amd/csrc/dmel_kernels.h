@@ -12,6 +12,9 @@ constexpr int kMaxFastNfft = 4096;     // largest transform of the fused wave-FF
 constexpr int kMaxNfft = 16384;        // largest transform overall: above kMaxFastNfft the one-frame-per-workgroup LDS FFT runs
 constexpr int kMinFastNfft = 32;       // below this the direct-DFT kernel runs
 
+// fp32 -> bf16 bits, round to nearest even (v_cvt_pk_bf16_f32 on gfx950); outputs only, the arithmetic stays fp32
+__device__ __forceinline__ unsigned short bf16_bits(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
+
 enum Mode : int { kTrain = 0, kInfer = 1, kSpec = 2, kSpecTrain = 3 };   // kSpec*: power spectrogram (B,F,T), no mel stage
 
 // Compile-time FFT plan for one wave: N = R * R * C, R points per lane (tools/wavefft_sim.py).
@@ -137,7 +140,8 @@ struct FbGradParams {
 };
 hipError_t launch_fbgrad(const FbGradParams& p, hipStream_t s);
 
-hipError_t launch_dot(const float* g, const float* t, long long count, int accumulate, double* partials,
+// g: fp32, or bf16 when g_bf16 != 0 (the gradient of a bf16 output); t (the tangent) is always fp32
+hipError_t launch_dot(const void* g, int g_bf16, const float* t, long long count, int accumulate, double* partials,
                       unsigned* counter, int max_partials, float* result, hipStream_t s);
 
 }  // namespace dmel

@@ -25,16 +25,17 @@ class _DmelFunction(torch.autograd.Function):
     filterbank tensor that requires grad was passed, dmel_backward_fb (adjoint of models.py:53)."""
 
     @staticmethod
-    def forward(ctx, x, lambd, plan, lam_host, log, eps, full_window=False, fb=None):
+    def forward(ctx, x, lambd, plan, lam_host, log, eps, full_window=False, fb=None, out_dtype=torch.float32):
         B = x.shape[0]
-        out = torch.empty((B, 1, plan.n_mels, plan.n_time), dtype=torch.float32, device=x.device)  # models.py:36
+        out = torch.empty((B, 1, plan.n_mels, plan.n_time), dtype=out_dtype, device=x.device)     # models.py:36 (fp32 there)
         want_tangent = ctx.needs_input_grad[1]
         want_fb = fb is not None and ctx.needs_input_grad[7]
-        tangent = torch.empty_like(out) if want_tangent else None
+        tangent = torch.empty(out.shape, dtype=torch.float32, device=x.device) if want_tangent else None
         flags = capi.DMEL_FLAG_FULL_WINDOW if full_window else 0
         with torch.cuda.device(x.device):
             plan.forward(x.data_ptr(), B, lam_host, out.data_ptr(), tangent.data_ptr() if want_tangent else None,
-                         log, eps, _stream_ptr(x.device), extra_flags=flags)
+                         log, eps, _stream_ptr(x.device),
+                         extra_flags=flags | (capi.DMEL_FLAG_OUT_BF16 if out_dtype == torch.bfloat16 else 0))
         ctx.plan = plan
         ctx.lambd_shape = lambd.shape
         ctx.lambd_dtype = lambd.dtype
@@ -53,23 +54,25 @@ class _DmelFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         saved = list(ctx.saved_tensors)
-        g = grad_out.to(torch.float32).contiguous()
+        bf16 = grad_out.dtype == torch.bfloat16          # gradient of a bf16 output: read as it is, widened in the kernel
+        g = grad_out.contiguous() if bf16 else grad_out.to(torch.float32).contiguous()
         dl = gfb = None
         with torch.cuda.device(g.device):
             if ctx.want_tangent:
                 tangent = saved.pop(0)
                 dl = torch.empty((1,), dtype=torch.float32, device=g.device)
-                ctx.plan.backward(g.data_ptr(), tangent.data_ptr(), g.numel(), dl.data_ptr(), _stream_ptr(g.device))
+                ctx.plan.backward(g.data_ptr(), tangent.data_ptr(), g.numel(), dl.data_ptr(), _stream_ptr(g.device), grad_bf16=bf16)
                 dl = dl.reshape(ctx.lambd_shape).to(ctx.lambd_dtype)
             if ctx.want_fb:
                 lam_host, log, flags, (fb_shape, fb_dtype) = ctx.fb_args
                 x = saved.pop(0)
-                out = saved.pop(0) if log else None
+                out = saved.pop(0).to(torch.float32) if log else None
+                g = g.to(torch.float32)
                 gfb = torch.empty(fb_shape, dtype=torch.float32, device=g.device)
                 ctx.plan.backward_fb(x.data_ptr(), x.shape[0], lam_host, g.data_ptr(), out.data_ptr() if log else None,
                                      gfb.data_ptr(), log, _stream_ptr(g.device), extra_flags=flags)
                 gfb = gfb.to(fb_dtype)
-        return None, dl, None, None, None, None, None, gfb
+        return None, dl, None, None, None, None, None, gfb, None
 
 
 class MelSpectrogramLayer(nn.Module):
@@ -84,12 +87,15 @@ class MelSpectrogramLayer(nn.Module):
     parameter ``mel_fb`` (initialised to the HTK bank) and returns its gradient; the matrix is tied to the
     n_fft it was built for, so the forward raises once ``lambd`` has moved to another power of two.  Off by
     default: the reference has no such parameter and its checkpoints have no such key.
+    ``out_dtype=torch.bfloat16`` stores the output as bf16 (the fp32 result rounded to nearest even; BASELINE config 2
+    "bf16 activations"); the arithmetic, the saved tangent and ``lambd.grad`` stay fp32.
 
     forward(x: (B, n_points)) -> (B, 1, n_mels, n_points // hop_length + 1) float32.
     """
 
     def __init__(self, init_lambd, n_mels, n_points, sample_rate, f_min=0, f_max=None, hop_length=1,
-                 device="cpu", optimized=False, normalize_window=False, *, log=False, eps=1e-10, learnable_fb=False):
+                 device="cpu", optimized=False, normalize_window=False, *, log=False, eps=1e-10, learnable_fb=False,
+                 out_dtype=torch.float32):
         super().__init__()
         if not torch.is_tensor(init_lambd):
             init_lambd = torch.tensor(float(init_lambd), dtype=torch.float32)
@@ -107,6 +113,9 @@ class MelSpectrogramLayer(nn.Module):
         self.n_points = n_points
         self.log = bool(log)
         self.eps = float(eps)
+        if out_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("out_dtype must be torch.float32 (the reference's, models.py:36) or torch.bfloat16")
+        self.out_dtype = out_dtype
         self._plans = {}                                              # device index -> capi.Plan (not state)
         self._fb_synced = {}                                          # device index -> (version, data_ptr) last sent to the plan
         if learnable_fb:
@@ -182,7 +191,7 @@ class MelSpectrogramLayer(nn.Module):
             if self._fb_synced.get(idx) != key:
                 plan.set_filterbank(n, fb.detach().to(torch.float32).cpu().numpy())      # host rebuild of the block tables
                 self._fb_synced[idx] = key
-        return _DmelFunction.apply(xf, self.lambd, plan, lam_host, self.log, self.eps, not self.optimized, fb)
+        return _DmelFunction.apply(xf, self.lambd, plan, lam_host, self.log, self.eps, not self.optimized, fb, self.out_dtype)
 
     def extra_repr(self):
         return (f"n_mels={self.n_mels}, n_points={self.n_points}, sample_rate={self.sample_rate}, "

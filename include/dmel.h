@@ -56,6 +56,11 @@ typedef struct dmel_plan dmel_plan;
 #define DMEL_FLAG_LOG 1u       /* fuse out = log(mel + eps)                        models.py:73 */
 #define DMEL_FLAG_FULL_WINDOW 2u /* the layer's optimized=False branch: window = whole clip, n_fft = 2*n_points
                                   (time_frequency.py:41,51); n_points must be a power of two <= 8192     */
+#define DMEL_FLAG_OUT_BF16 4u   /* dmel_forward writes `out` as bf16 (round to nearest even of the fp32 result; BASELINE
+                                  config 2 "bf16 activations / fp32 grad"): half the output bytes.  The arithmetic, the
+                                  tangent and d lambd stay fp32.  The reference's output is fp32 (models.py:36).          */
+#define DMEL_DTYPE_F32 0
+#define DMEL_DTYPE_BF16 1
 
 /* ---- host-side helpers (no device needed) ------------------------------------------------- */
 
@@ -96,7 +101,7 @@ dmel_status dmel_plan_set_filterbank(dmel_plan* plan, int32_t n_fft, const float
  *   x        device, (batch, n_points) fp32
  *   lambd    host value of the parameter (the reference reads it to the host too,
  *            time_frequency.py:39); may be negative or zero
- *   out      device, (batch, 1, n_mels, n_time) fp32
+ *   out      device, (batch, 1, n_mels, n_time) fp32 (bf16 elements with DMEL_FLAG_OUT_BF16: pass the pointer cast)
  *   tangent  device, same shape, or NULL for inference: receives d out / d lambd so that
  *            the backward is a single dot product (one trainable scalar -> forward mode)
  *   eps      the 1e-10 of models.py:73 (ignored without DMEL_FLAG_LOG)
@@ -113,6 +118,11 @@ dmel_status dmel_forward(dmel_plan* plan, const float* x, int32_t batch, float l
  */
 dmel_status dmel_backward(dmel_plan* plan, const float* grad_out, const float* tangent, int64_t count,
                           int32_t accumulate, float* dlambd, void* stream);
+
+/* dmel_backward for a gradient tensor of another element type: grad_dtype = DMEL_DTYPE_F32 or DMEL_DTYPE_BF16 (the
+ * gradient of a DMEL_FLAG_OUT_BF16 output; widened exactly, accumulated in fp64 like the fp32 path). */
+dmel_status dmel_backward_ex(dmel_plan* plan, const void* grad_out, int32_t grad_dtype, const float* tangent, int64_t count,
+                             int32_t accumulate, float* dlambd, void* stream);
 
 /*
  * Backward to the filterbank matrix ("mel params"): the adjoint of the contraction at models.py:53,

@@ -569,3 +569,28 @@ def test_full_window_branch_up_to_8192_points():
     y_ref, _ = O.forward(x_np, case["lambd"], case["hop"], case["n_mels"], case["sr"], case["f_min"], case["f_max"],
                          case["normalize_window"], apply_log=True, optimized=False)
     assert _log_err(y.detach().cpu().numpy(), y_ref) <= TOL
+
+
+# ---- bf16 activations (BASELINE config 2: "bf16 activations / fp32 grad") ----------------------------------------
+@pytest.mark.parametrize("name", ["g1_c1", "g2_c2", "g6_n256_ragged", "g6_n32"])
+def test_bf16_output_is_the_rounded_fp32_output(name):
+    from dmel_amd import MelSpectrogramLayer
+    case = C.BY_NAME[name]
+    x = torch.from_numpy(C.make_input(case).astype(np.float32)).to("cuda:0")
+    g32 = torch.from_numpy(C.make_cotangent(case)).to("cuda:0")
+    for log in (False, True):
+        for trainable in (True, False):
+            ref = _layer(case, log=log, trainable=trainable)
+            lay = MelSpectrogramLayer(torch.tensor(float(case["lambd"])), n_mels=case["n_mels"], n_points=case["L"], sample_rate=case["sr"],
+                                      f_min=case["f_min"], f_max=case["f_max"], hop_length=case["hop"], device="cuda:0", optimized=True,
+                                      normalize_window=case["normalize_window"], log=log, out_dtype=torch.bfloat16).to("cuda:0")
+            lay.requires_grad_(trainable)
+            y32, y16 = ref(x), lay(x)
+            assert y16.dtype == torch.bfloat16 and y16.shape == y32.shape
+            assert torch.equal(y16.detach(), y32.detach().to(torch.bfloat16))        # same fp32 value, one rounding
+            if trainable:
+                # the gradient arrives in bf16 and is widened exactly: same d lambd as an fp32 gradient of the same values
+                g16 = g32.to(torch.bfloat16)
+                (y16 * g16).sum().backward()
+                (y32 * g16.to(torch.float32)).sum().backward()
+                assert float(lay.lambd.grad) == float(ref.lambd.grad)
