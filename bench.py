@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--graph", action="store_true", help="replay each step from a HIP graph instead of launching it eagerly "
                     "(measured slower here: ~5 us of per-replay overhead against a ~35 us step)")
+    ap.add_argument("--bf16-activations", action="store_true", help="store the log-mel output and read its gradient as bf16 "
+                    "(DMEL_FLAG_OUT_BF16); the arithmetic, the tangent and d lambd stay fp32.  Default: fp32, the reference's output type")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-module-path", action="store_true")
     return ap.parse_args()
@@ -118,16 +120,19 @@ def main():
     # every rank owns a different shard of the global batch (seeded by rank); inputs are resident before timing
     x = torch.from_numpy(synth.waveforms(B, L, seed=100 * rank)).to(dev)
     g = torch.from_numpy(synth.cotangent((B, 1, M, T), seed=1 + 100 * rank)).to(dev)
-    out = torch.empty((B, 1, M, T), dtype=torch.float32, device=dev)
-    tan = torch.empty_like(out)
+    act = torch.bfloat16 if args.bf16_activations else torch.float32
+    g = g.to(act)
+    out = torch.empty((B, 1, M, T), dtype=act, device=dev)
+    tan = torch.empty((B, 1, M, T), dtype=torch.float32, device=dev)
     RING = 32  # gradient buffers: the all-reduce of step k may still be in flight while steps k+1 .. k+15 run
     dl = [torch.zeros(1, dtype=torch.float32, device=dev) for _ in range(RING)]
     plan = capi.Plan(L, hop, M, sr, max_batch=B)
     count = out.numel()
 
     def step_kernels(stream_ptr, k):
-        plan.forward(x.data_ptr(), B, lam, out.data_ptr(), tan.data_ptr(), True, 1e-10, stream_ptr)
-        plan.backward(g.data_ptr(), tan.data_ptr(), count, dl[k % RING].data_ptr(), stream_ptr)
+        plan.forward(x.data_ptr(), B, lam, out.data_ptr(), tan.data_ptr(), True, 1e-10, stream_ptr,
+                     extra_flags=capi.DMEL_FLAG_OUT_BF16 if args.bf16_activations else 0)
+        plan.backward(g.data_ptr(), tan.data_ptr(), count, dl[k % RING].data_ptr(), stream_ptr, grad_bf16=args.bf16_activations)
 
     cur = torch.cuda.current_stream(dev)
     step_kernels(cur.cuda_stream, 0)          # builds the per-n_fft tables (hipMalloc) outside any capture
@@ -207,7 +212,7 @@ def main():
     bwd_us = 1e3 * prof["bwd_ms"] / max(1, prof["bwd_launches"])
     # algorithmic bytes of ONE launch of the fused forward kernel:
     # read x once + write out and tangent once, fp32
-    alg_bytes = 4 * (B * L + 2 * B * M * T)
+    alg_bytes = 4 * (B * L + B * M * T) + (2 if args.bf16_activations else 4) * B * M * T
     achieved = alg_bytes / (fwd_us * 1e-6) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -225,6 +230,7 @@ def main():
         "metric": "spectrogram frames/sec (fwd+bwd)", "value": round(value, 1), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "activations": "bf16 (output and its gradient; arithmetic, tangent and d lambd fp32)" if args.bf16_activations else "f32",
         "config": {"workload": f"BASELINE config 2 per GPU: batch {B} x {L} samples @ {sr} Hz, n_fft {info['n_fft']} "
                                f"(lambd {lam}), hop {hop}, n_mels {M}, log fused, fwd + backward to lambd.grad"
                    if args.config == "c2" else f"{args.config}: batch {B} x {L} @ {sr}, lambd {lam}, hop {hop}, n_mels {M}",
