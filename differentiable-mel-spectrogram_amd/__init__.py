@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import importlib
 
-__all__ = ["MelSpectrogramLayer", "DifferentiableMelSpectrogram", "SpectrogramLayer", "dmel_log_mel", "capi", "synth", "dist", "nets"]
+__all__ = ["MelSpectrogramLayer", "DifferentiableMelSpectrogram", "SpectrogramLayer", "dmel_log_mel", "capi", "synth", "dist", "nets", "panns"]
 
 _LAZY = {
     "MelSpectrogramLayer": ("layer", "MelSpectrogramLayer"),
@@ -25,6 +25,6 @@ def __getattr__(name):
     if name in _LAZY:
         mod, attr = _LAZY[name]
         return getattr(importlib.import_module(f"dmel_amd.{mod}"), attr)
-    if name in ("capi", "synth", "layer", "dist", "nets"):
+    if name in ("capi", "synth", "layer", "dist", "nets", "panns"):
         return importlib.import_module(f"dmel_amd.{name}")
     raise AttributeError(name)

@@ -98,3 +98,32 @@ def sample_index(case) -> np.ndarray | None:
 def load(case) -> dict:
     z = np.load(os.path.join(_HERE, case["name"] + ".npz"))
     return {k: z[k] for k in z.files}
+
+
+# ---- deterministic weights for the wrapping nets (MelPANNsNet parity) ---------------------------
+PANNS_CFG = dict(n_classes=50, lambd=8000 * 0.035 / 6, n_mels=64, sr=8000, L=8000, hop=80, B=3, seed=31)
+
+
+def fill_state(net, seed=0):
+    """Overwrite every floating tensor of ``net.state_dict()`` except ``spectrogram_layer.*`` with closed-form pseudo-random
+    values keyed on the entry's name, so that the reference net (make_golden.py) and ours (tests) carry identical weights
+    without shipping them: N(0,1)/sqrt(fan_in) for weights of rank >= 2, 1 + 0.1 N for batch-norm scales, 1 + 0.1 |N| for
+    running variances, 0.1 N for everything else."""
+    import zlib
+    import torch
+    sd = net.state_dict()
+    for key, t in sd.items():
+        if key.startswith("spectrogram_layer.") or not t.is_floating_point():
+            continue
+        n = synth.waveforms(1, t.numel(), seed=seed + zlib.crc32(key.encode()) % 100003, scale=1.0).reshape(tuple(t.shape))
+        v = torch.from_numpy(n.astype(np.float32))
+        if t.dim() >= 2:
+            v = v / float(np.sqrt(t[0].numel()))
+        elif key.endswith("running_var"):
+            v = 1.0 + 0.1 * v.abs()
+        elif key.endswith("bn1.weight"):
+            v = 1.0 + 0.1 * v
+        else:
+            v = 0.1 * v
+        t.copy_(v.to(t.device))
+    return net

@@ -57,11 +57,19 @@ def _install_torchaudio_standin():
     tr = types.ModuleType("torchaudio.transforms")
     fn.melscale_fbanks = _melscale_fbanks
 
-    class _Unavailable:  # panns.py:141-142 / models.py:300 only touch these in code we never run
+    class _Unavailable:  # models.py:300 only touches this in code we never run
         def __init__(self, *a, **k):
             raise RuntimeError("torchaudio.transforms is not available in this image")
 
-    tr.TimeMasking = tr.FrequencyMasking = tr.MelSpectrogram = _Unavailable
+    class _NeverCalled(torch.nn.Module):  # panns.py:141-142 constructs the masks always, calls them only when augment=True
+        def __init__(self, *a, **k):
+            super().__init__()
+
+        def forward(self, x):
+            raise RuntimeError("torchaudio.transforms is not available in this image")
+
+    tr.TimeMasking = tr.FrequencyMasking = _NeverCalled
+    tr.MelSpectrogram = _Unavailable
     ta.functional, ta.transforms = fn, tr
     sys.modules["torchaudio"] = ta
     sys.modules["torchaudio.functional"] = fn
@@ -153,6 +161,29 @@ def run_fbgrad(models, tf, case):
     return dict(gfb_lin=g_lin.numpy().astype(np.float32), gfb_log=g_log.numpy().astype(np.float32))
 
 
+def run_panns(models):
+    """f4: the reference's MelPANNsNet (models.py:138-166 + panns.py:135-202) in eval mode with the closed-form weights of
+    cases.fill_state: clipwise outputs and the state_dict contract (keys + shapes)."""
+    import json
+    cfg = C.PANNS_CFG
+    from dmel_amd import synth
+    out = {}
+    for energy_normalize in (True, False):
+        net = models.MelPANNsNet(cfg["n_classes"], torch.tensor(cfg["lambd"]), "cpu", cfg["n_mels"], cfg["sr"], cfg["L"],
+                                 hop_length=cfg["hop"], optimized=True, energy_normalize=energy_normalize)
+        C.fill_state(net, seed=cfg["seed"])
+        net.eval()
+        x = torch.from_numpy(synth.waveforms(cfg["B"], cfg["L"], seed=cfg["seed"]))
+        with torch.no_grad():
+            y, s = net(x)
+        out["clipwise_log" if energy_normalize else "clipwise_lin"] = y.numpy().astype(np.float32)
+        if energy_normalize:
+            out["s_log"] = s.numpy().astype(np.float32)       # the log-mel the CNN saw: pins our Cnn6 on CPU
+    keys = {k: list(v.shape) for k, v in net.state_dict().items()}
+    json.dump(keys, open(os.path.join(HERE, "panns_state_keys.json"), "w"), indent=1)
+    return out
+
+
 def run_net_keys(models):
     """state_dict keys + shapes of the reference's wrapping nets (models.py:58-136): the checkpoint contract."""
     import json
@@ -172,10 +203,12 @@ def main(argv):
         argv = [a for a in argv if a != "net_keys"]
         if len(argv) == 1 and "net_keys" in sys.argv:
             return
-    names = argv[1:] or [c["name"] for c in C.CASES] + ["g7_dspec"] + ["g8_fbgrad_" + n for n in FBGRAD_CASES]
+    names = argv[1:] or [c["name"] for c in C.CASES] + ["g7_dspec"] + ["g8_fbgrad_" + n for n in FBGRAD_CASES] + ["g9_panns"]
     for name in names:
         if name == "g7_dspec":
             out = run_dspec(models, tf)
+        elif name == "g9_panns":
+            out = run_panns(models)
         elif name.startswith("g8_fbgrad_"):
             out = run_fbgrad(models, tf, C.BY_NAME[name[len("g8_fbgrad_"):]])
         else:

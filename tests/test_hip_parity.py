@@ -209,7 +209,7 @@ def test_error_behaviour():
     xt = torch.stack([x, x], dim=2)[:, :, 0]
     assert not xt.is_contiguous()
     assert torch.equal(layer(xt), layer(x))
-    assert float((layer(x.double()) - layer(x)).abs().max()) == 0.0
+    assert float((layer(x.double()) - layer(x)).detach().abs().max()) == 0.0
 
 
 def test_state_dict_and_param_groups():
@@ -594,3 +594,45 @@ def test_bf16_output_is_the_rounded_fp32_output(name):
                 (y16 * g16).sum().backward()
                 (y32 * g16.to(torch.float32)).sum().backward()
                 assert float(lay.lambd.grad) == float(ref.lambd.grad)
+
+
+# ---- MelPANNsNet end to end ----------------------------------------------------------------------
+def test_panns_net_matches_reference_outputs():
+    """Our front end + our Cnn6 (MIOpen) against the reference's MelPANNsNet run on CPU with identical closed-form weights."""
+    import os
+    from dmel_amd import panns, synth
+    cfg = C.PANNS_CFG
+    gold = np.load(os.path.join(os.path.dirname(C.__file__), "g9_panns.npz"))
+    x = torch.from_numpy(synth.waveforms(cfg["B"], cfg["L"], seed=cfg["seed"])).to("cuda:0")
+    for energy_normalize, key in ((True, "clipwise_log"), (False, "clipwise_lin")):
+        net = panns.MelPANNsNet(cfg["n_classes"], torch.tensor(cfg["lambd"]), "cuda:0", cfg["n_mels"], cfg["sr"], cfg["L"],
+                                hop_length=cfg["hop"], optimized=True, energy_normalize=energy_normalize).to("cuda:0")
+        C.fill_state(net, seed=cfg["seed"])
+        net.eval()
+        with torch.no_grad():
+            y, s = net(x)
+        assert s.shape == (cfg["B"], 1, cfg["n_mels"], cfg["L"] // cfg["hop"] + 1)
+        assert float(np.abs(y.cpu().numpy() - gold[key]).max()) <= 2e-4             # sigmoid scores in (0, 1)
+        if energy_normalize:
+            assert _log_err(s.cpu().numpy(), gold["s_log"]) <= TOL
+
+
+def test_panns_net_training_step():
+    from dmel_amd import nets, panns, synth
+    cfg = C.PANNS_CFG
+    net = panns.MelPANNsNet(cfg["n_classes"], torch.tensor(cfg["lambd"]), "cuda:0", cfg["n_mels"], cfg["sr"], cfg["L"],
+                            hop_length=cfg["hop"], optimized=True, energy_normalize=True, augment=True).to("cuda:0")
+    net.spectrogram_layer.requires_grad_(True)
+    opt = nets.make_optimizer(net, lr_model=1e-4, lr_tf=1.0, name="adam")
+    x = torch.from_numpy(synth.waveforms(4, cfg["L"], seed=5)).to("cuda:0")
+    target = torch.tensor([1, 7, 3, 49], device="cuda:0")
+    lam0 = float(net.spectrogram_layer.lambd.detach())
+    net.train()
+    for _ in range(2):
+        opt.zero_grad()
+        y, _ = net(x)
+        loss = torch.nn.functional.cross_entropy(y, target)
+        loss.backward()
+        assert torch.isfinite(net.spectrogram_layer.lambd.grad).all() and float(net.spectrogram_layer.lambd.grad.abs()) > 0
+        opt.step()
+    assert float(net.spectrogram_layer.lambd.detach()) != lam0 and torch.isfinite(loss)

@@ -24,3 +24,70 @@ def test_two_lr_groups():
     lrs = {id(g["params"][0]): g["lr"] for g in opt.param_groups}
     assert lrs[id(net.spectrogram_layer.lambd)] == 1.0
     assert all(v == 1e-4 for k, v in lrs.items() if k != id(net.spectrogram_layer.lambd))
+
+
+# ---- MelPANNsNet / Cnn6 --------------------------------------------------------------------------
+def test_panns_state_dict_contract_matches_reference():
+    """keys + shapes captured from the reference's MelPANNsNet (models.py:138-166, panns.py:135-202)."""
+    import cases as C
+    from dmel_amd import panns
+    cfg = C.PANNS_CFG
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "panns_state_keys.json")))
+    net = panns.MelPANNsNet(cfg["n_classes"], torch.tensor(cfg["lambd"]), "cpu", cfg["n_mels"], cfg["sr"], cfg["L"],
+                            hop_length=cfg["hop"], optimized=True, energy_normalize=True)
+    assert {k: list(v.shape) for k, v in net.state_dict().items()} == gold
+    assert [n for n, _ in net.named_parameters()][0] == "spectrogram_layer.lambd"
+
+
+def test_cnn6_matches_reference_outputs_on_cpu():
+    """The CNN half (stock torch ops) fed with the log-mel the reference's own run produced (g9_panns.npz: s_log) returns
+    the reference's clipwise outputs: same weights through cases.fill_state, eval mode."""
+    import numpy as np
+    import cases as C
+    from dmel_amd import panns
+    cfg = C.PANNS_CFG
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "g9_panns.npz"))
+    net = panns.MelPANNsNet(cfg["n_classes"], torch.tensor(cfg["lambd"]), "cpu", cfg["n_mels"], cfg["sr"], cfg["L"],
+                            hop_length=cfg["hop"], optimized=True, energy_normalize=True)
+    C.fill_state(net, seed=cfg["seed"])
+    net.eval()
+    with torch.no_grad():
+        y = net.spectrogram_model(torch.from_numpy(gold["s_log"]).transpose(2, 3))
+    assert y.shape == (cfg["B"], cfg["n_classes"])
+    assert float((y - torch.from_numpy(gold["clipwise_log"])).abs().max()) <= 1e-6
+
+
+def test_iid_axis_mask_zeroes_one_band_per_example():
+    from dmel_amd.panns import _IidAxisMask
+    torch.manual_seed(0)
+    x = torch.ones(64, 1, 50, 30)
+    for axis, param in ((2, 8), (3, 64)):
+        y = _IidAxisMask(param, axis)(x)
+        other = 3 if axis == 2 else 2
+        prof = y[:, 0].amin(dim=other - 1)                     # (B, size along axis): 0 inside the band
+        assert ((prof == 0) | (prof == 1)).all()
+        widths = (prof == 0).sum(dim=1)
+        assert int(widths.max()) < min(param, x.shape[axis]) + 1 and int(widths.max()) > 0
+        for row in prof:                                       # the zeros are contiguous
+            idx = torch.nonzero(row == 0).flatten()
+            assert idx.numel() == 0 or int(idx[-1] - idx[0]) + 1 == idx.numel()
+        assert not torch.equal(prof[0], prof[1]) or not torch.equal(prof[1], prof[2])     # iid across examples
+
+
+def test_load_cnn6_checkpoint_remaps_keys(tmp_path):
+    """utils.py:15-36: every key of checkpoint['model'] gets the prefix 'spectrogram_model.'; strict=False."""
+    import pytest
+    from dmel_amd import panns
+    donor = panns.Cnn6(527, 64)
+    state = {k: v.clone() for k, v in donor.state_dict().items() if not k.startswith("fc_esc50")}
+    state["fc_audioset.weight"] = torch.zeros(527, 512)          # the pretrained head has no counterpart
+    state["fc_audioset.bias"] = torch.zeros(527)
+    path = tmp_path / "Cnn6.pth"
+    torch.save({"model": state}, path)
+    net = panns.MelPANNsNet(50, torch.tensor(40.0), "cpu", 64, 8000, 8000, hop_length=80, optimized=True)
+    res = panns.load_cnn6_checkpoint(net, str(path))
+    assert sorted(res.unexpected_keys) == ["spectrogram_model.fc_audioset.bias", "spectrogram_model.fc_audioset.weight"]
+    assert sorted(res.missing_keys) == ["spectrogram_layer.lambd", "spectrogram_model.fc_esc50.bias", "spectrogram_model.fc_esc50.weight"]
+    assert torch.equal(net.spectrogram_model.conv_block3.conv1.weight, donor.conv_block3.conv1.weight)
+    with pytest.raises(FileNotFoundError):
+        panns.load_cnn6_checkpoint(net, str(tmp_path / "missing.pth"))
