@@ -27,7 +27,7 @@ DMEL_DTYPE_F32, DMEL_DTYPE_BF16 = 0, 1
 SYMBOLS = (
     "dmel_abi_version", "dmel_n_fft", "dmel_window_host", "dmel_mel_fbanks_host", "dmel_last_error",
     "dmel_device_count", "dmel_plan_create", "dmel_plan_destroy", "dmel_plan_set_filterbank",
-    "dmel_forward", "dmel_backward", "dmel_backward_ex", "dmel_backward_fb", "dmel_spectrogram", "dmel_plan_get_info",
+    "dmel_forward", "dmel_backward", "dmel_backward_ex", "dmel_backward_fb", "dmel_backward_x", "dmel_spectrogram", "dmel_plan_get_info",
     "dmel_plan_set_profiling", "dmel_plan_get_profile", "dmel_spectrogram_ex",
     "dmel_comm_unique_id", "dmel_comm_create", "dmel_comm_destroy", "dmel_comm_allreduce_async", "dmel_comm_wait",
 )
@@ -97,6 +97,8 @@ def load():
     L.dmel_backward_ex.restype = C.c_int
     L.dmel_backward_fb.argtypes = [vp, vp, C.c_int32, C.c_float, C.c_uint32, vp, vp, vp, vp]
     L.dmel_backward_fb.restype = C.c_int
+    L.dmel_backward_x.argtypes = [vp, vp, C.c_int32, C.c_float, C.c_uint32, vp, vp, vp, vp]
+    L.dmel_backward_x.restype = C.c_int
     L.dmel_spectrogram.argtypes = [vp, vp, C.c_int32, C.c_float, C.c_int32, vp, vp]
     L.dmel_spectrogram.restype = C.c_int
     L.dmel_spectrogram_ex.argtypes = [vp, vp, C.c_int32, C.c_float, C.c_int32, C.c_uint32, vp, vp, vp]
@@ -193,6 +195,12 @@ class Plan:
         _check(load().dmel_backward_fb(self._h, x_ptr, batch, C.c_float(float(lambd)),
                                        (DMEL_FLAG_LOG if log else 0) | int(extra_flags), grad_ptr, out_ptr if log else None,
                                        grad_fb_ptr, stream))
+
+    def backward_x(self, x_ptr: int, batch: int, lambd: float, grad_ptr: int, out_ptr: int | None, grad_x_ptr: int,
+                   log: bool, stream: int):
+        """grad of the loss w.r.t. the waveform (adjoint of models.py:38-53)."""
+        _check(load().dmel_backward_x(self._h, x_ptr, batch, C.c_float(float(lambd)), DMEL_FLAG_LOG if log else 0, grad_ptr,
+                                      out_ptr if log else None, grad_x_ptr, stream))
 
     def spectrogram(self, x_ptr: int, batch: int, lambd: float, spec_ptr: int, stream: int, remove_dc: bool = False):
         _check(load().dmel_spectrogram(self._h, x_ptr, batch, C.c_float(float(lambd)), int(remove_dc), spec_ptr, stream))

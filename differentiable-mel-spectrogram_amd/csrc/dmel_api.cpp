@@ -60,12 +60,13 @@ struct NfftTables {
     int ent_b_floats = 0;
     int4* tile_ranges = nullptr;
     float* fb_dense = nullptr;   // (F, M) for the direct-DFT kernel
-    float2* tw_long = nullptr;   // long transforms: (N/2) twiddles, (M, F) transposed bank, (M) bands
-    float* fbT = nullptr;
+    float2* tw_long = nullptr;   // (N/2) twiddles exp(-2 pi i k / N): LDS radix-2 kernels (long transforms, dL/dx)
+    float* fbT = nullptr;        // long transforms: (M, F) transposed bank, (M) bands
     int2* band = nullptr;
+    int2* rowband = nullptr;     // (F): non-zero column range of every filterbank row (dL/dx)
     void release()
     {
-        void* ptrs[] = {tw1, tw2, ent_b, ent_pre, tile_ranges, fb_dense, tw_long, fbT, band};
+        void* ptrs[] = {tw1, tw2, ent_b, ent_pre, tile_ranges, fb_dense, tw_long, fbT, band, rowband};
         for (void* q : ptrs) (void)hipFree(q);
         *this = NfftTables();
     }
@@ -86,8 +87,8 @@ struct dmel_plan {
     float* win = nullptr;          // 2 * kMaxNfft floats
     double* partials = nullptr;    // kMaxPartials doubles, followed by the ticket counter of the dot kernel
     unsigned* dot_counter = nullptr;
-    float* fbw = nullptr;          // workspace of dmel_backward_fb: spectrogram (B, F, T) followed by the slice partials
-    size_t fbw_floats = 0;
+    float* fbw = nullptr;          // workspace of dmel_backward_fb (spectrogram (B, F, T) + slice partials) and dmel_backward_x
+    size_t fbw_floats = 0;         // (frame gradients (B, T, N)); grown on demand
     std::mutex mu;
     dmel_plan_info info{};
     // optional event timing
@@ -140,12 +141,25 @@ dmel_status build_tables(dmel_plan* pl, int N, NfftTables** out)
     DMEL_HIP(hipMalloc(&tb.fb_dense, fb.size() * sizeof(float)));
     DMEL_HIP(hipMemcpy(tb.fb_dense, fb.data(), fb.size() * sizeof(float), hipMemcpyHostToDevice));
 
-    if (N > dmel::kMaxFastNfft) {
-        std::vector<float2> tw((size_t)N / 2);
+    {
+        std::vector<float2> tw((size_t)std::max(1, N / 2));
         for (int k = 0; k < N / 2; ++k) {
             const double th = -2.0 * M_PI * (double)k / (double)N;
             tw[k] = make_float2((float)std::cos(th), (float)std::sin(th));
         }
+        DMEL_HIP(hipMalloc(&tb.tw_long, tw.size() * sizeof(float2)));
+        DMEL_HIP(hipMemcpy(tb.tw_long, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
+        std::vector<int2> rowband(tb.F);
+        for (int f = 0; f < tb.F; ++f) {
+            int lo = M, hi = 0;
+            for (int m = 0; m < M; ++m)
+                if (fb[(size_t)f * M + m] != 0.f) { lo = std::min(lo, m); hi = m + 1; }
+            rowband[f] = make_int2(hi > lo ? lo : 0, hi > lo ? hi : 0);
+        }
+        DMEL_HIP(hipMalloc(&tb.rowband, rowband.size() * sizeof(int2)));
+        DMEL_HIP(hipMemcpy(tb.rowband, rowband.data(), rowband.size() * sizeof(int2), hipMemcpyHostToDevice));
+    }
+    if (N > dmel::kMaxFastNfft) {
         std::vector<float> fbT((size_t)M * tb.F);
         std::vector<int2> band(M);
         for (int m = 0; m < M; ++m) {
@@ -157,8 +171,6 @@ dmel_status build_tables(dmel_plan* pl, int N, NfftTables** out)
             }
             band[m] = make_int2(hi > lo ? lo : 0, hi > lo ? hi : 0);
         }
-        DMEL_HIP(hipMalloc(&tb.tw_long, tw.size() * sizeof(float2)));
-        DMEL_HIP(hipMemcpy(tb.tw_long, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
         DMEL_HIP(hipMalloc(&tb.fbT, fbT.size() * sizeof(float)));
         DMEL_HIP(hipMemcpy(tb.fbT, fbT.data(), fbT.size() * sizeof(float), hipMemcpyHostToDevice));
         DMEL_HIP(hipMalloc(&tb.band, band.size() * sizeof(int2)));
@@ -488,6 +500,7 @@ dmel_status dmel_plan_create(const dmel_config* cfg, dmel_plan** plan)
         return fail(DMEL_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", libdmel_hip is built for gfx950 only");
     DMEL_HIP(dmel::forward_prepare_attributes());
     DMEL_HIP(dmel::long_prepare_attributes());
+    DMEL_HIP(dmel::xgrad_prepare_attributes());
     dmel_plan* pl = new (std::nothrow) dmel_plan();
     if (!pl) return fail(DMEL_ERR_OUT_OF_MEMORY, "host allocation failed");
     pl->cfg = *cfg;
@@ -634,6 +647,52 @@ dmel_status dmel_backward_fb(dmel_plan* plan, const float* x, int32_t batch, flo
     fp.B = batch; fp.F = F; fp.M = M; fp.T = T; fp.splits = splits;
     const size_t m0 = prof_mark(plan, s);
     DMEL_HIP(dmel::launch_fbgrad(fp, s));
+    prof_span(plan, m0, prof_mark(plan, s), 2);
+    return DMEL_OK;
+}
+
+dmel_status dmel_backward_x(dmel_plan* plan, const float* x, int32_t batch, float lambd, uint32_t flags,
+                            const float* grad_out, const float* out, float* grad_x, void* stream)
+{
+    if (!plan) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
+    if (batch < 0) return fail(DMEL_ERR_INVALID_ARGUMENT, "batch < 0");
+    if (batch == 0) return DMEL_OK;
+    if (!x || !grad_out || !grad_x) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_backward_x: x / grad_out / grad_x is NULL");
+    if ((flags & DMEL_FLAG_LOG) && !out) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_backward_x: DMEL_FLAG_LOG needs the saved log output");
+    if (flags & DMEL_FLAG_FULL_WINDOW) return fail(DMEL_ERR_UNSUPPORTED, "dmel_backward_x: the optimized=False branch is not supported");
+    if (!std::isfinite(lambd)) return fail(DMEL_ERR_INVALID_ARGUMENT, "lambd is not finite");
+    const int N = dmel_n_fft(lambd);
+    if (N > dmel::kMaxNfft)
+        return fail(DMEL_ERR_UNSUPPORTED, "n_fft = " + std::to_string(N) + " > 16384 (|lambd| > 2730.6) is not supported by the HIP kernels");
+    std::lock_guard<std::mutex> lock(plan->mu);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    NfftTables* tb = nullptr;
+    dmel_status st = build_tables(plan, N, &tb);
+    if (st != DMEL_OK) return st;
+    if ((st = ensure_psum(plan, batch)) != DMEL_OK) return st;
+    const size_t need = (size_t)batch * plan->T * N;
+    if (need > plan->fbw_floats) {
+        DMEL_HIP(hipStreamSynchronize(s));
+        (void)hipFree(plan->fbw); plan->fbw = nullptr; plan->fbw_floats = 0;
+        DMEL_HIP(hipMalloc(&plan->fbw, need * sizeof(float)));
+        plan->fbw_floats = need;
+    }
+    // clip sums + window table (the tangent half of the table is not used here)
+    dmel::PrepParams pp{};
+    pp.x = x; pp.psum = plan->psum; pp.win2 = reinterpret_cast<float2*>(plan->win);
+    pp.B = batch; pp.L = plan->cfg.n_points; pp.nchunks = plan->nchunks; pp.chunk = plan->chunk;
+    pp.N = N; pp.normalize = plan->cfg.normalize_window; pp.lambd_abs = std::fabs(lambd); pp.dw_scale = 1.0f; pp.win_half = 0;
+    DMEL_HIP(dmel::launch_prep(pp, s));
+    dmel::XgradParams xp{};
+    xp.x = x; xp.psum = plan->psum; xp.win2 = reinterpret_cast<const float2*>(plan->win); xp.tw = tb->tw_long;
+    xp.fb = tb->fb_dense; xp.rowband = tb->rowband; xp.grad_out = grad_out; xp.out = (flags & DMEL_FLAG_LOG) ? out : nullptr;
+    xp.frames = plan->fbw; xp.grad_x = grad_x;
+    xp.B = batch; xp.L = plan->cfg.n_points; xp.T = plan->T; xp.hop = plan->cfg.hop_length; xp.M = plan->cfg.n_mels;
+    xp.nchunks = plan->nchunks; xp.N = N; xp.F = tb->F; xp.remove_dc = 1;
+    xp.logN = 0; while ((1 << xp.logN) < N) ++xp.logN;
+    xp.inv_L = 1.0f / (float)plan->cfg.n_points;
+    const size_t m0 = prof_mark(plan, s);
+    DMEL_HIP(dmel::launch_xgrad(xp, s));
     prof_span(plan, m0, prof_mark(plan, s), 2);
     return DMEL_OK;
 }

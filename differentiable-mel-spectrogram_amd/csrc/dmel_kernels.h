@@ -127,6 +127,21 @@ struct LongParams {
 hipError_t launch_long(const LongParams& p, hipStream_t s);
 hipError_t long_prepare_attributes();
 
+// gradient w.r.t. the waveform (dmel_xgrad.hip)
+struct XgradParams {
+    const float* x; const float* psum; const float2* win2; const float2* tw;
+    const float* fb;            // (F, M) dense filterbank
+    const int2* rowband;        // (F): [first, last+1) non-zero columns of every filterbank row
+    const float* grad_out;      // (B, M, T)
+    const float* out;           // (B, M, T) saved log output or nullptr
+    float* frames;              // (B, T, N) workspace: windowed gradient of every frame
+    float* grad_x;              // (B, L)
+    int B, L, T, hop, M, nchunks, N, F, logN, remove_dc;
+    float inv_L;
+};
+hipError_t launch_xgrad(const XgradParams& p, hipStream_t s);
+hipError_t xgrad_prepare_attributes();
+
 // gradient w.r.t. the filterbank matrix of models.py:53 (adjoint of  mel = spec^T @ fb):
 //   grad_fb[f][m] = sum_{b,t} spec[b][f][t] * gm[b][m][t],   gm = grad_out            (linear output)
 //                                                            gm = grad_out * exp(-out) (log output: d log(s+eps) = ds / (s+eps))

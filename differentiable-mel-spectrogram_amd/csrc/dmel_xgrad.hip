@@ -1,0 +1,158 @@
+// dmel_xgrad.hip -- gradient w.r.t. the waveform (optional output of the layer's backward; the reference never asks for
+// it, torch autograd would return it for x.requires_grad).  Adjoint of models.py:38 (DC removal),
+// time_frequency.py:43-53 (zero padding, framing, window, rfft, |.|^2) and models.py:53 (mel contraction):
+//
+//   gP[k][t]  = sum_m fb[k][m] gm[m][t]                 gm = grad_out, or grad_out * exp(-out) for the log output
+//   dv_t[n]   = sum_{k=0}^{N-1} H_k e^{+2 pi i k n / N}   H_k = c_k gP[k] X_t[k]  (c = 2 at k = 0 and N/2, else 1), Hermitian
+//   dx~[i]    = sum over the frames t that cover i of dv_t[i - t hop + N/2] w[i - t hop + N/2]
+//   dx        = dx~ - mean(dx~)
+//
+// Kernel 1 (one workgroup per pair of frames, any power-of-two n_fft up to 16384): both frames go through ONE complex
+// FFT held in LDS (in-place radix-2 decimation in frequency, spectrum in bit-reversed order), the two spectra are
+// separated, scaled by gP and written back -- conjugated, Hermitian-extended, packed as conj(H_a) + i conj(H_b)... -- at
+// the same bit-reversed addresses, which is exactly the input order of an in-place decimation-in-time FFT; its output
+// is conj(dv_a + i dv_b) in natural order.  No permutation pass, no second buffer.  The windowed frame gradients go to a
+// (B, T, N) workspace.
+// Kernel 2 (one workgroup per clip): overlap-add as a gather in increasing frame order (deterministic, no atomics), then
+// the mean of the clip's gradient is subtracted (fp64 block sum in a fixed order).
+// A correctness-first path: about 10x the time of the fused forward at config 2.
+#include "dmel_kernels.h"
+
+namespace dmel {
+
+constexpr int kXgThreads = 256;
+
+__global__ void __launch_bounds__(kXgThreads) dmel_xgrad_frames_kernel(XgradParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* Z = reinterpret_cast<float2*>(smem_raw);
+    const int tid = threadIdx.x;
+    const int N = p.N, M = p.M, T = p.T, sh = 32 - p.logN;
+    const int tiles = (T + 1) / 2;
+    const int b = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const int tA = 2 * tile, tB = tA + 1;
+    const bool hasB = tB < T;
+    const float* xb = p.x + (size_t)b * p.L;
+    float mean = 0.f;
+    {
+        double s = 0.0;
+        for (int c = 0; c < p.nchunks; ++c) s += (double)p.psum[(size_t)b * p.nchunks + c];
+        mean = (float)(s * (double)p.inv_L);
+    }
+    for (int n = tid; n < N; n += kXgThreads) {
+        const long long ia = (long long)tA * p.hop - N / 2 + n, ib = ia + p.hop;
+        const float va = (ia >= 0 && ia < p.L) ? (xb[ia] - mean) : 0.f;
+        const float vb = (hasB && ib >= 0 && ib < p.L) ? (xb[ib] - mean) : 0.f;
+        const float w = p.win2[n].x;
+        Z[n] = make_float2(va * w, vb * w);
+    }
+    __syncthreads();
+    // forward: decimation in frequency, natural order in, bit-reversed order out
+    for (int span = N >> 1, tstep = 1; span >= 1; span >>= 1, tstep <<= 1) {
+        for (int i = tid; i < (N >> 1); i += kXgThreads) {
+            const int j = i & (span - 1);
+            const int lo = ((i - j) << 1) + j, hi = lo + span;
+            const float2 a = Z[lo], c = Z[hi];
+            const float2 w = p.tw[j * tstep];
+            const float dx = a.x - c.x, dy = a.y - c.y;
+            Z[lo] = make_float2(a.x + c.x, a.y + c.y);
+            Z[hi] = make_float2(fmaf(dx, w.x, -(dy * w.y)), fmaf(dx, w.y, dy * w.x));
+        }
+        __syncthreads();
+    }
+    // spectra of the two frames, gradient of the power spectrum, conj(H_a) + i conj(H_b) back in place
+    const float* ga = p.grad_out + (size_t)b * M * T + tA;
+    const float* ya = p.out ? p.out + (size_t)b * M * T + tA : nullptr;
+    for (int k = tid; k <= (N >> 1); k += kXgThreads) {
+        const unsigned ak = N > 1 ? __brev((unsigned)k) >> sh : 0u, an = N > 1 ? __brev((unsigned)((N - k) & (N - 1))) >> sh : 0u;
+        const float2 zk = Z[ak], zn = Z[an];
+        // X_a = (Z_k + conj Z_{N-k}) / 2,  X_b = (Z_k - conj Z_{N-k}) / (2i)
+        const float xar = 0.5f * (zk.x + zn.x), xai = 0.5f * (zk.y - zn.y);
+        const float xbr = 0.5f * (zk.y + zn.y), xbi = -0.5f * (zk.x - zn.x);
+        float gpa = 0.f, gpb = 0.f;
+        const int2 band = p.rowband[k];
+        for (int m = band.x; m < band.y; ++m) {
+            const float c = p.fb[(size_t)k * M + m];
+            float g0 = ga[(size_t)m * T], g1 = hasB ? ga[(size_t)m * T + 1] : 0.f;
+            if (ya) { g0 *= expf(-ya[(size_t)m * T]); if (hasB) g1 *= expf(-ya[(size_t)m * T + 1]); }
+            gpa = fmaf(c, g0, gpa);
+            gpb = fmaf(c, g1, gpb);
+        }
+        const bool edge = (k == 0) || (2 * k == N);
+        const float sc = edge ? 2.f : 1.f;
+        const float har = sc * gpa * xar, hai = edge ? 0.f : gpa * xai;      // X is real at k = 0 and N/2
+        const float hbr = sc * gpb * xbr, hbi = edge ? 0.f : gpb * xbi;
+        // U_k = conj(H_a,k + i H_b,k) = (har + hbi) + i (-(hai) + ... ): conj(a + i b) with a = har + i hai, b = hbr + i hbi
+        //     = conj(har - hbi + i (hai + hbr)) = (har - hbi) - i (hai + hbr)
+        Z[ak] = make_float2(har - hbi, -(hai + hbr));
+        // k' = N - k carries conj(H_a,k) + i conj(H_b,k) = (har + hbi) + i (hbr - hai); conjugated: (har + hbi) - i (hbr - hai)
+        if (!edge) Z[an] = make_float2(har + hbi, hai - hbr);
+    }
+    __syncthreads();
+    // decimation in time, bit-reversed order in, natural order out: R = FFT(conj W) = conj(dv_a + i dv_b)
+    for (int span = 1, tstep = N >> 1; span < N; span <<= 1, tstep >>= 1) {
+        for (int i = tid; i < (N >> 1); i += kXgThreads) {
+            const int j = i & (span - 1);
+            const int lo = ((i - j) << 1) + j, hi = lo + span;
+            const float2 a = Z[lo], c0 = Z[hi];
+            const float2 w = p.tw[j * tstep];
+            const float cx = fmaf(c0.x, w.x, -(c0.y * w.y)), cy = fmaf(c0.x, w.y, c0.y * w.x);
+            Z[lo] = make_float2(a.x + cx, a.y + cy);
+            Z[hi] = make_float2(a.x - cx, a.y - cy);
+        }
+        __syncthreads();
+    }
+    float* fa = p.frames + ((size_t)b * T + tA) * N;
+    for (int n = tid; n < N; n += kXgThreads) {
+        const float2 r = Z[n];
+        const float w = p.win2[n].x;
+        fa[n] = r.x * w;
+        if (hasB) fa[N + n] = -r.y * w;
+    }
+}
+
+__global__ void __launch_bounds__(1024) dmel_xgrad_gather_kernel(XgradParams p)
+{
+    __shared__ double red[1024];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int N = p.N, T = p.T, hop = p.hop, half = N / 2;
+    const float* fr = p.frames + (size_t)b * T * N;
+    float* gx = p.grad_x + (size_t)b * p.L;
+    double acc = 0.0;
+    for (int i = tid; i < p.L; i += 1024) {
+        // frames with 0 <= i - t hop + N/2 < N, in increasing t
+        int t_lo = i + half - N + 1;
+        t_lo = t_lo <= 0 ? 0 : (t_lo + hop - 1) / hop;
+        int t_hi = (i + half) / hop;
+        if (t_hi > T - 1) t_hi = T - 1;
+        float s = 0.f;
+        for (int t = t_lo; t <= t_hi; ++t) s += fr[(size_t)t * N + (i - t * hop + half)];
+        gx[i] = s;
+        acc += (double)s;
+    }
+    if (!p.remove_dc) return;
+    red[tid] = acc;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    const float mean = (float)(red[0] / (double)p.L);
+    for (int i = tid; i < p.L; i += 1024) gx[i] -= mean;       // every thread revisits the elements it wrote itself
+}
+
+hipError_t xgrad_prepare_attributes()
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(dmel_xgrad_frames_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               kMaxNfft * (int)sizeof(float2));
+}
+
+hipError_t launch_xgrad(const XgradParams& p, hipStream_t s)
+{
+    const long long grid = (long long)p.B * ((p.T + 1) / 2);
+    if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(dmel_xgrad_frames_kernel, dim3((unsigned)grid), dim3(kXgThreads), (size_t)p.N * sizeof(float2), s, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(dmel_xgrad_gather_kernel, dim3((unsigned)p.B), dim3(1024), 0, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace dmel

@@ -30,6 +30,7 @@ class _DmelFunction(torch.autograd.Function):
         out = torch.empty((B, 1, plan.n_mels, plan.n_time), dtype=out_dtype, device=x.device)     # models.py:36 (fp32 there)
         want_tangent = ctx.needs_input_grad[1]
         want_fb = fb is not None and ctx.needs_input_grad[7]
+        want_x = ctx.needs_input_grad[0]
         tangent = torch.empty(out.shape, dtype=torch.float32, device=x.device) if want_tangent else None
         flags = capi.DMEL_FLAG_FULL_WINDOW if full_window else 0
         with torch.cuda.device(x.device):
@@ -39,12 +40,12 @@ class _DmelFunction(torch.autograd.Function):
         ctx.plan = plan
         ctx.lambd_shape = lambd.shape
         ctx.lambd_dtype = lambd.dtype
-        ctx.want_tangent, ctx.want_fb = want_tangent, want_fb
+        ctx.want_tangent, ctx.want_fb, ctx.want_x = want_tangent, want_fb, want_x
         ctx.fb_args = (lam_host, bool(log), flags, None if fb is None else (tuple(fb.shape), fb.dtype))
         saved = []
         if want_tangent:
             saved.append(tangent)
-        if want_fb:
+        if want_fb or want_x:
             saved.append(x)
             if log:
                 saved.append(out)
@@ -56,23 +57,29 @@ class _DmelFunction(torch.autograd.Function):
         saved = list(ctx.saved_tensors)
         bf16 = grad_out.dtype == torch.bfloat16          # gradient of a bf16 output: read as it is, widened in the kernel
         g = grad_out.contiguous() if bf16 else grad_out.to(torch.float32).contiguous()
-        dl = gfb = None
+        dl = gfb = gx = None
         with torch.cuda.device(g.device):
             if ctx.want_tangent:
                 tangent = saved.pop(0)
                 dl = torch.empty((1,), dtype=torch.float32, device=g.device)
                 ctx.plan.backward(g.data_ptr(), tangent.data_ptr(), g.numel(), dl.data_ptr(), _stream_ptr(g.device), grad_bf16=bf16)
                 dl = dl.reshape(ctx.lambd_shape).to(ctx.lambd_dtype)
-            if ctx.want_fb:
-                lam_host, log, flags, (fb_shape, fb_dtype) = ctx.fb_args
+            if ctx.want_fb or ctx.want_x:
+                lam_host, log, flags, fb_meta = ctx.fb_args
                 x = saved.pop(0)
                 out = saved.pop(0).to(torch.float32) if log else None
                 g = g.to(torch.float32)
+            if ctx.want_x:
+                gx = torch.empty_like(x)
+                ctx.plan.backward_x(x.data_ptr(), x.shape[0], lam_host, g.data_ptr(), out.data_ptr() if log else None,
+                                    gx.data_ptr(), log, _stream_ptr(g.device))
+            if ctx.want_fb:
+                fb_shape, fb_dtype = fb_meta
                 gfb = torch.empty(fb_shape, dtype=torch.float32, device=g.device)
                 ctx.plan.backward_fb(x.data_ptr(), x.shape[0], lam_host, g.data_ptr(), out.data_ptr() if log else None,
                                      gfb.data_ptr(), log, _stream_ptr(g.device), extra_flags=flags)
                 gfb = gfb.to(fb_dtype)
-        return None, dl, None, None, None, None, None, gfb, None
+        return gx, dl, None, None, None, None, None, gfb, None
 
 
 class MelSpectrogramLayer(nn.Module):
@@ -171,11 +178,12 @@ class MelSpectrogramLayer(nn.Module):
                 "do (search_spaces.py:11,44)")
         if not x.is_cuda:
             raise RuntimeError("dmel_amd runs on MI355X only: x must be a CUDA/HIP tensor (no CPU fallback)")
-        if x.requires_grad:
-            raise NotImplementedError("gradient w.r.t. the waveform is not implemented (the reference never uses it)")
+        if x.requires_grad and not self.optimized:
+            raise NotImplementedError("gradient w.r.t. the waveform is implemented for optimized=True only")
         if self.lambd.device != x.device:
             raise RuntimeError(f"lambd is on {self.lambd.device} but x is on {x.device}; call layer.to(x.device)")
-        xf = x.detach().to(torch.float32).contiguous()
+        # the waveform's gradient (dmel_backward_x) flows through torch's own dtype / layout conversions
+        xf = x.to(torch.float32).contiguous() if x.requires_grad else x.detach().to(torch.float32).contiguous()
         lam_host = self._lambd_host()
         plan = self._plan_for(x.device)
         fb = self.mel_fb

@@ -142,6 +142,17 @@ dmel_status dmel_backward_ex(dmel_plan* plan, const void* grad_out, int32_t grad
 dmel_status dmel_backward_fb(dmel_plan* plan, const float* x, int32_t batch, float lambd, uint32_t flags,
                              const float* grad_out, const float* out, float* grad_fb, void* stream);
 
+/*
+ * Backward to the waveform: what torch autograd returns for x.requires_grad through models.py:38 (DC removal),
+ * time_frequency.py:43-53 (zero padding, framing, window, rfft, |.|^2), models.py:53 (mel contraction) and, with
+ * DMEL_FLAG_LOG, models.py:73.  The reference never differentiates the waveform; provided for completeness
+ * (adversarial / saliency uses).  Arguments as dmel_backward_fb; grad_x: device, (batch, n_points) fp32, overwritten.
+ * The optimized=False branch (DMEL_FLAG_FULL_WINDOW) is not supported.  Deterministic (overlap-add as an ordered
+ * gather).  Asynchronous on `stream`; shares the plan-owned workspace with dmel_backward_fb.
+ */
+dmel_status dmel_backward_x(dmel_plan* plan, const float* x, int32_t batch, float lambd, uint32_t flags,
+                            const float* grad_out, const float* out, float* grad_x, void* stream);
+
 /* Power spectrogram only, (batch, n_fft/2+1, n_time) fp32 = time_frequency.differentiable_spectrogram
  * (time_frequency.py:32-58, optimized branch) applied per clip; remove_dc != 0 adds models.py:38. */
 dmel_status dmel_spectrogram(dmel_plan* plan, const float* x, int32_t batch, float lambd,

@@ -420,6 +420,77 @@ int dmel_oracle_fbgrad(const float* x, int B, int L, float lambd_raw, int hop, i
     return rc;
 }
 
+/* Gradient w.r.t. the waveform: the adjoint of models.py:38 (DC removal), time_frequency.py:43-53 (zero padding,
+ * framing, window, rfft, |.|^2) and models.py:53 (mel contraction), i.e. what autograd returns for x.requires_grad:
+ *   gP[k][t]  = sum_m fb[k][m] gm[m][t]
+ *   dv_t[n]   = sum_{k=0}^{N-1} H_k e^{+2 pi i k n / N},  H_k = c_k gP[k] X_t[k] (c = 2 at k = 0, N/2; 1 otherwise), Hermitian
+ *   dx~[i]   += dv_t[n] w[n]   at i = t hop - N/2 + n inside the clip
+ *   dx        = dx~ - mean(dx~)
+ * gm: gradient w.r.t. the LINEAR mel output, (B, M, T) fp64; fb: (F, M) fp32; grad_x: (B, L) fp64. */
+int dmel_oracle_xgrad(const float* x, int B, int L, float lambd_raw, int hop, int normalize_window,
+                      const double* gm, int n_mels, const float* fb, double* grad_x)
+{
+    if (!x || !gm || !fb || !grad_x || B < 0 || L < 1 || hop < 1 || n_mels < 1) return DMEL_ORACLE_EINVAL;
+    const int N = dmel_oracle_n_fft(lambd_raw);
+    const int F = N / 2 + 1, T = L / hop + 1, pad = N / 2, M = n_mels;
+    float* w = (float*)malloc(sizeof(float) * (size_t)N);
+    double* cs = (double*)malloc(sizeof(double) * (size_t)N);
+    double* sn = (double*)malloc(sizeof(double) * (size_t)N);
+    if (!w || !cs || !sn) { free(w); free(cs); free(sn); return DMEL_ORACLE_ENOMEM; }
+    dmel_oracle_window(lambd_raw, N, normalize_window, w, NULL);
+    for (int k = 0; k < N; ++k) { cs[k] = cos(2.0 * M_PI * k / N); sn[k] = sin(2.0 * M_PI * k / N); }
+    int rc = DMEL_ORACLE_OK;
+#pragma omp parallel
+    {
+        double* re = (double*)malloc(sizeof(double) * (size_t)N);
+        double* im = (double*)malloc(sizeof(double) * (size_t)N);
+        if (!re || !im) {
+#pragma omp critical
+            rc = DMEL_ORACLE_ENOMEM;
+        }
+#pragma omp for schedule(static)
+        for (int b = 0; b < B; ++b) {
+            if (!re || !im) continue;
+            const float* xb = x + (size_t)b * L;
+            double* gx = grad_x + (size_t)b * L;
+            double s = 0.0;
+            for (int i = 0; i < L; ++i) { s += (double)xb[i]; gx[i] = 0.0; }
+            const float mean = (float)(s / (double)L);
+            for (int t = 0; t < T; ++t) {
+                for (int n = 0; n < N; ++n) {
+                    long long sidx = (long long)t * hop - pad + n;
+                    float v = (sidx >= 0 && sidx < L) ? (xb[sidx] - mean) : 0.0f;
+                    re[n] = (double)(v * w[n]);
+                    im[n] = 0.0;
+                }
+                fft_c2c(re, im, N, cs, sn);
+                /* conj(H) in place, Hermitian extension, then forward FFT: dv = conj(FFT(conj H)) is real */
+                for (int k = 0; k < F; ++k) {
+                    double gp = 0.0;
+                    for (int m = 0; m < M; ++m) gp += (double)fb[(size_t)k * M + m] * gm[((size_t)b * M + m) * T + t];
+                    const double c = (k == 0 || k == N / 2) ? 2.0 : 1.0;
+                    const double hr = c * gp * re[k], hi = c * gp * im[k];
+                    re[k] = hr; im[k] = -hi;
+                    if (k > 0 && k < N / 2) { re[N - k] = hr; im[N - k] = hi; }
+                }
+                if (N >= 2) { im[0] = 0.0; im[N / 2] = 0.0; }
+                fft_c2c(re, im, N, cs, sn);
+                for (int n = 0; n < N; ++n) {
+                    long long sidx = (long long)t * hop - pad + n;
+                    if (sidx >= 0 && sidx < L) gx[sidx] += re[n] * (double)w[n];
+                }
+            }
+            double gs = 0.0;
+            for (int i = 0; i < L; ++i) gs += gx[i];
+            gs /= (double)L;
+            for (int i = 0; i < L; ++i) gx[i] -= gs;
+        }
+        free(re); free(im);
+    }
+    free(w); free(cs); free(sn);
+    return rc;
+}
+
 /* naive DFT for transform lengths that are not powers of two (non-optimized DSPEC with arbitrary n_points) */
 static void dft_c2c(const double* re, const double* im, int n, double* ore, double* oim)
 {

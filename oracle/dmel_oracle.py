@@ -50,6 +50,8 @@ def lib():
         L.dmel_oracle_spectrogram.restype = C.c_int
         L.dmel_oracle_fbgrad.argtypes = [fp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, dp, C.c_int, dp]
         L.dmel_oracle_fbgrad.restype = C.c_int
+        L.dmel_oracle_xgrad.argtypes = [fp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, dp, C.c_int, fp, dp]
+        L.dmel_oracle_xgrad.restype = C.c_int
         L.dmel_oracle_dspec.argtypes = [fp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, fp, fp]
         L.dmel_oracle_dspec.restype = C.c_int
         _lib = L
@@ -140,6 +142,30 @@ def backward_fb(x: np.ndarray, lambd: float, hop: int, grad_out: np.ndarray, out
     if rc != 0:
         raise RuntimeError(f"dmel_oracle_fbgrad failed rc={rc}")
     return gfb
+
+
+def backward_x(x: np.ndarray, lambd: float, hop: int, sample_rate: int, grad_out: np.ndarray, out: np.ndarray | None = None,
+               f_min: float = 0.0, f_max: float | None = None, normalize_window: bool = False, fb: np.ndarray | None = None) -> np.ndarray:
+    """d loss / d x, (B, L) fp64: adjoint of models.py:38-53.  ``out`` = the LOG output when the loss was taken on
+    log(mel + eps) (models.py:73), None for the linear layer; ``fb`` overrides the HTK bank."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    B, L = x.shape
+    g = np.asarray(grad_out, dtype=np.float64).reshape(B, -1, L // hop + 1)
+    if out is not None:
+        g = g * np.exp(-np.asarray(out, dtype=np.float64).reshape(g.shape))
+    g = np.ascontiguousarray(g)
+    M = g.shape[1]
+    N = n_fft(lambd)
+    if fb is None:
+        fb = mel_fbanks(N // 2 + 1, f_min, float(sample_rate // 2) if f_max is None else f_max, M, sample_rate)
+    fb = np.ascontiguousarray(fb, dtype=np.float32)
+    gx = np.empty((B, L), np.float64)
+    dp = C.POINTER(C.c_double)
+    rc = lib().dmel_oracle_xgrad(_fp(x), B, L, np.float32(lambd), hop, int(normalize_window), g.ctypes.data_as(dp), M, _fp(fb),
+                                 gx.ctypes.data_as(dp))
+    if rc != 0:
+        raise RuntimeError(f"dmel_oracle_xgrad failed rc={rc}")
+    return gx
 
 
 def dspec(x: np.ndarray, lambd: float, hop: int = 1, normalize_window: bool = False):

@@ -184,6 +184,26 @@ def run_panns(models):
     return out
 
 
+XGRAD_CASES = ("g1_c1", "g5_n128", "g6_n256_ragged", "g6_tone_dc", "g6_n32")
+
+
+def run_xgrad(models, tf, case):
+    """G10: d loss / d x out of the reference's own forward + torch autograd (x.requires_grad_()); stored as fp32, full."""
+    x = torch.from_numpy(C.make_input(case)).requires_grad_(True)
+    g = torch.from_numpy(C.make_cotangent(case))
+    layer = models.MelSpectrogramLayer(
+        init_lambd=torch.tensor(float(case["lambd"]), dtype=torch.float32),
+        n_mels=case["n_mels"], n_points=case["L"], sample_rate=case["sr"],
+        f_min=case["f_min"], f_max=case["f_max"], hop_length=case["hop"], device="cpu",
+        optimized=case["optimized"], normalize_window=case["normalize_window"])
+    mel = layer(x)
+    y = torch.log(mel + 1e-10)
+    (g_log,) = torch.autograd.grad((y * g).sum(), x, retain_graph=True)
+    (g_lin,) = torch.autograd.grad((mel * g).sum(), x)
+    keep = 2       # clips are independent: the first two pin the path, the fixtures stay small
+    return dict(gx_lin=g_lin.numpy().astype(np.float32)[:keep], gx_log=g_log.numpy().astype(np.float32)[:keep])
+
+
 def run_net_keys(models):
     """state_dict keys + shapes of the reference's wrapping nets (models.py:58-136): the checkpoint contract."""
     import json
@@ -203,10 +223,12 @@ def main(argv):
         argv = [a for a in argv if a != "net_keys"]
         if len(argv) == 1 and "net_keys" in sys.argv:
             return
-    names = argv[1:] or [c["name"] for c in C.CASES] + ["g7_dspec"] + ["g8_fbgrad_" + n for n in FBGRAD_CASES] + ["g9_panns"]
+    names = argv[1:] or [c["name"] for c in C.CASES] + ["g7_dspec"] + ["g8_fbgrad_" + n for n in FBGRAD_CASES] + ["g9_panns"] + ["g10_xgrad_" + n for n in XGRAD_CASES]
     for name in names:
         if name == "g7_dspec":
             out = run_dspec(models, tf)
+        elif name.startswith("g10_xgrad_"):
+            out = run_xgrad(models, tf, C.BY_NAME[name[len("g10_xgrad_"):]])
         elif name == "g9_panns":
             out = run_panns(models)
         elif name.startswith("g8_fbgrad_"):

@@ -636,3 +636,60 @@ def test_panns_net_training_step():
         assert torch.isfinite(net.spectrogram_layer.lambd.grad).all() and float(net.spectrogram_layer.lambd.grad.abs()) > 0
         opt.step()
     assert float(net.spectrogram_layer.lambd.detach()) != lam0 and torch.isfinite(loss)
+
+
+# ---- gradient w.r.t. the waveform (adjoint of models.py:38-53) ---------------------------------------------------
+def _gx_err(got, exp):
+    return float(np.abs(got.astype(np.float64) - exp).max() / (np.abs(exp).max() + 1e-30))
+
+
+@pytest.mark.parametrize("name", ["g1_c1", "g5_n128", "g6_n256_ragged", "g6_tone_dc", "g6_n32"])
+def test_xgrad_matches_reference_golden(name):
+    """x.requires_grad through the nn.Module against torch autograd through the reference (g10_xgrad_*.npz, first two
+    clips) and against the fp64 oracle (all clips)."""
+    import os
+    case = C.BY_NAME[name]
+    gold = np.load(os.path.join(os.path.dirname(C.__file__), f"g10_xgrad_{name}.npz"))
+    x_np = C.make_input(case).astype(np.float32)
+    g_np = C.make_cotangent(case)
+    g = torch.from_numpy(g_np).to("cuda:0")
+    for log, key in ((False, "gx_lin"), (True, "gx_log")):
+        x = torch.from_numpy(x_np).to("cuda:0").requires_grad_(True)
+        layer = _layer(case, log=log)
+        y = layer(x)
+        (y * g).sum().backward()
+        gx = x.grad.cpu().numpy()
+        assert gx.shape == x_np.shape and np.isfinite(gx).all()
+        k = gold[key].shape[0]
+        assert _gx_err(gx[:k], gold[key].astype(np.float64)) <= TOL
+        ref = O.backward_x(x_np, case["lambd"], case["hop"], case["sr"], g_np, y.detach().cpu().numpy() if log else None,
+                           case["f_min"], case["f_max"], case["normalize_window"])
+        assert _gx_err(gx, ref) <= TOL
+        assert float(np.abs(gx.sum(1)).max()) <= 1e-4 * float(np.abs(gx).sum(1).max())      # DC removal: zero-sum per clip
+        assert layer.lambd.grad is not None                                                # both gradients from one backward
+        # deterministic
+        x2 = torch.from_numpy(x_np).to("cuda:0").requires_grad_(True)
+        (_layer(case, log=log)(x2) * g).sum().backward()
+        assert torch.equal(x.grad, x2.grad)
+
+
+def test_xgrad_long_transform_and_finite_difference():
+    case = dict(C.BY_NAME["g6_fminmax"], name="xgrad_8192", B=1, L=12000, lambd=700.0, hop=600, n_mels=40)
+    x_np = C.make_input(case).astype(np.float32)
+    g_np = C.make_cotangent(case)
+    x = torch.from_numpy(x_np).to("cuda:0").requires_grad_(True)
+    layer = _layer(case, log=True)
+    y = layer(x)
+    (y * torch.from_numpy(g_np).to("cuda:0")).sum().backward()
+    ref = O.backward_x(x_np, case["lambd"], case["hop"], case["sr"], g_np, y.detach().cpu().numpy(), case["f_min"], case["f_max"])
+    assert _gx_err(x.grad.cpu().numpy(), ref) <= TOL
+    # directional finite difference on the oracle-free path: loss(x + h d) - loss(x - h d) ~ 2 h <grad, d>
+    d = torch.from_numpy(C.synth.waveforms(1, case["L"], seed=99, scale=1.0)).to("cuda:0")
+    h = 1e-3
+    with torch.no_grad():
+        gdev = torch.from_numpy(g_np).to("cuda:0").double()
+        lp = (layer(x.detach() + h * d).double() * gdev).sum()
+        lm = (layer(x.detach() - h * d).double() * gdev).sum()
+    fd = float(lp - lm) / (2 * h)
+    an = float((x.grad.double() * d.double()).sum())
+    assert abs(fd - an) <= 2e-2 * abs(an) + 1e-3

@@ -128,3 +128,30 @@ def test_oracle_fbgrad_matches_reference(name):
                      case["normalize_window"], apply_log=True, want_tangent=False)
     got_log = O.backward_fb(x, case["lambd"], case["hop"], g, y, case["normalize_window"])
     assert _gfb_err(got_log, gold["gfb_log"]) <= 1e-4
+
+
+XGRAD_CASES = ("g1_c1", "g5_n128", "g6_n256_ragged", "g6_tone_dc", "g6_n32")
+
+
+def _gx_err(got, exp):
+    return float(np.abs(got - exp).max() / (np.abs(exp).max() + 1e-30))
+
+
+@pytest.mark.parametrize("name", XGRAD_CASES)
+def test_oracle_xgrad_matches_reference(name):
+    """d loss / d x (adjoint of models.py:38-53) against torch autograd through the reference's own forward
+    (tests/golden/make_golden.py: run_xgrad; first two clips stored)."""
+    import os
+    case = C.BY_NAME[name]
+    gold = np.load(os.path.join(os.path.dirname(C.__file__), f"g10_xgrad_{name}.npz"))
+    x = C.make_input(case).astype(np.float32)
+    g = C.make_cotangent(case)
+    got_lin = O.backward_x(x, case["lambd"], case["hop"], case["sr"], g, None, case["f_min"], case["f_max"], case["normalize_window"])
+    k = gold["gx_lin"].shape[0]
+    assert _gx_err(got_lin[:k], gold["gx_lin"]) <= 1e-4
+    y, _ = O.forward(x, case["lambd"], case["hop"], case["n_mels"], case["sr"], case["f_min"], case["f_max"],
+                     case["normalize_window"], apply_log=True, want_tangent=False)
+    got_log = O.backward_x(x, case["lambd"], case["hop"], case["sr"], g, y, case["f_min"], case["f_max"], case["normalize_window"])
+    assert _gx_err(got_log[:k], gold["gx_log"]) <= 1e-4
+    # DC removal: the gradient of every clip sums to zero
+    assert np.abs(got_lin.sum(1)).max() <= 1e-9 * np.abs(got_lin).sum(1).max()

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Times dmel_backward_fb (spectrogram recompute + grad_fb GEMM + slice reduction) at BASELINE config 2 / 3."""
+"""Times the optional backward outputs at BASELINE config 2 / 3: dmel_backward_fb (spectrogram recompute + grad_fb GEMM +
+slice reduction) and dmel_backward_x (frame gradients + ordered overlap-add)."""
 import json
 import os
 import sys
@@ -38,6 +39,18 @@ def main():
             us = e0.elapsed_time(e1) * 1000 / 50
             flops = 2.0 * B * T * (n // 2 + 1) * M
             res[f"{name}_{'log' if log else 'lin'}"] = dict(us=round(us, 2), gemm_tflops=round(flops / us / 1e6, 2))
+        gx = torch.empty_like(x)
+        for log in (False, True):
+            for _ in range(3):
+                plan.backward_x(x.data_ptr(), B, lam, g.data_ptr(), y.data_ptr(), gx.data_ptr(), log, st)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                plan.backward_x(x.data_ptr(), B, lam, g.data_ptr(), y.data_ptr(), gx.data_ptr(), log, st)
+            e1.record()
+            torch.cuda.synchronize()
+            res[f"{name}_xgrad_{'log' if log else 'lin'}"] = dict(us=round(e0.elapsed_time(e1) * 1000 / 20, 2))
     print(json.dumps(res))
 
 
