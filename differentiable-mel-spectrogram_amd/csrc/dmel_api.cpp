@@ -127,6 +127,10 @@ dmel_status build_tables(dmel_plan* pl, int N, NfftTables** out)
     auto it = pl->tables.find(N);
     if (it != pl->tables.end()) { *out = &it->second; return DMEL_OK; }
     NfftTables tb;
+    struct Guard {          // a failed allocation half-way must not leak the tables made so far
+        NfftTables* t; bool keep = false;
+        ~Guard() { if (!keep) t->release(); }
+    } guard{&tb};
     tb.n_fft = N;
     tb.F = N / 2 + 1;
     const int M = pl->cfg.n_mels;
@@ -275,6 +279,7 @@ dmel_status build_tables(dmel_plan* pl, int N, NfftTables** out)
         DMEL_HIP(hipMemcpy(tb.tile_ranges, ranges.data(), ranges.size() * sizeof(int4), hipMemcpyHostToDevice));
     }
     auto ins = pl->tables.emplace(N, tb);
+    guard.keep = true;
     *out = &ins.first->second;
     return DMEL_OK;
 }
