@@ -51,4 +51,4 @@ print(json.dumps({
     "frontend_ms": round(front_ms, 4), "frontend_share": round(front_ms / (1e3 * dt), 4),
     "frontend_frames_per_s": round(B * T / (front_ms * 1e-3), 1),
     "frontend_kernels_ms": {"prep": round(pr["prep_ms"] / steps, 4), "fused_forward": round(pr["fwd_ms"] / steps, 4), "dot_backward": round(pr["bwd_ms"] / steps, 4)},
-    "lambd_after": float(net.spectrogram_layer.lambd), "loss": float(loss), "info": plan.info()}))
+    "lambd_after": float(net.spectrogram_layer.lambd.detach()), "loss": float(loss), "info": plan.info()}))
