@@ -636,7 +636,9 @@ dmel_status dmel_backward_fb(dmel_plan* plan, const float* x, int32_t batch, flo
     const int tiles = ((F + 31) / 32) * ((M + 127) / 128);
     const int splits = std::max(1, std::min(batch, (1024 + tiles - 1) / tiles));
     const size_t spec_floats = ((size_t)batch * F * T + 63) / 64 * 64;
-    const size_t need = spec_floats + (size_t)splits * F * M;
+    const size_t part_floats = ((size_t)splits * F * M + 63) / 64 * 64;
+    const size_t gm_floats = (flags & DMEL_FLAG_LOG) ? (size_t)batch * M * T + 16 : 0;
+    const size_t need = spec_floats + part_floats + gm_floats;
     if (need > plan->fbw_floats) {
         DMEL_HIP(hipStreamSynchronize(s));
         (void)hipFree(plan->fbw); plan->fbw = nullptr; plan->fbw_floats = 0;
@@ -649,6 +651,7 @@ dmel_status dmel_backward_fb(dmel_plan* plan, const float* x, int32_t batch, flo
     dmel::FbGradParams fp{};
     fp.spec = plan->fbw; fp.grad_out = grad_out; fp.out = (flags & DMEL_FLAG_LOG) ? out : nullptr;
     fp.partials = plan->fbw + spec_floats; fp.grad_fb = grad_fb;
+    fp.gm_ws = plan->fbw + spec_floats + part_floats;
     fp.B = batch; fp.F = F; fp.M = M; fp.T = T; fp.splits = splits;
     const size_t m0 = prof_mark(plan, s);
     DMEL_HIP(dmel::launch_fbgrad(fp, s));

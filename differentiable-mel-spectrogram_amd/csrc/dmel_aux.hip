@@ -328,11 +328,27 @@ hipError_t launch_long(const LongParams& p, hipStream_t s)
 // batch; exact-fp32 MFMA 16x16x4, A = spec rows, B = gm rows, both read straight from global memory as 16-byte
 // pieces along t (lane (row, kq) holds t = 16 j + 4 kq + i for k-step i -- any bijection of t onto (step, k) is
 // a valid K order as long as A and B use the same one).  Slices are summed in index order by a second kernel:
-// deterministic, no atomics.
+// deterministic, no atomics.  For the log output gm = grad_out * exp(-out) is formed once by a small pre-pass.
 typedef float floatx4_t __attribute__((ext_vector_type(4)));
+template <int I> struct IdxC { static constexpr int value = I; };
+template <int B, int E, class Fn> __device__ __forceinline__ void unrolled(Fn&& f)
+{
+    if constexpr (B < E) { f(IdxC<B>{}); unrolled<B + 1, E>(f); }
+}
 struct __attribute__((packed, aligned(4))) f4u { float v[4]; };       // 16-byte load that only needs 4-byte alignment
 
-template <bool LOG>
+// gm = grad_out * exp(-out): once per element instead of once per frequency tile
+__global__ void __launch_bounds__(256) dmel_fbgrad_gm_kernel(const float* __restrict__ g, const float* __restrict__ y, float* __restrict__ gm, long long n)
+{
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n && ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gm)) & 15) == 0) {
+        const float4 a = *reinterpret_cast<const float4*>(g + i), b = *reinterpret_cast<const float4*>(y + i);
+        *reinterpret_cast<float4*>(gm + i) = make_float4(a.x * expf(-b.x), a.y * expf(-b.y), a.z * expf(-b.z), a.w * expf(-b.w));
+    } else {
+        for (long long k = i; k < n && k < i + 4; ++k) gm[k] = g[k] * expf(-y[k]);
+    }
+}
+
 __global__ void __launch_bounds__(256) dmel_fbgrad_kernel(FbGradParams p)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -351,53 +367,60 @@ __global__ void __launch_bounds__(256) dmel_fbgrad_kernel(FbGradParams p)
     }
     floatx4_t acc[2][2];
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) acc[i][j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
-    const int tfull = T / 16 * 16;
-    for (int b = b_lo; b < b_hi; ++b) {
-        const float* pa[2]; const float* pg[2]; const float* py[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            pa[i] = p.spec + ((size_t)b * F + fr[i]) * T;
-            pg[i] = p.grad_out + ((size_t)b * M + mr[i]) * T;
-            py[i] = LOG ? p.out + ((size_t)b * M + mr[i]) * T : nullptr;
-        }
-        for (int t = 0; t < tfull; t += 16) {
-            f4u a[2], g[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[i] = *reinterpret_cast<const f4u*>(pa[i] + t + 4 * kq);
-                g[i] = *reinterpret_cast<const f4u*>(pg[i] + t + 4 * kq);
-                if constexpr (LOG) {
-                    const f4u y = *reinterpret_cast<const f4u*>(py[i] + t + 4 * kq);
-                    for (int u = 0; u < 4; ++u) g[i].v[u] *= expf(-y.v[u]);
-                }
+    // full blocks of 16 time steps, flattened over (clip, block): a ring of DEPTH register buffers keeps DEPTH blocks of
+    // loads in flight (the loop is otherwise one memory round trip per 16 MFMAs)
+    constexpr int DEPTH = 4;
+    const int ntc = T / 16, total = (b_hi - b_lo) * ntc;
+    f4u a[DEPTH][2], g[DEPTH][2];
+    auto issue = [&](int c, int slot) {          // always inlined with a constant slot
+        if (c >= total) return;
+        const int b = b_lo + c / ntc, t = (c % ntc) * 16 + 4 * kq;
+        a[slot][0] = *reinterpret_cast<const f4u*>(p.spec + ((size_t)b * F + fr[0]) * T + t);
+        a[slot][1] = *reinterpret_cast<const f4u*>(p.spec + ((size_t)b * F + fr[1]) * T + t);
+        g[slot][0] = *reinterpret_cast<const f4u*>(p.gm + ((size_t)b * M + mr[0]) * T + t);
+        g[slot][1] = *reinterpret_cast<const f4u*>(p.gm + ((size_t)b * M + mr[1]) * T + t);
+    };
+    unrolled<0, DEPTH>([&](auto dd) { issue(decltype(dd)::value, decltype(dd)::value); });
+    for (int c0 = 0; c0 < total; c0 += DEPTH) {
+        unrolled<0, DEPTH>([&](auto dd) {
+            constexpr int d = decltype(dd)::value;          // compile-time ring slot: the buffers stay in registers
+            if (c0 + d < total) {
+                unrolled<0, 4>([&](auto uu) {
+                    constexpr int u = decltype(uu)::value;
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[d][0].v[u], g[d][0].v[u], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[d][0].v[u], g[d][1].v[u], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[d][1].v[u], g[d][0].v[u], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[d][1].v[u], g[d][1].v[u], acc[1][1], 0, 0, 0);
+                });
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                for (int i = 0; i < 2; ++i)
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].v[u], g[j].v[u], acc[i][j], 0, 0, 0);
-        }
-        if (tfull < T) {
+            issue(c0 + DEPTH + d, d);
+        });
+    }
+    const int tfull = ntc * 16;
+    if (tfull < T) {
+        for (int b = b_lo; b < b_hi; ++b) {
             // last partial block of 16: element-wise, zero past the end of the row
-            float a[2][4], g[2][4];
+            float at[2][4], gt[2][4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int tt = tfull + 4 * kq + u;
                 const bool ok = tt < T;
                 const int tc = ok ? tt : T - 1;
+#pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const float av = pa[i][tc];
-                    float gv = pg[i][tc];
-                    if constexpr (LOG) gv *= expf(-py[i][tc]);
-                    a[i][u] = ok ? av : 0.f;
-                    g[i][u] = ok ? gv : 0.f;
+                    const float av = p.spec[((size_t)b * F + fr[i]) * T + tc];
+                    const float gv = p.gm[((size_t)b * M + mr[i]) * T + tc];
+                    at[i][u] = ok ? av : 0.f;
+                    gt[i][u] = ok ? gv : 0.f;
                 }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
+#pragma unroll
                 for (int i = 0; i < 2; ++i)
+#pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][u], g[j][u], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(at[i][u], gt[j][u], acc[i][j], 0, 0, 0);
         }
     }
     // D[4 * (lane >> 4) + r][lane & 15]: rows = freq, columns = mel
@@ -421,15 +444,32 @@ __global__ void __launch_bounds__(256) dmel_fbgrad_reduce_kernel(FbGradParams p)
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     float s = 0.f;
-    for (int q = 0; q < p.splits; ++q) s += p.partials[(size_t)q * n + i];     // fixed order
+    int q = 0;
+    for (; q + 8 <= p.splits; q += 8) {          // eight loads in flight, added in index order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p.partials[(size_t)(q + u) * n + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; q < p.splits; ++q) s += p.partials[(size_t)q * n + i];     // fixed order
     p.grad_fb[i] = s;
 }
 
-hipError_t launch_fbgrad(const FbGradParams& p, hipStream_t s)
+hipError_t launch_fbgrad(const FbGradParams& p_in, hipStream_t s)
 {
+    FbGradParams p = p_in;
+    if (p.out) {
+        const long long n = (long long)p.B * p.M * p.T;
+        hipLaunchKernelGGL(dmel_fbgrad_gm_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, p.grad_out, p.out, p.gm_ws, n);
+        hipError_t e0 = hipGetLastError();
+        if (e0 != hipSuccess) return e0;
+        p.gm = p.gm_ws;
+    } else {
+        p.gm = p.grad_out;
+    }
     const dim3 grid((p.F + 31) / 32, p.splits, (p.M + 127) / 128);
-    if (p.out) hipLaunchKernelGGL(dmel_fbgrad_kernel<true>, grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(dmel_fbgrad_kernel<false>, grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL(dmel_fbgrad_kernel, grid, dim3(256), 0, s, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const size_t n = (size_t)p.F * p.M;

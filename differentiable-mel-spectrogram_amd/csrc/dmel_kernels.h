@@ -149,6 +149,8 @@ struct FbGradParams {
     const float* spec;       // (B, F, T) power spectrogram of the same clips (kSpec pass)
     const float* grad_out;   // (B, M, T)
     const float* out;        // (B, M, T) saved log output, or nullptr for the linear layer
+    float* gm_ws;            // (B, M, T) workspace for gm when out != nullptr
+    const float* gm;         // set by launch_fbgrad: grad_out or gm_ws
     float* partials;         // (splits, F, M)
     float* grad_fb;          // (F, M)
     int B, F, M, T, splits;

@@ -38,7 +38,16 @@ def main():
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1000 / 50
             flops = 2.0 * B * T * (n // 2 + 1) * M
-            res[f"{name}_{'log' if log else 'lin'}"] = dict(us=round(us, 2), gemm_tflops=round(flops / us / 1e6, 2))
+            plan.set_profiling(True)
+            for _ in range(20):
+                plan.backward_fb(x.data_ptr(), B, lam, g.data_ptr(), y.data_ptr(), gfb.data_ptr(), log, st)
+            torch.cuda.synchronize()
+            pr = plan.get_profile()
+            plan.set_profiling(False)
+            spec_us = 1e3 * pr["fwd_ms"] / max(1, pr["fwd_launches"])
+            gemm_us = 1e3 * pr["bwd_ms"] / max(1, pr["bwd_launches"])
+            res[f"{name}_{'log' if log else 'lin'}"] = dict(us=round(us, 2), spectrogram_us=round(spec_us, 2), gemm_and_reduce_us=round(gemm_us, 2),
+                                                            gemm_tflops=round(flops / gemm_us / 1e6, 2))
         gx = torch.empty_like(x)
         for log in (False, True):
             for _ in range(3):
