@@ -678,7 +678,8 @@ dmel_status dmel_backward_x(dmel_plan* plan, const float* x, int32_t batch, floa
     dmel_status st = build_tables(plan, N, &tb);
     if (st != DMEL_OK) return st;
     if ((st = ensure_psum(plan, batch)) != DMEL_OK) return st;
-    const size_t need = (size_t)batch * plan->T * N;
+    const size_t frame_floats = ((size_t)batch * plan->T * N + 63) / 64 * 64;
+    const size_t need = frame_floats + 2 * (size_t)batch * dmel::xgrad_chunks(plan->cfg.n_points) + 16;    // + fp64 chunk sums
     if (need > plan->fbw_floats) {
         DMEL_HIP(hipStreamSynchronize(s));
         (void)hipFree(plan->fbw); plan->fbw = nullptr; plan->fbw_floats = 0;
@@ -695,6 +696,7 @@ dmel_status dmel_backward_x(dmel_plan* plan, const float* x, int32_t batch, floa
     xp.x = x; xp.psum = plan->psum; xp.win2 = reinterpret_cast<const float2*>(plan->win); xp.tw = tb->tw_long;
     xp.fb = tb->fb_dense; xp.rowband = tb->rowband; xp.grad_out = grad_out; xp.out = (flags & DMEL_FLAG_LOG) ? out : nullptr;
     xp.frames = plan->fbw; xp.grad_x = grad_x;
+    xp.csum = reinterpret_cast<double*>(plan->fbw + frame_floats);      // 256-byte aligned: frame_floats is a multiple of 64
     xp.B = batch; xp.L = plan->cfg.n_points; xp.T = plan->T; xp.hop = plan->cfg.hop_length; xp.M = plan->cfg.n_mels;
     xp.nchunks = plan->nchunks; xp.N = N; xp.F = tb->F; xp.remove_dc = 1;
     xp.logN = 0; while ((1 << xp.logN) < N) ++xp.logN;

@@ -136,11 +136,13 @@ struct XgradParams {
     const float* out;           // (B, M, T) saved log output or nullptr
     float* frames;              // (B, T, N) workspace: windowed gradient of every frame
     float* grad_x;              // (B, L)
+    double* csum;               // (B, chunks) fp64 sums of the gather chunks (mean of the clip's gradient)
     int B, L, T, hop, M, nchunks, N, F, logN, remove_dc;
     float inv_L;
 };
 hipError_t launch_xgrad(const XgradParams& p, hipStream_t s);
 hipError_t xgrad_prepare_attributes();
+int xgrad_chunks(int L);      // gather chunks per clip (size of XgradParams::csum per clip)
 
 // gradient w.r.t. the filterbank matrix of models.py:53 (adjoint of  mel = spec^T @ fb):
 //   grad_fb[f][m] = sum_{b,t} spec[b][f][t] * gm[b][m][t],   gm = grad_out            (linear output)

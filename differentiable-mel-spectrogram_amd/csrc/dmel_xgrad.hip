@@ -13,8 +13,8 @@
 // the same bit-reversed addresses, which is exactly the input order of an in-place decimation-in-time FFT; its output
 // is conj(dv_a + i dv_b) in natural order.  No permutation pass, no second buffer.  The windowed frame gradients go to a
 // (B, T, N) workspace.
-// Kernel 2 (one workgroup per clip): overlap-add as a gather in increasing frame order (deterministic, no atomics), then
-// the mean of the clip's gradient is subtracted (fp64 block sum in a fixed order).
+// Kernels 2 and 3 (one workgroup per 4096 samples): overlap-add as a gather in increasing frame order (deterministic, no
+// atomics) with an fp64 sum per chunk, then the mean of the clip's gradient (chunk sums in index order) is subtracted.
 // A correctness-first path: about 10x the time of the fused forward at config 2.
 #include "dmel_kernels.h"
 
@@ -111,15 +111,20 @@ __global__ void __launch_bounds__(kXgThreads) dmel_xgrad_frames_kernel(XgradPara
     }
 }
 
-__global__ void __launch_bounds__(1024) dmel_xgrad_gather_kernel(XgradParams p)
+// grid (chunks, B): every workgroup overlap-adds one chunk of kXgChunk samples of one clip and leaves the chunk's sum
+// (fp64, fixed tree) in csum[b][chunk]
+constexpr int kXgChunk = 4096;
+
+__global__ void __launch_bounds__(256) dmel_xgrad_gather_kernel(XgradParams p)
 {
-    __shared__ double red[1024];
-    const int tid = threadIdx.x, b = blockIdx.x;
+    __shared__ double red[256];
+    const int tid = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
     const int N = p.N, T = p.T, hop = p.hop, half = N / 2;
     const float* fr = p.frames + (size_t)b * T * N;
     float* gx = p.grad_x + (size_t)b * p.L;
+    const int lo = chunk * kXgChunk, hi = min(lo + kXgChunk, p.L);
     double acc = 0.0;
-    for (int i = tid; i < p.L; i += 1024) {
+    for (int i = lo + tid; i < hi; i += 256) {
         // frames with 0 <= i - t hop + N/2 < N, in increasing t
         int t_lo = i + half - N + 1;
         t_lo = t_lo <= 0 ? 0 : (t_lo + hop - 1) / hop;
@@ -130,12 +135,22 @@ __global__ void __launch_bounds__(1024) dmel_xgrad_gather_kernel(XgradParams p)
         gx[i] = s;
         acc += (double)s;
     }
-    if (!p.remove_dc) return;
     red[tid] = acc;
     __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
-    const float mean = (float)(red[0] / (double)p.L);
-    for (int i = tid; i < p.L; i += 1024) gx[i] -= mean;       // every thread revisits the elements it wrote itself
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    if (tid == 0) p.csum[(size_t)b * gridDim.x + chunk] = red[0];
+}
+
+// dx = dx~ - mean(dx~): the chunk sums are added in index order by every workgroup (same value everywhere)
+__global__ void __launch_bounds__(256) dmel_xgrad_mean_kernel(XgradParams p)
+{
+    const int tid = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
+    double tot = 0.0;
+    for (int c = 0; c < (int)gridDim.x; ++c) tot += p.csum[(size_t)b * gridDim.x + c];
+    const float mean = (float)(tot / (double)p.L);
+    float* gx = p.grad_x + (size_t)b * p.L;
+    const int lo = chunk * kXgChunk, hi = min(lo + kXgChunk, p.L);
+    for (int i = lo + tid; i < hi; i += 256) gx[i] -= mean;
 }
 
 hipError_t xgrad_prepare_attributes()
@@ -151,8 +166,14 @@ hipError_t launch_xgrad(const XgradParams& p, hipStream_t s)
     hipLaunchKernelGGL(dmel_xgrad_frames_kernel, dim3((unsigned)grid), dim3(kXgThreads), (size_t)p.N * sizeof(float2), s, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(dmel_xgrad_gather_kernel, dim3((unsigned)p.B), dim3(1024), 0, s, p);
+    const dim3 g2((unsigned)((p.L + kXgChunk - 1) / kXgChunk), (unsigned)p.B);
+    hipLaunchKernelGGL(dmel_xgrad_gather_kernel, g2, dim3(256), 0, s, p);
+    e = hipGetLastError();
+    if (e != hipSuccess || !p.remove_dc) return e;
+    hipLaunchKernelGGL(dmel_xgrad_mean_kernel, g2, dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
 }  // namespace dmel
+
+namespace dmel { int xgrad_chunks(int L) { return (L + kXgChunk - 1) / kXgChunk; } }
