@@ -29,3 +29,24 @@ pr = cProfile.Profile(); pr.enable()
 for _ in range(200): fb()
 pr.disable(); torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+
+
+# baseline: a do-nothing custom Function through the same engine path, and a pure-torch op of similar shape
+class _Noop(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, lam, buf):
+        return buf
+
+    @staticmethod
+    def backward(ctx, g_):
+        return torch.zeros((), device=g_.device), None
+
+
+lam_t = torch.tensor(1.0, device="cuda", requires_grad=True)
+buf = torch.empty_like(g)
+def noop():
+    y = _Noop.apply(lam_t, buf); y.backward(g)
+print("do-nothing Function fwd + backward", t(noop))
+def puretorch():
+    y = buf * lam_t; y.backward(g)
+print("pure torch (buf * lam).backward(g)", t(puretorch))
