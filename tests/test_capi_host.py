@@ -83,3 +83,22 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "dmel_oracle" not in text and "import oracle" not in text and "from oracle" not in text, f
+
+
+@pytest.mark.parametrize("F,M,sr,fmin,fmax", [(257, 64, 16000, 0, 8000), (513, 128, 16000, 0, 8000), (1025, 128, 16000, 0, 8000),
+                                             (1025, 128, 44100, 0, 22050), (2049, 64, 8000, 0, 4000), (129, 40, 16000, 125.0, 7000.0)])
+def test_filterbank_against_independent_implementation(F, M, sr, fmin, fmax):
+    """torchaudio is absent, but Hugging Face transformers ships an independent HTK triangular filterbank
+    (audio_utils.mel_filter_bank, documented as equivalent to torchaudio's melscale_fbanks for norm=None,
+    mel_scale='htk'); it works in fp64 where torchaudio works in fp32, hence the 5e-5 band (measured: <= 1.4e-5)."""
+    import warnings
+    au = pytest.importorskip("transformers.audio_utils")
+    from dmel_amd import capi
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = au.mel_filter_bank(F, M, fmin, fmax, sr, norm=None, mel_scale="htk")
+    fb = capi.mel_fbanks_host(F, fmin, fmax, M, sr)
+    assert ref.shape == fb.shape
+    assert float(np.abs(ref - fb).max()) <= 5e-5
+    # same support, up to entries that are zero in one and <= 5e-5 in the other
+    assert ((ref > 5e-5) <= (fb > 0)).all() and ((fb > 5e-5) <= (ref > 0)).all()
