@@ -693,3 +693,27 @@ def test_xgrad_long_transform_and_finite_difference():
     fd = float(lp - lm) / (2 * h)
     an = float((x.grad.double() * d.double()).sum())
     assert abs(fd - an) <= 2e-2 * abs(an) + 1e-3
+
+
+def test_optional_gradients_at_tiny_n_fft():
+    """dL/dx and dL/dfb where the forward runs on the direct-DFT kernel (n_fft 16, 2, 1)."""
+    from dmel_amd import capi
+    for lam, n in ((2.0, 16), (0.34, 2), (0.2, 1)):
+        case = dict(C.BY_NAME["g6_n32"], lambd=lam)
+        assert capi.n_fft(lam) == n
+        x_np = C.make_input(case).astype(np.float32)
+        g_np = C.make_cotangent(case)
+        x = torch.from_numpy(x_np).to("cuda:0").requires_grad_(True)
+        layer = _layer(case, log=True)
+        y = layer(x)
+        (y * torch.from_numpy(g_np).to("cuda:0")).sum().backward()
+        y_np = y.detach().cpu().numpy()
+        ref = O.backward_x(x_np, lam, case["hop"], case["sr"], g_np, y_np, case["f_min"], case["f_max"])
+        assert _gx_err(x.grad.cpu().numpy(), ref) <= TOL
+        plan = capi.Plan(case["L"], case["hop"], case["n_mels"], case["sr"])
+        gfb = torch.empty((n // 2 + 1, case["n_mels"]), dtype=torch.float32, device="cuda:0")
+        g = torch.from_numpy(g_np).to("cuda:0")
+        plan.backward_fb(x.detach().data_ptr(), case["B"], lam, g.data_ptr(), y.detach().data_ptr(), gfb.data_ptr(), True,
+                         torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert _gfb_err(gfb.cpu().numpy(), O.backward_fb(x_np, lam, case["hop"], g_np, y_np)) <= TOL
