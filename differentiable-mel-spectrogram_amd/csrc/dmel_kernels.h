@@ -45,7 +45,11 @@ constexpr int slot_stride_f2(int N, int R, int C)
     const int a = R * ex_stride(G, C);
     const int b = z_index_host(N - 1, R, C) + 1;
     const int need = (a > b ? a : b) * 8;
-    return ((need + 255) / 256 * 256 + 32) / 8;     // = 32 bytes (mod 256): A-fragment reads of 8 slots
+    // = 48 bytes (mod 128).  The A operands of phase 2 are read with ds_read_b32 / ds_read2_b32, which bank modulo 32 dwords
+    // (128 B) in two 32-lane groups: each group touches 16 B per slot, so the 8 slots must start 16 B apart modulo 128
+    // (a stride = 32 mod 256 put slots s and s+4 on the same banks: 2-way conflicts, SQ_LDS_BANK_CONFLICT = 25 % of the
+    // LDS-active cycles).  48 rather than 16 keeps the two frames a wave exchanges at n_fft 32 / 64 apart as before.
+    return ((need + 127) / 128 * 128 + 48) / 8;
 }
 
 template <int N> constexpr FftGeom geom()

@@ -19,4 +19,5 @@ def test_wave_fft_model(N):
     assert np.abs(W.wave_fft(x, N) - np.fft.fft(x, axis=1)).max() < 1e-11 * N
     conf = W.bank_conflicts_exchange(N)
     assert max(conf.values()) <= 2
-    assert W.slot_stride_bytes(N) % 256 == 32
+    assert W.slot_stride_bytes(N) % 128 == 48
+    assert W.a_operand_conflicts(N) == 1 and W.a_operand_conflicts(N, W.slot_stride_bytes(N) // 256 * 256 + 32) == 2

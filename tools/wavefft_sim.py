@@ -133,13 +133,37 @@ def bank_conflicts_exchange(N: int) -> dict:
 
 def slot_stride_bytes(N: int) -> int:
     """Bytes between consecutive FFT slots in LDS: room for the padded exchange image and the
-    padded spectrum, rounded so that stride = 32 (mod 256) (A-fragment reads, 8 slots x 32 B)."""
+    padded spectrum, rounded so that stride = 48 (mod 128): the A operands are read with ds_read_b32, which banks
+    modulo 128 B in 32-lane groups that touch 16 B per slot (see a_operand_conflicts)."""
     R, C = PLAN[N]
     G = N // R
     stride = G + (C if G >= 32 else 1)
     need = max(R * stride, z_index(N - 1, R, C) + 1) * 8
-    s = (need + 255) // 256 * 256 + 32
+    s = (need + 127) // 128 * 128 + 48
     return s
+
+
+def a_operand_conflicts(N: int, stride_bytes: int | None = None) -> int:
+    """Worst conflict degree of the phase-2 A-operand reads (ds_read_b32 / ds_read2_b32: two 32-lane groups, banks modulo
+    32 dwords): lane -> (slot8, P|D, k offset) as in dmel_fwd.hip."""
+    R, C = PLAN[N]
+    st = slot_stride_bytes(N) if stride_bytes is None else stride_bytes
+    lane = np.arange(WAVE)
+    row16 = lane & 15
+    slot8 = 2 * (row16 >> 2) + (row16 & 1)
+    typ = (row16 >> 1) & 1
+    kofs = lane >> 4
+    worst = 1
+    for ksg in range(0, min(8, N // 32)):
+        zk0 = np.array([z_index(int(k), R, C) for k in 16 * ksg + kofs])
+        for u in range(4):
+            addr = slot8 * st + typ * 4 + 8 * (zk0 + 4 * u)
+            for g0 in (0, 32):
+                banks = {}
+                for a in addr[g0:g0 + 32]:
+                    banks.setdefault((a // 4) % 32, set()).add(a // 4)
+                worst = max(worst, max(len(v) for v in banks.values()))
+    return worst
 
 
 if __name__ == "__main__":
