@@ -717,3 +717,28 @@ def test_optional_gradients_at_tiny_n_fft():
                          torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         assert _gfb_err(gfb.cpu().numpy(), O.backward_fb(x_np, lam, case["hop"], g_np, y_np)) <= TOL
+
+
+@pytest.mark.parametrize("name", ["g6_normwin", "g6_neglambd", "g6_fminmax", "g6_n2048_short", "g5_n4096"])
+def test_optional_gradients_on_edge_configurations(name):
+    """dL/dx and dL/dfb against the oracle where the fixtures do not reach: normalised window, negative lambd, a band-limited
+    bank, n_fft 2048 on clips shorter than two windows, n_fft 4096."""
+    from dmel_amd import capi
+    case = C.BY_NAME[name]
+    x_np = C.make_input(case).astype(np.float32)
+    g_np = C.make_cotangent(case)
+    g = torch.from_numpy(g_np).to("cuda:0")
+    x = torch.from_numpy(x_np).to("cuda:0").requires_grad_(True)
+    layer = _layer(case, log=True)
+    y = layer(x)
+    (y * g).sum().backward()
+    y_np = y.detach().cpu().numpy()
+    ref = O.backward_x(x_np, case["lambd"], case["hop"], case["sr"], g_np, y_np, case["f_min"], case["f_max"], case["normalize_window"])
+    assert _gx_err(x.grad.cpu().numpy(), ref) <= TOL
+    plan = capi.Plan(case["L"], case["hop"], case["n_mels"], case["sr"], case["f_min"], case["f_max"], case["normalize_window"])
+    n = capi.n_fft(case["lambd"])
+    gfb = torch.empty((n // 2 + 1, case["n_mels"]), dtype=torch.float32, device="cuda:0")
+    plan.backward_fb(x.detach().data_ptr(), case["B"], case["lambd"], g.data_ptr(), y.detach().data_ptr(), gfb.data_ptr(), True,
+                     torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert _gfb_err(gfb.cpu().numpy(), O.backward_fb(x_np, case["lambd"], case["hop"], g_np, y_np, case["normalize_window"])) <= TOL
