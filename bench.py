@@ -37,6 +37,7 @@ CONFIGS = {
     "c5": (32, 220500, 44100, 256.0, 441, 128),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 (matrix), v_mfma_f32_16x16x4_f32
 
 
 def parse():
@@ -221,10 +222,17 @@ def main():
             traffic = json.load(open(tpath)).get(args.config, {}).get("dmel_fwd_kernel_bytes_per_launch")
         except Exception:
             traffic = None
+    # the contraction stage on the matrix cores: executed fp32 MFMA flops of one launch = non-zero 4x16 filterbank blocks
+    # x 16-row tiles x 2048 flop per v_mfma_f32_16x16x4_f32 (SQ_INSTS_MFMA in profiles/r01_pmc_sq_c2.json counts the same
+    # instructions), against the dense fp32 matrix peak
+    mfma_flops = 2048.0 * info["fb_blocks"] * (B * ((T + info["frames_per_tile"] - 1) // info["frames_per_tile"])) if info["kernel_path"] == 0 else 0.0
+    mfma = {"executed_tflops": round(mfma_flops / (fwd_us * 1e-6) / 1e12, 2), "peak_tflops": FP32_MFMA_PEAK_TFLOPS,
+            "frac": round(mfma_flops / (fwd_us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+            "note": "banded filterbank: only the non-zero blocks are multiplied (dense would be fb_blocks_dense); the kernel is not MFMA-bound"}
     roofline = {"bound": "hbm", "kernel": f"dmel_fwd_kernel<{info['n_fft']},train>", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(fwd_us, 2),
-                "other_kernels_us": {"prep": round(prep_us, 2), "backward_dot": round(bwd_us, 2)}}
+                "other_kernels_us": {"prep": round(prep_us, 2), "backward_dot": round(bwd_us, 2)}, "mfma_stage": mfma}
 
     result = {
         "metric": "spectrogram frames/sec (fwd+bwd)", "value": round(value, 1), "unit": "frames/s",
