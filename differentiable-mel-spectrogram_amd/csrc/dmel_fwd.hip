@@ -1,18 +1,21 @@
 // dmel_fwd.hip -- fused forward of the DMEL layer for gfx950 (MI355X).
 //
-// One workgroup (4 waves) produces a tile of consecutive STFT frames of one clip, from waveform
+// One workgroup (4 or 8 waves) produces a tile of consecutive STFT frames of one clip, from waveform
 // samples to log-mel values, without touching HBM in between:
 //
+//   phase 0: the window table (w, dw/dlambd) is built in LDS and, for clips up to 32768 samples, the clip
+//            is summed for the DC removal (longer clips: partial sums from dmel_prep_kernel).
 //   phase 1 (VALU + LDS, per wave): DC-removed, Gaussian-windowed frame -> complex FFT.  A wave
 //            holds R points per lane and transforms 64/G frames at a time: radix-R butterflies in
 //            registers, one transposition through LDS, radix-R again, and a radix-C stage across
 //            adjacent lanes with DPP quad permutes (tools/wavefft_sim.py is the index model).
 //            Two real sequences ride in one complex FFT: (x~ w, x~ dw/dlambd) when the tangent is
-//            wanted (training), two neighbouring frames otherwise.  The spectrum Z stays in LDS.
-//   phase 2 (MFMA): the mel contraction of models.py:53.  A-fragments are formed on the fly from
-//            Z (|X|^2 and d|X|^2/dlambd rows), B-fragments are the non-zero 4x16 blocks of the
-//            filterbank, v_mfma_f32_16x16x4_f32 accumulates exact fp32.  Each wave owns two mel
-//            tiles, so no cross-wave reduction is needed.
+//            wanted (training), two neighbouring frames otherwise.  The pairing pass separates them
+//            once per bin and leaves PD[k] = (|X|^2, d|X|^2/dlambd) (or the two frames' |X|^2) in LDS.
+//   phase 2 (MFMA): the mel contraction of models.py:53.  A operands are plain reads of PD,
+//            B fragments are the non-zero 4x16 blocks of the filterbank (prefetched into registers
+//            before phase 1), v_mfma_f32_16x16x4_f32 accumulates exact fp32.  With 4 waves each wave
+//            owns two mel tiles; with 8 waves each owns two half tiles and the halves meet through LDS.
 //   epilogue: scale, log(mel + eps) (models.py:73), tangent d out / d lambd, straight from the
 //            accumulators into the (B,1,M,T) layout of models.py:36.
 //
@@ -287,7 +290,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.ent_b, (unsigned)p.ent_b_floats * 4u);
 
     // ---- requests that phase 2 will need, issued before anything else --------------------------
-    // (ks0, nks, boff, tile) of this wave's mel tiles in group 0 and their first four B fragments
+    // (ks0, nks, boff, tile) of this wave's mel runs in group 0 and their first NBPRE B fragments
     // The first NBPRE k-steps of every tile (all of them for the HTK bank at the usual sizes) sit in
     // registers from here on: nothing in phase 2 then waits on global memory.
     constexpr int NBPRE = g.NBPRE;
