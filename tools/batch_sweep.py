@@ -22,5 +22,11 @@ for B in (64, 128, 256, 512, 1024, 2048, 4096):
         plan.forward(x.data_ptr(), B, lam, out.data_ptr(), tan.data_ptr(), True, 1e-10, st)
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1000 / n
-    res[B] = dict(us=round(us, 2), ns_per_frame=round(us * 1000 / (B * T), 3), rounds=B * T / 8 / 512)
+    e0.record()
+    for _ in range(n):
+        plan.forward(x.data_ptr(), B, lam, out.data_ptr(), None, True, 1e-10, st)       # inference: no tangent, two frames per FFT
+    e1.record(); torch.cuda.synchronize()
+    us_inf = e0.elapsed_time(e1) * 1000 / n
+    res[B] = dict(us=round(us, 2), ns_per_frame=round(us * 1000 / (B * T), 3), rounds=B * T / 8 / 512,
+                  inference_us=round(us_inf, 2), inference_ns_per_frame=round(us_inf * 1000 / (B * T), 3))
 print(json.dumps(res))
