@@ -742,3 +742,38 @@ def test_optional_gradients_on_edge_configurations(name):
                      torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert _gfb_err(gfb.cpu().numpy(), O.backward_fb(x_np, case["lambd"], case["hop"], g_np, y_np, case["normalize_window"])) <= TOL
+
+
+ODD_SHAPES = [
+    dict(C.BY_NAME["g1_c1"], name="hop_gt_nfft", B=3, L=9000, lambd=20.0, hop=300, n_mels=32),            # n_fft 128 < hop
+    dict(C.BY_NAME["g1_c1"], name="single_frame", B=2, L=700, lambd=40.0, hop=1000, n_mels=16),             # T = 1
+    dict(C.BY_NAME["g1_c1"], name="one_mel", B=2, L=4000, lambd=30.0, hop=100, n_mels=1),
+    dict(C.BY_NAME["g1_c1"], name="many_mels", B=2, L=16000, lambd=170.0, hop=400, n_mels=200),             # two mel groups, n_fft 1024
+    dict(C.BY_NAME["g1_c1"], name="many_mels_2048", B=1, L=16000, lambd=300.0, hop=800, n_mels=300),
+    dict(C.BY_NAME["g1_c1"], name="short_clip", B=4, L=37, lambd=10.0, hop=5, n_mels=8),                    # clip shorter than n_fft 64
+]
+
+
+@pytest.mark.parametrize("case", ODD_SHAPES, ids=[c["name"] for c in ODD_SHAPES])
+def test_unusual_shapes_match_oracle(case):
+    x_np = C.make_input(case).astype(np.float32)
+    g_np = C.make_cotangent(case)
+    x = torch.from_numpy(x_np).to("cuda:0").requires_grad_(True)
+    for log in (False, True):
+        layer = _layer(case, log=log)
+        y = layer(x)
+        assert y.shape == C.out_shape(case)
+        x.grad = None
+        (y * torch.from_numpy(g_np).to("cuda:0")).sum().backward()
+        o_ref, t_ref = O.forward(x_np, case["lambd"], case["hop"], case["n_mels"], case["sr"], case["f_min"], case["f_max"],
+                                 case["normalize_window"], apply_log=log)
+        o = y.detach().cpu().numpy()
+        assert (_log_err(o, o_ref) if log else _rel_err(o, o_ref)) <= TOL
+        exp_d = O.backward(g_np, t_ref)
+        assert abs(float(layer.lambd.grad) - exp_d) <= _dlam_tol(exp_d, g_np, t_ref)
+        ref_x = O.backward_x(x_np, case["lambd"], case["hop"], case["sr"], g_np, o if log else None, case["f_min"], case["f_max"])
+        assert _gx_err(x.grad.cpu().numpy(), ref_x) <= TOL
+        with torch.no_grad():
+            yi = _layer(case, log=log, trainable=False)(x.detach())
+        oi = yi.cpu().numpy()
+        assert (_log_err(oi, o_ref) if log else _rel_err(oi, o_ref)) <= TOL
