@@ -142,6 +142,7 @@ struct XgradParams {
     float* grad_x;              // (B, L)
     double* csum;               // (B, chunks) fp64 sums of the gather chunks (mean of the clip's gradient)
     int B, L, T, hop, M, nchunks, N, F, logN, remove_dc;
+    int tw_in_lds;              // set by launch_xgrad: the twiddle table is copied behind the sequence in LDS
     float inv_L;
 };
 hipError_t launch_xgrad(const XgradParams& p, hipStream_t s);

@@ -22,10 +22,15 @@ namespace dmel {
 
 constexpr int kXgThreads = 256;
 
+template <bool TWLDS>
 __global__ void __launch_bounds__(kXgThreads) dmel_xgrad_frames_kernel(XgradParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* Z = reinterpret_cast<float2*>(smem_raw);
+    // twiddle table in LDS behind the sequence when it fits (n_fft <= 8192): every butterfly stage would otherwise wait for
+    // a global (L1) load per twiddle, twenty-odd dependent round trips per workgroup
+    float2* twl = Z + p.N;                                     // TWLDS only
+    auto twiddle = [&](int k) -> float2 { if constexpr (TWLDS) return twl[k]; else return p.tw[k]; };
     const int tid = threadIdx.x;
     const int N = p.N, M = p.M, T = p.T, sh = 32 - p.logN;
     const int tiles = (T + 1) / 2;
@@ -46,6 +51,7 @@ __global__ void __launch_bounds__(kXgThreads) dmel_xgrad_frames_kernel(XgradPara
         const float w = p.win2[n].x;
         Z[n] = make_float2(va * w, vb * w);
     }
+    if constexpr (TWLDS) for (int k = tid; k < (N >> 1); k += kXgThreads) twl[k] = p.tw[k];
     __syncthreads();
     // forward: decimation in frequency, natural order in, bit-reversed order out
     for (int span = N >> 1, tstep = 1; span >= 1; span >>= 1, tstep <<= 1) {
@@ -53,7 +59,7 @@ __global__ void __launch_bounds__(kXgThreads) dmel_xgrad_frames_kernel(XgradPara
             const int j = i & (span - 1);
             const int lo = ((i - j) << 1) + j, hi = lo + span;
             const float2 a = Z[lo], c = Z[hi];
-            const float2 w = p.tw[j * tstep];
+            const float2 w = twiddle(j * tstep);
             const float dx = a.x - c.x, dy = a.y - c.y;
             Z[lo] = make_float2(a.x + c.x, a.y + c.y);
             Z[hi] = make_float2(fmaf(dx, w.x, -(dy * w.y)), fmaf(dx, w.y, dy * w.x));
@@ -95,7 +101,7 @@ __global__ void __launch_bounds__(kXgThreads) dmel_xgrad_frames_kernel(XgradPara
             const int j = i & (span - 1);
             const int lo = ((i - j) << 1) + j, hi = lo + span;
             const float2 a = Z[lo], c0 = Z[hi];
-            const float2 w = p.tw[j * tstep];
+            const float2 w = twiddle(j * tstep);
             const float cx = fmaf(c0.x, w.x, -(c0.y * w.y)), cy = fmaf(c0.x, w.y, c0.y * w.x);
             Z[lo] = make_float2(a.x + cx, a.y + cy);
             Z[hi] = make_float2(a.x - cx, a.y - cy);
@@ -155,15 +161,22 @@ __global__ void __launch_bounds__(256) dmel_xgrad_mean_kernel(XgradParams p)
 
 hipError_t xgrad_prepare_attributes()
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(dmel_xgrad_frames_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               kMaxNfft * (int)sizeof(float2));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dmel_xgrad_frames_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       kMaxNfft * (int)sizeof(float2));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(dmel_xgrad_frames_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               8192 * 12);
 }
 
 hipError_t launch_xgrad(const XgradParams& p, hipStream_t s)
 {
     const long long grid = (long long)p.B * ((p.T + 1) / 2);
     if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(dmel_xgrad_frames_kernel, dim3((unsigned)grid), dim3(kXgThreads), (size_t)p.N * sizeof(float2), s, p);
+    XgradParams q = p;
+    q.tw_in_lds = p.N <= 8192 ? 1 : 0;
+    const size_t lds = (size_t)p.N * sizeof(float2) + (q.tw_in_lds ? (size_t)(p.N / 2) * sizeof(float2) : 0);
+    if (q.tw_in_lds) hipLaunchKernelGGL(dmel_xgrad_frames_kernel<true>, dim3((unsigned)grid), dim3(kXgThreads), lds, s, q);
+    else hipLaunchKernelGGL(dmel_xgrad_frames_kernel<false>, dim3((unsigned)grid), dim3(kXgThreads), lds, s, q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const dim3 g2((unsigned)((p.L + kXgChunk - 1) / kXgChunk), (unsigned)p.B);
