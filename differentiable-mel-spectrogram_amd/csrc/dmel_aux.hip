@@ -4,6 +4,7 @@
 //   * dmel_naive_* : direct-DFT forward for n_fft < 32 (lambd < 5.5 samples) and as an on-device
 //                    cross-check of the wave-FFT kernel; same semantics (models.py:33-56, :73).
 #include "dmel_kernels.h"
+#include "dmel_ldsfft.h"
 
 namespace dmel {
 
@@ -192,8 +193,8 @@ hipError_t launch_naive(const NaiveParams& p, hipStream_t s)
 // ---- long transforms -----------------------------------------------------------------------------
 // n_fft 8192 and 16384 (|lambd| > 682.6 samples: windows of 0.5 s and more) do not fit the register-resident wave FFT.
 // One workgroup of 1024 threads transforms one complex sequence of N points held in LDS (128 KB at N = 16384): in-place
-// radix-2 decimation in frequency, log2 N barrier-separated stages, spectrum left in bit-reversed order and read
-// back through __brev.  Same packing as the fused kernel: training mode transforms x~ w + i x~ w' (one frame and its
+// decimation in frequency with the radix-2 stages fused in pairs (dmel_ldsfft.h),
+// spectrum left in bit-reversed order and read back through __brev.  Same packing as the fused kernel: training mode transforms x~ w + i x~ w' (one frame and its
 // lambd-tangent), inference / spectrogram modes transform two frames at once; the pairing pass is identical.  The
 // mel stage is a band-limited dot product per mel band (one wave per band, fixed-order reduction).  A correctness
 // path for rarely reached sizes, not a tuned one.
@@ -205,10 +206,12 @@ __device__ __forceinline__ float wave_sum_shfl(float v)
     return v;
 }
 
+template <bool TWLDS>
 __global__ void __launch_bounds__(kLongThreads) dmel_long_kernel(LongParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* Z = reinterpret_cast<float2*>(smem_raw);
+    float2* twl = Z + p.N;                 // TWLDS: the twiddle table sits behind the sequence (small n_fft only, see launch_long)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = p.N, F = p.F, sh = 32 - p.logN;
     const bool pair = (p.mode == kInfer || p.mode == kSpec);
@@ -234,19 +237,10 @@ __global__ void __launch_bounds__(kLongThreads) dmel_long_kernel(LongParams p)
             Z[n] = make_float2(va * wd.x, va * wd.y);
         }
     }
+    if (TWLDS) for (int k = tid; k < (N >> 1); k += kLongThreads) twl[k] = p.tw[k];
     __syncthreads();
-    for (int span = N >> 1, tstep = 1; span >= 1; span >>= 1, tstep <<= 1) {
-        for (int i = tid; i < (N >> 1); i += kLongThreads) {
-            const int j = i & (span - 1);
-            const int lo = ((i - j) << 1) + j, hi = lo + span;
-            const float2 a = Z[lo], c = Z[hi];
-            const float2 w = p.tw[j * tstep];                                 // exp(-2 pi i j / (2 span))
-            const float dx = a.x - c.x, dy = a.y - c.y;
-            Z[lo] = make_float2(a.x + c.x, a.y + c.y);
-            Z[hi] = make_float2(fmaf(dx, w.x, -(dy * w.y)), fmaf(dx, w.y, dy * w.x));
-        }
-        __syncthreads();
-    }
+    if (TWLDS) lds_fft_dif<kLongThreads>(Z, N, p.logN, tid, [&](int k) { return twl[k]; });
+    else lds_fft_dif<kLongThreads>(Z, N, p.logN, tid, [&](int k) { return p.tw[k]; });
     // pairing pass (see dmel_fwd.hip): PD[k] = (|S|^2, Im(conj S * D)) or (|S|^2, |D|^2), in place at Z[brev(k)];
     // the two addresses a thread touches belong to no other thread
     for (int k = tid; k <= (N >> 1); k += kLongThreads) {
@@ -308,8 +302,10 @@ __global__ void __launch_bounds__(kLongThreads) dmel_long_kernel(LongParams p)
 
 hipError_t long_prepare_attributes()
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(dmel_long_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               kMaxNfft * (int)sizeof(float2));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dmel_long_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       kMaxNfft * (int)sizeof(float2));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(dmel_long_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 12);
 }
 
 hipError_t launch_long(const LongParams& p, hipStream_t s)
@@ -318,7 +314,12 @@ hipError_t launch_long(const LongParams& p, hipStream_t s)
     const long long tiles = pair ? (p.T + 1) / 2 : p.T;
     const long long grid = tiles * p.B;
     if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(dmel_long_kernel, dim3((unsigned)grid), dim3(kLongThreads), (size_t)p.N * sizeof(float2), s, p);
+    // the twiddle table goes to LDS only where that does not cost a resident workgroup: at n_fft 8192 it would (64 + 32 KB:
+    // one workgroup per CU instead of two; measured 5 % slower), at 16384 it does not fit
+    if (p.N <= 4096)
+        hipLaunchKernelGGL(dmel_long_kernel<true>, dim3((unsigned)grid), dim3(kLongThreads), (size_t)p.N * 12, s, p);
+    else
+        hipLaunchKernelGGL(dmel_long_kernel<false>, dim3((unsigned)grid), dim3(kLongThreads), (size_t)p.N * sizeof(float2), s, p);
     return hipGetLastError();
 }
 

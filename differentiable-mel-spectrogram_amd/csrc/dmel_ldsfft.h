@@ -1,0 +1,84 @@
+// dmel_ldsfft.h -- in-place complex FFT of one sequence held in LDS, shared by the long-transform kernel (dmel_aux.hip)
+// and the waveform-gradient kernel (dmel_xgrad.hip).  Radix-2 stages are fused in pairs (radix-4 butterflies in registers):
+// half the barriers and half the LDS traffic of a plain radix-2 loop, with exactly the radix-2 data flow, so the output
+// order stays the bit-reversed one that __brev addresses.
+//   lds_fft_dif: natural order in, bit-reversed order out (decimation in frequency)
+//   lds_fft_dit: bit-reversed order in, natural order out (decimation in time)
+// Both use the forward kernel exp(-2 pi i k n / N); `twiddle(k)` returns exp(-2 pi i k / N) for 0 <= k < N/2 (from LDS or
+// from global memory).  Every stage ends with __syncthreads(); the caller synchronises before the first stage.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace dmel {
+
+__device__ __forceinline__ float2 c_add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 c_sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 c_mul(float2 a, float2 w) { return make_float2(fmaf(a.x, w.x, -(a.y * w.y)), fmaf(a.x, w.y, a.y * w.x)); }
+__device__ __forceinline__ float2 c_mul_mi(float2 a) { return make_float2(a.y, -a.x); }          // a * (-i)
+
+template <int THREADS, class TW>
+__device__ __forceinline__ void lds_fft_dif(float2* Z, int N, int logN, int tid, TW&& twiddle)
+{
+    int top = N >> 1;                 // span of the next radix-2 stage
+    if (logN & 1) {                   // odd number of stages: one plain radix-2 stage first
+        for (int i = tid; i < (N >> 1); i += THREADS) {
+            const float2 a = Z[i], c = Z[i + top];
+            Z[i] = c_add(a, c);
+            Z[i + top] = c_mul(c_sub(a, c), twiddle(i));
+        }
+        __syncthreads();
+        top >>= 1;
+    }
+    // fused pairs (span 2s, span s)
+    for (int s = top >> 1; s >= 1; s >>= 2) {
+        const int ta = N / (4 * s);
+        for (int i = tid; i < (N >> 2); i += THREADS) {
+            const int j = i & (s - 1);
+            const int lo = ((i - j) << 2) + j;
+            const float2 e0 = Z[lo], e1 = Z[lo + s], e2 = Z[lo + 2 * s], e3 = Z[lo + 3 * s];
+            const float2 w1 = twiddle(j * ta), w2 = twiddle(2 * j * ta);
+            const float2 a0 = c_add(e0, e2), a2 = c_mul(c_sub(e0, e2), w1);
+            const float2 a1 = c_add(e1, e3), a3 = c_mul_mi(c_mul(c_sub(e1, e3), w1));
+            Z[lo] = c_add(a0, a1);
+            Z[lo + s] = c_mul(c_sub(a0, a1), w2);
+            Z[lo + 2 * s] = c_add(a2, a3);
+            Z[lo + 3 * s] = c_mul(c_sub(a2, a3), w2);
+        }
+        __syncthreads();
+    }
+}
+
+template <int THREADS, class TW>
+__device__ __forceinline__ void lds_fft_dit(float2* Z, int N, int logN, int tid, TW&& twiddle)
+{
+    int s = 1;                        // span of the next radix-2 stage
+    if (logN & 1) {                   // odd number of stages: one plain radix-2 stage (span 1, twiddle 1) first
+        for (int i = tid; i < (N >> 1); i += THREADS) {
+            const float2 a = Z[2 * i], c = Z[2 * i + 1];
+            Z[2 * i] = c_add(a, c);
+            Z[2 * i + 1] = c_sub(a, c);
+        }
+        __syncthreads();
+        s = 2;
+    }
+    // fused pairs (span s, span 2s)
+    for (; 4 * s <= N; s <<= 2) {
+        const int tb = N / (4 * s);
+        for (int i = tid; i < (N >> 2); i += THREADS) {
+            const int j = i & (s - 1);
+            const int lo = ((i - j) << 2) + j;
+            const float2 e0 = Z[lo], e1 = Z[lo + s], e2 = Z[lo + 2 * s], e3 = Z[lo + 3 * s];
+            const float2 u1 = twiddle(2 * j * tb), v = twiddle(j * tb);
+            const float2 c1 = c_mul(e1, u1), c3 = c_mul(e3, u1);
+            const float2 a0 = c_add(e0, c1), a1 = c_sub(e0, c1), a2 = c_add(e2, c3), a3 = c_sub(e2, c3);
+            const float2 d2 = c_mul(a2, v), d3 = c_mul_mi(c_mul(a3, v));
+            Z[lo] = c_add(a0, d2);
+            Z[lo + 2 * s] = c_sub(a0, d2);
+            Z[lo + s] = c_add(a1, d3);
+            Z[lo + 3 * s] = c_sub(a1, d3);
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace dmel

@@ -8,7 +8,7 @@
 //   dx        = dx~ - mean(dx~)
 //
 // Kernel 1 (one workgroup per pair of frames, any power-of-two n_fft up to 16384): both frames go through ONE complex
-// FFT held in LDS (in-place radix-2 decimation in frequency, spectrum in bit-reversed order), the two spectra are
+// FFT held in LDS (in-place decimation in frequency, radix-2 stages fused in pairs, spectrum in bit-reversed order), the two spectra are
 // separated, scaled by gP and written back -- conjugated, Hermitian-extended, packed as conj(H_a) + i conj(H_b)... -- at
 // the same bit-reversed addresses, which is exactly the input order of an in-place decimation-in-time FFT; its output
 // is conj(dv_a + i dv_b) in natural order.  No permutation pass, no second buffer.  The windowed frame gradients go to a
@@ -17,6 +17,7 @@
 // atomics) with an fp64 sum per chunk, then the mean of the clip's gradient (chunk sums in index order) is subtracted.
 // A correctness-first path: about 10x the time of the fused forward at config 2.
 #include "dmel_kernels.h"
+#include "dmel_ldsfft.h"
 
 namespace dmel {
 
@@ -54,18 +55,7 @@ __global__ void __launch_bounds__(kXgThreads) dmel_xgrad_frames_kernel(XgradPara
     if constexpr (TWLDS) for (int k = tid; k < (N >> 1); k += kXgThreads) twl[k] = p.tw[k];
     __syncthreads();
     // forward: decimation in frequency, natural order in, bit-reversed order out
-    for (int span = N >> 1, tstep = 1; span >= 1; span >>= 1, tstep <<= 1) {
-        for (int i = tid; i < (N >> 1); i += kXgThreads) {
-            const int j = i & (span - 1);
-            const int lo = ((i - j) << 1) + j, hi = lo + span;
-            const float2 a = Z[lo], c = Z[hi];
-            const float2 w = twiddle(j * tstep);
-            const float dx = a.x - c.x, dy = a.y - c.y;
-            Z[lo] = make_float2(a.x + c.x, a.y + c.y);
-            Z[hi] = make_float2(fmaf(dx, w.x, -(dy * w.y)), fmaf(dx, w.y, dy * w.x));
-        }
-        __syncthreads();
-    }
+    lds_fft_dif<kXgThreads>(Z, N, p.logN, tid, twiddle);
     // spectra of the two frames, gradient of the power spectrum, conj(H_a) + i conj(H_b) back in place
     const float* ga = p.grad_out + (size_t)b * M * T + tA;
     const float* ya = p.out ? p.out + (size_t)b * M * T + tA : nullptr;
@@ -96,18 +86,7 @@ __global__ void __launch_bounds__(kXgThreads) dmel_xgrad_frames_kernel(XgradPara
     }
     __syncthreads();
     // decimation in time, bit-reversed order in, natural order out: R = FFT(conj W) = conj(dv_a + i dv_b)
-    for (int span = 1, tstep = N >> 1; span < N; span <<= 1, tstep >>= 1) {
-        for (int i = tid; i < (N >> 1); i += kXgThreads) {
-            const int j = i & (span - 1);
-            const int lo = ((i - j) << 1) + j, hi = lo + span;
-            const float2 a = Z[lo], c0 = Z[hi];
-            const float2 w = twiddle(j * tstep);
-            const float cx = fmaf(c0.x, w.x, -(c0.y * w.y)), cy = fmaf(c0.x, w.y, c0.y * w.x);
-            Z[lo] = make_float2(a.x + cx, a.y + cy);
-            Z[hi] = make_float2(a.x - cx, a.y - cy);
-        }
-        __syncthreads();
-    }
+    lds_fft_dit<kXgThreads>(Z, N, p.logN, tid, twiddle);
     float* fa = p.frames + ((size_t)b * T + tA) * N;
     for (int n = tid; n < N; n += kXgThreads) {
         const float2 r = Z[n];
