@@ -267,6 +267,9 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
     float2* wtab = reinterpret_cast<float2*>(smem_raw + g.AUX_OFF);   // window table (phase 1 only)
     float* red = reinterpret_cast<float*>(smem_raw + g.RED_OFF);
     constexpr bool WIN_LDS = g.WIN_LDS != 0;
+    // radix-C twiddles through LDS: the table has R*C entries but a wave-wide global load of it still moves 512 B
+    constexpr bool TW2_LDS = (C > 1) && (N <= 2048);
+    float2* tw2l = reinterpret_cast<float2*>(smem_raw + g.RED_OFF + 64);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -346,6 +349,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
             }
         });
         STAMP(1);   // loads issued
+        if constexpr (TW2_LDS) { if (tid < R * C) tw2l[tid] = p.tw2[tid]; }          // visible after the barrier below
         // ---- window table into LDS (time_frequency.py:21-30): every workgroup evaluates the same fp32
         // expression, so the table is identical everywhere; this replaces a separate kernel launch
         if constexpr (WIN_LDS) {
@@ -506,7 +510,11 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                 v2f v = u[bitrev(p1, LB)];
                 int p2 = 0;
                 if constexpr (C > 1) {
-                    if constexpr (p1 != 0) v = cmul(v, p.tw2[p1 * C + r]);
+                    if constexpr (p1 != 0) {
+                        float2 w2;
+                        if constexpr (TW2_LDS) w2 = tw2l[p1 * C + r]; else w2 = p.tw2[p1 * C + r];
+                        v = cmul(v, w2);
+                    }
                 }
                 if constexpr (C == 2) {
                     const v2f o = v2f{quad_xor1(v.x), quad_xor1(v.y)};

@@ -68,7 +68,8 @@ template <int N> constexpr FftGeom geom()
     const int win = g.WIN_LDS ? N * 8 : 0;
     g.AUX_OFF = g.SLOTS * g.SLOT_STRIDE_F2 * 8;
     g.RED_OFF = g.AUX_OFF + (xch > win ? xch : win);
-    g.LDS_BYTES = g.RED_OFF + 64;
+    // [8 sums (64 B)][tw2 table: R x C complex, the radix-C twiddles: every lane of a wave reads one of C values per p1]
+    g.LDS_BYTES = g.RED_OFF + 64 + ((P::C > 1 && N <= 2048) ? P::R * P::C * 8 : 0);
     return g;
 }
 
