@@ -28,3 +28,21 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_libraries():
+    """The shared objects are build products (git-ignored): a fresh checkout has none.  Build what is missing once per
+    session -- the HIP library cross-compiles without a GPU (about a minute), the oracle is a single C file -- so that the
+    suite does not depend on `__graft_entry__.build()` having run first."""
+    import importlib.util
+    import shutil
+    pkg = os.path.join(ROOT, "differentiable-mel-spectrogram_amd")
+    if not os.path.exists(os.path.join(pkg, "libdmel_hip.so")) and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        spec = importlib.util.spec_from_file_location("_dmel_build", os.path.join(pkg, "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build()
+    from oracle import dmel_oracle
+    dmel_oracle.build()
+    yield
