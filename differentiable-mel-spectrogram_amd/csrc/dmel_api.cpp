@@ -57,6 +57,7 @@ struct NfftTables {
     float2* tw2 = nullptr;
     float* ent_b = nullptr;
     float* ent_pre = nullptr;
+    int pre_groups[16] = {};     // per (wave, run) of group 0: real groups of 4 k-steps inside ent_pre
     int ent_b_floats = 0;
     int4* tile_ranges = nullptr;
     float* fb_dense = nullptr;   // (F, M) for the direct-DFT kernel
@@ -265,6 +266,7 @@ dmel_status build_tables(dmel_plan* pl, int N, NfftTables** out)
                 for (int loc = 0; loc < 2; ++loc) {
                     const int4 tr = ranges[(size_t)w * 2 + loc];
                     const int n = std::min(tr.y, nbpre);
+                    tb.pre_groups[w * 2 + loc] = (n + 3) / 4;
                     if (n > 0)
                         std::copy(bfr.begin() + tr.z, bfr.begin() + tr.z + (size_t)n * 64, pre.begin() + ((size_t)(w * 2 + loc) * nbpre) * 64);
                 }
@@ -377,6 +379,7 @@ dmel_status run_forward_nolock(dmel_plan* pl, const float* x, int batch, float l
     dmel::FwdParams fp{};
     fp.x = x; fp.out = out; fp.tangent = tangent; fp.psum = need_sums ? pl->psum : nullptr; fp.win2 = reinterpret_cast<const float2*>(pl->win);
     fp.tw1 = tb->tw1; fp.tw2 = tb->tw2; fp.ent_b = tb->ent_b; fp.tile_ranges = tb->tile_ranges; fp.ent_b_floats = tb->ent_b_floats; fp.ent_pre = tb->ent_pre;
+    for (int i = 0; i < 16; ++i) fp.pre_groups[i] = tb->pre_groups[i];
     fp.B = batch; fp.L = pl->cfg.n_points; fp.T = pl->T; fp.hop = pl->cfg.hop_length; fp.M = pl->cfg.n_mels;
     fp.nchunks = pl->nchunks; fp.groups = tb->groups;
     const int fpt = dmel::forward_frames_per_tile(N, mode);

@@ -308,9 +308,17 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
         const float* pre_lane = p.ent_pre + ((unsigned)(wave * (NLOC * NBPRE * 64)) + (unsigned)lane);
         static_for<0, NLOC>([&](auto l) {
             constexpr int loc = decltype(l)::value;
-            static_for<0, NBPRE>([&](auto u) {
-                // fixed layout (wave, run, k-step, lane): the address does not wait for tile_ranges
-                bpre[loc][decltype(u)::value] = pre_lane[(loc * NBPRE + decltype(u)::value) * 64];
+            // fixed layout (wave, run, k-step, lane): the address does not wait for tile_ranges; the number of real groups of
+            // 4 k-steps comes with the kernel arguments (scalar load), so the padding of short runs is not fetched
+            const int ng = p.pre_groups[wave * NLOC + loc];
+            static_for<0, NBPRE / 4>([&](auto qq) {
+                constexpr int q4 = decltype(qq)::value;
+                if (q4 < ng) {
+                    static_for<0, 4>([&](auto u) {
+                        constexpr int u4 = q4 * 4 + decltype(u)::value;
+                        bpre[loc][u4] = pre_lane[(loc * NBPRE + u4) * 64];
+                    });
+                }
             });
         });
     }

@@ -87,6 +87,7 @@ struct FwdParams {
     const int4* tile_ranges;   // (groups, WAVES, 2): {first k-step, #k-steps (multiple of 4), offset into ent_b, mel tile or -1}
     int ent_b_floats;          // size of ent_b (buffer bounds)
     const float* ent_pre;      // (WAVES, 2, NBPRE, 64): the first NBPRE k-steps of every run of mel group 0, zero padded
+    int pre_groups[16];        // per (wave, run): how many groups of 4 k-steps of ent_pre are real (the rest is padding nobody reads)
     int B, L, T, hop, M, nchunks, groups, tiles_per_clip;
     float inv_L, sign, eps;
     float lambd_abs, dw_scale;  // for the in-kernel window table (time_frequency.py:21-30)
