@@ -212,19 +212,23 @@ def main():
     prep_us = 1e3 * prof["prep_ms"] / max(1, prof["prep_launches"])
     bwd_us = 1e3 * prof["bwd_ms"] / max(1, prof["bwd_launches"])
     # An event pair around ONE launch also times the launch packets around it (1.5-4 us, varying from box to box).  The
-    # dominant kernel's average launch duration is therefore taken from a train of launches between two HIP events on the
-    # launch stream (same kernel, same arguments, back to back): what rocprofv3 reports as the dispatch duration plus the
-    # sub-microsecond gap between dependent dispatches.
+    # dominant kernel's average launch duration is therefore taken from trains of launches between two HIP events on the
+    # launch stream: a train of whole steps (forward + dot, the timed region's own mix, so the forward sees the cache state
+    # the dot kernel leaves) minus a train of the dot launches alone.  This is what rocprofv3 reports as the dispatch
+    # duration plus the sub-microsecond gap between dependent dispatches.
     ntrain = 100
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    fwd_flags = capi.DMEL_FLAG_OUT_BF16 if args.bf16_activations else 0
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     with torch.cuda.stream(cur):
-        e0.record(cur)
-        for _ in range(ntrain):
-            plan.forward(x.data_ptr(), B, lam, out.data_ptr(), tan.data_ptr(), True, 1e-10, cur.cuda_stream, extra_flags=fwd_flags)
-        e1.record(cur)
+        ev[0].record(cur)
+        for k in range(ntrain):
+            step_kernels(cur.cuda_stream, k)
+        ev[1].record(cur)
+        ev[2].record(cur)
+        for k in range(ntrain):
+            plan.backward(g.data_ptr(), tan.data_ptr(), count, dl[k % RING].data_ptr(), cur.cuda_stream, grad_bf16=args.bf16_activations)
+        ev[3].record(cur)
     torch.cuda.synchronize()
-    fwd_us = 1e3 * e0.elapsed_time(e1) / ntrain
+    fwd_us = 1e3 * (ev[0].elapsed_time(ev[1]) - ev[2].elapsed_time(ev[3])) / ntrain
     if prep_us > 0:
         fwd_us -= prep_us          # long clips: every forward also launched the partial-sum kernel
     # algorithmic bytes of ONE launch of the fused forward kernel:
