@@ -14,11 +14,17 @@
  *   mel filterbank       models.py:42-48               torchaudio 0.13.1 functional.melscale_fbanks
  *                                                      (htk, norm=None) -- NOT in /root/reference and
  *                                                      absent from the image: restated from the
- *                                                      published algorithm, PARITY-UNPINNED.
+ *                                                      published algorithm, PARITY-UNPINNED (checked
+ *                                                      against transformers.audio_utils.mel_filter_bank,
+ *                                                      an independent fp64 implementation in the image:
+ *                                                      max abs difference 1.4e-5, tests/test_capi_host.py).
  *   contraction          models.py:53                  (T x F) @ (F x M), laid out (B,1,M,T)
  *   log compression      models.py:73                  log(s + 1e-10)
  *   d/d lambd            train.py:47 (autograd)        closed form of SURVEY.md 3.2, carried in
  *                                                      forward mode (one trainable scalar)
+ *   d/d mel_fb, d/d x    autograd through models.py:38-53 with the bank / the waveform made a leaf
+ *                                                      (dmel_oracle_fbgrad, dmel_oracle_xgrad)
+ *   DSPEC layer          models.py:171-200             dmel_oracle_dspec
  *
  * Pinning: tests/test_oracle_golden.py checks every function here against the fixtures in
  * tests/golden/NAME.npz, which tests/golden/make_golden.py captured from the reference's own
