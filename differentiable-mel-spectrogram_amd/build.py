@@ -1,5 +1,8 @@
-"""Builds libdmel_hip.so (gfx950 only) in-tree with hipcc.  No torch headers, no JIT cache:
-the shared object sits next to this file so that it travels with the source tree."""
+"""Builds the two shared objects of the package in-tree (no JIT cache: they sit next to this file and travel with the
+source tree):
+  libdmel_hip.so    every kernel + the C ABI of include/dmel.h; hipcc, gfx950 only, no torch headers
+  libdmel_torch.so  TORCH_LIBRARY(dmel, ...): the torch-registered ops over that C ABI (csrc/dmel_torch.cpp); plain g++
+                    against the installed torch's headers, no device code"""
 from __future__ import annotations
 
 import os
@@ -10,6 +13,7 @@ import sys
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libdmel_hip.so")
+TORCH_LIB_PATH = os.path.join(PKG_DIR, "libdmel_torch.so")
 OBJ_DIR = os.path.join(PKG_DIR, "build")
 SOURCES = ["dmel_fwd.hip", "dmel_aux.hip", "dmel_xgrad.hip", "dmel_api.cpp", "dmel_comm.cpp"]
 HEADERS = [os.path.join(CSRC, "dmel_kernels.h"), os.path.join(CSRC, "dmel_ldsfft.h"), os.path.join(os.path.dirname(PKG_DIR), "include", "dmel.h")]
@@ -48,7 +52,32 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    build_torch(force=force, verbose=verbose)
     return LIB_PATH
+
+
+def build_torch(force: bool = False, verbose: bool = False) -> str:
+    """libdmel_torch.so: links against libdmel_hip.so (rpath $ORIGIN) and the torch the interpreter imports."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        raise RuntimeError("torch is not importable: libdmel_torch.so cannot be built")
+    tdir = list(spec.submodule_search_locations)[0]
+    src = os.path.join(CSRC, "dmel_torch.cpp")
+    if not (force or _stale(TORCH_LIB_PATH, [src, HEADERS[-1], LIB_PATH])):
+        return TORCH_LIB_PATH
+    cxx = os.environ.get("CXX") or shutil.which("g++") or shutil.which("c++")
+    if not cxx:
+        raise RuntimeError("no C++ compiler found for libdmel_torch.so")
+    inc = os.path.join(tdir, "include")
+    cmd = [cxx, "-O2", "-fPIC", "-shared", "-std=c++17", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-D_GLIBCXX_USE_CXX11_ABI=1",
+           "-I" + inc, "-I" + os.path.join(inc, "torch", "csrc", "api", "include"), "-I/opt/rocm/include",
+           src, "-o", TORCH_LIB_PATH, "-L" + PKG_DIR, "-ldmel_hip", "-L" + os.path.join(tdir, "lib"),
+           "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-lc10", "-lc10_hip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return TORCH_LIB_PATH
 
 
 if __name__ == "__main__":

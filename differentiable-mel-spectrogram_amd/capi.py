@@ -18,10 +18,12 @@ DMEL_ERR_UNSUPPORTED = 2
 DMEL_ERR_HIP = 3
 DMEL_ERR_NO_DEVICE = 4
 DMEL_ERR_OUT_OF_MEMORY = 5
+DMEL_ERR_LAMBD_TRACKING = 6
 DMEL_FLAG_LOG = 1
 DMEL_FLAG_FULL_WINDOW = 2
 DMEL_FLAG_OUT_BF16 = 4
 DMEL_DTYPE_F32, DMEL_DTYPE_BF16 = 0, 1
+MAX_NFFT = 16384          # largest transform of the HIP kernels (kMaxNfft in csrc/dmel_kernels.h)
 
 # every symbol include/dmel.h declares (tests check the library exports exactly these)
 SYMBOLS = (
@@ -30,7 +32,10 @@ SYMBOLS = (
     "dmel_forward", "dmel_backward", "dmel_backward_ex", "dmel_backward_fb", "dmel_backward_x", "dmel_spectrogram", "dmel_plan_get_info",
     "dmel_plan_set_profiling", "dmel_plan_get_profile", "dmel_spectrogram_ex",
     "dmel_comm_unique_id", "dmel_comm_create", "dmel_comm_destroy", "dmel_comm_allreduce_async", "dmel_comm_wait",
+    "dmel_comm_allreduce", "dmel_scratch_bytes", "dmel_forward_scratch", "dmel_forward_dev", "dmel_backward_scratch", "dmel_plan_get_config",
+    "dmel_plan_lambd_status", "dmel_plan_set_tracking", "dmel_plan_lambd_reset",
 )
+TORCH_LIB_PATH = os.path.join(_PKG_DIR, "libdmel_torch.so")
 
 
 class DmelConfig(C.Structure):
@@ -46,6 +51,12 @@ class DmelPlanInfo(C.Structure):
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class DmelLambdStatus(C.Structure):
+    _fields_ = [("known", C.c_int32), ("lambd_seen", C.c_float), ("n_fft_seen", C.c_int32), ("seq_issued", C.c_uint32),
+                ("seq_seen", C.c_uint32), ("rate", C.c_float), ("guards", C.c_int32), ("error", C.c_int32),
+                ("error_seq", C.c_uint32), ("error_lambd", C.c_float)]
 
 
 class DmelProfile(C.Structure):
@@ -111,6 +122,8 @@ def load():
     L.dmel_comm_destroy.restype = C.c_int
     L.dmel_comm_allreduce_async.argtypes = [vp, vp, C.c_int32, vp, C.POINTER(C.c_int32)]
     L.dmel_comm_allreduce_async.restype = C.c_int
+    L.dmel_comm_allreduce.argtypes = [vp, vp, C.c_int32, vp]
+    L.dmel_comm_allreduce.restype = C.c_int
     L.dmel_comm_wait.argtypes = [vp, C.c_int32, vp]
     L.dmel_comm_wait.restype = C.c_int
     L.dmel_plan_get_info.argtypes = [vp, C.POINTER(DmelPlanInfo)]
@@ -119,8 +132,42 @@ def load():
     L.dmel_plan_set_profiling.restype = C.c_int
     L.dmel_plan_get_profile.argtypes = [vp, C.POINTER(DmelProfile)]
     L.dmel_plan_get_profile.restype = C.c_int
+    L.dmel_scratch_bytes.argtypes = [vp, C.c_int32]
+    L.dmel_scratch_bytes.restype = C.c_size_t
+    L.dmel_forward_scratch.argtypes = [vp, vp, C.c_int32, C.c_float, C.c_uint32, C.c_double, vp, vp, vp, vp]
+    L.dmel_forward_scratch.restype = C.c_int
+    L.dmel_forward_dev.argtypes = [vp, vp, C.c_int32, vp, C.c_uint32, C.c_double, vp, vp, vp, vp]
+    L.dmel_forward_dev.restype = C.c_int
+    L.dmel_backward_scratch.argtypes = [vp, vp, C.c_int32, vp, C.c_int64, C.c_int32, vp, vp, vp]
+    L.dmel_backward_scratch.restype = C.c_int
+    L.dmel_plan_get_config.argtypes = [vp, C.POINTER(DmelConfig)]
+    L.dmel_plan_get_config.restype = C.c_int
+    L.dmel_plan_lambd_status.argtypes = [vp, C.POINTER(DmelLambdStatus)]
+    L.dmel_plan_lambd_status.restype = C.c_int
+    L.dmel_plan_set_tracking.argtypes = [vp, C.c_int32, C.c_int32]
+    L.dmel_plan_set_tracking.restype = C.c_int
+    L.dmel_plan_lambd_reset.argtypes = [vp]
+    L.dmel_plan_lambd_reset.restype = C.c_int
     _lib = L
     return L
+
+
+_torch_ops = None
+
+
+def torch_ops():
+    """The torch-registered ops (TORCH_LIBRARY(dmel, ...), csrc/dmel_torch.cpp): ``torch.ops.dmel``.  Loads libdmel_torch.so
+    (and through it libdmel_hip.so) on first use; raises if it has not been built."""
+    global _torch_ops
+    if _torch_ops is None:
+        import torch
+        load()
+        if not os.path.exists(TORCH_LIB_PATH):
+            raise RuntimeError(f"{TORCH_LIB_PATH} is missing: build it first (python differentiable-mel-spectrogram_amd/build.py). "
+                               "There is no CPU fallback for the DMEL layer.")
+        torch.ops.load_library(TORCH_LIB_PATH)
+        _torch_ops = torch.ops.dmel
+    return _torch_ops
 
 
 def _check(status: int):
@@ -177,10 +224,47 @@ class Plan:
         except Exception:
             pass
 
+    def __deepcopy__(self, memo):
+        raise TypeError("a dmel plan is a cache of device tables bound to one GPU: copy the layer, not the plan")
+
+    def __reduce__(self):
+        raise TypeError("a dmel plan is a cache of device tables bound to one GPU and cannot be pickled; the layers drop "
+                        "their plans when copied or pickled and rebuild them on first use")
+
     def forward(self, x_ptr: int, batch: int, lambd: float, out_ptr: int, tangent_ptr: int | None,
                 log: bool, eps: float, stream: int, extra_flags: int = 0):
         _check(load().dmel_forward(self._h, x_ptr, batch, C.c_float(float(lambd)),
                                    (DMEL_FLAG_LOG if log else 0) | int(extra_flags), float(eps), out_ptr, tangent_ptr, stream))
+
+    @property
+    def handle(self) -> int:
+        """The dmel_plan* as an integer (what the torch ops take)."""
+        return int(self._h.value or 0)
+
+    def scratch_bytes(self, batch: int) -> int:
+        return int(load().dmel_scratch_bytes(self._h, int(batch)))
+
+    def forward_dev(self, x_ptr: int, batch: int, lambd_ptr: int, out_ptr: int, tangent_ptr: int | None, log: bool, eps: float,
+                    stream: int, scratch_ptr: int | None = None, extra_flags: int = 0):
+        """dmel_forward_dev: lambd stays on the device (no host read)."""
+        _check(load().dmel_forward_dev(self._h, x_ptr, batch, lambd_ptr, (DMEL_FLAG_LOG if log else 0) | int(extra_flags), float(eps),
+                                       out_ptr, tangent_ptr, scratch_ptr, stream))
+
+    def backward_scratch(self, grad_ptr: int, tangent_ptr: int, count: int, dlambd_ptr: int, stream: int, scratch_ptr: int | None,
+                         accumulate: bool = False, grad_bf16: bool = False):
+        _check(load().dmel_backward_scratch(self._h, grad_ptr, DMEL_DTYPE_BF16 if grad_bf16 else DMEL_DTYPE_F32, tangent_ptr,
+                                            int(count), int(accumulate), dlambd_ptr, scratch_ptr, stream))
+
+    def lambd_status(self) -> dict:
+        st = DmelLambdStatus()
+        _check(load().dmel_plan_lambd_status(self._h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in st._fields_}
+
+    def set_tracking(self, max_ahead: int = 8, guard_mode: int = 0):
+        _check(load().dmel_plan_set_tracking(self._h, int(max_ahead), int(guard_mode)))
+
+    def lambd_reset(self):
+        _check(load().dmel_plan_lambd_reset(self._h))
 
     def backward(self, grad_ptr: int, tangent_ptr: int, count: int, dlambd_ptr: int, stream: int, accumulate: bool = False,
                  grad_bf16: bool = False):
@@ -255,6 +339,10 @@ class Comm:
         t = C.c_int32(-1)
         _check(load().dmel_comm_allreduce_async(self._h, buf_ptr, int(count), stream, C.byref(t)))
         return int(t.value)
+
+    def allreduce(self, buf_ptr: int, count: int, stream: int) -> None:
+        """In-stream SUM all-reduce (ordered like a kernel launch on ``stream``)."""
+        _check(load().dmel_comm_allreduce(self._h, buf_ptr, int(count), stream))
 
     def wait(self, ticket: int, stream: int) -> None:
         _check(load().dmel_comm_wait(self._h, int(ticket), stream))

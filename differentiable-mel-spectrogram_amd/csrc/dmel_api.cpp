@@ -83,13 +83,26 @@ struct dmel_plan {
     double f_max = 0;
     std::map<int, NfftTables> tables;
     std::map<int, std::vector<float>> custom_fb;
-    float* psum = nullptr;
-    int psum_clips = 0;
-    float* win = nullptr;          // 2 * kMaxNfft floats
-    double* partials = nullptr;    // kMaxPartials doubles, followed by the ticket counter of the dot kernel
-    unsigned* dot_counter = nullptr;
+    // Plan-owned scratch of the entry points that take none from the caller (layout: dmel_scratch_bytes).  Calls that use it
+    // are ordered across streams by `xev` (see order_after_last_stream): two streams through one plan serialise, never race.
+    unsigned char* own_scratch = nullptr;
+    int own_scratch_clips = 0;
     float* fbw = nullptr;          // workspace of dmel_backward_fb (spectrogram (B, F, T) + slice partials) and dmel_backward_x
     size_t fbw_floats = 0;         // (frame gradients (B, T, N)); grown on demand
+    hipStream_t last_stream = nullptr;
+    bool last_stream_valid = false;
+    hipEvent_t xev = nullptr;
+    // device-resident lambd (dmel_forward_dev): what the kernels report back and what the host has concluded from it
+    unsigned long long* host_words = nullptr;   // pinned, device-visible: [0] seen = (seq << 32) | bits(lambd), [1] sticky error
+    unsigned issued = 0;           // call number of the most recent dmel_forward_dev
+    bool lam_known = false;        // lam_seen / seq_seen hold an observation
+    float lam_seen = 0.f;
+    unsigned seq_seen = 0;
+    int n_obs = 0;                 // observations since the last reset
+    float lam_rate = 0.f;          // decayed maximum of |d lambd| per call
+    int max_ahead = 8;             // calls the host may run ahead of the last observation (0: unbounded)
+    int guard_mode = 0;            // 0 auto, 1 always both neighbours, 2 never
+    int last_guards = 0;           // bit 0: n_fft/2 launched, bit 1: 2 n_fft launched (most recent call)
     std::mutex mu;
     dmel_plan_info info{};
     // optional event timing
@@ -286,74 +299,112 @@ dmel_status build_tables(dmel_plan* pl, int N, NfftTables** out)
     return DMEL_OK;
 }
 
-dmel_status ensure_psum(dmel_plan* pl, int batch)
+// ---- per-call device scratch -----------------------------------------------------------------------------------------
+// [0] handled word of the launch group | [64] 1024 fp64 partials of the dot kernel | [8256] its ticket counter |
+// [8320] window table (w, w d^2 2^-2e) for the kernels that read it from memory | [kScratchPsum] partial clip sums
+constexpr size_t kScratchPartials = 64, kScratchCounter = 64 + 8192, kScratchWin = 8320;
+constexpr size_t kScratchPsum = kScratchWin + (size_t)dmel::kMaxNfft * 8;
+
+struct Scratch {
+    unsigned* handled = nullptr; double* partials = nullptr; unsigned* counter = nullptr; float2* win = nullptr; float* psum = nullptr;
+};
+
+size_t scratch_bytes(const dmel_plan* pl, int batch)
 {
-    if (batch <= pl->psum_clips) return DMEL_OK;
-    if (pl->psum) { (void)hipFree(pl->psum); pl->psum = nullptr; pl->psum_clips = 0; }
-    const int clips = std::max(batch, pl->cfg.max_batch);
-    DMEL_HIP(hipMalloc(&pl->psum, (size_t)clips * pl->nchunks * sizeof(float)));
-    pl->psum_clips = clips;
+    const size_t ps = ((size_t)std::max(batch, 1) * pl->nchunks * sizeof(float) + 255) / 256 * 256;
+    return kScratchPsum + ps;
+}
+
+Scratch carve(void* base)
+{
+    unsigned char* b = static_cast<unsigned char*>(base);
+    Scratch sc;
+    sc.handled = reinterpret_cast<unsigned*>(b);
+    sc.partials = reinterpret_cast<double*>(b + kScratchPartials);
+    sc.counter = reinterpret_cast<unsigned*>(b + kScratchCounter);
+    sc.win = reinterpret_cast<float2*>(b + kScratchWin);
+    sc.psum = reinterpret_cast<float*>(b + kScratchPsum);
+    return sc;
+}
+
+bool is_capturing(hipStream_t s)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return st != hipStreamCaptureStatusNone;
+}
+
+// Plan-owned buffers (own_scratch, fbw) are shared by every call on the plan: a call on another stream than the previous
+// one first waits for that stream's work (one event), so concurrent streams serialise on the plan instead of racing.
+dmel_status order_after_last_stream(dmel_plan* pl, hipStream_t s)
+{
+    if (pl->last_stream_valid && pl->last_stream != s && !is_capturing(s)) {
+        if (hipEventRecord(pl->xev, pl->last_stream) == hipSuccess) DMEL_HIP(hipStreamWaitEvent(s, pl->xev, 0));
+        else { (void)hipGetLastError(); DMEL_HIP(hipDeviceSynchronize()); }      // the old stream is gone: be safe
+    }
+    pl->last_stream = s;
+    pl->last_stream_valid = true;
     return DMEL_OK;
 }
 
-// shared body of dmel_forward / dmel_spectrogram
-dmel_status run_forward_nolock(dmel_plan* pl, const float* x, int batch, float lambd, unsigned flags, double eps,
-                        float* out, float* tangent, int mode, int remove_dc, void* stream,
-                        int n_fft_override = 0, int win_half = 0)
+dmel_status ensure_own_scratch(dmel_plan* pl, int batch, hipStream_t s, Scratch* sc)
 {
-    if (!pl) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
-    if (batch < 0) return fail(DMEL_ERR_INVALID_ARGUMENT, "batch < 0");
-    if (batch == 0) return DMEL_OK;
-    if (!x || !out) return fail(DMEL_ERR_INVALID_ARGUMENT, "x / out is NULL");
-    if (batch > 65534) return fail(DMEL_ERR_INVALID_ARGUMENT, "batch > 65534 (split the call)");
-    if (!std::isfinite(lambd)) return fail(DMEL_ERR_INVALID_ARGUMENT, "lambd is not finite");
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int N = n_fft_override > 0 ? n_fft_override : dmel_n_fft(lambd);
-    if (n_fft_override > 0 && (N & (N - 1)))
+    if (!pl->own_scratch || batch > pl->own_scratch_clips) {
+        if (is_capturing(s)) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan scratch must grow but the stream is capturing: run one call eagerly first or pass scratch");
+        if (pl->own_scratch) { DMEL_HIP(hipDeviceSynchronize()); (void)hipFree(pl->own_scratch); pl->own_scratch = nullptr; pl->own_scratch_clips = 0; }
+        const int clips = std::max(batch, pl->cfg.max_batch);
+        const size_t bytes = scratch_bytes(pl, clips);
+        DMEL_HIP(hipMalloc(&pl->own_scratch, bytes));
+        DMEL_HIP(hipMemset(pl->own_scratch, 0, kScratchWin));
+        pl->own_scratch_clips = clips;
+    }
+    *sc = carve(pl->own_scratch);
+    return DMEL_OK;
+}
+
+// One launch (plus, when needed, the partial-sum / window-table kernel in front of it) of the forward for a given n_fft.
+// `lam` says where lambd comes from and whether the kernels check it against N (dmel_kernels.h); `sc` is the scratch of
+// this call.  Shared by every entry point; the plan mutex is held by the caller.
+dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dmel::LamArgs lam, unsigned flags, double eps,
+                             float* out, float* tangent, int mode, int remove_dc, const Scratch& sc, hipStream_t s, int win_half,
+                             bool* sums_done)
+{
+    if (N < 1 || (N & (N - 1)))
         return fail(DMEL_ERR_UNSUPPORTED, "n_fft = " + std::to_string(N) + " is not a power of two");
     if (N > dmel::kMaxNfft)
-        return fail(DMEL_ERR_UNSUPPORTED, "n_fft = " + std::to_string(N) + " > 16384 (|lambd| > 2730.6) is not supported by the HIP kernels");
+        return fail(DMEL_ERR_UNSUPPORTED, "n_fft = " + std::to_string(N) + " > " + std::to_string(dmel::kMaxNfft) + " is not supported by the HIP kernels");
     NfftTables* tb = nullptr;
     dmel_status st = build_tables(pl, N, &tb);
     if (st != DMEL_OK) return st;
-    if ((st = ensure_psum(pl, batch)) != DMEL_OK) return st;
-
-    // x~*w and x~*dw/dlambd share one complex FFT; dw/dlambd is ~1/|lambd| times smaller than w, and the
-    // even/odd split that separates the two spectra leaves an error of eps * (the larger one) in each.
-    // Pre-multiplying dw by a power of two ~|lambd| (exact) keeps both at the same scale; the
-    // epilogue divides it out again through `sign` (also exact).
-    int ex = 0;
-    (void)std::frexp(std::fabs(lambd) > 1e-30f ? std::fabs(lambd) : 1.0f, &ex);
-    ex = std::max(-60, std::min(60, ex));
-    const float dw_scale = std::ldexp(1.0f, ex);
 
     // The fused kernel builds its own window table (n_fft <= 2048) and, for clips up to 32768 samples, its
     // own clip mean; the prep kernel only runs for what is left: partial sums of long clips, the window
     // table of n_fft 4096, and everything the direct-DFT kernel (n_fft < 32) needs.
     const bool fast = N >= dmel::kMinFastNfft && N <= dmel::kMaxFastNfft;
     const bool kernel_mean = fast && pl->cfg.n_points <= 32768;
-    const bool need_sums = remove_dc && !kernel_mean;
+    const bool need_sums = remove_dc && !kernel_mean && !*sums_done;                  // the launches of one group share the sums
     const bool need_window = !fast || N > 2048;
     const size_t m0 = prof_mark(pl, s);
     if (need_sums || need_window) {
         dmel::PrepParams pp{};
-        pp.x = x; pp.psum = pl->psum; pp.win2 = reinterpret_cast<float2*>(pl->win);
+        pp.x = x; pp.psum = sc.psum; pp.win2 = sc.win;
         pp.B = need_sums ? batch : 0; pp.L = pl->cfg.n_points; pp.nchunks = pl->nchunks; pp.chunk = pl->chunk;
-        pp.N = N; pp.normalize = pl->cfg.normalize_window; pp.lambd_abs = std::fabs(lambd); pp.dw_scale = dw_scale; pp.win_half = win_half;
+        pp.N = need_window ? N : 0; pp.normalize = pl->cfg.normalize_window; pp.win_half = win_half;
+        pp.lam = lam; pp.lam.role = dmel::kLamQuiet;
         DMEL_HIP(dmel::launch_prep(pp, s));
+        if (need_sums) *sums_done = true;
     }
     const size_t m1 = prof_mark(pl, s);
     if (need_sums || need_window) prof_span(pl, m0, m1, 0);
 
-    const float sign = (lambd > 0.f ? 1.f : (lambd < 0.f ? -1.f : 0.f)) / dw_scale;
     pl->info.n_fft = N; pl->info.n_freqs = tb->F; pl->info.n_time = pl->T;
+    const float inv_L = 1.0f / (float)pl->cfg.n_points;
     if (N < dmel::kMinFastNfft) {
         dmel::NaiveParams np{};
-        np.x = x; np.out = out; np.tangent = tangent; np.psum = pl->psum; np.win2 = reinterpret_cast<const float2*>(pl->win); np.fb = tb->fb_dense;
+        np.x = x; np.out = out; np.tangent = tangent; np.psum = sc.psum; np.win2 = sc.win; np.fb = tb->fb_dense;
         np.B = batch; np.L = pl->cfg.n_points; np.T = pl->T; np.hop = pl->cfg.hop_length; np.M = pl->cfg.n_mels;
         np.nchunks = pl->nchunks; np.N = N; np.F = tb->F; np.mode = mode;
-        np.inv_L = 1.0f / (float)pl->cfg.n_points; np.sign = sign; np.eps = (float)eps; np.flags = flags;
-        np.remove_dc = remove_dc;
+        np.inv_L = inv_L; np.eps = (float)eps; np.flags = flags; np.remove_dc = remove_dc; np.lam = lam;
         DMEL_HIP(dmel::launch_naive(np, s));
         prof_span(pl, m1, prof_mark(pl, s), 1);
         pl->info.kernel_path = 1; pl->info.frames_per_tile = 1; pl->info.grid_fwd = batch * pl->T;
@@ -362,12 +413,12 @@ dmel_status run_forward_nolock(dmel_plan* pl, const float* x, int batch, float l
     }
     if (N > dmel::kMaxFastNfft) {
         dmel::LongParams lp{};
-        lp.x = x; lp.out = out; lp.tangent = tangent; lp.psum = pl->psum; lp.win2 = reinterpret_cast<const float2*>(pl->win);
+        lp.x = x; lp.out = out; lp.tangent = tangent; lp.psum = sc.psum; lp.win2 = sc.win;
         lp.tw = tb->tw_long; lp.fbT = tb->fbT; lp.band = tb->band;
         lp.B = batch; lp.L = pl->cfg.n_points; lp.T = pl->T; lp.hop = pl->cfg.hop_length; lp.M = pl->cfg.n_mels;
         lp.nchunks = pl->nchunks; lp.N = N; lp.F = tb->F; lp.mode = mode;
         lp.logN = 0; while ((1 << lp.logN) < N) ++lp.logN;
-        lp.inv_L = 1.0f / (float)pl->cfg.n_points; lp.sign = sign; lp.eps = (float)eps; lp.flags = flags; lp.remove_dc = remove_dc;
+        lp.inv_L = inv_L; lp.eps = (float)eps; lp.flags = flags; lp.remove_dc = remove_dc; lp.lam = lam;
         DMEL_HIP(dmel::launch_long(lp, s));
         prof_span(pl, m1, prof_mark(pl, s), 1);
         const bool pair = (mode == dmel::kInfer || mode == dmel::kSpec);
@@ -377,21 +428,15 @@ dmel_status run_forward_nolock(dmel_plan* pl, const float* x, int batch, float l
         return DMEL_OK;
     }
     dmel::FwdParams fp{};
-    fp.x = x; fp.out = out; fp.tangent = tangent; fp.psum = need_sums ? pl->psum : nullptr; fp.win2 = reinterpret_cast<const float2*>(pl->win);
+    fp.x = x; fp.out = out; fp.tangent = tangent; fp.psum = (remove_dc && !kernel_mean) ? sc.psum : nullptr; fp.win2 = sc.win;
     fp.tw1 = tb->tw1; fp.tw2 = tb->tw2; fp.ent_b = tb->ent_b; fp.tile_ranges = tb->tile_ranges; fp.ent_b_floats = tb->ent_b_floats; fp.ent_pre = tb->ent_pre;
     for (int i = 0; i < 16; ++i) fp.pre_groups[i] = tb->pre_groups[i];
     fp.B = batch; fp.L = pl->cfg.n_points; fp.T = pl->T; fp.hop = pl->cfg.hop_length; fp.M = pl->cfg.n_mels;
     fp.nchunks = pl->nchunks; fp.groups = tb->groups;
     const int fpt = dmel::forward_frames_per_tile(N, mode);
     fp.tiles_per_clip = (pl->T + fpt - 1) / fpt;
-    fp.inv_L = 1.0f / (float)pl->cfg.n_points; fp.sign = sign; fp.eps = (float)eps; fp.flags = flags;
-    fp.remove_dc = remove_dc; fp.normalize = pl->cfg.normalize_window;
-    fp.lambd_abs = std::fabs(lambd); fp.dw_scale = dw_scale; fp.win_half = win_half;
-    {
-        const double den = (double)(std::fabs(lambd) + 1e-15f);
-        const double k3 = (double)dw_scale / (den * den * den);
-        fp.dw_k3 = std::isfinite(k3) && k3 < 3.0e38 ? (float)k3 : 0.f;     // lambd == 0: w' is 0 wherever w is not
-    }
+    fp.inv_L = inv_L; fp.eps = (float)eps; fp.flags = flags; fp.lam = lam;
+    fp.remove_dc = remove_dc; fp.normalize = pl->cfg.normalize_window; fp.win_half = win_half;
     const long long grid = (long long)batch * fp.tiles_per_clip;
     if (grid > 0x7fffffffLL) return fail(DMEL_ERR_INVALID_ARGUMENT, "too many tiles for one launch");
     DMEL_HIP(dmel::launch_forward(N, mode, fp, (int)grid, s));
@@ -402,13 +447,70 @@ dmel_status run_forward_nolock(dmel_plan* pl, const float* x, int batch, float l
     return DMEL_OK;
 }
 
+dmel_status check_forward_args(dmel_plan* pl, const float* x, int batch, const void* out)
+{
+    if (!pl) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
+    if (batch < 0) return fail(DMEL_ERR_INVALID_ARGUMENT, "batch < 0");
+    if (batch > 0 && (!x || !out)) return fail(DMEL_ERR_INVALID_ARGUMENT, "x / out is NULL");
+    if (batch > 65534) return fail(DMEL_ERR_INVALID_ARGUMENT, "batch > 65534 (split the call)");
+    return DMEL_OK;
+}
+
+// lambd by value (the host has read it, as time_frequency.py:39 does): one launch, plan-owned scratch unless given.
+// The plan mutex is held by the caller.
+dmel_status run_forward_nolock(dmel_plan* pl, const float* x, int batch, float lambd, unsigned flags, double eps,
+                        float* out, float* tangent, int mode, int remove_dc, void* stream,
+                        int n_fft_override = 0, int win_half = 0, void* scratch = nullptr)
+{
+    dmel_status st = check_forward_args(pl, x, batch, out);
+    if (st != DMEL_OK) return st;
+    if (batch == 0) return DMEL_OK;
+    if (!std::isfinite(lambd)) return fail(DMEL_ERR_INVALID_ARGUMENT, "lambd is not finite");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int N = n_fft_override > 0 ? n_fft_override : dmel_n_fft(lambd);
+    Scratch sc;
+    if (scratch) sc = carve(scratch);
+    else {
+        if ((st = order_after_last_stream(pl, s)) != DMEL_OK) return st;
+        if ((st = ensure_own_scratch(pl, batch, s, &sc)) != DMEL_OK) return st;
+    }
+    dmel::LamArgs lam{};
+    lam.dev = nullptr; lam.val = lambd; lam.n_expected = 0;      // N was derived from this very value (or given explicitly)
+    lam.role = dmel::kLamFirst | dmel::kLamLast;
+    lam.dot_counter = scratch ? sc.counter : nullptr;            // plan-owned counters are zeroed at allocation and reset themselves
+    bool sums_done = false;
+    return launch_forward_n(pl, x, batch, N, lam, flags, eps, out, tangent, mode, remove_dc, sc, s, win_half, &sums_done);
+}
+
 dmel_status run_forward(dmel_plan* pl, const float* x, int batch, float lambd, unsigned flags, double eps,
                         float* out, float* tangent, int mode, int remove_dc, void* stream,
-                        int n_fft_override = 0, int win_half = 0)
+                        int n_fft_override = 0, int win_half = 0, void* scratch = nullptr)
 {
     if (!pl) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
     std::lock_guard<std::mutex> lock(pl->mu);
-    return run_forward_nolock(pl, x, batch, lambd, flags, eps, out, tangent, mode, remove_dc, stream, n_fft_override, win_half);
+    return run_forward_nolock(pl, x, batch, lambd, flags, eps, out, tangent, mode, remove_dc, stream, n_fft_override, win_half, scratch);
+}
+
+// ---- device-resident lambd ---------------------------------------------------------------------------------------------
+void lam_reset(dmel_plan* pl)
+{
+    pl->lam_known = false; pl->n_obs = 0; pl->lam_rate = 0.f; pl->seq_seen = pl->issued;
+}
+
+// fold the kernels' latest report into the host's picture; returns false if nothing new
+bool lam_observe(dmel_plan* pl)
+{
+    const unsigned long long w = __atomic_load_n(&pl->host_words[0], __ATOMIC_RELAXED);
+    const unsigned seq = (unsigned)(w >> 32);
+    if (seq == 0 || (pl->lam_known && seq == pl->seq_seen) || (int)(seq - pl->seq_seen) < 0) return false;
+    float lam; const unsigned bits = (unsigned)w; std::memcpy(&lam, &bits, 4);
+    if (pl->lam_known && pl->n_obs >= 1) {
+        const unsigned dseq = seq - pl->seq_seen;
+        const float r = std::fabs(lam - pl->lam_seen) / (float)(dseq ? dseq : 1);
+        pl->lam_rate = std::max(0.98f * pl->lam_rate, r);
+    }
+    pl->lam_seen = lam; pl->seq_seen = seq; pl->lam_known = true; ++pl->n_obs;
+    return true;
 }
 
 }  // namespace
@@ -519,13 +621,14 @@ dmel_status dmel_plan_create(const dmel_config* cfg, dmel_plan** plan)
     nch = std::max(1, std::min(nch, dmel::kMaxChunks));
     pl->nchunks = nch;
     pl->chunk = ((cfg->n_points + nch - 1) / nch + 3) / 4 * 4;   // multiple of 4 samples: chunks keep 16-byte alignment
-    hipError_t e = hipMalloc(&pl->win, 2 * dmel::kMaxNfft * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc(&pl->partials, (kMaxPartials + 2) * sizeof(double));
-    if (e == hipSuccess) e = hipMemset(pl->partials, 0, (kMaxPartials + 2) * sizeof(double));
-    if (e == hipSuccess) pl->dot_counter = reinterpret_cast<unsigned*>(pl->partials + kMaxPartials);
-    if (e != hipSuccess) { dmel_plan_destroy(pl); return fail(DMEL_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
-    if (cfg->max_batch > 0) {
-        dmel_status st = ensure_psum(pl, cfg->max_batch);
+    hipError_t e = hipEventCreateWithFlags(&pl->xev, hipEventDisableTiming);
+    // two words the kernels write and the host reads without synchronising (device-resident lambd, dmel_forward_dev)
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&pl->host_words), 64, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e != hipSuccess) { dmel_plan_destroy(pl); return fail(DMEL_ERR_HIP, std::string("plan resources: ") + hipGetErrorString(e)); }
+    std::memset(pl->host_words, 0, 64);
+    {
+        Scratch sc;
+        dmel_status st = ensure_own_scratch(pl, std::max(1, cfg->max_batch), nullptr, &sc);
         if (st != DMEL_OK) { dmel_plan_destroy(pl); return st; }
     }
     *plan = pl;
@@ -537,7 +640,9 @@ dmel_status dmel_plan_destroy(dmel_plan* plan)
     if (!plan) return DMEL_OK;
     for (auto& kv : plan->tables) kv.second.release();
     for (hipEvent_t e : plan->ev_pool) (void)hipEventDestroy(e);
-    (void)hipFree(plan->psum); (void)hipFree(plan->win); (void)hipFree(plan->partials); (void)hipFree(plan->fbw);
+    (void)hipFree(plan->own_scratch); (void)hipFree(plan->fbw);
+    if (plan->host_words) (void)hipHostFree(plan->host_words);
+    if (plan->xev) (void)hipEventDestroy(plan->xev);
     delete plan;
     return DMEL_OK;
 }
@@ -560,19 +665,166 @@ dmel_status dmel_plan_set_filterbank(dmel_plan* plan, int32_t n_fft, const float
     return DMEL_OK;
 }
 
-dmel_status dmel_forward(dmel_plan* plan, const float* x, int32_t batch, float lambd, uint32_t flags,
-                         double eps, float* out, float* tangent, void* stream)
+dmel_status dmel_forward_scratch(dmel_plan* plan, const float* x, int32_t batch, float lambd, uint32_t flags,
+                                 double eps, void* out, float* tangent, void* scratch, void* stream)
 {
     if (flags & DMEL_FLAG_FULL_WINDOW) {
         if (!plan) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
         const int L = plan->cfg.n_points;
         if ((L & (L - 1)) || 2 * L > dmel::kMaxNfft)
-            return fail(DMEL_ERR_UNSUPPORTED, "DMEL_FLAG_FULL_WINDOW needs n_points to be a power of two <= 8192");
-        return run_forward(plan, x, batch, lambd, flags & ~DMEL_FLAG_FULL_WINDOW, eps, out, tangent,
-                           tangent ? dmel::kTrain : dmel::kInfer, 1, stream, 2 * L, 1);
+            return fail(DMEL_ERR_UNSUPPORTED, "DMEL_FLAG_FULL_WINDOW needs n_points to be a power of two <= " + std::to_string(dmel::kMaxNfft / 2));
+        return run_forward(plan, x, batch, lambd, flags & ~DMEL_FLAG_FULL_WINDOW, eps, static_cast<float*>(out), tangent,
+                           tangent ? dmel::kTrain : dmel::kInfer, 1, stream, 2 * L, 1, scratch);
     }
-    return run_forward(plan, x, batch, lambd, flags, eps, out, tangent,
-                       tangent ? dmel::kTrain : dmel::kInfer, /*remove_dc=*/1, stream);
+    return run_forward(plan, x, batch, lambd, flags, eps, static_cast<float*>(out), tangent,
+                       tangent ? dmel::kTrain : dmel::kInfer, /*remove_dc=*/1, stream, 0, 0, scratch);
+}
+
+dmel_status dmel_forward(dmel_plan* plan, const float* x, int32_t batch, float lambd, uint32_t flags,
+                         double eps, float* out, float* tangent, void* stream)
+{
+    return dmel_forward_scratch(plan, x, batch, lambd, flags, eps, out, tangent, nullptr, stream);
+}
+
+dmel_status dmel_plan_get_config(const dmel_plan* plan, dmel_config* cfg)
+{
+    if (!plan || !cfg) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan / cfg is NULL");
+    *cfg = plan->cfg;
+    return DMEL_OK;
+}
+
+size_t dmel_scratch_bytes(const dmel_plan* plan, int32_t batch)
+{
+    if (!plan || batch < 0) return 0;
+    return scratch_bytes(plan, batch);
+}
+
+dmel_status dmel_forward_dev(dmel_plan* plan, const float* x, int32_t batch, const float* lambd_dev, uint32_t flags,
+                             double eps, void* out, float* tangent, void* scratch, void* stream)
+{
+    dmel_status st = check_forward_args(plan, x, batch, out);
+    if (st != DMEL_OK) return st;
+    if (!lambd_dev) return fail(DMEL_ERR_INVALID_ARGUMENT, "lambd_dev is NULL");
+    if (flags & DMEL_FLAG_FULL_WINDOW)
+        return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_forward_dev: DMEL_FLAG_FULL_WINDOW has a fixed n_fft, use dmel_forward");
+    std::lock_guard<std::mutex> lock(plan->mu);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool capturing = is_capturing(s);
+
+    // a forward that no launch covered: its outputs are NaN on the device; tell the caller once and start over
+    const unsigned long long err = __atomic_load_n(&plan->host_words[1], __ATOMIC_RELAXED);
+    if (err != 0) {
+        float lam; const unsigned bits = (unsigned)err; std::memcpy(&lam, &bits, 4);
+        __atomic_store_n(&plan->host_words[1], 0ull, __ATOMIC_RELAXED);
+        const float seen = plan->lam_seen;
+        lam_reset(plan);
+        return fail(DMEL_ERR_LAMBD_TRACKING,
+                    "lambd moved from " + std::to_string(seen) + " (n_fft " + std::to_string(dmel_n_fft(seen)) + ") to " +
+                    std::to_string(lam) + " (n_fft " + std::to_string(dmel_n_fft(lam)) + ") faster than the sync-free forward "
+                    "tracks it: call " + std::to_string((unsigned)(err >> 32)) + " produced NaN.  Tracking has been reset; use "
+                    "dmel_forward (host read per call), dmel_plan_set_tracking(plan, max_ahead, 1) or a smaller run-ahead");
+    }
+    if (batch == 0) return DMEL_OK;
+    lam_observe(plan);
+    if (!plan->lam_known) {
+        // cold start: the one blocking read (the reference does one per sample, time_frequency.py:39)
+        if (capturing) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_forward_dev: run the layer once eagerly before capturing it into a graph");
+        float lam = 0.f;
+        DMEL_HIP(hipMemcpyAsync(&lam, lambd_dev, sizeof(float), hipMemcpyDeviceToHost, s));
+        DMEL_HIP(hipStreamSynchronize(s));
+        if (!std::isfinite(lam)) return fail(DMEL_ERR_INVALID_ARGUMENT, "lambd is not finite");
+        plan->lam_seen = lam; plan->seq_seen = plan->issued; plan->lam_known = true; plan->n_obs = 0; plan->lam_rate = 0.f;
+    } else if (!capturing && plan->max_ahead > 0) {
+        // bounded run-ahead: the picture of lambd the launches are chosen from is at most max_ahead calls old
+        for (long spins = 0; plan->issued - plan->seq_seen > (unsigned)plan->max_ahead && spins < 200000000L; ++spins) {
+            if (!lam_observe(plan) && (spins & 1023) == 1023 && hipStreamQuery(s) == hipSuccess) { lam_observe(plan); break; }
+        }
+        (void)hipGetLastError();
+    }
+    const float a = std::fabs(plan->lam_seen);
+    const int N = dmel_n_fft(plan->lam_seen);
+    // neighbours that could become the right n_fft before the host notices: both while the drift per call is unknown,
+    // under graph capture (the host is not there at replay) and on request; otherwise only within reach of a boundary
+    int guards = 0;
+    if (plan->guard_mode == 1 || capturing) guards = 3;
+    else if (plan->guard_mode == 0) {
+        if (plan->n_obs < 2) guards = 3;
+        else {
+            const float stale = (float)(plan->issued - plan->seq_seen) + 2.0f;
+            const float reach = 2.0f * plan->lam_rate * stale + 1e-5f * a;
+            if ((a - reach) * 6.0f < (float)(N / 2 + 1)) guards |= 1;
+            if ((a + reach) * 6.0f >= (float)N + 1.0f) guards |= 2;
+        }
+    }
+    // tables of the neighbouring sizes exist before they are needed: building them allocates and copies (not allowed
+    // under capture, and a stall at the moment of a crossing otherwise)
+    if (!capturing) {
+        NfftTables* tb = nullptr;
+        for (int n : {N, 2 * N, N / 2})
+            if (n >= 1 && n <= dmel::kMaxNfft && (st = build_tables(plan, n, &tb)) != DMEL_OK) return st;
+    }
+    int cand[3], nc = 0;
+    cand[nc++] = N;
+    if ((guards & 2) && 2 * N <= dmel::kMaxNfft) cand[nc++] = 2 * N;
+    if ((guards & 1) && N >= 2) cand[nc++] = N / 2;
+    plan->last_guards = (nc > 1 && cand[1] == 2 * N ? 2 : 0) | ((nc > 1 && cand[nc - 1] == N / 2) ? 1 : 0);
+
+    Scratch sc;
+    if (scratch) sc = carve(scratch);
+    else {
+        if ((st = order_after_last_stream(plan, s)) != DMEL_OK) return st;
+        if ((st = ensure_own_scratch(plan, batch, s, &sc)) != DMEL_OK) return st;
+    }
+    const unsigned seq = ++plan->issued;
+    bool sums_done = false;
+    for (int i = 0; i < nc; ++i) {
+        dmel::LamArgs lam{};
+        lam.dev = lambd_dev; lam.val = 0.f; lam.n_expected = cand[i];
+        lam.role = (i == 0 ? dmel::kLamFirst : 0u) | (i == nc - 1 ? dmel::kLamLast : 0u);
+        lam.seq = seq; lam.handled = sc.handled;
+        lam.host_seen = &plan->host_words[0]; lam.host_error = &plan->host_words[1];
+        lam.dot_counter = scratch ? sc.counter : nullptr;
+        st = launch_forward_n(plan, x, batch, cand[i], lam, flags, eps, static_cast<float*>(out), tangent,
+                              tangent ? dmel::kTrain : dmel::kInfer, /*remove_dc=*/1, sc, s, 0, &sums_done);
+        if (st != DMEL_OK) return st;
+    }
+    plan->info.n_fft = N;
+    return DMEL_OK;
+}
+
+dmel_status dmel_plan_lambd_status(dmel_plan* plan, dmel_lambd_status* status)
+{
+    if (!plan || !status) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan / status is NULL");
+    std::lock_guard<std::mutex> lock(plan->mu);
+    lam_observe(plan);
+    dmel_lambd_status r{};
+    r.known = plan->lam_known ? 1 : 0;
+    r.lambd_seen = plan->lam_seen;
+    r.n_fft_seen = plan->lam_known ? dmel_n_fft(plan->lam_seen) : 0;
+    r.seq_issued = plan->issued; r.seq_seen = plan->seq_seen;
+    r.rate = plan->lam_rate; r.guards = plan->last_guards;
+    const unsigned long long err = __atomic_load_n(&plan->host_words[1], __ATOMIC_RELAXED);
+    r.error = err != 0 ? 1 : 0;
+    r.error_seq = (uint32_t)(err >> 32);
+    { const unsigned bits = (unsigned)err; std::memcpy(&r.error_lambd, &bits, 4); }
+    *status = r;
+    return DMEL_OK;
+}
+
+dmel_status dmel_plan_set_tracking(dmel_plan* plan, int32_t max_ahead, int32_t guard_mode)
+{
+    if (!plan || max_ahead < 0 || guard_mode < 0 || guard_mode > 2) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_plan_set_tracking: bad arguments");
+    std::lock_guard<std::mutex> lock(plan->mu);
+    plan->max_ahead = max_ahead; plan->guard_mode = guard_mode;
+    return DMEL_OK;
+}
+
+dmel_status dmel_plan_lambd_reset(dmel_plan* plan)
+{
+    if (!plan) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
+    std::lock_guard<std::mutex> lock(plan->mu);
+    lam_reset(plan);
+    return DMEL_OK;
 }
 
 dmel_status dmel_spectrogram(dmel_plan* plan, const float* x, int32_t batch, float lambd,
@@ -597,11 +849,29 @@ dmel_status dmel_backward_ex(dmel_plan* plan, const void* grad_out, int32_t grad
         return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_backward: bad arguments");
     if (grad_dtype != DMEL_DTYPE_F32 && grad_dtype != DMEL_DTYPE_BF16)
         return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_backward_ex: grad_dtype must be DMEL_DTYPE_F32 or DMEL_DTYPE_BF16");
+    return dmel_backward_scratch(plan, grad_out, grad_dtype, tangent, count, accumulate, dlambd, nullptr, stream);
+}
+
+dmel_status dmel_backward_scratch(dmel_plan* plan, const void* grad_out, int32_t grad_dtype, const float* tangent, int64_t count,
+                                  int32_t accumulate, float* dlambd, void* scratch, void* stream)
+{
+    if (!plan) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
+    if (count < 0 || !dlambd || (count > 0 && (!grad_out || !tangent)))
+        return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_backward: bad arguments");
+    if (grad_dtype != DMEL_DTYPE_F32 && grad_dtype != DMEL_DTYPE_BF16)
+        return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_backward: grad_dtype must be DMEL_DTYPE_F32 or DMEL_DTYPE_BF16");
     std::lock_guard<std::mutex> lock(plan->mu);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    Scratch sc;
+    if (scratch) sc = carve(scratch);
+    else {
+        dmel_status st = order_after_last_stream(plan, s);
+        if (st != DMEL_OK) return st;
+        if ((st = ensure_own_scratch(plan, 1, s, &sc)) != DMEL_OK) return st;
+    }
     const size_t m0 = prof_mark(plan, s);
-    DMEL_HIP(dmel::launch_dot(grad_out, grad_dtype == DMEL_DTYPE_BF16, tangent, (long long)count, accumulate, plan->partials,
-                              plan->dot_counter, kMaxPartials, dlambd, s));
+    DMEL_HIP(dmel::launch_dot(grad_out, grad_dtype == DMEL_DTYPE_BF16, tangent, (long long)count, accumulate, sc.partials,
+                              sc.counter, kMaxPartials, dlambd, s));
     prof_span(plan, m0, prof_mark(plan, s), 2);
     return DMEL_OK;
 }
@@ -630,11 +900,15 @@ dmel_status dmel_backward_fb(dmel_plan* plan, const float* x, int32_t batch, flo
     }
     const int N = n_over ? n_over : dmel_n_fft(lambd);
     if (N > dmel::kMaxNfft)
-        return fail(DMEL_ERR_UNSUPPORTED, "n_fft = " + std::to_string(N) + " > 16384 (|lambd| > 2730.6) is not supported by the HIP kernels");
+        return fail(DMEL_ERR_UNSUPPORTED, "n_fft = " + std::to_string(N) + " > " + std::to_string(dmel::kMaxNfft) + " is not supported by the HIP kernels");
     const int F = N / 2 + 1, M = plan->cfg.n_mels, T = plan->T;
     std::lock_guard<std::mutex> lock(plan->mu);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (batch == 0) { DMEL_HIP(hipMemsetAsync(grad_fb, 0, (size_t)F * M * sizeof(float), s)); return DMEL_OK; }
+    {
+        dmel_status so = order_after_last_stream(plan, s);       // fbw is shared by every call on the plan
+        if (so != DMEL_OK) return so;
+    }
     // enough batch slices to fill the chip a few times over, never more than clips
     const int tiles = ((F + 31) / 32) * ((M + 127) / 128);
     const int splits = std::max(1, std::min(batch, (1024 + tiles - 1) / tiles));
@@ -674,13 +948,15 @@ dmel_status dmel_backward_x(dmel_plan* plan, const float* x, int32_t batch, floa
     if (!std::isfinite(lambd)) return fail(DMEL_ERR_INVALID_ARGUMENT, "lambd is not finite");
     const int N = dmel_n_fft(lambd);
     if (N > dmel::kMaxNfft)
-        return fail(DMEL_ERR_UNSUPPORTED, "n_fft = " + std::to_string(N) + " > 16384 (|lambd| > 2730.6) is not supported by the HIP kernels");
+        return fail(DMEL_ERR_UNSUPPORTED, "n_fft = " + std::to_string(N) + " > " + std::to_string(dmel::kMaxNfft) + " is not supported by the HIP kernels");
     std::lock_guard<std::mutex> lock(plan->mu);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     NfftTables* tb = nullptr;
     dmel_status st = build_tables(plan, N, &tb);
     if (st != DMEL_OK) return st;
-    if ((st = ensure_psum(plan, batch)) != DMEL_OK) return st;
+    if ((st = order_after_last_stream(plan, s)) != DMEL_OK) return st;
+    Scratch sc;
+    if ((st = ensure_own_scratch(plan, batch, s, &sc)) != DMEL_OK) return st;
     const size_t frame_floats = ((size_t)batch * plan->T * N + 63) / 64 * 64;
     const size_t need = frame_floats + 2 * (size_t)batch * dmel::xgrad_chunks(plan->cfg.n_points) + 16;    // + fp64 chunk sums
     if (need > plan->fbw_floats) {
@@ -691,12 +967,13 @@ dmel_status dmel_backward_x(dmel_plan* plan, const float* x, int32_t batch, floa
     }
     // clip sums + window table (the tangent half of the table is not used here)
     dmel::PrepParams pp{};
-    pp.x = x; pp.psum = plan->psum; pp.win2 = reinterpret_cast<float2*>(plan->win);
+    pp.x = x; pp.psum = sc.psum; pp.win2 = sc.win;
     pp.B = batch; pp.L = plan->cfg.n_points; pp.nchunks = plan->nchunks; pp.chunk = plan->chunk;
-    pp.N = N; pp.normalize = plan->cfg.normalize_window; pp.lambd_abs = std::fabs(lambd); pp.dw_scale = 1.0f; pp.win_half = 0;
+    pp.N = N; pp.normalize = plan->cfg.normalize_window; pp.win_half = 0;
+    pp.lam.val = lambd; pp.lam.role = dmel::kLamQuiet;
     DMEL_HIP(dmel::launch_prep(pp, s));
     dmel::XgradParams xp{};
-    xp.x = x; xp.psum = plan->psum; xp.win2 = reinterpret_cast<const float2*>(plan->win); xp.tw = tb->tw_long;
+    xp.x = x; xp.psum = sc.psum; xp.win2 = sc.win; xp.tw = tb->tw_long;
     xp.fb = tb->fb_dense; xp.rowband = tb->rowband; xp.grad_out = grad_out; xp.out = (flags & DMEL_FLAG_LOG) ? out : nullptr;
     xp.frames = plan->fbw; xp.grad_x = grad_x;
     xp.csum = reinterpret_cast<double*>(plan->fbw + frame_floats);      // 256-byte aligned: frame_floats is a multiple of 64

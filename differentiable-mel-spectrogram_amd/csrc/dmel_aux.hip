@@ -125,6 +125,20 @@ __global__ void __launch_bounds__(128) dmel_naive_kernel(NaiveParams p)
     const int tid = threadIdx.x;
     const int b = blockIdx.x / p.T, t = blockIdx.x % p.T;
     const float* xb = p.x + (size_t)b * p.L;
+    const bool spec_mode = (p.mode == kSpec || p.mode == kSpecTrain);
+    const LamState ls = lam_prologue(p.lam, p.N, blockIdx.x == 0 && tid == 0);
+    if (ls.action != kLamRun) {
+        if (ls.action == kLamPoison) {           // no launch of this forward matched the device lambd (dmel_kernels.h)
+            const int rows = spec_mode ? p.F : p.M;
+            for (int rr = tid; rr < rows; rr += blockDim.x) {
+                const size_t o = ((size_t)b * rows + rr) * p.T + t;
+                if (p.flags & 4u) reinterpret_cast<unsigned short*>(p.out)[o] = 0x7fc0u; else p.out[o] = __builtin_nanf("");
+                if (p.tangent) p.tangent[o] = __builtin_nanf("");
+            }
+        }
+        return;
+    }
+    const float ctan = lam_tangent_scale(ls);
     float mean = 0.f;
     if (p.remove_dc) {
         double s = 0.0;
@@ -152,11 +166,11 @@ __global__ void __launch_bounds__(128) dmel_naive_kernel(NaiveParams p)
         D[f] = 2.f * (xr * yr + xi * yi);
     }
     __syncthreads();
-    if (p.mode == kSpec || p.mode == kSpecTrain) {
+    if (spec_mode) {
         for (int f = tid; f < p.F; f += blockDim.x) {
             const size_t o = ((size_t)b * p.F + f) * p.T + t;
             p.out[o] = P[f];
-            if (p.tangent) p.tangent[o] = p.sign * D[f];
+            if (p.tangent) p.tangent[o] = ctan * D[f];
         }
         return;
     }
@@ -168,7 +182,7 @@ __global__ void __launch_bounds__(128) dmel_naive_kernel(NaiveParams p)
             mel = fmaf(c, P[f], mel);
             dmel = fmaf(c, D[f], dmel);
         }
-        dmel *= p.sign;
+        dmel *= ctan;
         const size_t o = ((size_t)b * p.M + m) * p.T + t;
         const bool out_bf16 = (p.flags & 4u) != 0;
         auto put = [&](float v) { if (out_bf16) reinterpret_cast<unsigned short*>(p.out)[o] = bf16_bits(v); else p.out[o] = v; };
@@ -219,6 +233,21 @@ __global__ void __launch_bounds__(kLongThreads) dmel_long_kernel(LongParams p)
     const int b = blockIdx.x / tiles, tile = blockIdx.x % tiles;
     const int tA = pair ? 2 * tile : tile, tB = tA + 1;
     const float* xb = p.x + (size_t)b * p.L;
+    const LamState ls = lam_prologue(p.lam, N, blockIdx.x == 0 && tid == 0);
+    if (ls.action != kLamRun) {
+        if (ls.action == kLamPoison) {           // no launch of this forward matched the device lambd (dmel_kernels.h)
+            const int rows = (p.mode == kSpec || p.mode == kSpecTrain) ? F : p.M;
+            for (int rr = tid; rr < rows; rr += kLongThreads) {
+                const size_t o = ((size_t)b * rows + rr) * p.T;
+                for (int tt = tA; tt <= (pair ? tB : tA) && tt < p.T; ++tt) {
+                    if (p.flags & 4u) reinterpret_cast<unsigned short*>(p.out)[o + tt] = 0x7fc0u; else p.out[o + tt] = __builtin_nanf("");
+                    if (p.tangent) p.tangent[o + tt] = __builtin_nanf("");
+                }
+            }
+        }
+        return;
+    }
+    const float htan = 0.5f * lam_tangent_scale(ls);
     float mean = 0.f;
     if (p.remove_dc) {
         double s = 0.0;
@@ -260,7 +289,7 @@ __global__ void __launch_bounds__(kLongThreads) dmel_long_kernel(LongParams p)
                 if (tB < p.T) p.out[o + tB] = 0.25f * pd.y;
             } else {
                 p.out[o + tA] = 0.25f * pd.x;
-                if (p.tangent) p.tangent[o + tA] = 0.5f * p.sign * pd.y;
+                if (p.tangent) p.tangent[o + tA] = htan * pd.y;
             }
         }
         return;
@@ -287,7 +316,7 @@ __global__ void __launch_bounds__(kLongThreads) dmel_long_kernel(LongParams p)
             put(tA, do_log ? logf(ma + p.eps) : ma);
             if (tB < p.T) put(tB, do_log ? logf(mb + p.eps) : mb);
         } else {
-            const float mel = 0.25f * s0, dmel = 0.5f * p.sign * s1;
+            const float mel = 0.25f * s0, dmel = htan * s1;
             if (do_log) {
                 const float me = mel + p.eps;
                 put(tA, logf(me));

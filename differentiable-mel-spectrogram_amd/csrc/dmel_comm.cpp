@@ -151,6 +151,14 @@ dmel_status dmel_comm_allreduce_async(dmel_comm* c, float* buf, int32_t count, v
     return DMEL_OK;
 }
 
+dmel_status dmel_comm_allreduce(dmel_comm* c, float* buf, int32_t count, void* stream)
+{
+    if (!c || !buf || count < 1) return dmel::set_error(DMEL_ERR_INVALID_ARGUMENT, "dmel_comm_allreduce: bad arguments");
+    const int rc = rccl().all_reduce(buf, buf, (size_t)count, /*ncclFloat32*/ 7, /*ncclSum*/ 0, c->comm, reinterpret_cast<hipStream_t>(stream));
+    if (rc != 0) return dmel::set_error(DMEL_ERR_HIP, nccl_msg(rc));
+    return DMEL_OK;
+}
+
 dmel_status dmel_comm_wait(dmel_comm* c, int32_t ticket, void* stream)
 {
     if (!c || ticket < 0 || ticket >= kRing) return dmel::set_error(DMEL_ERR_INVALID_ARGUMENT, "dmel_comm_wait: bad ticket");

@@ -151,18 +151,21 @@ __global__ void __launch_bounds__(kThreads) dmel_prep_kernel(PrepParams p)
     __shared__ double red[kThreads];
     const int tid = threadIdx.x;
     if (blockIdx.y == (unsigned)p.B) {
-        // window block: time_frequency.py:21-30 in fp32, derivative in fp64
+        // window block: time_frequency.py:21-30 in fp32; second entry = w d^2 2^(-2e), the tangent window up to the
+        // factor lam_tangent_scale() that the forward kernels apply in their epilogue (fp64 here: d^2 needs 30 bits)
         if (blockIdx.x != 0) return;
-        const float denom = p.lambd_abs + 1e-15f;
-        const double den = (double)denom;
+        const LamState ls = lam_prologue(p.lam, p.N, false);
+        if (ls.action != kLamRun) return;
+        const float denom = ls.denom;
+        const double s2 = (double)ls.s2;
         double s_ww = 0.0, s_wd = 0.0;
         for (int n = tid; n < p.N; n += kThreads) {
             const float d = (float)n - (float)p.N / 2.0f;
             const float t = d / denom;
             float w = expf(-0.5f * (t * t));
             if (p.win_half && (n < p.N / 4 || n >= 3 * p.N / 4)) w = 0.f;
-            const double dw = (double)w * (double)d * (double)d / (den * den * den);
-            p.win2[n] = make_float2(w, (float)(dw * (double)p.dw_scale));
+            const double dw = (double)w * (double)d * (double)d * s2;
+            p.win2[n] = make_float2(w, (float)dw);
             s_ww += (double)w * (double)w;
             s_wd += (double)w * dw;
         }
@@ -176,12 +179,10 @@ __global__ void __launch_bounds__(kThreads) dmel_prep_kernel(PrepParams p)
         const double wd = red[0];
         const double nrm = sqrt(ww);
         for (int n = tid; n < p.N; n += kThreads) {
-            const double w = (double)p.win2[n].x, dw = (double)p.win2[n].y;
-            // dw was rounded to fp32 above; recompute it in fp64 for the quotient rule
+            const double w = (double)p.win2[n].x;
             const float d = (float)n - (float)p.N / 2.0f;
-            const double dwe = w * (double)d * (double)d / (den * den * den);
-            (void)dw;
-            p.win2[n] = make_float2((float)(w / nrm), (float)((dwe / nrm - w * wd / (nrm * nrm * nrm)) * (double)p.dw_scale));
+            const double dwe = w * (double)d * (double)d * s2;       // recomputed in fp64 (the table holds it rounded)
+            p.win2[n] = make_float2((float)(w / nrm), (float)(dwe / nrm - w * wd / (nrm * nrm * nrm)));
         }
         return;
     }
@@ -286,8 +287,13 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
     const int b = wg / p.tiles_per_clip;
     const int t0 = (wg % p.tiles_per_clip) * FPT;
     STAMP(0);
-    const bool dbg_skip_fft = (p.flags & 0x200u) != 0;     // timing ablations only (tools/ablate.py)
+#ifdef DMEL_ABLATE
+    // timing ablations (tools/ablate.py builds its own library with -DDMEL_ABLATE; never in libdmel_hip.so)
+    const bool dbg_skip_fft = (p.flags & 0x200u) != 0;
     const bool dbg_skip_gemm = (p.flags & 0x100u) != 0;
+#else
+    constexpr bool dbg_skip_fft = false, dbg_skip_gemm = false;
+#endif
 
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (size_t)b * p.L, (unsigned)p.L * 4u);
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.ent_b, (unsigned)p.ent_b_floats * 4u);
@@ -326,6 +332,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
     // ================= phase 1: FFT of this wave's frames ====================================
     const int j = lane / G, lg = lane % G;
     const int qp = lg / C, r = lg % C;
+    int lam_bits = 0;
     if (!dbg_skip_fft) {
         // Samples of every pass are requested up front.  Frames that lie wholly inside the clip (all but
         // the first/last few) use plain offsets; the others clamp every index into the clip and are
@@ -357,20 +364,38 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
             }
         });
         STAMP(1);   // loads issued
+        // lambd (device scalar or by value) and the check that this launch is the n_fft the device value asks for
+        const LamState ls = lam_prologue(p.lam, N, blockIdx.x == 0 && tid == 0);
+        if (ls.action != kLamRun) {
+            if (ls.action == kLamPoison) {
+                // no launch of this forward matched the device lambd: NaN instead of stale memory (the host raises too)
+                const int rows = IS_SPEC ? F : p.M;
+                const float qn = __builtin_nanf("");
+                for (int idx = tid; idx < rows * FPT; idx += THREADS) {
+                    const int rr = idx / FPT, t = t0 + idx % FPT;
+                    if (t >= p.T) continue;
+                    const size_t o = ((size_t)b * rows + rr) * p.T + t;
+                    if (p.flags & 4u) reinterpret_cast<unsigned short*>(p.out)[o] = 0x7fc0u; else p.out[o] = qn;
+                    if (p.tangent) p.tangent[o] = qn;
+                }
+            }
+            return;
+        }
+        lam_bits = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ls.lam));
         if constexpr (TW2_LDS) { if (tid < R * C) tw2l[tid] = p.tw2[tid]; }          // visible after the barrier below
         // ---- window table into LDS (time_frequency.py:21-30): every workgroup evaluates the same fp32
         // expression, so the table is identical everywhere; this replaces a separate kernel launch
         if constexpr (WIN_LDS) {
-            const float denom = p.lambd_abs + 1e-15f;
+            const float denom = ls.denom;
             float s_ww = 0.f, s_wd = 0.f;
             for (int n = tid; n < N; n += THREADS) {
                 const float d = (float)n - (float)N / 2.0f;
                 const float t = d / denom;
                 float w = expf(-0.5f * (t * t));
                 if (p.win_half && (n < N / 4 || n >= 3 * N / 4)) w = 0.f;     // torch.stft pads a win_length = N/2 window
-                // dw/d|lambd| * 2^e = w * d^2 * (2^e / |lambd|^3): d^2 is exact in fp32 (|d| <= 2048), the constant comes
-                // from the host in fp64 -> fp32, so the product is within 1.5 ulp
-                const float dw = w * (d * d) * p.dw_k3;
+                // tangent window up to a constant: w d^2 2^(-2e) (d^2 and the scaling are exact in fp32: one rounding); the
+                // factor sign 2^(2e) / (|lambd| + 1e-15)^3 is applied once per output in the epilogue (lam_tangent_scale)
+                const float dw = w * (d * d) * ls.s2;
                 wtab[n] = make_float2(w, dw);
                 s_ww += w * w; s_wd += w * dw;
             }
@@ -585,7 +610,20 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
     STAMP(7);   // twiddle + cross-lane radix-C + spectrum to LDS + pairing pass
     __syncthreads();
     STAMP(8);   // barrier
+#ifdef DMEL_ABLATE
     if (dbg_skip_gemm) { if (tid == 0 && lds[0].x == 12345.678f) p.out[0] = 0.f; return; }
+#endif
+    // d out / d lambd = htan * (contraction of the scaled tangent spectrum): see lam_prologue / lam_tangent_scale
+    float htan = 0.f;
+    if constexpr (MODE == kTrain || MODE == kSpecTrain) {
+        LamState lt;
+        lt.lam = __builtin_bit_cast(float, lam_bits);
+        lt.denom = __builtin_fabsf(lt.lam) + 1e-15f;
+        int e = 1;
+        if (__builtin_fabsf(lt.lam) > 1e-30f) e = __builtin_amdgcn_frexp_expf(__builtin_fabsf(lt.lam));
+        lt.e2 = 2 * (e < -30 ? -30 : (e > 30 ? 30 : e));
+        htan = 0.5f * lam_tangent_scale(lt);
+    }
 
     if constexpr (IS_SPEC) {
         // power spectrogram (time_frequency.py:53), layout (B, F, T); kSpecTrain also writes d P / d lambd
@@ -602,7 +640,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                 if (t < p.T) {
                     const size_t o = ((size_t)b * F + k) * p.T + t;
                     p.out[o] = 0.25f * pdv.x;
-                    if (p.tangent) p.tangent[o] = 0.5f * p.sign * pdv.y;
+                    if (p.tangent) p.tangent[o] = htan * pdv.y;
                 }
             }
         }
@@ -631,7 +669,10 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                 const int ks0 = __builtin_amdgcn_readfirstlane(tr.x), nks = __builtin_amdgcn_readfirstlane(tr.y);
                 const int boff = __builtin_amdgcn_readfirstlane(tr.z);
                 tile_of[loc] = __builtin_amdgcn_readfirstlane(tr.w);
-                if (nks <= 0 || (p.flags & 0x800u)) return;       // 0x800: timing ablation, skip the MFMA loop
+#ifdef DMEL_ABLATE
+                if (p.flags & 0x800u) return;                       // timing ablation: skip the MFMA loop
+#endif
+                if (nks <= 0) return;
                 const int bbase = (boff + lane) * 4;
                 // One group = 4 consecutive k-steps = 16 consecutive bins starting at a multiple of 16 (the host
                 // aligns every run to 4 k-steps), so the 4 reads of Z[k] share one base address and, except at one
@@ -693,7 +734,9 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                 tile_of[1] = -1;
             }
             STAMP(10);  // half-tile exchange
-            if (p.flags & 0x400u) continue;                        // 0x400: timing ablation, skip the epilogue
+#ifdef DMEL_ABLATE
+            if (p.flags & 0x400u) continue;                        // timing ablation: skip the epilogue
+#endif
             static_for<0, NLOC>([&](auto l) {
                 constexpr int loc = decltype(l)::value;
                 const int nt = tile_of[loc];
@@ -717,7 +760,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                             static_for<0, 2>([&](auto ss) {
                                 constexpr int s = decltype(ss)::value;
                                 const float mel = 0.25f * a[s];
-                                const float dmel = 0.5f * p.sign * a[2 + s];
+                                const float dmel = htan * a[2 + s];
                                 const float me = mel + p.eps;
                                 (s == 0 ? o2.x : o2.y) = do_log ? logf(me) : mel;
                                 (s == 0 ? t2.x : t2.y) = do_log ? dmel / me : dmel;
@@ -732,7 +775,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                             const int t = t0 + slot;
                             if (slot < SLOTS && t < p.T) {
                                 const float mel = 0.25f * a[s];
-                                const float dmel = 0.5f * p.sign * a[2 + s];
+                                const float dmel = htan * a[2 + s];
                                 if (do_log) {
                                     const float me = mel + p.eps;
                                     put(t, logf(me));

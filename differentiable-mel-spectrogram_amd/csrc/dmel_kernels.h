@@ -17,6 +17,95 @@ __device__ __forceinline__ unsigned short bf16_bits(float v) { return __builtin_
 
 enum Mode : int { kTrain = 0, kInfer = 1, kSpec = 2, kSpecTrain = 3 };   // kSpec*: power spectrogram (B,F,T), no mel stage
 
+// ---- where lambd comes from, and what a launch does when it was built for another n_fft ------------------------------
+// The reference derives n_fft from the parameter on the host at every forward (time_frequency.py:39: a device->host
+// read per sample).  Here lambd may stay on the device: every kernel of the forward reads it with a scalar load, derives
+// the window constants itself and checks that next_pow2(int(6|lambd|)) is the n_fft it was launched for.  A forward is a
+// GROUP of launches on one stream: the primary (the n_fft the host last saw) and, near a power-of-two boundary, guard
+// launches for the neighbouring n_fft that return at once unless the device value says the work is theirs.  If no launch
+// of the group matches, the last one fills the outputs with NaN and raises a sticky error word in pinned host memory.
+constexpr unsigned kLamFirst = 1u, kLamLast = 2u, kLamQuiet = 4u;   // quiet: read and check only (the window-table kernel)
+struct LamArgs {
+    const float* dev;                 // device scalar (nullptr: use val)
+    float val;                        // lambd by value (dmel_forward: the host read it, as the reference does)
+    int n_expected;                   // 0: no check (explicit n_fft: optimized=False branches, dmel_spectrogram_ex)
+    unsigned role;                    // kLamFirst | kLamLast inside the group
+    unsigned seq;                     // call number, echoed into host_seen
+    unsigned* handled;                // device word of the group (caller scratch): set by the launch that does the work
+    unsigned long long* host_seen;    // pinned: (seq << 32) | bits(lambd), written by the first launch of every group
+    unsigned long long* host_error;   // pinned, sticky: (seq << 32) | bits(lambd) of a forward no launch covered
+    unsigned* dot_counter;            // ticket word of the caller's dot scratch, zeroed by the first launch (or nullptr)
+};
+
+enum LamAction : int { kLamRun = 0, kLamSkip = 1, kLamPoison = 2 };
+struct LamState {
+    float lam, a, denom;              // lambd, |lambd| (models.py:38), |lambd| + 1e-15 (time_frequency.py:24)
+    float s2;                         // 2^(-2e), 2^(e-1) <= |lambd| < 2^e: the tangent window is stored as w d^2 2^(-2e) (same scale as w)
+    int e2;                           // 2e
+    int action;
+};
+
+#if defined(__HIPCC__)
+// time_frequency.py:39,60-65 on the device, bit for bit the host's dmel_n_fft: fp32 product, int() truncation, 1 << bit_length(x-1)
+__device__ __forceinline__ int lam_n_fft(float a)
+{
+    const float prod = a * 6.0f;
+    if (!(prod < 9.0e15f)) return 0x40000000;
+    const long long v = (long long)prod - 1;
+    const int bits = v < 0 ? 1 : (v == 0 ? 0 : 64 - __builtin_clzll((unsigned long long)v));
+    return bits > 30 ? 0x40000000 : (1 << bits);
+}
+
+// `leader` = one thread of the whole grid.  n_launch = the n_fft this kernel instance computes.
+__device__ __forceinline__ LamState lam_prologue(const LamArgs& la, int n_launch, bool leader)
+{
+    LamState st;
+    st.lam = la.dev ? __builtin_nontemporal_load(la.dev) : la.val;
+    st.a = __builtin_fabsf(st.lam);
+    st.denom = st.a + 1e-15f;
+    int e = 1;
+    if (st.a > 1e-30f) e = __builtin_amdgcn_frexp_expf(st.a);
+    e = e < -30 ? -30 : (e > 30 ? 30 : e);
+    st.e2 = 2 * e;
+    st.s2 = __builtin_ldexpf(1.0f, -2 * e);
+    const bool match = la.n_expected == 0 || lam_n_fft(st.a) == n_launch;
+    st.action = match ? kLamRun : kLamSkip;
+    if (la.role & kLamQuiet) return st;
+    if (la.role & kLamFirst) {
+        if (leader) {
+            if (la.host_seen)
+                __hip_atomic_store(la.host_seen, ((unsigned long long)la.seq << 32) | __builtin_bit_cast(unsigned, st.lam),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (la.dot_counter) *la.dot_counter = 0u;
+            if (la.handled) *la.handled = match ? 1u : 0u;
+        }
+    } else if (match && leader && la.handled) {
+        *la.handled = 1u;
+    }
+    if (!match && (la.role & kLamLast)) {
+        // earlier launches of the group are complete (stream order): their word is visible to a plain load
+        const unsigned prior = ((la.role & kLamFirst) || !la.handled) ? 0u : *la.handled;
+        if (!prior) {
+            st.action = kLamPoison;
+            if (leader && la.host_error)
+                __hip_atomic_store(la.host_error, ((unsigned long long)la.seq << 32) | __builtin_bit_cast(unsigned, st.lam),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    return st;
+}
+
+// sign(lambd) 2^(2e) / (|lambd| + 1e-15)^3: what turns the contraction of the scaled tangent window into d / d lambd
+// (fp64, rounded once; lambd == 0 gives 0, an overflow gives 0: w' vanishes wherever w does not)
+__device__ __forceinline__ float lam_tangent_scale(const LamState& st)
+{
+    const double den = (double)st.denom;
+    const double sg = st.lam > 0.f ? 1.0 : (st.lam < 0.f ? -1.0 : 0.0);
+    const float c = (float)(sg * __builtin_ldexp(1.0, st.e2) / (den * den * den));
+    return (c == c && __builtin_fabsf(c) < 3.0e38f) ? c : 0.f;
+}
+#endif
+
 // Compile-time FFT plan for one wave: N = R * R * C, R points per lane (tools/wavefft_sim.py).
 // MINW: waves per SIMD the register allocation must allow (what the LDS footprint admits).
 // WAVES waves per workgroup; each wave runs PASSES rounds of FPW = 64/G frames.  In the contraction phase
@@ -80,7 +169,7 @@ struct FwdParams {
     float* out;                // (B, 1, M, T) or spec (B, F, T) in kSpec mode
     float* tangent;            // same shape as out or nullptr
     const float* psum;         // (B, nchunks) partial sums of x, or nullptr: the kernel sums the clip itself (short clips)
-    const float2* win2;        // [n] = (w[n], dw[n]/d|lambd| * dw_scale)
+    const float2* win2;        // [n] = (w[n], w[n] d^2 2^(-2e)) from the prep kernel (n_fft 4096 only)
     const float2* tw1;         // (R, G): w_N^(lg*q)
     const float2* tw2;         // (R, C): w_G^(r*p1)
     const float* ent_b;        // 64 floats per 4x16 block, blocks of one mel tile contiguous in k
@@ -89,9 +178,8 @@ struct FwdParams {
     const float* ent_pre;      // (WAVES, 2, NBPRE, 64): the first NBPRE k-steps of every run of mel group 0, zero padded
     int pre_groups[16];        // per (wave, run): how many groups of 4 k-steps of ent_pre are real (the rest is padding nobody reads)
     int B, L, T, hop, M, nchunks, groups, tiles_per_clip;
-    float inv_L, sign, eps;
-    float lambd_abs, dw_scale;  // for the in-kernel window table (time_frequency.py:21-30)
-    float dw_k3;                // dw_scale / (|lambd| + 1e-15)^3, computed on the host in fp64
+    float inv_L, eps;
+    LamArgs lam;                // lambd (device scalar or by value) + the n_fft check
     unsigned flags;
     int remove_dc, normalize;
     int win_half;               // window support = middle half of n_fft (DSPEC: win_length = n_fft / 2)
@@ -100,8 +188,7 @@ struct FwdParams {
 struct PrepParams {
     const float* x; float* psum; float2* win2;
     int B, L, nchunks, chunk, N, normalize;
-    float lambd_abs;
-    float dw_scale;   // power of two ~ |lambd|: the dw table is stored pre-multiplied by it (see dmel_api.cpp)
+    LamArgs lam;      // the window block reads lambd itself (role 0: it neither reports nor poisons)
     int win_half;
 };
 
@@ -117,7 +204,8 @@ hipError_t forward_prepare_attributes();   // raises the dynamic-LDS limit of ev
 struct NaiveParams {
     const float* x; float* out; float* tangent; const float* psum; const float2* win2; const float* fb;
     int B, L, T, hop, M, nchunks, N, F, mode;
-    float inv_L, sign, eps; unsigned flags; int remove_dc;
+    float inv_L, eps; unsigned flags; int remove_dc;
+    LamArgs lam;
 };
 hipError_t launch_naive(const NaiveParams& p, hipStream_t s);
 
@@ -128,7 +216,8 @@ struct LongParams {
     const float* fbT;        // (M, F): filterbank transposed, so that one band is contiguous
     const int2* band;        // (M): [first, last+1) non-zero rows of every filterbank column
     int B, L, T, hop, M, nchunks, N, F, mode, logN;
-    float inv_L, sign, eps; unsigned flags; int remove_dc;
+    float inv_L, eps; unsigned flags; int remove_dc;
+    LamArgs lam;
 };
 hipError_t launch_long(const LongParams& p, hipStream_t s);
 hipError_t long_prepare_attributes();

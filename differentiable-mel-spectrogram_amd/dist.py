@@ -54,20 +54,47 @@ class ScalarAllReduce:
         self.group = group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.native, self.why, self._comm = False, "", None
+        dev = "cuda" if torch.cuda.is_available() and dist.get_backend(group) == "nccl" else "cpu"
+
+        def agree(ok: bool) -> bool:        # every rank calls this the same number of times, whatever happened locally
+            flag = torch.tensor([1 if ok else 0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            return int(flag.item()) == 1
+
+        # 1. can every rank load RCCL through the C ABI?  (a local probe: nothing collective can hang on a rank that cannot)
+        capi = None
         try:
-            from . import capi
-            ids = [capi.Comm.unique_id() if self.rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0, group=group)
-            self._comm = capi.Comm(ids[0], self.rank, self.world)
-            self.native = True
+            from . import capi as _capi
+            _capi.Comm.unique_id()
+            capi, ok = _capi, True
         except Exception as e:      # noqa: BLE001 -- any failure means: use the torch path
-            self.why = f"{type(e).__name__}: {e}"
-        # every rank must take the same path
-        flag = torch.tensor([1 if self.native else 0], device="cuda" if torch.cuda.is_available() else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-        if int(flag.item()) == 0 and self.native:
-            self._comm.close()
-            self.native, self.why = False, "another rank could not create the native communicator"
+            ok, self.why = False, f"{type(e).__name__}: {e}"
+        if not agree(ok):
+            self.why = self.why or "another rank cannot load RCCL through libdmel_hip.so"
+            return
+        # 2. rank 0's id to everyone (unconditional broadcast), 3. the collective communicator init, 4. agree on the outcome
+        ids = [capi.Comm.unique_id() if self.rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0, group=group)
+        try:
+            self._comm = capi.Comm(ids[0], self.rank, self.world)
+            ok = True
+        except Exception as e:      # noqa: BLE001
+            ok, self.why = False, f"{type(e).__name__}: {e}"
+        if agree(ok):
+            self.native = True
+        else:
+            if self._comm is not None:
+                self._comm.close()
+                self._comm = None
+            self.why = self.why or "another rank could not create the native communicator"
+
+    def reduce(self, grad: torch.Tensor, stream: int) -> None:
+        """SUM all-reduce of ``grad`` in place, issued IN ``stream`` like a kernel launch: what a training step needs when
+        the optimizer update that follows consumes the reduced gradient.  Capturable into a HIP graph with the step."""
+        if self.native:
+            self._comm.allreduce(grad.data_ptr(), grad.numel(), stream)
+        else:
+            dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.group)
 
     def reduce_async(self, grad: torch.Tensor, stream: int):
         """SUM all-reduce of ``grad`` in place after the work already queued on ``stream``; returns a ticket."""

@@ -5,8 +5,16 @@ shape/dtype and error behaviour of the reference's ``models.MelSpectrogramLayer`
 (models.py:14-56) so that the wrapping nets (models.py:58-166), the two-LR-group optimizer keyed
 on ``"spectrogram_layer.lambd"`` (main.py:36-48) and ``load_state_dict(strict=True)``
 (utils.py:270) work unchanged.  The arithmetic runs in the HIP kernels behind the C ABI
-(``capi.py`` -> ``include/dmel.h``); torch is used for device memory, streams and autograd
-plumbing only.  There is no CPU fallback.
+(``include/dmel.h``), reached in two ways: the hot path goes through the torch-registered ops
+``torch.ops.dmel.*`` (csrc/dmel_torch.cpp, a C++ autograd function: forward + backward to
+``lambd.grad``), the optional gradients (waveform, learnable filterbank) and the DSPEC layer through
+``ctypes`` (``capi.py``).  torch is used for device memory, streams and autograd plumbing only.
+There is no CPU fallback.
+
+``lambd`` normally never leaves the device (``lambd_sync=False``): the kernels read it themselves and
+check the n_fft they were launched for (include/dmel.h, dmel_forward_dev), so a training step queues
+without the host waiting and can be captured into a HIP graph.  ``lambd_sync=True`` reads it to the
+host at every forward, as the reference does (time_frequency.py:39).
 """
 from __future__ import annotations
 
@@ -47,16 +55,20 @@ class _DmelFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, lambd, plan, lam_host, log, eps, full_window=False, fb=None, out_dtype=torch.float32):
         B = x.shape[0]
-        out = torch.empty((B, 1, plan.n_mels, plan.n_time), dtype=out_dtype, device=x.device)     # models.py:36 (fp32 there)
         want_tangent = ctx.needs_input_grad[1]
         want_fb = fb is not None and ctx.needs_input_grad[7]
         want_x = ctx.needs_input_grad[0]
+        # dL/dx and dL/dfb rebuild 1 / (mel + eps) from the saved log output: that needs the fp32 values, so a bf16 output
+        # is produced by rounding an fp32 one here instead of in the kernel (bit-identical either way)
+        round_later = out_dtype == torch.bfloat16 and log and (want_x or want_fb)
+        kdtype = torch.float32 if round_later else out_dtype
+        out = torch.empty((B, 1, plan.n_mels, plan.n_time), dtype=kdtype, device=x.device)     # models.py:36 (fp32 there)
         tangent = torch.empty(out.shape, dtype=torch.float32, device=x.device) if want_tangent else None
         flags = capi.DMEL_FLAG_FULL_WINDOW if full_window else 0
         with _on_device(x.device):
             plan.forward(x.data_ptr(), B, lam_host, out.data_ptr(), tangent.data_ptr() if want_tangent else None,
                          log, eps, _stream_ptr(x.device),
-                         extra_flags=flags | (capi.DMEL_FLAG_OUT_BF16 if out_dtype == torch.bfloat16 else 0))
+                         extra_flags=flags | (capi.DMEL_FLAG_OUT_BF16 if kdtype == torch.bfloat16 else 0))
         ctx.plan = plan
         ctx.lambd_shape = lambd.shape
         ctx.lambd_dtype = lambd.dtype
@@ -70,7 +82,7 @@ class _DmelFunction(torch.autograd.Function):
             if log:
                 saved.append(out)
         ctx.save_for_backward(*saved)
-        return out
+        return out.to(torch.bfloat16) if round_later else out
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -109,6 +121,17 @@ class _DmelFunction(torch.autograd.Function):
         return gx, dl, None, None, None, None, None, gfb, None
 
 
+_MEL_OP = None
+
+
+def _mel_op():
+    """torch.ops.dmel.mel_spectrogram.default, resolved once (the packet lookup costs microseconds per call)."""
+    global _MEL_OP
+    if _MEL_OP is None:
+        _MEL_OP = capi.torch_ops().mel_spectrogram.default
+    return _MEL_OP
+
+
 class MelSpectrogramLayer(nn.Module):
     """Differentiable (log-)Mel spectrogram with a trainable Gaussian window width.
 
@@ -123,13 +146,18 @@ class MelSpectrogramLayer(nn.Module):
     default: the reference has no such parameter and its checkpoints have no such key.
     ``out_dtype=torch.bfloat16`` stores the output as bf16 (the fp32 result rounded to nearest even; BASELINE config 2
     "bf16 activations"); the arithmetic, the saved tangent and ``lambd.grad`` stay fp32.
+    ``lambd_sync=False`` (default) keeps ``lambd`` on the device: no host read per forward, the step is HIP-graph
+    capturable; a change of ``lambd`` that crosses a power-of-two n_fft boundary is followed by guard launches (see
+    include/dmel.h), and one the guards do not cover (e.g. ``lambd`` rewritten by hand to a far value in the middle of a
+    run: call ``resync()`` after that) yields NaN outputs and a RuntimeError at the next forward.  ``lambd_sync=True``
+    reads ``lambd`` to the host at every forward like the reference (time_frequency.py:39).
 
     forward(x: (B, n_points)) -> (B, 1, n_mels, n_points // hop_length + 1) float32.
     """
 
     def __init__(self, init_lambd, n_mels, n_points, sample_rate, f_min=0, f_max=None, hop_length=1,
                  device="cpu", optimized=False, normalize_window=False, *, log=False, eps=1e-10, learnable_fb=False,
-                 out_dtype=torch.float32):
+                 out_dtype=torch.float32, lambd_sync=False):
         super().__init__()
         if not torch.is_tensor(init_lambd):
             init_lambd = torch.tensor(float(init_lambd), dtype=torch.float32)
@@ -150,6 +178,7 @@ class MelSpectrogramLayer(nn.Module):
         if out_dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("out_dtype must be torch.float32 (the reference's, models.py:36) or torch.bfloat16")
         self.out_dtype = out_dtype
+        self.lambd_sync = bool(lambd_sync)
         self._plans = {}                                              # device index -> capi.Plan (not state)
         self._fb_synced = {}                                          # device index -> (version, data_ptr) last sent to the plan
         if learnable_fb:
@@ -167,6 +196,8 @@ class MelSpectrogramLayer(nn.Module):
             with torch.cuda.device(idx):
                 plan = capi.Plan(self.n_points, self.hop_length, self.n_mels, self.sample_rate, float(self.f_min),
                                  float(self.f_max), bool(self.normalize_window))
+            if getattr(self, "_tracking", None) is not None:
+                plan.set_tracking(*self._tracking)
             self._plans[idx] = plan
         return plan
 
@@ -175,20 +206,42 @@ class MelSpectrogramLayer(nn.Module):
         return self._plan_for(dev).info()
 
     def _lambd_host(self) -> float:
-        """Host value of lambd: one device->host read per forward (the reference does one per sample,
-        time_frequency.py:39), skipped while the parameter is unchanged (torch bumps ``_version`` on every in-place
-        update, e.g. optimizer.step()), so inference and frozen front ends never synchronise."""
-        key = (self.lambd._version, self.lambd.data_ptr())
-        cached = getattr(self, "_lam_cache", None)
-        if cached is None or cached[0] != key:
-            cached = (key, float(self.lambd.detach()))
-            self._lam_cache = cached
-        return cached[1]
+        """Host value of lambd: a device->host read (the reference does one per sample, time_frequency.py:39).  Never
+        cached: writes through ``lambd.data`` leave no trace torch could be asked about."""
+        return float(self.lambd.detach())
 
     def n_fft(self) -> int:
         """n_fft the next forward will use: next_pow2(int(6*|lambd|)) (time_frequency.py:39,60-65), or 2*n_points
-        in the optimized=False branch (time_frequency.py:51)."""
+        in the optimized=False branch (time_frequency.py:51).  Reads lambd to the host."""
         return capi.n_fft(self._lambd_host()) if self.optimized else 2 * self.n_points
+
+    def resync(self):
+        """Forget what the sync-free path knows about lambd (call after rewriting it from outside the optimizer, e.g.
+        ``layer.lambd.data.fill_(v)``); the next forward reads it once.  ``load_state_dict`` does this by itself."""
+        for plan in self._plans.values():
+            plan.lambd_reset()
+
+    def lambd_status(self, device=None) -> dict:
+        """What the kernels last reported (no synchronisation): see dmel_lambd_status in include/dmel.h."""
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        return self._plan_for(dev).lambd_status()
+
+    def set_tracking(self, max_ahead: int = 8, guard_mode: int = 0):
+        """Run-ahead bound and guard policy of the sync-free path (dmel_plan_set_tracking); applies to plans made later too."""
+        self._tracking = (int(max_ahead), int(guard_mode))
+        for plan in self._plans.values():
+            plan.set_tracking(*self._tracking)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self.resync()
+
+    # plans are caches of device tables: copies and pickles of the layer start without them
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_plans"] = {}
+        state["_fb_synced"] = {}
+        return state
 
     # -- forward ------------------------------------------------------------------------------
     def forward(self, x):
@@ -198,11 +251,11 @@ class MelSpectrogramLayer(nn.Module):
         if n_points != self.n_points:
             # the reference fails here too (RuntimeError from the slice-assign at models.py:54)
             raise RuntimeError(f"input has {n_points} points, the layer was built for n_points={self.n_points}")
-        if not self.optimized and (n_points & (n_points - 1) or n_points > 8192):
+        if not self.optimized and (n_points & (n_points - 1) or n_points > capi.MAX_NFFT // 2):
             raise NotImplementedError(
                 "optimized=False (window = whole signal, n_fft = 2*n_points; time_frequency.py:41,51) runs on the HIP path "
-                "only for power-of-two n_points <= 8192; construct the layer with optimized=True as all mel experiments "
-                "do (search_spaces.py:11,44)")
+                f"only for power-of-two n_points <= {capi.MAX_NFFT // 2}; construct the layer with optimized=True as all mel "
+                "experiments do (search_spaces.py:11,44)")
         if not x.is_cuda:
             raise RuntimeError("dmel_amd runs on MI355X only: x must be a CUDA/HIP tensor (no CPU fallback)")
         if x.requires_grad and not self.optimized:
@@ -216,11 +269,18 @@ class MelSpectrogramLayer(nn.Module):
             xf = xf.to(torch.float32)
         if not xf.is_contiguous():
             xf = xf.contiguous()
-        lam_host = self._lambd_host()
         plan = self._plan_for(x.device)
         fb = self.mel_fb
+        if fb is None and not x.requires_grad:
+            # the hot path: torch-registered op, C++ autograd node, lambd read on the device unless lambd_sync
+            flags = (capi.DMEL_FLAG_LOG if self.log else 0) | (0 if self.optimized else capi.DMEL_FLAG_FULL_WINDOW)
+            lam = self.lambd
+            if lam.dtype != torch.float32:
+                lam = lam.to(torch.float32)
+            return _mel_op()(xf, lam, plan.handle, flags, self.eps, self.lambd_sync, self.out_dtype == torch.bfloat16)
+        lam_host = self._lambd_host()
         if fb is not None:
-            n = self.n_fft()
+            n = capi.n_fft(lam_host) if self.optimized else 2 * self.n_points
             if fb.shape[0] != n // 2 + 1:
                 raise RuntimeError(f"mel_fb was built for n_fft={2 * (fb.shape[0] - 1)} but lambd={lam_host} now gives n_fft={n}; "
                                    "a learnable filterbank is tied to one n_fft")
@@ -228,8 +288,9 @@ class MelSpectrogramLayer(nn.Module):
                 raise RuntimeError(f"mel_fb is on {fb.device} but x is on {x.device}; call layer.to(x.device)")
             key = (fb._version, fb.data_ptr(), n)
             idx = x.device.index if x.device.index is not None else torch.cuda.current_device()
-            if self._fb_synced.get(idx) != key:
-                plan.set_filterbank(n, fb.detach().to(torch.float32).cpu().numpy())      # host rebuild of the block tables
+            if fb.requires_grad or self._fb_synced.get(idx) != key:      # a trainable bank changes every step
+                with _on_device(x.device):
+                    plan.set_filterbank(n, fb.detach().to(torch.float32).cpu().numpy())      # host rebuild of the block tables
                 self._fb_synced[idx] = key
         return _DmelFunction.apply(xf, self.lambd, plan, lam_host, self.log, self.eps, not self.optimized, fb, self.out_dtype)
 
@@ -290,6 +351,11 @@ class SpectrogramLayer(nn.Module):
         self.normalize_window = normalize_window
         self._plans = {}
 
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_plans"] = {}
+        return state
+
     def forward(self, x):
         if x.dim() != 2:
             raise ValueError(f"expected x of shape (batch, n_points), got {tuple(x.shape)}")
@@ -306,8 +372,8 @@ class SpectrogramLayer(nn.Module):
                 raise RuntimeError(f"size={tuple(self.size)} but the spectrogram is {expect}")
         else:
             n_fft, half = 2 * n_points, True
-            if n_fft & (n_fft - 1) or n_fft > 16384 or n_fft < 2:
-                raise NotImplementedError(f"optimized=False needs n_points to be a power of two <= 8192 on the HIP path, got {n_points}")
+            if n_fft & (n_fft - 1) or n_fft > capi.MAX_NFFT or n_fft < 2:
+                raise NotImplementedError(f"optimized=False needs n_points to be a power of two <= {capi.MAX_NFFT // 2} on the HIP path, got {n_points}")
         key = (x.device.index, n_points)
         plan = self._plans.get(key)
         if plan is None:

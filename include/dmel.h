@@ -15,7 +15,8 @@
  *   - tangent             : same shape as out, d out / d lambd (raw, signed parameter)
  *   - lambd is the trainable window std-dev in samples (models.py:19); the kernels use |lambd|
  *     (models.py:38) and n_fft = next_pow2(int(6*|lambd|)) (time_frequency.py:39,60-65).
- *   - a plan owns its device tables/workspace; one stream may use a plan at a time.
+ *   - a plan owns its device tables and a default scratch; calls that use the plan's scratch from different streams
+ *     are ordered after each other by the library (an event), calls with caller scratch are independent.
  */
 #ifndef DMEL_H
 #define DMEL_H
@@ -27,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DMEL_ABI_VERSION 1
+#define DMEL_ABI_VERSION 2
 
 typedef enum dmel_status {
     DMEL_OK = 0,
@@ -35,7 +36,8 @@ typedef enum dmel_status {
     DMEL_ERR_UNSUPPORTED = 2,       /* n_fft outside [1, 16384] for the HIP kernels       */
     DMEL_ERR_HIP = 3,               /* a HIP runtime call failed (message has the detail) */
     DMEL_ERR_NO_DEVICE = 4,         /* no gfx950 device visible                           */
-    DMEL_ERR_OUT_OF_MEMORY = 5
+    DMEL_ERR_OUT_OF_MEMORY = 5,
+    DMEL_ERR_LAMBD_TRACKING = 6     /* dmel_forward_dev: lambd changed n_fft faster than the sync-free path covers   */
 } dmel_status;
 
 /* Constructor arguments of the layer: models.py:15-30 (MelSpectrogramLayer.__init__). */
@@ -89,6 +91,7 @@ int32_t dmel_device_count(void);
 /* MelSpectrogramLayer.__init__ (models.py:15-30).  Binds to the current HIP device. */
 dmel_status dmel_plan_create(const dmel_config* cfg, dmel_plan** plan);
 dmel_status dmel_plan_destroy(dmel_plan* plan);
+dmel_status dmel_plan_get_config(const dmel_plan* plan, dmel_config* cfg);
 
 /* Replace the mel filterbank of the plan by a caller-supplied (n_freqs, n_mels) fp32 HOST matrix for
  * the given n_fft (n_freqs = n_fft/2+1): the contraction of models.py:53 then uses it instead of the
@@ -111,6 +114,50 @@ dmel_status dmel_forward(dmel_plan* plan, const float* x, int32_t batch, float l
                          double eps, float* out, float* tangent, void* stream);
 
 /*
+ * The same forward with lambd left ON THE DEVICE: no device->host read, so a training step (forward, backward,
+ * optimizer update of lambd) can be queued without the host ever waiting, and captured into a HIP graph.  The
+ * reference reads lambd to the host once per sample to derive n_fft (time_frequency.py:39); here every kernel reads
+ * the device scalar itself, derives the window from it and checks that next_pow2(int(6|lambd|)) is the n_fft it was
+ * launched for.  The host picks that n_fft from what the kernels last reported (a pinned word, no synchronisation)
+ * and, while lambd is within reach of a power-of-two boundary (or under graph capture), adds guard launches for the
+ * neighbouring n_fft that return at once unless the work is theirs.  A forward that no launch covers (lambd crossed
+ * more than the guards allow while the host was running ahead) writes NaN to its outputs and the NEXT call returns
+ * DMEL_ERR_LAMBD_TRACKING once; the run-ahead is bounded (dmel_plan_set_tracking) to keep that out of reach.
+ *   lambd_dev  device, 1 fp32 (e.g. the nn.Parameter's storage); read by the kernels at execution time
+ *   out        device, fp32 (bf16 with DMEL_FLAG_OUT_BF16)
+ *   scratch    device, dmel_scratch_bytes(plan, batch) bytes owned by the caller for this call and for the
+ *              dmel_backward_scratch that consumes its tangent (no initialisation needed), or NULL to use the plan's
+ *              own (then calls on different streams are serialised by the plan)
+ * The first call on a plan (and the first after an error or dmel_plan_lambd_reset) reads lambd once, blocking.
+ * DMEL_FLAG_FULL_WINDOW is not accepted (its n_fft does not depend on lambd: use dmel_forward).
+ */
+size_t dmel_scratch_bytes(const dmel_plan* plan, int32_t batch);
+/* dmel_forward (lambd by value) with the caller's scratch instead of the plan's */
+dmel_status dmel_forward_scratch(dmel_plan* plan, const float* x, int32_t batch, float lambd, uint32_t flags,
+                                 double eps, void* out, float* tangent, void* scratch, void* stream);
+dmel_status dmel_forward_dev(dmel_plan* plan, const float* x, int32_t batch, const float* lambd_dev, uint32_t flags,
+                             double eps, void* out, float* tangent, void* scratch, void* stream);
+
+typedef struct dmel_lambd_status {
+    int32_t known;            /* 0 until a value has been seen                                             */
+    float lambd_seen;         /* lambd as read by the most recent forward that has EXECUTED                */
+    int32_t n_fft_seen;
+    uint32_t seq_issued;      /* dmel_forward_dev calls issued / the call the observation belongs to       */
+    uint32_t seq_seen;
+    float rate;               /* decayed maximum of |change of lambd| per call                             */
+    int32_t guards;           /* most recent call: bit 0 = n_fft/2 guard launched, bit 1 = 2 n_fft guard   */
+    int32_t error;            /* 1: a forward was not covered (reported by the next dmel_forward_dev)      */
+    uint32_t error_seq;
+    float error_lambd;
+} dmel_lambd_status;
+dmel_status dmel_plan_lambd_status(dmel_plan* plan, dmel_lambd_status* status);
+/* max_ahead: calls the host may be ahead of the last observation before dmel_forward_dev waits (0 = unbounded, default 8);
+ * guard_mode: 0 = near boundaries only (default), 1 = always both neighbours, 2 = never */
+dmel_status dmel_plan_set_tracking(dmel_plan* plan, int32_t max_ahead, int32_t guard_mode);
+/* forget what was seen (after lambd was rewritten from outside, e.g. load_state_dict): the next call reads it again */
+dmel_status dmel_plan_lambd_reset(dmel_plan* plan);
+
+/*
  * Backward to lambd.grad (what loss.backward() reaches through the layer, train.py:47):
  *   dlambd[0] = sum_i grad_out[i] * tangent[i]        (accumulate != 0: += instead of =)
  * grad_out, tangent: device fp32, `count` elements; dlambd: device fp32 scalar.
@@ -123,6 +170,11 @@ dmel_status dmel_backward(dmel_plan* plan, const float* grad_out, const float* t
  * gradient of a DMEL_FLAG_OUT_BF16 output; widened exactly, accumulated in fp64 like the fp32 path). */
 dmel_status dmel_backward_ex(dmel_plan* plan, const void* grad_out, int32_t grad_dtype, const float* tangent, int64_t count,
                              int32_t accumulate, float* dlambd, void* stream);
+/* dmel_backward_ex with the reduction's partials and ticket in the caller's `scratch` (the block given to the
+ * dmel_forward_dev that produced `tangent`, which also zeroed the ticket): nothing plan-owned is touched, so any number of
+ * streams may run steps of one plan concurrently.  scratch = NULL: the plan's own. */
+dmel_status dmel_backward_scratch(dmel_plan* plan, const void* grad_out, int32_t grad_dtype, const float* tangent, int64_t count,
+                                  int32_t accumulate, float* dlambd, void* scratch, void* stream);
 
 /*
  * Backward to the filterbank matrix ("mel params"): the adjoint of the contraction at models.py:53,
@@ -187,6 +239,9 @@ dmel_status dmel_comm_destroy(dmel_comm* comm);
 /* in-place SUM of `count` fp32 at device address `buf`, after everything already queued on `stream`;
  * `ticket` (0..63, a ring) names the operation for dmel_comm_wait */
 dmel_status dmel_comm_allreduce_async(dmel_comm* comm, float* buf, int32_t count, void* stream, int32_t* ticket);
+/* the same all-reduce issued IN `stream` (ordered like a kernel launch: what a step needs when the optimizer update that
+ * follows consumes the reduced gradient; capturable into a HIP graph together with the step) */
+dmel_status dmel_comm_allreduce(dmel_comm* comm, float* buf, int32_t count, void* stream);
 /* make `stream` wait for the all-reduce `ticket`; the host does not block */
 dmel_status dmel_comm_wait(dmel_comm* comm, int32_t ticket, void* stream);
 

@@ -47,7 +47,23 @@ v = torch.tensor([float(rank + 1), 10.0 * (rank + 1)])
 t = sar.reduce_async(v, 0)
 sar.wait(t, 0)
 assert torch.allclose(v, torch.tensor([3.0, 30.0])), v
+w = torch.tensor([float(rank + 1)])
+sar.reduce(w, 0)                       # the in-stream form a training step uses before optimizer.step()
+assert float(w) == 3.0
 sar.close()
+# a failure on ONE rank only (here: rank 1 cannot load RCCL) must make every rank fall back, not hang (the ranks run
+# the same collectives in the same order whatever happens locally)
+from dmel_amd import capi
+if rank == 1:
+    def boom():
+        raise RuntimeError("injected: RCCL not loadable on this rank")
+    capi.Comm.unique_id = staticmethod(boom)
+sar2 = ddist.ScalarAllReduce()
+assert sar2.native is False and sar2.why
+z = torch.tensor([2.0 * (rank + 1)])
+sar2.reduce(z, 0)
+assert float(z) == 6.0
+sar2.close()
 dist.destroy_process_group()
 print("rank", rank, "ok", lo, hi)
 '''

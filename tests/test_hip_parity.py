@@ -354,21 +354,34 @@ def test_dspec_layer_matches_reference_and_oracle():
     assert _rel_err(so.detach().cpu().numpy()[:, 0], O.spectrogram(xo, case["lambd"], case["hop"], remove_dc=True)) <= TOL
 
 
-def test_lambd_host_cache_tracks_updates():
-    """The module re-reads lambd from the device only when the parameter changed (in-place updates bump _version)."""
+@pytest.mark.parametrize("sync", [False, True])
+def test_lambd_updates_are_always_seen(sync):
+    """Neither path caches lambd on the host: in-place updates, writes through .data (which bump no version counter) and
+    a replaced storage all reach the next forward.  (Round 1 cached the host value on (_version, data_ptr).)"""
+    from dmel_amd import MelSpectrogramLayer
     case = C.BY_NAME["g1_c1"]
-    layer = _layer(case)
-    x = torch.from_numpy(C.make_input(case)).to("cuda:0")
+    layer = MelSpectrogramLayer(torch.tensor(64.0), n_mels=case["n_mels"], n_points=case["L"], sample_rate=case["sr"],
+                                hop_length=case["hop"], device="cuda:0", optimized=True, lambd_sync=sync).to("cuda:0")
+    layer.set_tracking(8, 1)          # sync-free path: both neighbouring n_fft guarded, so a doubling / halving is covered
+    x_np = C.make_input(case)
+    x = torch.from_numpy(x_np).to("cuda:0")
+
+    def ref(lam):
+        return O.forward(x_np, lam, case["hop"], case["n_mels"], case["sr"], want_tangent=False)[0]
+
     y0 = layer(x)
-    assert layer.n_fft() == 512
+    assert layer.n_fft() == 512 and _rel_err(y0.detach().cpu().numpy(), ref(64.0)) <= TOL
     with torch.no_grad():
         layer.lambd.mul_(2.0)                      # what optimizer.step() does: an in-place update
-    assert layer.n_fft() == 1024
     y1 = layer(x)
-    ref, _ = O.forward(C.make_input(case), 128.0, case["hop"], case["n_mels"], case["sr"], want_tangent=False)
-    assert _rel_err(y1.detach().cpu().numpy(), ref) <= TOL and not torch.equal(y0, y1)
+    assert layer.n_fft() == 1024 and _rel_err(y1.detach().cpu().numpy(), ref(128.0)) <= TOL
+    layer.lambd.data.mul_(0.5)                     # no version bump, same storage
+    y2 = layer(x)
+    assert _rel_err(y2.detach().cpu().numpy(), ref(64.0)) <= TOL and torch.equal(y2, y0)
+    layer.lambd.data.fill_(100.0)
+    assert _rel_err(layer(x).detach().cpu().numpy(), ref(100.0)) <= TOL
     layer.lambd.data = torch.tensor(64.0, device="cuda:0")      # replacing the storage is seen too
-    assert layer.n_fft() == 512
+    assert torch.equal(layer(x), y0)
 
 
 def test_c3_full_size_properties():
