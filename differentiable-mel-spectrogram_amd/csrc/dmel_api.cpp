@@ -502,7 +502,7 @@ bool lam_observe(dmel_plan* pl)
 {
     const unsigned long long w = __atomic_load_n(&pl->host_words[0], __ATOMIC_RELAXED);
     const unsigned seq = (unsigned)(w >> 32);
-    if (seq == 0 || (pl->lam_known && seq == pl->seq_seen) || (int)(seq - pl->seq_seen) < 0) return false;
+    if (seq == 0 || (int)(seq - pl->seq_seen) <= 0) return false;      // nothing newer than what is known (or than the last reset)
     float lam; const unsigned bits = (unsigned)w; std::memcpy(&lam, &bits, 4);
     if (pl->lam_known && pl->n_obs >= 1) {
         const unsigned dseq = seq - pl->seq_seen;
@@ -777,6 +777,7 @@ dmel_status dmel_forward_dev(dmel_plan* plan, const float* x, int32_t batch, con
     }
     const unsigned seq = ++plan->issued;
     bool sums_done = false;
+    dmel_plan_info primary_info = plan->info;
     for (int i = 0; i < nc; ++i) {
         dmel::LamArgs lam{};
         lam.dev = lambd_dev; lam.val = 0.f; lam.n_expected = cand[i];
@@ -787,8 +788,9 @@ dmel_status dmel_forward_dev(dmel_plan* plan, const float* x, int32_t batch, con
         st = launch_forward_n(plan, x, batch, cand[i], lam, flags, eps, static_cast<float*>(out), tangent,
                               tangent ? dmel::kTrain : dmel::kInfer, /*remove_dc=*/1, sc, s, 0, &sums_done);
         if (st != DMEL_OK) return st;
+        if (i == 0) primary_info = plan->info;
     }
-    plan->info.n_fft = N;
+    plan->info = primary_info;        // dmel_plan_get_info describes the launch the host expected to do the work
     return DMEL_OK;
 }
 

