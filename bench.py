@@ -1,16 +1,23 @@
 #!/usr/bin/env python3
-"""bench.py -- frames/s (forward + backward) of the DMEL layer on N MI355X, BASELINE.json's metric.
+"""bench.py -- frames/s (forward + backward + optimizer update of lambd) of the DMEL layer on N MI355X: BASELINE.json's metric.
 
-A step = one pass of the hot path over one batch of synthetic waveforms already resident in HBM:
-  forward : DC removal -> Gaussian-window STFT -> |.|^2 -> mel contraction -> log(. + 1e-10)
-            (dmel_forward: ONE fused kernel at this clip length, carrying d out / d lambd)
-  backward: lambd.grad = <grad_out, tangent>   (dmel_backward: one deterministic fp64 dot kernel)
-  N > 1   : + one all-reduce (RCCL) of the scalar gradient, batch sharded over ranks (weak scaling)
-Workload at every N: BASELINE config 2 per GPU (256 x 16000 @16 kHz, n_fft 1024 (lambd 128),
-hop 512, 128 mels; config 4 is exactly 8 of these).  The step is driven through the C ABI
-(include/dmel.h): two kernel launches (fused forward, dot) queued eagerly on the current stream, the
-host runs ahead of the device.  `--graph` replays the step from a HIP graph instead (slower here), and
-the nn.Module path (autograd, one host read of lambd per step) is reported beside it as "module_path".
+A step = one pass of the hot path over one batch of synthetic waveforms already resident in HBM, driven through the
+drop-in boundary, the nn.Module:
+    opt.zero_grad();  y = MelSpectrogramLayer(x);  y.backward(G_Y);  [N > 1: all-reduce lambd.grad];  opt.step()
+  forward : DC removal -> Gaussian-window STFT -> |.|^2 -> mel contraction -> log(. + 1e-10): ONE fused kernel at this
+            clip length (torch.ops.dmel.mel_spectrogram -> dmel_forward_dev), carrying d out / d lambd
+  backward: lambd.grad = <G_Y, tangent>: one deterministic fp64 dot kernel (dmel_backward_scratch)
+  update  : torch.optim.Adam on lambd (the reference's optimizer, main.py:52; lr small enough that n_fft stays the
+            metric's 1024 over the run: the reference's lr_tf = 1.0 would leave the band within ~40 steps)
+lambd never leaves the device (the reference reads it to the host per sample, time_frequency.py:39; here the kernels read
+it and check their n_fft themselves, include/dmel.h), so nothing in the step waits for the host.  `value` is timed over
+that step either queued eagerly or replayed from a HIP graph captured once from the same Python code (whichever is
+faster on this host; both are printed under "module_step"); the bare two-launch C-ABI step of round 1 (no autograd, no
+optimizer) is kept as the side key "c_abi_kernels".
+
+Workload at every N: BASELINE config 2 per GPU (256 x 16000 @16 kHz, n_fft 1024 (lambd 128), hop 512, 128 mels; config 4
+is exactly 8 of these, weak scaling).  N > 1: one process per GPU; run plainly (`python bench.py --gpus N`) the script
+spawns the N ranks itself, under torchrun it joins the group it finds in the environment.
 
 Prints ONE JSON line (rank 0).  See DESIGN.md for the roofline accounting.
 """
@@ -19,15 +26,14 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-
-import numpy as np
-import torch
 
 CONFIGS = {
     # name: (B per GPU, L, sample_rate, lambd, hop, n_mels)
@@ -38,26 +44,67 @@ CONFIGS = {
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 (matrix), v_mfma_f32_16x16x4_f32
+ADAM_LR = 1e-3
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--graph", action="store_true", help="replay each step from a HIP graph instead of launching it eagerly "
-                    "(measured slower here: ~5 us of per-replay overhead against a ~35 us step)")
+    ap.add_argument("--mode", default="auto", choices=["auto", "eager", "graph"],
+                    help="how the timed steps are issued: eagerly from Python, replayed from a HIP graph captured from the same code, "
+                         "or (auto) whichever a short trial finds faster")
     ap.add_argument("--bf16-activations", action="store_true", help="store the log-mel output and read its gradient as bf16 "
                     "(DMEL_FLAG_OUT_BF16); the arithmetic, the tangent and d lambd stay fp32.  Default: fp32, the reference's output type")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-module-path", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the config 3 / config 5 side measurements")
+    ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the launcher and the reporting path (gloo, no kernels): "
+                    "what tests/test_bench_launcher_cpu.py runs")
+    return ap.parse_args(argv)
 
 
+# ---- launcher: `python bench.py --gpus N` spawns its own ranks -------------------------------------------------------------
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args) -> int:
+    """Start one fresh process per GPU (nothing in THIS process has touched the GPU: a process that has must never be
+    replaced or forked), wait for them, pass rank 0's JSON line through.  Returns the exit code."""
+    port = _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), DMEL_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "8")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    line = ""
+    for ln in (out0 or b"").decode("utf-8", "replace").splitlines():
+        if ln.startswith("{"):
+            line = ln
+    if line:
+        print(line, flush=True)
+    rc = max((abs(c) for c in codes), default=0)
+    if rc == 0 and not line:
+        rc = 1
+    return rc
+
+
+# ---- CPU baseline --------------------------------------------------------------------------------------------------
 def cpu_baseline(cfg):
     """The reference's algorithm on this host's cores (rank 0, N=1 only): the C oracle and the batched
     torch restatement, each best of 5 on one full batch of the same workload; the faster one is reported."""
+    import torch
     from oracle import dmel_oracle as O
     from oracle import torch_restatement as TR
     from dmel_amd import synth
@@ -93,22 +140,72 @@ def cpu_baseline(cfg):
             "host_cpus": cores}
 
 
+def dry_run(args, rank, world):
+    """No GPU: rehearse group set-up, the barrier / max-over-ranks timing and the JSON line (gloo)."""
+    import torch
+    import torch.distributed as dist
+    from dmel_amd import dist as ddist
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, L, sr, lam, hop, M = CONFIGS[args.config]
+    T = L // hop + 1
+    sar = ddist.ScalarAllReduce() if world > 1 else None
+    grad = torch.tensor([float(rank + 1)])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        pass
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if sar is not None:
+            grad.fill_(float(rank + 1))
+            sar.reduce(grad, 0)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        assert float(grad) == world * (world + 1) / 2
+    if rank == 0:
+        print(json.dumps({"metric": "spectrogram frames/sec (fwd+bwd)", "value": round(world * B * T * args.steps / max(elapsed, 1e-9), 1),
+                          "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(1e3 * elapsed / max(1, args.steps), 5), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "none (dry run: launcher and collective only, no kernels)",
+                          "config": {"workload": "dry run", "parallelism": f"batch-sharded x{world}",
+                                     "collective": "none" if sar is None else ("native dmel_comm" if sar.native else "torch.distributed: " + sar.why)}}),
+              flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    in_group = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not in_group:
+        raise SystemExit(spawn_ranks(args))          # before anything here has touched a GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
+    if in_group and args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if args.dry_run:
+        return dry_run(args, rank, world)
+
+    import numpy as np
+    import torch
+    assert torch.cuda.is_available(), "bench.py needs a GPU (use --dry-run for the CPU rehearsal of the launcher)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1 or os.environ.get("DMEL_BENCH_FORCE_DIST") == "1":     # the env knob exercises the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from dmel_amd import MelSpectrogramLayer, capi, synth
@@ -120,177 +217,315 @@ def main():
     frames_per_rank = B * T
     # every rank owns a different shard of the global batch (seeded by rank); inputs are resident before timing
     x = torch.from_numpy(synth.waveforms(B, L, seed=100 * rank)).to(dev)
-    g = torch.from_numpy(synth.cotangent((B, 1, M, T), seed=1 + 100 * rank)).to(dev)
+    g32 = torch.from_numpy(synth.cotangent((B, 1, M, T), seed=1 + 100 * rank)).to(dev)
     act = torch.bfloat16 if args.bf16_activations else torch.float32
-    g = g.to(act)
-    out = torch.empty((B, 1, M, T), dtype=act, device=dev)
-    tan = torch.empty((B, 1, M, T), dtype=torch.float32, device=dev)
-    RING = 32  # gradient buffers: the all-reduce of step k may still be in flight while steps k+1 .. k+15 run
-    dl = [torch.zeros(1, dtype=torch.float32, device=dev) for _ in range(RING)]
-    plan = capi.Plan(L, hop, M, sr, max_batch=B)
-    count = out.numel()
+    g = g32.to(act)
 
-    def step_kernels(stream_ptr, k):
-        plan.forward(x.data_ptr(), B, lam, out.data_ptr(), tan.data_ptr(), True, 1e-10, stream_ptr,
-                     extra_flags=capi.DMEL_FLAG_OUT_BF16 if args.bf16_activations else 0)
-        plan.backward(g.data_ptr(), tan.data_ptr(), count, dl[k % RING].data_ptr(), stream_ptr, grad_bf16=args.bf16_activations)
-
-    cur = torch.cuda.current_stream(dev)
-    step_kernels(cur.cuda_stream, 0)          # builds the per-n_fft tables (hipMalloc) outside any capture
-    torch.cuda.synchronize()
-    info = plan.info()
-
-    graphs = None
-    if args.graph:
-        graphs = []
-        for k in range(RING):                 # one graph per gradient buffer
-            gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr):
-                step_kernels(torch.cuda.current_stream(dev).cuda_stream, k)
-            graphs.append(gr)
-
-    # one all-reduce of the scalar gradient per step, natively over RCCL on its own stream (dmel_comm_*),
-    # falling back to torch.distributed (stream-ordered, no overlap) if the native communicator is unavailable
+    # ---- the step through the boundary ----------------------------------------------------------------------------------
+    layer = MelSpectrogramLayer(torch.tensor(lam), n_mels=M, n_points=L, sample_rate=sr, hop_length=hop, device=str(dev),
+                                optimized=True, log=True, out_dtype=act).to(dev)
+    try:
+        opt = torch.optim.Adam([layer.lambd], lr=ADAM_LR, fused=True, capturable=True)
+        opt_kind = "Adam(fused=True, capturable=True)"
+    except Exception:                                                   # noqa: BLE001
+        opt = torch.optim.Adam([layer.lambd], lr=ADAM_LR, capturable=True)
+        opt_kind = "Adam(capturable=True)"
     sar = ddist.ScalarAllReduce() if dist is not None else None
-    main_stream = torch.cuda.current_stream(dev).cuda_stream
-    tick = [None] * 64
-    nstep = [0]
+    lam_param = layer.lambd
 
-    def one_step(_k):
-        k = nstep[0]
-        nstep[0] += 1
-        i = k % RING
-        # Buffer i was last reduced by the collective of step k-32.  Ordering the compute stream after a collective
-        # costs a barrier packet, so it is done once per 16 steps, on the collective of step k-17: the
-        # communicator's stream runs them in order, hence everything up to k-17 is then complete, which covers the
-        # buffers steps k .. k+15 overwrite.
-        if sar is not None and k % 16 == 0 and k >= 17 and tick[(k - 17) % 64] is not None:
-            sar.wait(tick[(k - 17) % 64], main_stream)
-        if graphs is not None:
-            graphs[i].replay()
-        else:
-            step_kernels(main_stream, k)
-        if sar is not None:
-            tick[k % 64] = sar.reduce_async(dl[i], main_stream)
+    def module_step():
+        opt.zero_grad(set_to_none=True)
+        layer(x).backward(g)
+        if sar is not None:                                             # data-parallel: the update needs the SUM over ranks
+            sar.reduce(lam_param.grad, torch.cuda.current_stream(dev).cuda_stream)
+        opt.step()
 
-    def drain():
-        k = nstep[0]
-        if sar is not None and k >= 1 and tick[(k - 1) % 64] is not None:
-            sar.wait(tick[(k - 1) % 64], main_stream)      # the last collective (they complete in order)
+    for _ in range(3):                                                  # tables, allocator, optimizer state, lambd tracking
+        module_step()
+    torch.cuda.synchronize()
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        one_step(k)
-    drain()
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        one_step(k)
-    drain()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def time_loop(fn, warm, steps):
+        for _ in range(warm):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    # ways of issuing the same step: eagerly from Python, or replayed from a HIP graph captured from that very code
+    # (dmel_amd.GraphedStep: watches the lambd the kernels report and re-captures when the n_fft or its guards change);
+    # "graph xk" unrolls k steps into one graph, which pays the ~8 us between two graph launches once per k steps
+    from dmel_amd import GraphedStep
+    modes, graph_why = {"eager": (module_step, 1)}, ""
+    if args.mode in ("auto", "graph"):
+        ks = [1] + [k for k in (4,) if args.steps % k == 0]
+        for k in ks:
+            try:
+                gs = GraphedStep(module_step, [layer], max_ahead=8, steps_per_replay=k)
+                gs()
+                torch.cuda.synchronize()
+                modes["graph" if k == 1 else f"graph x{k}"] = (gs, k)
+            except Exception as e:                                      # noqa: BLE001 -- report and fall back to eager issue
+                graph_why = f"{type(e).__name__}: {e}"[:300]
+                torch.cuda.synchronize()
+                break
+
+    def run_mode(name, warm, steps):
+        fn, k = modes[name]
+        return time_loop(fn, (warm + k - 1) // k, steps // k)
+
+    chosen = args.mode
+    trial = {}
+    if chosen == "graph":
+        chosen = "graph" if "graph" in modes else "eager"
+    if chosen in ("auto", "graph") and len(modes) > 1:
+        ntrial = 40
+        names = [m for m in modes if (args.mode == "auto" or m != "eager")]
+        for name in names:
+            trial[name] = run_mode(name, 4, ntrial) / ntrial
+        chosen = min(trial, key=trial.get)
+        if dist is not None:                                            # every rank must take the same path
+            order = list(modes)
+            pick = torch.tensor([order.index(chosen)], device=dev)
+            dist.all_reduce(pick, op=dist.ReduceOp.MIN)
+            chosen = order[int(pick.item())]
+    elif chosen == "auto":
+        chosen = "eager"
+    elapsed = run_mode(chosen, args.warmup, args.steps)                 # <- the timed region: W untimed, exactly K timed steps
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * frames_per_rank * args.steps / elapsed
+    status = layer.lambd_status()
+    lam_end = float(layer.lambd.detach())
+    assert status["error"] == 0 and capi.n_fft(lam_end) == capi.n_fft(lam), (status, lam_end)
+    module_step_info = {"issued": chosen, "optimizer": f"{opt_kind}, lr {ADAM_LR}", "lambd_end": round(lam_end, 4),
+                        "trial_ms_per_step": {k: round(1e3 * v, 4) for k, v in trial.items()},
+                        "guards_last_call": status["guards"], "graph_unavailable": graph_why or None,
+                        "graph_captures": {m: modes[m][0].captures for m in modes if m != "eager"}}
+    if dist is None:
+        for m in modes:                                                 # the other ways of issuing the same step, for the record
+            if m != chosen:
+                module_step_info[m.replace(" ", "_") + "_ms_per_step"] = round(1e3 * run_mode(m, 8, 80) / 80, 4)
+        module_step_info[chosen.replace(" ", "_") + "_ms_per_step"] = round(ms_per_step, 4)
 
-    # ---- per-kernel device time with HIP events around each launch (eager pass, same stream) --------
-    plan.set_profiling(True)
-    nprof = max(20, min(args.steps, 200))
-    for k in range(nprof):
-        step_kernels(cur.cuda_stream, k)
+    # ---- the bare kernels through the C ABI (round 1's headline): fused forward + dot, lambd by value, no autograd, no update -
+    plan = capi.Plan(L, hop, M, sr, max_batch=B)
+    out = torch.empty((B, 1, M, T), dtype=act, device=dev)
+    tan = torch.empty((B, 1, M, T), dtype=torch.float32, device=dev)
+    dl = torch.zeros(1, dtype=torch.float32, device=dev)
+    count = out.numel()
+    cur = torch.cuda.current_stream(dev)
+
+    def step_kernels():
+        plan.forward(x.data_ptr(), B, lam, out.data_ptr(), tan.data_ptr(), True, 1e-10, cur.cuda_stream,
+                     extra_flags=capi.DMEL_FLAG_OUT_BF16 if args.bf16_activations else 0)
+        plan.backward(g.data_ptr(), tan.data_ptr(), count, dl.data_ptr(), cur.cuda_stream, grad_bf16=args.bf16_activations)
+
+    step_kernels()
     torch.cuda.synchronize()
-    prof = plan.get_profile()
-    plan.set_profiling(False)
-    fwd_pair_us = 1e3 * prof["fwd_ms"] / max(1, prof["fwd_launches"])
-    prep_us = 1e3 * prof["prep_ms"] / max(1, prof["prep_launches"])
-    bwd_us = 1e3 * prof["bwd_ms"] / max(1, prof["bwd_launches"])
+    info = plan.info()
+    n_k = max(20, min(200, args.steps))
+    for _ in range(10):
+        step_kernels()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_k):
+        step_kernels()
+    torch.cuda.synchronize()
+    kern_ms = 1e3 * (time.perf_counter() - t0) / n_k
+
+    # ---- dominant kernel: average launch duration from HIP events on the launch stream ------------------------------------
     # An event pair around ONE launch also times the launch packets around it (1.5-4 us, varying from box to box).  The
-    # dominant kernel's average launch duration is therefore taken from trains of launches between two HIP events on the
-    # launch stream: a train of whole steps (forward + dot, the timed region's own mix, so the forward sees the cache state
-    # the dot kernel leaves) minus a train of the dot launches alone.  This is what rocprofv3 reports as the dispatch
-    # duration plus the sub-microsecond gap between dependent dispatches.
-    ntrain = 100
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    with torch.cuda.stream(cur):
+    # duration is therefore taken from trains of launches between two HIP events on the launch stream: a train of whole steps
+    # (forward + dot, so the forward sees the cache state the dot kernel leaves) minus a train of the dot launches alone.
+    # This is what rocprofv3 reports as the dispatch duration plus the sub-microsecond gap between dependent dispatches.
+    def kernel_times(pl, xx, gg, oo, tt, dd, lam_v, n_elems, batch, bf16):
+        pl.set_profiling(True)
+        for _ in range(20):
+            pl.forward(xx.data_ptr(), batch, lam_v, oo.data_ptr(), tt.data_ptr(), True, 1e-10, cur.cuda_stream,
+                       extra_flags=capi.DMEL_FLAG_OUT_BF16 if bf16 else 0)
+            pl.backward(gg.data_ptr(), tt.data_ptr(), n_elems, dd.data_ptr(), cur.cuda_stream, grad_bf16=bf16)
+        torch.cuda.synchronize()
+        prof = pl.get_profile()
+        pl.set_profiling(False)
+        pair = 1e3 * prof["fwd_ms"] / max(1, prof["fwd_launches"])
+        prep = 1e3 * prof["prep_ms"] / max(1, prof["prep_launches"])
+        bwd = 1e3 * prof["bwd_ms"] / max(1, prof["bwd_launches"])
+        ntrain = 100
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         ev[0].record(cur)
-        for k in range(ntrain):
-            step_kernels(cur.cuda_stream, k)
+        for _ in range(ntrain):
+            pl.forward(xx.data_ptr(), batch, lam_v, oo.data_ptr(), tt.data_ptr(), True, 1e-10, cur.cuda_stream,
+                       extra_flags=capi.DMEL_FLAG_OUT_BF16 if bf16 else 0)
+            pl.backward(gg.data_ptr(), tt.data_ptr(), n_elems, dd.data_ptr(), cur.cuda_stream, grad_bf16=bf16)
         ev[1].record(cur)
         ev[2].record(cur)
-        for k in range(ntrain):
-            plan.backward(g.data_ptr(), tan.data_ptr(), count, dl[k % RING].data_ptr(), cur.cuda_stream, grad_bf16=args.bf16_activations)
+        for _ in range(ntrain):
+            pl.backward(gg.data_ptr(), tt.data_ptr(), n_elems, dd.data_ptr(), cur.cuda_stream, grad_bf16=bf16)
         ev[3].record(cur)
-    torch.cuda.synchronize()
-    fwd_us = 1e3 * (ev[0].elapsed_time(ev[1]) - ev[2].elapsed_time(ev[3])) / ntrain
-    if prep_us > 0:
-        fwd_us -= prep_us          # long clips: every forward also launched the partial-sum kernel
-    # algorithmic bytes of ONE launch of the fused forward kernel:
-    # read x once + write out and tangent once, fp32
+        torch.cuda.synchronize()
+        step_us = 1e3 * ev[0].elapsed_time(ev[1]) / ntrain
+        dot_us = 1e3 * ev[2].elapsed_time(ev[3]) / ntrain
+        fwd = step_us - dot_us - (prep if prep > 0 else 0.0)   # long clips: every forward also launched the partial-sum kernel
+        return fwd, pair, prep, bwd, step_us
+
+    fwd_us, fwd_pair_us, prep_us, bwd_us, _ = kernel_times(plan, x, g, out, tan, dl, lam, count, B, args.bf16_activations)
+    # algorithmic bytes of ONE launch of the fused forward kernel: read x once + write out and tangent once
     alg_bytes = 4 * (B * L + B * M * T) + (2 if args.bf16_activations else 4) * B * M * T
     achieved = alg_bytes / (fwd_us * 1e-6) / 1e9
-    traffic = None
+    # HBM-side bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read from inside the
+    # process); the committed measurement is quoted only if it was taken on THIS kernel source, otherwise traffic is null
+    traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(args.config, {}).get("dmel_fwd_kernel_bytes_per_launch")
-        except Exception:
+            import hashlib
+            tj = json.load(open(tpath))
+            src = open(os.path.join(ROOT, "differentiable-mel-spectrogram_amd", "csrc", "dmel_fwd.hip"), "rb").read()
+            sha = hashlib.sha256(src).hexdigest()[:16]
+            if tj.get("kernel_source_sha16") == sha:
+                traffic = tj.get(args.config, {}).get("dmel_fwd_kernel_bytes_per_launch")
+                traffic_src = f"profiles/hbm_traffic.json (rocprofv3 --pmc, dmel_fwd.hip sha16 {sha})"
+            else:
+                traffic_src = f"profiles/hbm_traffic.json was measured on another build of dmel_fwd.hip (have {sha}): not quoted"
+        except Exception:                                               # noqa: BLE001
             traffic = None
     # the contraction stage on the matrix cores: executed fp32 MFMA flops of one launch = non-zero 4x16 filterbank blocks
-    # x 16-row tiles x 2048 flop per v_mfma_f32_16x16x4_f32 (SQ_INSTS_MFMA in profiles/r01_pmc_sq_c2.json counts the same
-    # instructions), against the dense fp32 matrix peak
+    # x 16-row tiles x 2048 flop per v_mfma_f32_16x16x4_f32, against the dense fp32 matrix peak
     mfma_flops = 2048.0 * info["fb_blocks"] * (B * ((T + info["frames_per_tile"] - 1) // info["frames_per_tile"])) if info["kernel_path"] == 0 else 0.0
     mfma = {"executed_tflops": round(mfma_flops / (fwd_us * 1e-6) / 1e12, 2), "peak_tflops": FP32_MFMA_PEAK_TFLOPS,
             "frac": round(mfma_flops / (fwd_us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
             "note": "banded filterbank: only the non-zero blocks are multiplied (dense would be fb_blocks_dense); the kernel is not MFMA-bound"}
     roofline = {"bound": "hbm", "kernel": f"dmel_fwd_kernel<{info['n_fft']},train>", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(fwd_us, 2),
                 "avg_launch_us_single_event_pair": round(fwd_pair_us, 2),
                 "other_kernels_us": {"prep": round(prep_us, 2), "backward_dot": round(bwd_us, 2)}, "mfma_stage": mfma}
 
+    par = f"batch-sharded x{world}"
+    if sar is not None:
+        par += ", one all-reduce (SUM) of lambd.grad per step before the update (RCCL, " + \
+               ("native dmel_comm in the step's stream" if sar.native else "torch.distributed: " + sar.why) + ")"
     result = {
         "metric": "spectrogram frames/sec (fwd+bwd)", "value": round(value, 1), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "activations": "bf16 (output and its gradient; arithmetic, tangent and d lambd fp32)" if args.bf16_activations else "f32",
         "config": {"workload": f"BASELINE config 2 per GPU: batch {B} x {L} samples @ {sr} Hz, n_fft {info['n_fft']} "
-                               f"(lambd {lam}), hop {hop}, n_mels {M}, log fused, fwd + backward to lambd.grad"
+                               f"(lambd {lam}), hop {hop}, n_mels {M}, log fused; step = nn.Module forward + backward to lambd.grad + Adam update of lambd"
                    if args.config == "c2" else f"{args.config}: batch {B} x {L} @ {sr}, lambd {lam}, hop {hop}, n_mels {M}",
-                   "global_batch": B * world, "frames_per_step": frames_per_rank * world,
-                   "parallelism": f"batch-sharded x{world}" + (f", one all-reduce of d lambd per step (RCCL, " + ("native dmel_comm on its own stream, up to 17 in flight" if sar.native else "torch.distributed fallback: " + sar.why) + ")" if sar is not None else ""),
-                   "launch": "hip-graph replay" if args.graph else "eager, 2 launches per step (fused forward, dot)"},
+                   "global_batch": B * world, "frames_per_step": frames_per_rank * world, "parallelism": par,
+                   "launch": ("eager from Python: torch.ops.dmel.mel_spectrogram + autograd + optimizer.step()" if chosen == "eager" else
+                              f"HIP graph captured from the nn.Module step (dmel_amd.GraphedStep), {modes[chosen][1]} step(s) per replay") +
+                             "; lambd stays on the device, no host synchronisation inside the timed region"},
+        "module_step": module_step_info,
+        "c_abi_kernels": {"frames_per_s": round(frames_per_rank / (kern_ms * 1e-3), 1), "ms_per_step": round(kern_ms, 5),
+                          "note": "fused forward + dot through include/dmel.h, lambd by value, no autograd, no optimizer (round 1's headline)"},
         "roofline": roofline,
         "kernel_info": info,
     }
 
-    if rank == 0 and world == 1:
-        if not args.no_module_path:
-            layer = MelSpectrogramLayer(torch.tensor(lam), n_mels=M, n_points=L, sample_rate=sr, hop_length=hop,
-                                        device=str(dev), optimized=True, log=True).to(dev)
-            n_mod = max(10, min(args.steps, 100))
-            for i in range(n_mod + 5):
-                if i == 5:
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
-                layer.lambd.grad = None
-                (layer(x) * g).sum().backward()
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t1) / n_mod
-            result["module_path"] = {"frames_per_s": round(frames_per_rank / dt, 1), "ms_per_step": round(1e3 * dt, 4),
-                                     "note": "nn.Module + autograd, eager, includes the loss (mul+sum) and one host read of lambd per step"}
-        if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(cfg)
-    if rank == 0:
-        print(json.dumps(result), flush=True)
+    if rank == 0 and world == 1 and not args.no_other_configs and args.config == "c2":
+        result["other_configs"] = other_configs(torch, capi, synth, dev, kernel_times)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(cfg)
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        _flush_c_stdio()            # RCCL prints a version banner through C stdio: keep the JSON line the last one
+        print(json.dumps(result), flush=True)
+
+
+def _flush_c_stdio():
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:               # noqa: BLE001
+        pass
+
+
+def other_configs(torch, capi, synth, dev, kernel_times):
+    """BASELINE configs 3 and 5 (both n_fft 2048), not bench lines of their own: kernel times of the forward + dot through the
+    C ABI and the same roofline accounting, plus config 5's front end isolated inside a real MelConvNet training step."""
+    res = {}
+    for name in ("c3", "c5"):
+        B, L, sr, lam, hop, M = CONFIGS[name]
+        T = L // hop + 1
+        x = torch.from_numpy(synth.waveforms(B, L, seed=7)).to(dev)
+        g = torch.from_numpy(synth.cotangent((B, 1, M, T), seed=8)).to(dev)
+        out, tan, dl = torch.empty((B, 1, M, T), device=dev), torch.empty((B, 1, M, T), device=dev), torch.zeros(1, device=dev)
+        plan = capi.Plan(L, hop, M, sr, max_batch=B)
+        plan.forward(x.data_ptr(), B, lam, out.data_ptr(), tan.data_ptr(), True, 1e-10, torch.cuda.current_stream(dev).cuda_stream)
+        torch.cuda.synchronize()
+        info = plan.info()
+        fwd_us, _, prep_us, bwd_us, step_us = kernel_times(plan, x, g, out, tan, dl, lam, out.numel(), B, False)
+        alg = 4 * (B * L + 2 * B * M * T)
+        res[name] = {"workload": f"batch {B} x {L} @ {sr} Hz, n_fft {info['n_fft']} (lambd {lam}), hop {hop}, n_mels {M}",
+                     "frames_per_step": B * T, "step_us": round(step_us, 2), "frames_per_s": round(B * T / (step_us * 1e-6), 1),
+                     "kernels_us": {"prep_partial_sums": round(prep_us, 2), "fused_forward": round(fwd_us, 2), "backward_dot": round(bwd_us, 2)},
+                     "roofline": {"bound": "hbm", "kernel": f"dmel_fwd_kernel<{info['n_fft']},train>",
+                                  "achieved": round(alg / (fwd_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(alg / (fwd_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": alg,
+                                  "avg_launch_us": round(fwd_us, 2), "traffic": None},
+                     "lds_bytes": info["lds_bytes"], "grid": info["grid_fwd"]}
+        del plan, x, g, out, tan
+    try:
+        res["c5"]["train_step"] = c5_train_step(torch, synth, dev)
+    except Exception as e:                                              # noqa: BLE001
+        res["c5"]["train_step"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    return res
+
+
+def c5_train_step(torch, synth, dev, steps=8):
+    """config 5: ESC-50-shaped clips through MelConvNet (models.py:105-136), CrossEntropy, Adam with the two learning-rate
+    groups of main.py:36-53; the front end's kernels isolated with the library's HIP-event profiling."""
+    from dmel_amd import nets
+    B, L, sr, lam, hop, M = CONFIGS["c5"]
+    ncls = 50
+    torch.manual_seed(0)
+    net = nets.MelConvNet(ncls, torch.tensor(lam), str(dev), M, sr, L, hop_length=hop, optimized=True, energy_normalize=True).to(dev)
+    opt = nets.make_optimizer(net, lr_model=1e-4, lr_tf=1.0)
+    loss_fn = torch.nn.CrossEntropyLoss()
+    x = torch.from_numpy(synth.waveforms(B, L, seed=0)).to(dev)
+    y = (torch.arange(B, device=dev) * 7) % ncls
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        logits, _ = net(x)
+        loss = loss_fn(logits, y)
+        loss.backward()
+        opt.step()
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    plan = net.spectrogram_layer._plan_for(torch.device(dev))
+    plan.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    pr = plan.get_profile()
+    plan.set_profiling(False)
+    front_ms = (pr["prep_ms"] + pr["fwd_ms"] + pr["bwd_ms"]) / steps
+    return {"step_ms": round(1e3 * dt, 3), "frontend_ms": round(front_ms, 4), "frontend_share": round(front_ms / (1e3 * dt), 4),
+            "frontend_frames_per_s": round(B * (L // hop + 1) / (front_ms * 1e-3), 1),
+            "launches_per_step": {"prep": pr["prep_launches"] / steps, "forward": pr["fwd_launches"] / steps, "backward": pr["bwd_launches"] / steps},
+            "note": "MelConvNet + CrossEntropy + Adam (lr_model 1e-4, lr_tf 1.0), batch 32; front end = HIP-event time of its kernels "
+                    "(each event pair also brackets the launch packets)"}
 
 
 if __name__ == "__main__":

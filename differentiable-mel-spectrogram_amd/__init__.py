@@ -11,13 +11,15 @@ from __future__ import annotations
 
 import importlib
 
-__all__ = ["MelSpectrogramLayer", "DifferentiableMelSpectrogram", "SpectrogramLayer", "dmel_log_mel", "capi", "synth", "dist", "nets", "panns"]
+__all__ = ["MelSpectrogramLayer", "DifferentiableMelSpectrogram", "SpectrogramLayer", "dmel_log_mel", "GraphedStep", "capi", "synth", "dist",
+           "nets", "panns", "graph"]
 
 _LAZY = {
     "MelSpectrogramLayer": ("layer", "MelSpectrogramLayer"),
     "DifferentiableMelSpectrogram": ("layer", "DifferentiableMelSpectrogram"),
     "dmel_log_mel": ("layer", "dmel_log_mel"),
     "SpectrogramLayer": ("layer", "SpectrogramLayer"),
+    "GraphedStep": ("graph", "GraphedStep"),
 }
 
 
@@ -25,6 +27,6 @@ def __getattr__(name):
     if name in _LAZY:
         mod, attr = _LAZY[name]
         return getattr(importlib.import_module(f"dmel_amd.{mod}"), attr)
-    if name in ("capi", "synth", "layer", "dist", "nets", "panns"):
+    if name in ("capi", "synth", "layer", "dist", "nets", "panns", "graph"):
         return importlib.import_module(f"dmel_amd.{name}")
     raise AttributeError(name)

@@ -56,7 +56,7 @@ class DmelPlanInfo(C.Structure):
 class DmelLambdStatus(C.Structure):
     _fields_ = [("known", C.c_int32), ("lambd_seen", C.c_float), ("n_fft_seen", C.c_int32), ("seq_issued", C.c_uint32),
                 ("seq_seen", C.c_uint32), ("rate", C.c_float), ("guards", C.c_int32), ("error", C.c_int32),
-                ("error_seq", C.c_uint32), ("error_lambd", C.c_float)]
+                ("error_seq", C.c_uint32), ("error_lambd", C.c_float), ("next_n_fft", C.c_int32), ("next_guards", C.c_int32)]
 
 
 class DmelProfile(C.Structure):

@@ -98,6 +98,7 @@ struct dmel_plan {
     bool lam_known = false;        // lam_seen / seq_seen hold an observation
     float lam_seen = 0.f;
     unsigned seq_seen = 0;
+    unsigned seq_floor = 0;        // reports with a smaller call number predate the last reset
     int n_obs = 0;                 // observations since the last reset
     float lam_rate = 0.f;          // decayed maximum of |d lambd| per call
     int max_ahead = 8;             // calls the host may run ahead of the last observation (0: unbounded)
@@ -494,7 +495,30 @@ dmel_status run_forward(dmel_plan* pl, const float* x, int batch, float lambd, u
 // ---- device-resident lambd ---------------------------------------------------------------------------------------------
 void lam_reset(dmel_plan* pl)
 {
-    pl->lam_known = false; pl->n_obs = 0; pl->lam_rate = 0.f; pl->seq_seen = pl->issued;
+    pl->lam_known = false; pl->n_obs = 0; pl->lam_rate = 0.f; pl->seq_seen = pl->issued; pl->seq_floor = pl->issued + 1;
+}
+
+// which n_fft the next dmel_forward_dev launches for and which neighbours it guards (bit 0: n_fft / 2, bit 1: 2 n_fft), from
+// the host's current picture: both neighbours while the drift per call is unknown, on request, and under a graph capture
+// nobody manages; otherwise only the ones within reach of a boundary before the host would notice
+void lam_decide(const dmel_plan* pl, bool capturing, int* n_fft, int* guards)
+{
+    const float a = std::fabs(pl->lam_seen);
+    const int N = dmel_n_fft(pl->lam_seen);
+    int g = 0;
+    if (pl->guard_mode == 1 || (capturing && pl->guard_mode != 3 && pl->guard_mode != 2)) g = 3;
+    else if (pl->guard_mode == 0 || pl->guard_mode == 3) {
+        if (pl->n_obs < 2) g = 3;
+        else {
+            const float stale = (float)(pl->issued - pl->seq_seen) + 2.0f + (capturing ? (float)pl->max_ahead : 0.f);
+            const float reach = 2.0f * pl->lam_rate * stale + 1e-5f * a;
+            if ((a - reach) * 6.0f < (float)(N / 2 + 1)) g |= 1;
+            if ((a + reach) * 6.0f >= (float)N + 1.0f) g |= 2;
+        }
+    }
+    if (2 * N > dmel::kMaxNfft) g &= ~2;
+    if (N < 2) g &= ~1;
+    *n_fft = N; *guards = g;
 }
 
 // fold the kernels' latest report into the host's picture; returns false if nothing new
@@ -502,8 +526,10 @@ bool lam_observe(dmel_plan* pl)
 {
     const unsigned long long w = __atomic_load_n(&pl->host_words[0], __ATOMIC_RELAXED);
     const unsigned seq = (unsigned)(w >> 32);
-    if (seq == 0 || (int)(seq - pl->seq_seen) <= 0) return false;      // nothing newer than what is known (or than the last reset)
+    if (seq == 0 || (int)(seq - pl->seq_floor) < 0 || (int)(seq - pl->seq_seen) < 0) return false;    // older than the last reset
     float lam; const unsigned bits = (unsigned)w; std::memcpy(&lam, &bits, 4);
+    // a replayed graph reports under the call number it was captured with: the same seq with another value is news too
+    if (pl->lam_known && seq == pl->seq_seen && lam == pl->lam_seen) return false;
     if (pl->lam_known && pl->n_obs >= 1) {
         const unsigned dseq = seq - pl->seq_seen;
         const float r = std::fabs(lam - pl->lam_seen) / (float)(dseq ? dseq : 1);
@@ -741,21 +767,8 @@ dmel_status dmel_forward_dev(dmel_plan* plan, const float* x, int32_t batch, con
         }
         (void)hipGetLastError();
     }
-    const float a = std::fabs(plan->lam_seen);
-    const int N = dmel_n_fft(plan->lam_seen);
-    // neighbours that could become the right n_fft before the host notices: both while the drift per call is unknown,
-    // under graph capture (the host is not there at replay) and on request; otherwise only within reach of a boundary
-    int guards = 0;
-    if (plan->guard_mode == 1 || capturing) guards = 3;
-    else if (plan->guard_mode == 0) {
-        if (plan->n_obs < 2) guards = 3;
-        else {
-            const float stale = (float)(plan->issued - plan->seq_seen) + 2.0f;
-            const float reach = 2.0f * plan->lam_rate * stale + 1e-5f * a;
-            if ((a - reach) * 6.0f < (float)(N / 2 + 1)) guards |= 1;
-            if ((a + reach) * 6.0f >= (float)N + 1.0f) guards |= 2;
-        }
-    }
+    int N = 0, guards = 0;
+    lam_decide(plan, capturing, &N, &guards);
     // tables of the neighbouring sizes exist before they are needed: building them allocates and copies (not allowed
     // under capture, and a stall at the moment of a crossing otherwise)
     if (!capturing) {
@@ -765,9 +778,9 @@ dmel_status dmel_forward_dev(dmel_plan* plan, const float* x, int32_t batch, con
     }
     int cand[3], nc = 0;
     cand[nc++] = N;
-    if ((guards & 2) && 2 * N <= dmel::kMaxNfft) cand[nc++] = 2 * N;
-    if ((guards & 1) && N >= 2) cand[nc++] = N / 2;
-    plan->last_guards = (nc > 1 && cand[1] == 2 * N ? 2 : 0) | ((nc > 1 && cand[nc - 1] == N / 2) ? 1 : 0);
+    if (guards & 2) cand[nc++] = 2 * N;
+    if (guards & 1) cand[nc++] = N / 2;
+    plan->last_guards = guards;
 
     Scratch sc;
     if (scratch) sc = carve(scratch);
@@ -805,6 +818,7 @@ dmel_status dmel_plan_lambd_status(dmel_plan* plan, dmel_lambd_status* status)
     r.n_fft_seen = plan->lam_known ? dmel_n_fft(plan->lam_seen) : 0;
     r.seq_issued = plan->issued; r.seq_seen = plan->seq_seen;
     r.rate = plan->lam_rate; r.guards = plan->last_guards;
+    if (plan->lam_known) lam_decide(plan, false, &r.next_n_fft, &r.next_guards);
     const unsigned long long err = __atomic_load_n(&plan->host_words[1], __ATOMIC_RELAXED);
     r.error = err != 0 ? 1 : 0;
     r.error_seq = (uint32_t)(err >> 32);
@@ -815,7 +829,7 @@ dmel_status dmel_plan_lambd_status(dmel_plan* plan, dmel_lambd_status* status)
 
 dmel_status dmel_plan_set_tracking(dmel_plan* plan, int32_t max_ahead, int32_t guard_mode)
 {
-    if (!plan || max_ahead < 0 || guard_mode < 0 || guard_mode > 2) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_plan_set_tracking: bad arguments");
+    if (!plan || max_ahead < 0 || guard_mode < 0 || guard_mode > 3) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_plan_set_tracking: bad arguments");
     std::lock_guard<std::mutex> lock(plan->mu);
     plan->max_ahead = max_ahead; plan->guard_mode = guard_mode;
     return DMEL_OK;

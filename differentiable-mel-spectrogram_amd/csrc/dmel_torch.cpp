@@ -86,7 +86,7 @@ std::tuple<at::Tensor, at::Tensor> dmel_forward_op(const at::Tensor& x, const at
     return {out, buf};
 }
 
-at::Tensor dmel_backward_op(const at::Tensor& grad_out, const at::Tensor& tangent_buf, int64_t plan_h)
+at::Tensor dmel_backward_impl(const at::Tensor& grad_out, const at::Tensor& tangent_buf, int64_t plan_h, bool scalar_shape)
 {
     TORCH_CHECK(grad_out.is_cuda() && tangent_buf.is_cuda(), "dmel::backward: tensors must be on the GPU");
     dmel_plan* plan = as_plan(plan_h);
@@ -99,11 +99,17 @@ at::Tensor dmel_backward_op(const at::Tensor& grad_out, const at::Tensor& tangen
     const int64_t tan_bytes = (count * 4 + kAlign - 1) / kAlign * kAlign;
     TORCH_CHECK(tangent_buf.numel() * 4 >= tan_bytes + (int64_t)dmel_scratch_bytes(plan, 1),
                 "dmel::backward: tangent buffer does not belong to a forward of this shape");
-    at::Tensor dl = at::empty({1}, g.options().dtype(at::kFloat));
+    // allocated in lambd's own shape: AccumulateGrad then keeps it as it is (a reshaped view would be copied by one more kernel)
+    at::Tensor dl = scalar_shape ? at::empty({}, g.options().dtype(at::kFloat)) : at::empty({1}, g.options().dtype(at::kFloat));
     char* base = reinterpret_cast<char*>(tangent_buf.data_ptr<float>());
     check(dmel_backward_scratch(plan, g.data_ptr(), bf16 ? DMEL_DTYPE_BF16 : DMEL_DTYPE_F32, reinterpret_cast<const float*>(base), count,
                                 /*accumulate=*/0, dl.data_ptr<float>(), base + tan_bytes, stream_of(g)));
     return dl;
+}
+
+at::Tensor dmel_backward_op(const at::Tensor& grad_out, const at::Tensor& tangent_buf, int64_t plan_h)
+{
+    return dmel_backward_impl(grad_out, tangent_buf, plan_h, false);
 }
 
 at::Tensor dmel_mel_fbanks_op(int64_t n_freqs, double f_min, double f_max, int64_t n_mels, int64_t sample_rate)
@@ -132,8 +138,7 @@ struct DmelFn : public torch::autograd::Function<DmelFn> {
         at::Tensor dl;
         if (ctx->saved_data["want"].toBool() && grads[0].defined()) {
             const auto saved = ctx->get_saved_variables();
-            dl = dmel_backward_op(grads[0], saved[0], ctx->saved_data["plan"].toInt());
-            if (ctx->saved_data["lam_dim"].toInt() == 0) dl = dl.reshape({});
+            dl = dmel_backward_impl(grads[0], saved[0], ctx->saved_data["plan"].toInt(), ctx->saved_data["lam_dim"].toInt() == 0);
         }
         return {at::Tensor(), dl, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
     }

@@ -149,10 +149,15 @@ typedef struct dmel_lambd_status {
     int32_t error;            /* 1: a forward was not covered (reported by the next dmel_forward_dev)      */
     uint32_t error_seq;
     float error_lambd;
+    int32_t next_n_fft;       /* what a dmel_forward_dev issued now would launch for, and guard (bits as `guards`)        */
+    int32_t next_guards;
 } dmel_lambd_status;
 dmel_status dmel_plan_lambd_status(dmel_plan* plan, dmel_lambd_status* status);
 /* max_ahead: calls the host may be ahead of the last observation before dmel_forward_dev waits (0 = unbounded, default 8);
- * guard_mode: 0 = near boundaries only (default), 1 = always both neighbours, 2 = never */
+ * guard_mode: 0 = near boundaries only, and both neighbours whenever the stream is capturing (default: a captured forward
+ * is replayed without the host looking); 1 = always both neighbours; 2 = never; 3 = near boundaries only, also under
+ * capture -- for callers that watch dmel_plan_lambd_status between replays and re-capture when next_n_fft / next_guards
+ * differ from what the graph holds (dmel_amd.graph.GraphedStep does; max_ahead is then the replays it lets queue up) */
 dmel_status dmel_plan_set_tracking(dmel_plan* plan, int32_t max_ahead, int32_t guard_mode);
 /* forget what was seen (after lambd was rewritten from outside, e.g. load_state_dict): the next call reads it again */
 dmel_status dmel_plan_lambd_reset(dmel_plan* plan);

@@ -269,3 +269,48 @@ def test_torch_ops_are_registered():
         assert hasattr(ops, name)
     fb = ops.mel_fbanks(513, 0.0, 8000.0, 128, 16000)
     assert np.array_equal(fb.numpy(), O.mel_fbanks(513, 0.0, 8000.0, 128, 16000))
+
+
+@pytest.mark.parametrize("k", [1, 2])
+def test_graphed_step_recaptures_when_n_fft_changes(k):
+    """dmel_amd.GraphedStep: the step replays from a HIP graph; the object reads what the kernels report about lambd between
+    replays (pinned word, no synchronisation) and re-captures when the launch the library would choose has changed.  The
+    trajectory equals the eagerly issued one across the 512 -> 1024 boundary, with guards only while the boundary is near."""
+    from dmel_amd import GraphedStep, capi
+    case = C.BY_NAME["g1_c1"]
+    x = torch.from_numpy(C.make_input(case)).to(DEV)
+    g = torch.from_numpy(C.make_cotangent(case)).to(DEV)
+    lam0, steps = 84.0, 32
+    ref_layer = _mk(case, lam=lam0, sync=True)
+    ref_opt = torch.optim.Adam([ref_layer.lambd], lr=0.25, capturable=True)
+    ref = []
+    for _ in range(steps + 40):                               # GraphedStep adds eager steps: 3 before the first capture, 1 per re-capture
+        ref_opt.zero_grad(set_to_none=True)
+        ref_layer(x).backward(g)
+        ref_opt.step()
+        ref.append(float(ref_layer.lambd.detach()))
+    layer = _mk(case, lam=lam0, sync=False)
+    opt = torch.optim.Adam([layer.lambd], lr=0.25, capturable=True)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        layer(x).backward(g)
+        opt.step()
+
+    gs = GraphedStep(step, [layer], max_ahead=4, steps_per_replay=k, warmup=3)
+    got, guards_seen = [], set()
+    n_eager = 3
+    for _ in range(steps // k):
+        before = gs.captures
+        gs()
+        if gs.captures != before and before > 0:
+            n_eager += 1                                      # every re-capture runs one eager step first
+        torch.cuda.synchronize()
+        got.append(float(layer.lambd.detach()))
+        guards_seen.add(layer.lambd_status()["guards"])
+    total = n_eager + (steps // k) * k
+    # capture itself does not execute the step; replays do: the layer has taken n_eager + steps steps in all
+    np.testing.assert_allclose(got[-1], ref[total - 1], rtol=1e-5)
+    assert gs.captures >= 2, "lambd crossed 85.5 (n_fft 512 -> 1024): the graph must have been re-captured"
+    assert {capi.n_fft(v) for v in got} == {512, 1024} or capi.n_fft(got[0]) == 1024
+    assert layer.lambd_status()["error"] == 0

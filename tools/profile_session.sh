@@ -1,0 +1,17 @@
+#!/bin/bash
+# One profiling session on the GPU box (run through gpurun from the repo root): kernel trace + stats of the bench command,
+# FETCH_SIZE / WRITE_SIZE / SQ counter passes (each in its own run, --pmc never combined with other trace domains),
+# the un-profiled bench line of the same build.  Raw output under gpurun_out/prof_$TAG; tools/summarize_profile.py turns
+# it into the files committed under profiles/.
+TAG=${1:-r02}
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+BENCH="python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-other-configs"
+python3 bench.py --steps 300 --warmup 30 > $OUT/bench_c2.json 2> $OUT/bench_c2.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $BENCH > $OUT/kt.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --steps 30 --warmup 5 --mode eager --no-cpu-baseline --no-other-configs > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --steps 30 --warmup 5 --mode eager --no-cpu-baseline --no-other-configs > $OUT/write.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $OUT/sq1 -- python3 bench.py --steps 30 --warmup 5 --mode eager --no-cpu-baseline --no-other-configs > $OUT/sq1.log 2>&1
+rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/sq2 -- python3 bench.py --steps 30 --warmup 5 --mode eager --no-cpu-baseline --no-other-configs > $OUT/sq2.log 2>&1
+ls -R $OUT | head -50
