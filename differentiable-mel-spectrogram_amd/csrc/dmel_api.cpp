@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -438,9 +439,13 @@ dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dm
     fp.tiles_per_clip = (pl->T + fpt - 1) / fpt;
     fp.inv_L = inv_L; fp.eps = (float)eps; fp.flags = flags; fp.lam = lam;
     fp.remove_dc = remove_dc; fp.normalize = pl->cfg.normalize_window; fp.win_half = win_half;
-    const long long grid = (long long)batch * fp.tiles_per_clip;
+    static const int force_tpw = std::getenv("DMEL_TILES_PER_WG") ? std::atoi(std::getenv("DMEL_TILES_PER_WG")) : 0;   // diagnostics
+    int tpw = dmel::forward_tiles_per_wg(N, batch, fp.tiles_per_clip);
+    if (force_tpw == 1 || (force_tpw == 2 && N >= 256 && N <= 2048)) tpw = force_tpw;
+    fp.wgs_per_clip = (fp.tiles_per_clip + tpw - 1) / tpw;
+    const long long grid = (long long)batch * fp.wgs_per_clip;
     if (grid > 0x7fffffffLL) return fail(DMEL_ERR_INVALID_ARGUMENT, "too many tiles for one launch");
-    DMEL_HIP(dmel::launch_forward(N, mode, fp, (int)grid, s));
+    DMEL_HIP(dmel::launch_forward(N, mode, tpw, fp, (int)grid, s));
     prof_span(pl, m1, prof_mark(pl, s), 1);
     pl->info.kernel_path = 0; pl->info.frames_per_tile = fpt; pl->info.grid_fwd = (int)grid;
     pl->info.fb_blocks = tb->n_entries; pl->info.fb_blocks_dense = tb->n_dense;

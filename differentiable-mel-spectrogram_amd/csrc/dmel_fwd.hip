@@ -246,11 +246,28 @@ __device__ __forceinline__ void stamp(int wgid, int wave, int lane, int idx)
     if (lane == 0 && wgid < 4096) g_stamps[((size_t)wgid * 8 + wave) * kStampSlots + idx] = t;
 }
 #define STAMP(i) stamp(blockIdx.x, wave, lane, i)
+// where the workgroup runs: HW_ID (wave / SIMD / CU / SH / SE ids) and XCC_ID, slots 12 and 13
+__device__ __forceinline__ void stamp_place(int wgid, int wave, int lane)
+{
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if (lane == 0 && wgid < 4096) {
+        g_stamps[((size_t)wgid * 8 + wave) * kStampSlots + 12] = hw;
+        g_stamps[((size_t)wgid * 8 + wave) * kStampSlots + 13] = xcc;
+    }
+}
+#define STAMP_PLACE() stamp_place(blockIdx.x, wave, lane)
 #else
 #define STAMP(i) do {} while (0)
+#define STAMP_PLACE() do {} while (0)
 #endif
 
-template <int N, int MODE>
+// TPW = tiles one workgroup produces, one after the other.  With TPW = 2 the prologue (lambd, window table, clip sum: a third
+// of a tile's lifetime, mostly spent waiting for memory) is paid once for twice the frames, the samples of the second tile
+// are requested while the first is transformed, and a launch needs half the workgroups (one round of resident workgroups
+// instead of two at BASELINE config 2).
+template <int N, int MODE, int TPW>
 __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_kernel(FwdParams p)
 {
     constexpr FftGeom g = geom<N>();
@@ -270,7 +287,10 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
     constexpr bool WIN_LDS = g.WIN_LDS != 0;
     // radix-C twiddles through LDS: the table has R*C entries but a wave-wide global load of it still moves 512 B
     constexpr bool TW2_LDS = (C > 1) && (N <= 2048);
-    float2* tw2l = reinterpret_cast<float2*>(smem_raw + g.RED_OFF + 64);
+    float2* tw2l = reinterpret_cast<float2*>(smem_raw + g.RED_OFF + kRedBytes);
+    // the half-tile exchange of phase 2 (8 waves) lives where the window table does: a second tile needs the table back
+    constexpr bool WIN_ALIASED = WIN_LDS && WAVES == 8;
+    constexpr int WPT = (N / 2 + THREADS - 1) / THREADS;       // window entries a thread computes (and keeps when TPW > 1)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -284,85 +304,100 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
         const int nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7, xcd = wg & 7;
         wg = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (wg >> 3);
     }
-    const int b = wg / p.tiles_per_clip;
-    const int t0 = (wg % p.tiles_per_clip) * FPT;
+    const int b = wg / p.wgs_per_clip;
+    const int tile0 = (wg % p.wgs_per_clip) * TPW;              // first tile of this workgroup inside its clip
     STAMP(0);
+    STAMP_PLACE();
 #ifdef DMEL_ABLATE
     // timing ablations (tools/ablate.py builds its own library with -DDMEL_ABLATE; never in libdmel_hip.so)
     const bool dbg_skip_fft = (p.flags & 0x200u) != 0;
     const bool dbg_skip_gemm = (p.flags & 0x100u) != 0;
 #else
-    constexpr bool dbg_skip_fft = false, dbg_skip_gemm = false;
+    constexpr bool dbg_skip_fft = false;
 #endif
 
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (size_t)b * p.L, (unsigned)p.L * 4u);
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.ent_b, (unsigned)p.ent_b_floats * 4u);
 
-    // ---- requests that phase 2 will need, issued before anything else --------------------------
-    // (ks0, nks, boff, tile) of this wave's mel runs in group 0 and their first NBPRE B fragments
-    // The first NBPRE k-steps of every tile (all of them for the HTK bank at the usual sizes) sit in
-    // registers from here on: nothing in phase 2 then waits on global memory.
+    // ---- what phase 2 needs from global memory: (ks0, nks, boff, tile) of this wave's mel runs in group 0 and their
+    // first NBPRE B fragments (all of them for the HTK bank at the usual sizes).  Requested after the FFT of a tile, when
+    // its registers are free: the pairing pass and the barrier behind it cover the round trip, nothing in phase 2 waits.
     constexpr int NBPRE = g.NBPRE;
     int4 tr0[NLOC];
     float bpre[NLOC][NBPRE];
-    if constexpr (!IS_SPEC) {
-        static_for<0, NLOC>([&](auto l) {
-            constexpr int loc = decltype(l)::value;
-            tr0[loc] = p.tile_ranges[wave * NLOC + loc];
-        });
-        // one 64-bit base per lane, compile-time offsets from it
-        const float* pre_lane = p.ent_pre + ((unsigned)(wave * (NLOC * NBPRE * 64)) + (unsigned)lane);
-        static_for<0, NLOC>([&](auto l) {
-            constexpr int loc = decltype(l)::value;
-            // fixed layout (wave, run, k-step, lane): the address does not wait for tile_ranges; the number of real groups of
-            // 4 k-steps comes with the kernel arguments (scalar load), so the padding of short runs is not fetched
-            const int ng = p.pre_groups[wave * NLOC + loc];
-            static_for<0, NBPRE / 4>([&](auto qq) {
-                constexpr int q4 = decltype(qq)::value;
-                if (q4 < ng) {
-                    static_for<0, 4>([&](auto u) {
-                        constexpr int u4 = q4 * 4 + decltype(u)::value;
-                        bpre[loc][u4] = pre_lane[(loc * NBPRE + u4) * 64];
-                    });
-                }
+    auto fetch_bpre = [&]() {
+        if constexpr (!IS_SPEC) {
+            static_for<0, NLOC>([&](auto l) {
+                constexpr int loc = decltype(l)::value;
+                tr0[loc] = p.tile_ranges[wave * NLOC + loc];
             });
-        });
-    }
+            // one 64-bit base per lane, compile-time offsets from it
+            const float* pre_lane = p.ent_pre + ((unsigned)(wave * (NLOC * NBPRE * 64)) + (unsigned)lane);
+            static_for<0, NLOC>([&](auto l) {
+                constexpr int loc = decltype(l)::value;
+                // fixed layout (wave, run, k-step, lane): the address does not wait for tile_ranges; the number of real groups of
+                // 4 k-steps comes with the kernel arguments (scalar load), so the padding of short runs is not fetched
+                const int ng = p.pre_groups[wave * NLOC + loc];
+                static_for<0, NBPRE / 4>([&](auto qq) {
+                    constexpr int q4 = decltype(qq)::value;
+                    if (q4 < ng) {
+                        static_for<0, 4>([&](auto u) {
+                            constexpr int u4 = q4 * 4 + decltype(u)::value;
+                            bpre[loc][u4] = pre_lane[(loc * NBPRE + u4) * 64];
+                        });
+                    } else {
+                        // defined on every path: the registers are then dead between two tiles instead of carrying the
+                        // previous tile's values through the next FFT
+                        static_for<0, 4>([&](auto u) { bpre[loc][q4 * 4 + decltype(u)::value] = 0.f; });
+                    }
+                });
+            });
+        }
+    };
 
-    // ================= phase 1: FFT of this wave's frames ====================================
     const int j = lane / G, lg = lane % G;
     const int qp = lg / C, r = lg % C;
-    int lam_bits = 0;
-    if (!dbg_skip_fft) {
-        // Samples of every pass are requested up front.  Frames that lie wholly inside the clip (all but
-        // the first/last few) use plain offsets; the others clamp every index into the clip and are
-        // zeroed by a select below.  (The hardware range check of buffer loads is not relied upon: it
-        // covers voffset + immediate but not soffset, and hipcc chooses that split.)
-        float xa[PASSES][R];
-        float xb2[PAIR ? PASSES : 1][PAIR ? R : 1];
-        bool inside[PASSES];
+
+    // ---- samples: one register set per tile of the workgroup; tile ti + 1 is requested while tile ti is transformed.
+    // Frames that lie wholly inside the clip (all but the first/last few) use plain offsets; the others clamp every index
+    // into the clip and are zeroed by a select at windowing time.  (The hardware range check of buffer loads is not relied
+    // upon: it covers voffset + immediate but not soffset, and hipcc chooses that split.)
+    float xa[TPW][PASSES][R];
+    float xb2[TPW][PAIR ? PASSES : 1][PAIR ? R : 1];
+    bool inside[TPW][PASSES];
+    auto load_tile = [&](auto tt) {
+        constexpr int ti = decltype(tt)::value;
+        const int t0 = (tile0 + ti) * FPT;
         static_for<0, PASSES>([&](auto pp) {
             constexpr int pass = decltype(pp)::value;
             const int slot = pass * (WAVES * FPW) + wave * FPW + j;
             const int tA = PAIR ? (t0 + 2 * slot) : (t0 + slot);
             const int f0 = tA * p.hop - N / 2;                       // first sample of frame tA
             const int f1 = PAIR ? f0 + p.hop : f0;
-            inside[pass] = __all((f0 >= 0) && (f1 + N <= p.L));
+            inside[ti][pass] = __all((f0 >= 0) && (f1 + N <= p.L));
             const int sA = f0 + lg;
-            if (inside[pass]) {
+            if (inside[ti][pass]) {
                 static_for<0, R>([&](auto aa) {
                     constexpr int a = decltype(aa)::value;
-                    xa[pass][a] = buf_f32(rx, (sA + G * a) * 4);
-                    if constexpr (PAIR) xb2[pass][a] = buf_f32(rx, (sA + p.hop + G * a) * 4);
+                    xa[ti][pass][a] = buf_f32(rx, (sA + G * a) * 4);
+                    if constexpr (PAIR) xb2[ti][pass][a] = buf_f32(rx, (sA + p.hop + G * a) * 4);
                 });
             } else {
                 static_for<0, R>([&](auto aa) {
                     constexpr int a = decltype(aa)::value;
-                    xa[pass][a] = buf_f32(rx, clampi(sA + G * a, p.L - 1) * 4);
-                    if constexpr (PAIR) xb2[pass][a] = buf_f32(rx, clampi(sA + p.hop + G * a, p.L - 1) * 4);
+                    xa[ti][pass][a] = buf_f32(rx, clampi(sA + G * a, p.L - 1) * 4);
+                    if constexpr (PAIR) xb2[ti][pass][a] = buf_f32(rx, clampi(sA + p.hop + G * a, p.L - 1) * 4);
                 });
             }
         });
+    };
+
+    // ================= prologue, once per workgroup ============================================
+    float mean = 0.f;
+    float2 wkeep[WPT];                                          // this thread's window entries (TPW > 1: written back per tile)
+    float2 wmid = make_float2(1.f, 0.f);                        // ... and the centre entry
+    if (!dbg_skip_fft) {
+        load_tile(IC<0>{});
         STAMP(1);   // loads issued
         // lambd (device scalar or by value) and the check that this launch is the n_fft the device value asks for
         const LamState ls = lam_prologue(p.lam, N, blockIdx.x == 0 && tid == 0);
@@ -371,8 +406,8 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                 // no launch of this forward matched the device lambd: NaN instead of stale memory (the host raises too)
                 const int rows = IS_SPEC ? F : p.M;
                 const float qn = __builtin_nanf("");
-                for (int idx = tid; idx < rows * FPT; idx += THREADS) {
-                    const int rr = idx / FPT, t = t0 + idx % FPT;
+                for (int idx = tid; idx < rows * FPT * TPW; idx += THREADS) {
+                    const int rr = idx / (FPT * TPW), t = tile0 * FPT + idx % (FPT * TPW);
                     if (t >= p.T) continue;
                     const size_t o = ((size_t)b * rows + rr) * p.T + t;
                     if (p.flags & 4u) reinterpret_cast<unsigned short*>(p.out)[o] = 0x7fc0u; else p.out[o] = qn;
@@ -381,24 +416,41 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
             }
             return;
         }
-        lam_bits = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ls.lam));
+        // d out / d lambd = htan * (contraction of the scaled tangent spectrum): an fp64 division, done by ONE wave of the
+        // workgroup and handed to the epilogue through LDS (every barrier below lies between this store and that load)
+        if constexpr (MODE == kTrain || MODE == kSpecTrain) {
+            if (wave == 0) { const float h = 0.5f * lam_tangent_scale(ls); if (lane == 0) red[16] = h; }
+        }
         if constexpr (TW2_LDS) { if (tid < R * C) tw2l[tid] = p.tw2[tid]; }          // visible after the barrier below
         // ---- window table into LDS (time_frequency.py:21-30): every workgroup evaluates the same fp32
         // expression, so the table is identical everywhere; this replaces a separate kernel launch
         if constexpr (WIN_LDS) {
             const float denom = ls.denom;
             float s_ww = 0.f, s_wd = 0.f;
-            for (int n = tid; n < N; n += THREADS) {
-                const float d = (float)n - (float)N / 2.0f;
-                const float t = d / denom;
-                float w = expf(-0.5f * (t * t));
-                if (p.win_half && (n < N / 4 || n >= 3 * N / 4)) w = 0.f;     // torch.stft pads a win_length = N/2 window
-                // tangent window up to a constant: w d^2 2^(-2e) (d^2 and the scaling are exact in fp32: one rounding); the
-                // factor sign 2^(2e) / (|lambd| + 1e-15)^3 is applied once per output in the epilogue (lam_tangent_scale)
-                const float dw = w * (d * d) * ls.s2;
-                wtab[n] = make_float2(w, dw);
-                s_ww += w * w; s_wd += w * dw;
-            }
+            // w[N/2 + d] = w[N/2 - d]: entry n < N/2 is computed once and stored at n and N - n (n = 0 has no mirror);
+            // the centre is exp(-0) = 1 with a zero tangent
+            static_for<0, WPT>([&](auto ww_) {
+                constexpr int wi = decltype(ww_)::value;
+                const int n = tid + THREADS * wi;
+                wkeep[wi] = make_float2(0.f, 0.f);
+                if (n < N / 2) {
+                    const float d = (float)n - (float)N / 2.0f;
+                    const float t = d / denom;
+                    float w = expf(-0.5f * (t * t));
+                    if (p.win_half && n < N / 4) w = 0.f;                         // torch.stft pads a win_length = N/2 window
+                    // tangent window up to a constant: w d^2 2^(-2e) (d^2 and the scaling are exact in fp32: one rounding); the
+                    // factor sign 2^(2e) / (|lambd| + 1e-15)^3 is applied once per output in the epilogue (lam_tangent_scale)
+                    const float dw = w * (d * d) * ls.s2;
+                    wkeep[wi] = make_float2(w, dw);
+                    wtab[n] = wkeep[wi];
+                    // the half-length window of torch.stft sits at [N/4, 3N/4): its mirror image stops one entry short
+                    const bool has_mirror = n > 0 && !(p.win_half && n <= N / 4);
+                    if (n > 0) wtab[N - n] = has_mirror ? wkeep[wi] : make_float2(0.f, 0.f);
+                    const float mult = has_mirror ? 2.f : 1.f;
+                    s_ww += mult * (w * w); s_wd += mult * (w * dw);
+                }
+            });
+            if (tid == 0) { wtab[N / 2] = make_float2(1.f, 0.f); s_ww += 1.f; }
             if (p.normalize) {
                 // time_frequency.py:25: w / sqrt(sum w^2) and the derivative of the quotient (fixed-order sums)
                 s_ww = wave_sum(s_ww);
@@ -414,16 +466,23 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                     const float2 e = wtab[n];
                     wtab[n] = make_float2(e.x * inv, e.y * inv - e.x * wd * inv * inv * inv);
                 }
+                if constexpr (TPW > 1) {
+                    __syncthreads();
+                    static_for<0, WPT>([&](auto ww_) {
+                        constexpr int wi = decltype(ww_)::value;
+                        const int n = tid + THREADS * wi;
+                        if (n < N / 2) wkeep[wi] = wtab[n];
+                    });
+                    wmid = wtab[N / 2];
+                }
             }
         }
         // ---- clip mean (models.py:38) --------------------------------------------------------------
-        float mean = 0.f;
         if (p.remove_dc && p.psum == nullptr) {
             // short clips: every workgroup adds up its clip itself (L2 hits after the first toucher), in a
             // fixed order, instead of a separate pass over x
             // Loads go out in batches of 8 per thread before anything is added: one memory round trip per batch
-            // instead of one per load (a plain loop waits for every load before issuing the next).  Hoisting the first
-            // batch above the sample loads, and the filterbank prefetch below the mean, was measured: no change.
+            // instead of one per load (a plain loop waits for every load before issuing the next).
             const float* xc = p.x + (size_t)b * p.L;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
             int i = 0;
@@ -470,371 +529,416 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
             }
         }
         STAMP(2);   // window table + clip mean done
-        static_for<0, PASSES>([&](auto pp) {
-            constexpr int pass = decltype(pp)::value;
-            const int slot = pass * (WAVES * FPW) + wave * FPW + j;
-            v2f* sl = lds + slot * SS;
-            const int tA = PAIR ? (t0 + 2 * slot) : (t0 + slot);
-            const int f0 = tA * p.hop - N / 2;                       // first sample of frame tA
-            const int f1 = PAIR ? f0 + p.hop : f0;
-            // zero padding of torch.stft(center=True, pad_mode='constant') applies AFTER the DC removal
-            const bool inside_w = inside[pass];
-            v2f z[R];
-            // window entries of this lane: one base register + compile-time offsets (ds_read_b64 offset:512a)
-            int wbyte = (WIN_LDS ? g.AUX_OFF : 0) + lg * 8;
-            asm volatile("" : "+v"(wbyte));
-            auto wload = [&](int a) -> v2f {
-                float2 wd2;                                              // (w[n], dw[n] / d|lambd| * scale)
-                if constexpr (WIN_LDS) wd2 = *reinterpret_cast<const float2*>(smem_raw + wbyte + G * 8 * a);
-                else wd2 = *reinterpret_cast<const float2*>(reinterpret_cast<const unsigned char*>(p.win2) + wbyte + G * 8 * a);
-                return v2f{wd2.x, wd2.y};
-            };
-            if (inside_w) {
-                static_for<0, R>([&](auto aa) {
-                    constexpr int a = decltype(aa)::value;
-                    const v2f wd = wload(a);
-                    const float va = xa[pass][a] - mean;
-                    if constexpr (!PAIR) z[a] = splat(va) * wd;
-                    else z[a] = v2f{va, xb2[pass][a] - mean} * wd.xx;
-                });
-            } else {
-                static_for<0, R>([&](auto aa) {
-                    constexpr int a = decltype(aa)::value;
-                    const int n = lg + G * a;
-                    const v2f wd = wload(a);
-                    const int ia = f0 + n;
-                    const float va = ((ia >= 0) && (ia < p.L)) ? xa[pass][a] - mean : 0.f;
-                    if constexpr (!PAIR) z[a] = splat(va) * wd;
-                    else {
-                        const int ib = f1 + n;
-                        const float vb = ((ib >= 0) && (ib < p.L)) ? xb2[pass][a] - mean : 0.f;
-                        z[a] = v2f{va, vb} * wd.xx;
-                    }
-                });
-            }
-            STAMP(3);   // samples arrived, windowed
-            fft_reg<R>(z);
-            STAMP(4);   // radix-R #1
-            // twiddle w_N^(lg*q), transposition through LDS: S[q][lg]
-            static_for<0, R>([&](auto qq) {
-                constexpr int q = decltype(qq)::value;
-                v2f v = z[bitrev(q, LB)];
-                if constexpr (q != 0) v = cmul(v, p.tw1[q * G + lg]);
-                sl[q * EXS + lg] = v;
-            });
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            v2f u[R];
-            static_for<0, R>([&](auto bb) {
-                constexpr int bi = decltype(bb)::value;
-                u[bi] = sl[qp * EXS + r + C * bi];
-            });
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            STAMP(5);   // twiddle + LDS transposition
-            fft_reg<R>(u);
-            STAMP(6);   // radix-R #2
-            // twiddle w_G^(r*p1), radix-C across adjacent lanes, spectrum to LDS in natural order
-            const v2f rot_f = splat((C == 4 && r == 3) ? 0.f : 1.f);
-            const v2f rot_e = (C == 4 && r == 3) ? v2f{1.f, -1.f} : v2f{0.f, 0.f};
-            static_for<0, R>([&](auto pp1) {
-                constexpr int p1 = decltype(pp1)::value;
-                v2f v = u[bitrev(p1, LB)];
-                int p2 = 0;
-                if constexpr (C > 1) {
-                    if constexpr (p1 != 0) {
-                        float2 w2;
-                        if constexpr (TW2_LDS) w2 = tw2l[p1 * C + r]; else w2 = p.tw2[p1 * C + r];
-                        v = cmul(v, w2);
-                    }
-                }
-                if constexpr (C == 2) {
-                    const v2f o = v2f{quad_xor1(v.x), quad_xor1(v.y)};
-                    v = __builtin_elementwise_fma(splat((r == 0) ? 1.f : -1.f), v, o);
-                    p2 = r;
-                } else if constexpr (C == 4) {
-                    v2f o = v2f{quad_xor2(v.x), quad_xor2(v.y)};
-                    v2f t = __builtin_elementwise_fma(splat((r < 2) ? 1.f : -1.f), v, o);
-                    t = __builtin_elementwise_fma(t.yx, rot_e, t * rot_f);      // lane r == 3: t * (-i); others: t
-                    o = v2f{quad_xor1(t.x), quad_xor1(t.y)};
-                    v = __builtin_elementwise_fma(splat(((r & 1) == 0) ? 1.f : -1.f), t, o);
-                    p2 = ((r & 1) << 1) | (r >> 1);
-                }
-                const int k = qp + R * p1 + R * R * p2;
-                sl[z_index<R, C>(k)] = v;
-            });
-            // ---- pairing pass: the two real spectra packed in Z are separated ONCE per bin here, by the wave
-            // that owns the slot, instead of by every A-fragment builder in phase 2:
-            //   S = Z[k] + conj Z[N-k], D = Z[k] - conj Z[N-k];  PD[k] = (|S|^2, Im(conj S * D))   (train: 4|X|^2, 2 d|X|^2)
-            //                                                    PD[k] = (|S|^2, |D|^2)           (pairs: 4|Xa|^2, 4|Xb|^2)
-            // stored in place over Z[0 .. N/2] (all reads of the wave precede its writes: LDS is in order per wave)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            constexpr int NPAIR = N / (2 * G) + 1;           // bins lg + G*i <= N/2
-            // Addresses are one of four per-lane byte bases plus a compile-time offset (ds_read_b64 offset:...):
-            //   Z[k],   k = lg + G i:            zb + 8 (G i + pad(G i))
-            //   Z[N-k], lg >= 1:                 mb + 8 (c_i + pad(c_i)),  mb = slot + 8 (G - lg),  c_i = N - G (i + 1)
-            //   lane 0: N - G i itself; it sits one padding step further when it starts an R*R block (mbA), and
-            //   wraps to bin 0 for i = 0 (mb0).
-            constexpr int PADC = (C > 1) ? 4 : 0, RR = R * R;
-            const int slot_b = slot * (SS * 8);
-            int zb = slot_b + lg * 8;
-            int mb = slot_b + (G - lg) * 8;
-            int mbA = mb + ((lg == 0) ? PADC * 8 : 0);
-            int mb0 = (lg == 0) ? slot_b : mb + (N - G + PADC * ((N - G) / RR)) * 8;       // full address of Z[N-k] for i = 0
-            asm volatile("" : "+v"(zb), "+v"(mb), "+v"(mbA), "+v"(mb0));
-            v2f pd[NPAIR];
-            static_for<0, NPAIR>([&](auto ii) {
-                constexpr int i = decltype(ii)::value;
-                constexpr int ck = G * i, cm = N - G * (i + 1);
-                constexpr bool crossing = PADC != 0 && ((N - G * i) % RR) == 0;
-                const int mbase = (i == 0) ? mb0 : (crossing ? mbA : mb);
-                const v2f zk = *reinterpret_cast<const v2f*>(smem_raw + zb + (ck + PADC * (ck / RR)) * 8);
-                const v2f zn = *reinterpret_cast<const v2f*>(smem_raw + mbase + ((i == 0) ? 0 : (cm + PADC * (cm / RR)) * 8));
-                const float sx = zk.x + zn.x, sy = zk.y - zn.y, dx = zk.x - zn.x, dy = zk.y + zn.y;
-                if constexpr (!PAIR) pd[i] = v2f{fmaf(sx, sx, sy * sy), fmaf(sx, dy, -(sy * dx))};
-                else pd[i] = v2f{fmaf(sx, sx, sy * sy), fmaf(dx, dx, dy * dy)};
-            });
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            static_for<0, NPAIR>([&](auto ii) {
-                constexpr int i = decltype(ii)::value;
-                constexpr int ck = G * i;
-                v2f* dst = reinterpret_cast<v2f*>(smem_raw + zb + (ck + PADC * (ck / RR)) * 8);
-                if (i < NPAIR - 1 || lg == 0) *dst = pd[i];          // the last round holds only the Nyquist bin
-            });
-        });
-    }
-    STAMP(7);   // twiddle + cross-lane radix-C + spectrum to LDS + pairing pass
-    __syncthreads();
-    STAMP(8);   // barrier
-#ifdef DMEL_ABLATE
-    if (dbg_skip_gemm) { if (tid == 0 && lds[0].x == 12345.678f) p.out[0] = 0.f; return; }
-#endif
-    // d out / d lambd = htan * (contraction of the scaled tangent spectrum): see lam_prologue / lam_tangent_scale
-    float htan = 0.f;
-    if constexpr (MODE == kTrain || MODE == kSpecTrain) {
-        LamState lt;
-        lt.lam = __builtin_bit_cast(float, lam_bits);
-        lt.denom = __builtin_fabsf(lt.lam) + 1e-15f;
-        int e = 1;
-        if (__builtin_fabsf(lt.lam) > 1e-30f) e = __builtin_amdgcn_frexp_expf(__builtin_fabsf(lt.lam));
-        lt.e2 = 2 * (e < -30 ? -30 : (e > 30 ? 30 : e));
-        htan = 0.5f * lam_tangent_scale(lt);
     }
 
-    if constexpr (IS_SPEC) {
-        // power spectrogram (time_frequency.py:53), layout (B, F, T); kSpecTrain also writes d P / d lambd
-        for (int idx = tid; idx < SLOTS * F; idx += THREADS) {
-            const int k = idx / SLOTS, slot = idx % SLOTS;
-            const v2f pdv = (lds + slot * SS)[z_index<R, C>(k)];
-            if constexpr (MODE == kSpec) {
-                const int t = t0 + 2 * slot;
-                float* o = p.out + ((size_t)b * F + k) * p.T;
-                if (t < p.T) o[t] = 0.25f * pdv.x;
-                if (t + 1 < p.T) o[t + 1] = 0.25f * pdv.y;
-            } else {
-                const int t = t0 + slot;
-                if (t < p.T) {
-                    const size_t o = ((size_t)b * F + k) * p.T + t;
-                    p.out[o] = 0.25f * pdv.x;
-                    if (p.tangent) p.tangent[o] = htan * pdv.y;
-                }
+    // ================= the tiles of this workgroup ==============================================
+    static_for<0, TPW>([&](auto tt) {
+        constexpr int ti = decltype(tt)::value;
+        if (ti > 0 && tile0 + ti >= p.tiles_per_clip) return;          // the clip has no such tile (same answer in every wave)
+        const int t0 = (tile0 + ti) * FPT;
+        if constexpr (ti > 0) {
+            // the FFT slots (every wave has read the previous tile's spectra before the barriers of its phase 2 or the one
+            // here) and the window table / half-tile exchange region are used again
+            __syncthreads();
+            // this tile's samples: requested here (behind the barrier, where the registers of the previous tile's matrix phase
+            // are free; requested earlier they have to live through that phase and spill); the window rewrite covers part
+            // of the round trip, and the lines were touched by the neighbouring frames before
+            __builtin_amdgcn_sched_barrier(0);
+            if (!dbg_skip_fft) load_tile(IC<ti>{});
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (WIN_ALIASED) {
+                static_for<0, WPT>([&](auto ww_) {
+                    constexpr int wi = decltype(ww_)::value;
+                    const int n = tid + THREADS * wi;
+                    if (n < N / 2) {
+                        wtab[n] = wkeep[wi];
+                        if (n > 0) wtab[N - n] = (p.win_half && n <= N / 4) ? make_float2(0.f, 0.f) : wkeep[wi];
+                    }
+                });
+                if (tid == 0) wtab[N / 2] = wmid;
+                __syncthreads();
             }
         }
-        return;
-    } else {
-        // ================= phase 2: mel contraction on the matrix cores ======================
-        const int row16 = lane & 15;
-        const int slot8 = 2 * (row16 >> 2) + (row16 & 1);
-        const int type = (row16 >> 1) & 1;
-        const int kofs = lane >> 4;
-        const int cg = lane >> 4;      // accumulator row group of this lane (C/D layout)
-        const int col = lane & 15;
-
-        for (int grp = 0; grp < p.groups; ++grp) {
-            // acc[loc][mt][parity]: two accumulators per tile so that consecutive MFMAs never wait on each other
-            floatx4 acc[NLOC][MT][2];
-            static_for<0, NLOC>([&](auto l) { static_for<0, MT>([&](auto m) { static_for<0, 2>([&](auto e) {
-                acc[decltype(l)::value][decltype(m)::value][decltype(e)::value] = floatx4{0.f, 0.f, 0.f, 0.f}; }); }); });
-            int tile_of[NLOC];
-            static_for<0, NLOC>([&](auto l) {
-                constexpr int loc = decltype(l)::value;
-                // (ks0, nks, boff, tile): the filterbank is banded, so the non-zero 4x16 blocks of one mel tile
-                // form ONE contiguous run of k-steps; nks is padded to a multiple of 4 with zero blocks
-                int4 tr = tr0[loc];
-                if (grp > 0) tr = p.tile_ranges[(grp * WAVES + wave) * NLOC + loc];
-                const int ks0 = __builtin_amdgcn_readfirstlane(tr.x), nks = __builtin_amdgcn_readfirstlane(tr.y);
-                const int boff = __builtin_amdgcn_readfirstlane(tr.z);
-                tile_of[loc] = __builtin_amdgcn_readfirstlane(tr.w);
-#ifdef DMEL_ABLATE
-                if (p.flags & 0x800u) return;                       // timing ablation: skip the MFMA loop
-#endif
-                if (nks <= 0) return;
-                const int bbase = (boff + lane) * 4;
-                // One group = 4 consecutive k-steps = 16 consecutive bins starting at a multiple of 16 (the host
-                // aligns every run to 4 k-steps), so the 4 reads of Z[k] share one base address and, except at one
-                // bin per 256, so do the 4 reads of the mirrored Z[N-k].
-                auto group4 = [&](int ksg, float b0, float b1, float b2, float b3) {
-                    const float bq[4] = {b0, b1, b2, b3};
-                    const int k0 = 4 * ksg + kofs;                               // bin of k-step 0 for this lane
-                    const int zk0 = z_index<R, C>(k0 & (N - 1));
-                    static_for<0, MT>([&](auto m) {
-                        constexpr int mt = decltype(m)::value;
-                        const int slot = mt * 8 + slot8;
-                        const bool valid = slot < SLOTS;
-                        // rows of type 0 read PD.x (|S|^2), rows of type 1 PD.y: the A operand is a plain 4-byte LDS read
-                        const float* slf = reinterpret_cast<const float*>(lds + (valid ? slot : 0) * SS) + type;
-                        float av[4];
-                        static_for<0, 4>([&](auto uu) { constexpr int u = decltype(uu)::value; av[u] = slf[2 * (zk0 + 4 * u)]; });
-                        static_for<0, 4>([&](auto uu) {
-                            constexpr int u = decltype(uu)::value;
-                            float val = av[u];
-                            if constexpr (SLOTS < 8) val = valid ? val : 0.f;
-                            acc[loc][mt][u & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(val, bq[u], acc[loc][mt][u & 1], 0, 0, 0);
-                        });
-                    });
+        // ================= phase 1: FFT of this wave's frames ====================================
+        if (!dbg_skip_fft) {
+            static_for<0, PASSES>([&](auto pp) {
+                constexpr int pass = decltype(pp)::value;
+                const int slot = pass * (WAVES * FPW) + wave * FPW + j;
+                v2f* sl = lds + slot * SS;
+                const int tA = PAIR ? (t0 + 2 * slot) : (t0 + slot);
+                const int f0 = tA * p.hop - N / 2;                       // first sample of frame tA
+                const int f1 = PAIR ? f0 + p.hop : f0;
+                // zero padding of torch.stft(center=True, pad_mode='constant') applies AFTER the DC removal
+                const bool inside_w = inside[ti][pass];
+                v2f z[R];
+                // window entries of this lane: one base register + compile-time offsets (ds_read_b64 offset:512a)
+                int wbyte = (WIN_LDS ? g.AUX_OFF : 0) + lg * 8;
+                asm volatile("" : "+v"(wbyte));
+                auto wload = [&](int a) -> v2f {
+                    float2 wd2;                                              // (w[n], dw[n] / d|lambd| * scale)
+                    if constexpr (WIN_LDS) wd2 = *reinterpret_cast<const float2*>(smem_raw + wbyte + G * 8 * a);
+                    else wd2 = *reinterpret_cast<const float2*>(reinterpret_cast<const unsigned char*>(p.win2) + wbyte + G * 8 * a);
+                    return v2f{wd2.x, wd2.y};
                 };
-                if (grp == 0) {
-                    // k-steps whose B fragments are already in registers
-                    static_for<0, NBPRE / 4>([&](auto qq) {
-                        constexpr int i = decltype(qq)::value * 4;
-                        if (i < nks) group4(ks0 + i, bpre[loc][i], bpre[loc][i + 1], bpre[loc][i + 2], bpre[loc][i + 3]);
+                if (inside_w) {
+                    static_for<0, R>([&](auto aa) {
+                        constexpr int a = decltype(aa)::value;
+                        const v2f wd = wload(a);
+                        const float va = xa[ti][pass][a] - mean;
+                        if constexpr (!PAIR) z[a] = splat(va) * wd;
+                        else z[a] = v2f{va, xb2[ti][pass][a] - mean} * wd.xx;
+                    });
+                } else {
+                    static_for<0, R>([&](auto aa) {
+                        constexpr int a = decltype(aa)::value;
+                        const int n = lg + G * a;
+                        const v2f wd = wload(a);
+                        const int ia = f0 + n;
+                        const float va = ((ia >= 0) && (ia < p.L)) ? xa[ti][pass][a] - mean : 0.f;
+                        if constexpr (!PAIR) z[a] = splat(va) * wd;
+                        else {
+                            const int ib = f1 + n;
+                            const float vb = ((ib >= 0) && (ib < p.L)) ? xb2[ti][pass][a] - mean : 0.f;
+                            z[a] = v2f{va, vb} * wd.xx;
+                        }
                     });
                 }
-                // the rest (long runs: dense custom filterbanks, further mel groups) streams with a 4-step prefetch
-                const int istart = (grp == 0) ? NBPRE : 0;
-                if (istart < nks) {
-                    float bc[4], bn[4];
-                    static_for<0, 4>([&](auto u) { bc[decltype(u)::value] = buf_f32(rb, bbase + (istart + decltype(u)::value) * 256); });
-                    for (int i = istart; i < nks; i += 4) {
-                        static_for<0, 4>([&](auto u) { bn[decltype(u)::value] = buf_f32(rb, bbase + (i + 4 + decltype(u)::value) * 256); });
-                        group4(ks0 + i, bc[0], bc[1], bc[2], bc[3]);
-                        static_for<0, 4>([&](auto u) { bc[decltype(u)::value] = bn[decltype(u)::value]; });
+                STAMP(3);   // samples arrived, windowed
+                fft_reg<R>(z);
+                STAMP(4);   // radix-R #1
+                // twiddle w_N^(lg*q), transposition through LDS: S[q][lg]
+                static_for<0, R>([&](auto qq) {
+                    constexpr int q = decltype(qq)::value;
+                    v2f v = z[bitrev(q, LB)];
+                    if constexpr (q != 0) v = cmul(v, p.tw1[q * G + lg]);
+                    sl[q * EXS + lg] = v;
+                });
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                v2f u[R];
+                static_for<0, R>([&](auto bb) {
+                    constexpr int bi = decltype(bb)::value;
+                    u[bi] = sl[qp * EXS + r + C * bi];
+                });
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                STAMP(5);   // twiddle + LDS transposition
+                // the radix-C twiddles w_G^(r*p1) are requested before the second radix-R stage, not one by one inside the
+                // cross-lane stage (each read there was waited for on the spot)
+                float2 tw2r[R];
+                if constexpr (C > 1) {
+                    static_for<1, R>([&](auto pp1) {
+                        constexpr int p1 = decltype(pp1)::value;
+                        if constexpr (TW2_LDS) tw2r[p1] = tw2l[p1 * C + r]; else tw2r[p1] = p.tw2[p1 * C + r];
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                fft_reg<R>(u);
+                STAMP(6);   // radix-R #2
+                // twiddle w_G^(r*p1), radix-C across adjacent lanes, spectrum to LDS in natural order
+                const v2f rot_f = splat((C == 4 && r == 3) ? 0.f : 1.f);
+                const v2f rot_e = (C == 4 && r == 3) ? v2f{1.f, -1.f} : v2f{0.f, 0.f};
+                static_for<0, R>([&](auto pp1) {
+                    constexpr int p1 = decltype(pp1)::value;
+                    v2f v = u[bitrev(p1, LB)];
+                    int p2 = 0;
+                    if constexpr (C > 1) {
+                        if constexpr (p1 != 0) v = cmul(v, tw2r[p1]);
+                    }
+                    if constexpr (C == 2) {
+                        const v2f o = v2f{quad_xor1(v.x), quad_xor1(v.y)};
+                        v = __builtin_elementwise_fma(splat((r == 0) ? 1.f : -1.f), v, o);
+                        p2 = r;
+                    } else if constexpr (C == 4) {
+                        v2f o = v2f{quad_xor2(v.x), quad_xor2(v.y)};
+                        v2f t = __builtin_elementwise_fma(splat((r < 2) ? 1.f : -1.f), v, o);
+                        t = __builtin_elementwise_fma(t.yx, rot_e, t * rot_f);      // lane r == 3: t * (-i); others: t
+                        o = v2f{quad_xor1(t.x), quad_xor1(t.y)};
+                        v = __builtin_elementwise_fma(splat(((r & 1) == 0) ? 1.f : -1.f), t, o);
+                        p2 = ((r & 1) << 1) | (r >> 1);
+                    }
+                    const int k = qp + R * p1 + R * R * p2;
+                    sl[z_index<R, C>(k)] = v;
+                });
+                // the filterbank fragments of phase 2 are requested here: the registers of the FFT are free, and the pairing
+                // pass plus the barrier behind it cover the round trip
+                if constexpr (pass == PASSES - 1) { fetch_bpre(); __builtin_amdgcn_sched_barrier(0); }
+                // ---- pairing pass: the two real spectra packed in Z are separated ONCE per bin here, by the wave
+                // that owns the slot, instead of by every A-fragment builder in phase 2:
+                //   S = Z[k] + conj Z[N-k], D = Z[k] - conj Z[N-k];  PD[k] = (|S|^2, Im(conj S * D))   (train: 4|X|^2, 2 d|X|^2)
+                //                                                    PD[k] = (|S|^2, |D|^2)           (pairs: 4|Xa|^2, 4|Xb|^2)
+                // stored in place over Z[0 .. N/2] (all reads of the wave precede its writes: LDS is in order per wave)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                constexpr int NPAIR = N / (2 * G) + 1;           // bins lg + G*i <= N/2
+                // Addresses are one of four per-lane byte bases plus a compile-time offset (ds_read_b64 offset:...):
+                //   Z[k],   k = lg + G i:            zb + 8 (G i + pad(G i))
+                //   Z[N-k], lg >= 1:                 mb + 8 (c_i + pad(c_i)),  mb = slot + 8 (G - lg),  c_i = N - G (i + 1)
+                //   lane 0: N - G i itself; it sits one padding step further when it starts an R*R block (mbA), and
+                //   wraps to bin 0 for i = 0 (mb0).
+                constexpr int PADC = (C > 1) ? 4 : 0, RR = R * R;
+                const int slot_b = slot * (SS * 8);
+                int zb = slot_b + lg * 8;
+                int mb = slot_b + (G - lg) * 8;
+                int mbA = mb + ((lg == 0) ? PADC * 8 : 0);
+                int mb0 = (lg == 0) ? slot_b : mb + (N - G + PADC * ((N - G) / RR)) * 8;       // full address of Z[N-k] for i = 0
+                asm volatile("" : "+v"(zb), "+v"(mb), "+v"(mbA), "+v"(mb0));
+                v2f pd[NPAIR];
+                static_for<0, NPAIR>([&](auto ii) {
+                    constexpr int i = decltype(ii)::value;
+                    constexpr int ck = G * i, cm = N - G * (i + 1);
+                    constexpr bool crossing = PADC != 0 && ((N - G * i) % RR) == 0;
+                    const int mbase = (i == 0) ? mb0 : (crossing ? mbA : mb);
+                    const v2f zk = *reinterpret_cast<const v2f*>(smem_raw + zb + (ck + PADC * (ck / RR)) * 8);
+                    const v2f zn = *reinterpret_cast<const v2f*>(smem_raw + mbase + ((i == 0) ? 0 : (cm + PADC * (cm / RR)) * 8));
+                    const float sx = zk.x + zn.x, sy = zk.y - zn.y, dx = zk.x - zn.x, dy = zk.y + zn.y;
+                    if constexpr (!PAIR) pd[i] = v2f{fmaf(sx, sx, sy * sy), fmaf(sx, dy, -(sy * dx))};
+                    else pd[i] = v2f{fmaf(sx, sx, sy * sy), fmaf(dx, dx, dy * dy)};
+                });
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                static_for<0, NPAIR>([&](auto ii) {
+                    constexpr int i = decltype(ii)::value;
+                    constexpr int ck = G * i;
+                    v2f* dst = reinterpret_cast<v2f*>(smem_raw + zb + (ck + PADC * (ck / RR)) * 8);
+                    if (i < NPAIR - 1 || lg == 0) *dst = pd[i];          // the last round holds only the Nyquist bin
+                });
+            });
+        }
+        STAMP(7);   // twiddle + cross-lane radix-C + spectrum to LDS + pairing pass
+        __syncthreads();
+        STAMP(8);   // barrier
+#ifdef DMEL_ABLATE
+        if (dbg_skip_gemm) { if (tid == 0 && lds[0].x == 12345.678f) p.out[0] = 0.f; return; }
+#endif
+        float htan = 0.f;
+        if constexpr (MODE == kTrain || MODE == kSpecTrain) htan = red[16];       // see the prologue
+        if constexpr (IS_SPEC) {
+            // power spectrogram (time_frequency.py:53), layout (B, F, T); kSpecTrain also writes d P / d lambd
+            for (int idx = tid; idx < SLOTS * F; idx += THREADS) {
+                const int k = idx / SLOTS, slot = idx % SLOTS;
+                const v2f pdv = (lds + slot * SS)[z_index<R, C>(k)];
+                if constexpr (MODE == kSpec) {
+                    const int t = t0 + 2 * slot;
+                    float* o = p.out + ((size_t)b * F + k) * p.T;
+                    if (t < p.T) o[t] = 0.25f * pdv.x;
+                    if (t + 1 < p.T) o[t + 1] = 0.25f * pdv.y;
+                } else {
+                    const int t = t0 + slot;
+                    if (t < p.T) {
+                        const size_t o = ((size_t)b * F + k) * p.T + t;
+                        p.out[o] = 0.25f * pdv.x;
+                        if (p.tangent) p.tangent[o] = htan * pdv.y;
                     }
                 }
-            });
-            STAMP(9);   // MFMA loops
-            // ---- epilogue: accumulators -> (B,1,M,T) ------------------------------------------
-            const bool do_log = (p.flags & 1u) != 0;
-            const bool out_bf16 = (p.flags & 4u) != 0;
-            floatx4 tot[NLOC][MT];
-            static_for<0, NLOC>([&](auto l) { static_for<0, MT>([&](auto m) {
-                tot[decltype(l)::value][decltype(m)::value] = acc[decltype(l)::value][decltype(m)::value][0] + acc[decltype(l)::value][decltype(m)::value][1]; }); });
-            if constexpr (WAVES == 8) {
-                // run 1 of this wave is the second half of tile 7-wave: hand it to its owner through LDS
-                static_assert(MT == 1, "the half-tile exchange assumes one M-tile");
-                floatx4* xch = reinterpret_cast<floatx4*>(smem_raw + SLOTS * SS * 8);
-                xch[(7 - wave) * 64 + lane] = tot[1][0];
-                __syncthreads();
-                tot[0][0] += xch[wave * 64 + lane];
-                if (p.groups > 1) __syncthreads();
-                tile_of[1] = -1;
             }
-            STAMP(10);  // half-tile exchange
+        } else {
+            // ================= phase 2: mel contraction on the matrix cores ======================
+            const int row16 = lane & 15;
+            const int slot8 = 2 * (row16 >> 2) + (row16 & 1);
+            const int type = (row16 >> 1) & 1;
+            const int kofs = lane >> 4;
+            const int cg = lane >> 4;      // accumulator row group of this lane (C/D layout)
+            const int col = lane & 15;
+
+            for (int grp = 0; grp < p.groups; ++grp) {
+                // acc[loc][mt][parity]: two accumulators per tile so that consecutive MFMAs never wait on each other
+                floatx4 acc[NLOC][MT][2];
+                static_for<0, NLOC>([&](auto l) { static_for<0, MT>([&](auto m) { static_for<0, 2>([&](auto e) {
+                    acc[decltype(l)::value][decltype(m)::value][decltype(e)::value] = floatx4{0.f, 0.f, 0.f, 0.f}; }); }); });
+                int tile_of[NLOC];
+                static_for<0, NLOC>([&](auto l) {
+                    constexpr int loc = decltype(l)::value;
+                    // (ks0, nks, boff, tile): the filterbank is banded, so the non-zero 4x16 blocks of one mel tile
+                    // form ONE contiguous run of k-steps; nks is padded to a multiple of 4 with zero blocks
+                    int4 tr = tr0[loc];
+                    if (grp > 0) tr = p.tile_ranges[(grp * WAVES + wave) * NLOC + loc];
+                    const int ks0 = __builtin_amdgcn_readfirstlane(tr.x), nks = __builtin_amdgcn_readfirstlane(tr.y);
+                    const int boff = __builtin_amdgcn_readfirstlane(tr.z);
+                    tile_of[loc] = __builtin_amdgcn_readfirstlane(tr.w);
 #ifdef DMEL_ABLATE
-            if (p.flags & 0x400u) continue;                        // timing ablation: skip the epilogue
+                    if (p.flags & 0x800u) return;                       // timing ablation: skip the MFMA loop
 #endif
-            static_for<0, NLOC>([&](auto l) {
-                constexpr int loc = decltype(l)::value;
-                const int nt = tile_of[loc];
-                if (nt < 0) return;
-                const int m = 16 * nt + col;
-                if (m >= p.M) return;
-                const size_t rbase = ((size_t)b * p.M + m) * p.T;
-                float* orow = p.out + rbase;
-                unsigned short* orow_h = reinterpret_cast<unsigned short*>(p.out) + rbase;     // DMEL_FLAG_OUT_BF16: out is bf16
-                float* trow = p.tangent ? p.tangent + rbase : nullptr;
-                auto put = [&](int t, float v) { if (out_bf16) orow_h[t] = bf16_bits(v); else orow[t] = v; };
-                static_for<0, MT>([&](auto mm) {
-                    constexpr int mt = decltype(mm)::value;
-                    const floatx4 a = tot[loc][mt];
-                    if constexpr (MODE == kTrain) {
-                        // rows 4cg+i: i=0,1 -> |X|^2 of slots 2cg, 2cg+1; i=2,3 -> d|X|^2 of the same slots
-                        const int tp = t0 + mt * 8 + 2 * cg;
-                        if (((p.T | t0) & 1) == 0 && mt * 8 + 2 * cg + 1 < SLOTS && tp + 1 < p.T) {
-                            // even T: both frames of this lane form one aligned 8-byte store per tensor
-                            float2 o2, t2;
+                    if (nks <= 0) return;
+                    const int bbase = (boff + lane) * 4;
+                    // One group = 4 consecutive k-steps = 16 consecutive bins starting at a multiple of 16 (the host
+                    // aligns every run to 4 k-steps), so the 4 reads of Z[k] share one base address and, except at one
+                    // bin per 256, so do the 4 reads of the mirrored Z[N-k].
+                    auto group4 = [&](int ksg, float b0, float b1, float b2, float b3) {
+                        const float bq[4] = {b0, b1, b2, b3};
+                        const int k0 = 4 * ksg + kofs;                               // bin of k-step 0 for this lane
+                        const int zk0 = z_index<R, C>(k0 & (N - 1));
+                        static_for<0, MT>([&](auto m) {
+                            constexpr int mt = decltype(m)::value;
+                            const int slot = mt * 8 + slot8;
+                            const bool valid = slot < SLOTS;
+                            // rows of type 0 read PD.x (|S|^2), rows of type 1 PD.y: the A operand is a plain 4-byte LDS read
+                            const float* slf = reinterpret_cast<const float*>(lds + (valid ? slot : 0) * SS) + type;
+                            float av[4];
+                            static_for<0, 4>([&](auto uu) { constexpr int u = decltype(uu)::value; av[u] = slf[2 * (zk0 + 4 * u)]; });
+                            static_for<0, 4>([&](auto uu) {
+                                constexpr int u = decltype(uu)::value;
+                                float val = av[u];
+                                if constexpr (SLOTS < 8) val = valid ? val : 0.f;
+                                acc[loc][mt][u & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(val, bq[u], acc[loc][mt][u & 1], 0, 0, 0);
+                            });
+                        });
+                    };
+                    if (grp == 0) {
+                        // k-steps whose B fragments are already in registers
+                        static_for<0, NBPRE / 4>([&](auto qq) {
+                            constexpr int i = decltype(qq)::value * 4;
+                            if (i < nks) group4(ks0 + i, bpre[loc][i], bpre[loc][i + 1], bpre[loc][i + 2], bpre[loc][i + 3]);
+                        });
+                    }
+                    // the rest (long runs: dense custom filterbanks, further mel groups) streams with a 4-step prefetch
+                    const int istart = (grp == 0) ? NBPRE : 0;
+                    if (istart < nks) {
+                        float bc[4], bn[4];
+                        static_for<0, 4>([&](auto u) { bc[decltype(u)::value] = buf_f32(rb, bbase + (istart + decltype(u)::value) * 256); });
+                        for (int i = istart; i < nks; i += 4) {
+                            static_for<0, 4>([&](auto u) { bn[decltype(u)::value] = buf_f32(rb, bbase + (i + 4 + decltype(u)::value) * 256); });
+                            group4(ks0 + i, bc[0], bc[1], bc[2], bc[3]);
+                            static_for<0, 4>([&](auto u) { bc[decltype(u)::value] = bn[decltype(u)::value]; });
+                        }
+                    }
+                });
+                STAMP(9);   // MFMA loops
+                // ---- epilogue: accumulators -> (B,1,M,T) ------------------------------------------
+                const bool do_log = (p.flags & 1u) != 0;
+                const bool out_bf16 = (p.flags & 4u) != 0;
+                floatx4 tot[NLOC][MT];
+                static_for<0, NLOC>([&](auto l) { static_for<0, MT>([&](auto m) {
+                    tot[decltype(l)::value][decltype(m)::value] = acc[decltype(l)::value][decltype(m)::value][0] + acc[decltype(l)::value][decltype(m)::value][1]; }); });
+                if constexpr (WAVES == 8) {
+                    // run 1 of this wave is the second half of tile 7-wave: hand it to its owner through LDS
+                    floatx4* xch = reinterpret_cast<floatx4*>(smem_raw + SLOTS * SS * 8);
+                    static_for<0, MT>([&](auto mm) { constexpr int mt = decltype(mm)::value; xch[((7 - wave) * MT + mt) * 64 + lane] = tot[1][mt]; });
+                    __syncthreads();
+                    static_for<0, MT>([&](auto mm) { constexpr int mt = decltype(mm)::value; tot[0][mt] += xch[(wave * MT + mt) * 64 + lane]; });
+                    if (p.groups > 1) __syncthreads();
+                    tile_of[1] = -1;
+                }
+                STAMP(10);  // half-tile exchange
+#ifdef DMEL_ABLATE
+                if (p.flags & 0x400u) continue;                        // timing ablation: skip the epilogue
+#endif
+                static_for<0, NLOC>([&](auto l) {
+                    constexpr int loc = decltype(l)::value;
+                    const int nt = tile_of[loc];
+                    if (nt < 0) return;
+                    const int m = 16 * nt + col;
+                    if (m >= p.M) return;
+                    const size_t rbase = ((size_t)b * p.M + m) * p.T;
+                    float* orow = p.out + rbase;
+                    unsigned short* orow_h = reinterpret_cast<unsigned short*>(p.out) + rbase;     // DMEL_FLAG_OUT_BF16: out is bf16
+                    float* trow = p.tangent ? p.tangent + rbase : nullptr;
+                    auto put = [&](int t, float v) { if (out_bf16) orow_h[t] = bf16_bits(v); else orow[t] = v; };
+                    static_for<0, MT>([&](auto mm) {
+                        constexpr int mt = decltype(mm)::value;
+                        const floatx4 a = tot[loc][mt];
+                        if constexpr (MODE == kTrain) {
+                            // rows 4cg+i: i=0,1 -> |X|^2 of slots 2cg, 2cg+1; i=2,3 -> d|X|^2 of the same slots
+                            const int tp = t0 + mt * 8 + 2 * cg;
+                            if (((p.T | t0) & 1) == 0 && mt * 8 + 2 * cg + 1 < SLOTS && tp + 1 < p.T) {
+                                // even T: both frames of this lane form one aligned 8-byte store per tensor
+                                float2 o2, t2;
+                                static_for<0, 2>([&](auto ss) {
+                                    constexpr int s = decltype(ss)::value;
+                                    const float mel = 0.25f * a[s];
+                                    const float dmel = htan * a[2 + s];
+                                    const float me = mel + p.eps;
+                                    (s == 0 ? o2.x : o2.y) = do_log ? logf(me) : mel;
+                                    (s == 0 ? t2.x : t2.y) = do_log ? dmel * __builtin_amdgcn_rcpf(me) : dmel;
+                                });
+                                if (out_bf16) *reinterpret_cast<unsigned*>(orow_h + tp) = (unsigned)bf16_bits(o2.x) | ((unsigned)bf16_bits(o2.y) << 16);
+                                else *reinterpret_cast<float2*>(orow + tp) = o2;
+                                if (trow) *reinterpret_cast<float2*>(trow + tp) = t2;
+                            } else
                             static_for<0, 2>([&](auto ss) {
                                 constexpr int s = decltype(ss)::value;
-                                const float mel = 0.25f * a[s];
-                                const float dmel = htan * a[2 + s];
-                                const float me = mel + p.eps;
-                                (s == 0 ? o2.x : o2.y) = do_log ? logf(me) : mel;
-                                (s == 0 ? t2.x : t2.y) = do_log ? dmel / me : dmel;
-                            });
-                            if (out_bf16) *reinterpret_cast<unsigned*>(orow_h + tp) = (unsigned)bf16_bits(o2.x) | ((unsigned)bf16_bits(o2.y) << 16);
-                            else *reinterpret_cast<float2*>(orow + tp) = o2;
-                            if (trow) *reinterpret_cast<float2*>(trow + tp) = t2;
-                        } else
-                        static_for<0, 2>([&](auto ss) {
-                            constexpr int s = decltype(ss)::value;
-                            const int slot = mt * 8 + 2 * cg + s;
-                            const int t = t0 + slot;
-                            if (slot < SLOTS && t < p.T) {
-                                const float mel = 0.25f * a[s];
-                                const float dmel = htan * a[2 + s];
-                                if (do_log) {
-                                    const float me = mel + p.eps;
-                                    put(t, logf(me));
-                                    if (trow) trow[t] = dmel / me;
-                                } else {
-                                    put(t, mel);
-                                    if (trow) trow[t] = dmel;
+                                const int slot = mt * 8 + 2 * cg + s;
+                                const int t = t0 + slot;
+                                if (slot < SLOTS && t < p.T) {
+                                    const float mel = 0.25f * a[s];
+                                    const float dmel = htan * a[2 + s];
+                                    if (do_log) {
+                                        const float me = mel + p.eps;
+                                        put(t, logf(me));
+                                        if (trow) trow[t] = dmel * __builtin_amdgcn_rcpf(me);
+                                    } else {
+                                        put(t, mel);
+                                        if (trow) trow[t] = dmel;
+                                    }
                                 }
-                            }
-                        });
-                    } else {
-                        // slot holds frames (2*slot, 2*slot+1) as (type 0, type 1)
-                        static_for<0, 4>([&](auto ii) {
-                            constexpr int i = decltype(ii)::value;
-                            const int slot = mt * 8 + 2 * cg + (i & 1);
-                            const int t = t0 + 2 * slot + (i >> 1);
-                            if (slot < SLOTS && t < p.T) {
-                                const float mel = 0.25f * a[i];
-                                put(t, do_log ? logf(mel + p.eps) : mel);
-                            }
-                        });
-                    }
+                            });
+                        } else {
+                            // slot holds frames (2*slot, 2*slot+1) as (type 0, type 1)
+                            static_for<0, 4>([&](auto ii) {
+                                constexpr int i = decltype(ii)::value;
+                                const int slot = mt * 8 + 2 * cg + (i & 1);
+                                const int t = t0 + 2 * slot + (i >> 1);
+                                if (slot < SLOTS && t < p.T) {
+                                    const float mel = 0.25f * a[i];
+                                    put(t, do_log ? logf(mel + p.eps) : mel);
+                                }
+                            });
+                        }
+                    });
                 });
-            });
-            STAMP(11);  // epilogue stores issued
+                STAMP(11);  // epilogue stores issued
+            }
         }
-    }
+    });
 }
 
-template <int N, int MODE> static hipError_t launch_one(const FwdParams& p, int grid, hipStream_t s)
+template <int N, int MODE, int TPW> static hipError_t launch_one(const FwdParams& p, int grid, hipStream_t s)
 {
     constexpr FftGeom g = geom<N>();
     constexpr int lds = g.LDS_BYTES;
-    hipLaunchKernelGGL((dmel_fwd_kernel<N, MODE>), dim3(grid), dim3(g.THREADS), lds, s, p);
+    hipLaunchKernelGGL((dmel_fwd_kernel<N, MODE, TPW>), dim3(grid), dim3(g.THREADS), lds, s, p);
     return hipGetLastError();
 }
 
-template <int N> static hipError_t launch_n(int mode, const FwdParams& p, int grid, hipStream_t s)
+// two tiles per workgroup are built for the sizes whose launches are large enough to use them (forward_tiles_per_wg)
+template <int N> constexpr bool has_tpw2() { return N >= 256 && N <= 2048; }
+
+template <int N> static hipError_t launch_n(int mode, int tpw, const FwdParams& p, int grid, hipStream_t s)
 {
+    if constexpr (has_tpw2<N>()) {
+        if (tpw == 2) {
+            switch (mode) {
+                case kTrain: return launch_one<N, kTrain, 2>(p, grid, s);
+                case kInfer: return launch_one<N, kInfer, 2>(p, grid, s);
+                case kSpec: return launch_one<N, kSpec, 2>(p, grid, s);
+                case kSpecTrain: return launch_one<N, kSpecTrain, 2>(p, grid, s);
+            }
+            return hipErrorInvalidValue;
+        }
+    }
+    if (tpw != 1) return hipErrorInvalidValue;
     switch (mode) {
-        case kTrain: return launch_one<N, kTrain>(p, grid, s);
-        case kInfer: return launch_one<N, kInfer>(p, grid, s);
-        case kSpec: return launch_one<N, kSpec>(p, grid, s);
-        case kSpecTrain: return launch_one<N, kSpecTrain>(p, grid, s);
+        case kTrain: return launch_one<N, kTrain, 1>(p, grid, s);
+        case kInfer: return launch_one<N, kInfer, 1>(p, grid, s);
+        case kSpec: return launch_one<N, kSpec, 1>(p, grid, s);
+        case kSpecTrain: return launch_one<N, kSpecTrain, 1>(p, grid, s);
     }
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_forward(int n_fft, int mode, const FwdParams& p, int grid, hipStream_t s)
+hipError_t launch_forward(int n_fft, int mode, int tpw, const FwdParams& p, int grid, hipStream_t s)
 {
     switch (n_fft) {
-        case 32: return launch_n<32>(mode, p, grid, s);
-        case 64: return launch_n<64>(mode, p, grid, s);
-        case 128: return launch_n<128>(mode, p, grid, s);
-        case 256: return launch_n<256>(mode, p, grid, s);
-        case 512: return launch_n<512>(mode, p, grid, s);
-        case 1024: return launch_n<1024>(mode, p, grid, s);
-        case 2048: return launch_n<2048>(mode, p, grid, s);
-        case 4096: return launch_n<4096>(mode, p, grid, s);
+        case 32: return launch_n<32>(mode, tpw, p, grid, s);
+        case 64: return launch_n<64>(mode, tpw, p, grid, s);
+        case 128: return launch_n<128>(mode, tpw, p, grid, s);
+        case 256: return launch_n<256>(mode, tpw, p, grid, s);
+        case 512: return launch_n<512>(mode, tpw, p, grid, s);
+        case 1024: return launch_n<1024>(mode, tpw, p, grid, s);
+        case 2048: return launch_n<2048>(mode, tpw, p, grid, s);
+        case 4096: return launch_n<4096>(mode, tpw, p, grid, s);
     }
     return hipErrorInvalidValue;
 }
@@ -864,6 +968,20 @@ int forward_frames_per_tile(int n_fft, int mode)
     return (mode == kTrain || mode == kSpecTrain) ? slots : 2 * slots;
 }
 
+// Tiles per workgroup for a launch over `batch` clips of `tiles_per_clip` tiles.  A launch runs in rounds of the workgroups
+// the chip holds at once (160 KB of LDS per CU, 256 CUs); a two-tile workgroup lives about 1.9 times as long as a one-tile
+// one (it pays the prologue once: measured 21.97 against 23.1 us at BASELINE config 2, one round instead of two).  Two tiles
+// are used when that model says the launch gets shorter -- e.g. not for 5 rounds becoming 3 double ones (config 3).
+int forward_tiles_per_wg(int n_fft, int batch, int tiles_per_clip)
+{
+    if (n_fft < 256 || n_fft > 2048 || tiles_per_clip < 2 || batch < 1) return 1;
+    const int lds = forward_lds_bytes(n_fft);
+    const long long resident = 256LL * (lds > 0 && 163840 / lds > 0 ? 163840 / lds : 1);
+    const long long wg1 = (long long)batch * tiles_per_clip, wg2 = (long long)batch * ((tiles_per_clip + 1) / 2);
+    const long long r1 = (wg1 + resident - 1) / resident, r2 = (wg2 + resident - 1) / resident;
+    return 19 * r2 < 10 * r1 ? 2 : 1;
+}
+
 int forward_waves(int n_fft)
 {
     switch (n_fft) {
@@ -884,18 +1002,25 @@ int forward_nbpre(int n_fft)
     return -1;
 }
 
-template <int N, int MODE> static hipError_t set_attr()
+template <int N, int MODE, int TPW> static hipError_t set_attr()
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&dmel_fwd_kernel<N, MODE>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&dmel_fwd_kernel<N, MODE, TPW>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_of<N>());
 }
 template <int N> static hipError_t set_attr_n()
 {
     hipError_t e;
-    if ((e = set_attr<N, kTrain>()) != hipSuccess) return e;
-    if ((e = set_attr<N, kInfer>()) != hipSuccess) return e;
-    if ((e = set_attr<N, kSpec>()) != hipSuccess) return e;
-    return set_attr<N, kSpecTrain>();
+    if ((e = set_attr<N, kTrain, 1>()) != hipSuccess) return e;
+    if ((e = set_attr<N, kInfer, 1>()) != hipSuccess) return e;
+    if ((e = set_attr<N, kSpec, 1>()) != hipSuccess) return e;
+    if ((e = set_attr<N, kSpecTrain, 1>()) != hipSuccess) return e;
+    if constexpr (has_tpw2<N>()) {
+        if ((e = set_attr<N, kTrain, 2>()) != hipSuccess) return e;
+        if ((e = set_attr<N, kInfer, 2>()) != hipSuccess) return e;
+        if ((e = set_attr<N, kSpec, 2>()) != hipSuccess) return e;
+        if ((e = set_attr<N, kSpecTrain, 2>()) != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t forward_prepare_attributes()

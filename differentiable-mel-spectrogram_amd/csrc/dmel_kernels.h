@@ -46,13 +46,16 @@ struct LamState {
 };
 
 #if defined(__HIPCC__)
-// time_frequency.py:39,60-65 on the device, bit for bit the host's dmel_n_fft: fp32 product, int() truncation, 1 << bit_length(x-1)
+// time_frequency.py:39,60-65 on the device, bit for bit the host's dmel_n_fft: fp32 product, int() truncation,
+// 1 << bit_length(x-1).  lambd is uniform: after one multiply and one conversion the value is moved to a scalar register and
+// the rest is scalar integer arithmetic (the conversion saturates at INT_MAX, which lands in the same "too large" answer
+// as the host's 64-bit path; NaN converts to 0).
 __device__ __forceinline__ int lam_n_fft(float a)
 {
     const float prod = a * 6.0f;
-    if (!(prod < 9.0e15f)) return 0x40000000;
-    const long long v = (long long)prod - 1;
-    const int bits = v < 0 ? 1 : (v == 0 ? 0 : 64 - __builtin_clzll((unsigned long long)v));
+    const int x = __builtin_amdgcn_readfirstlane((int)prod);
+    const int v = x - 1;
+    const int bits = v < 0 ? 1 : (v == 0 ? 0 : 32 - __builtin_clz((unsigned)v));
     return bits > 30 ? 0x40000000 : (1 << bits);
 }
 
@@ -60,14 +63,13 @@ __device__ __forceinline__ int lam_n_fft(float a)
 __device__ __forceinline__ LamState lam_prologue(const LamArgs& la, int n_launch, bool leader)
 {
     LamState st;
-    st.lam = la.dev ? __builtin_nontemporal_load(la.dev) : la.val;
+    st.lam = la.dev ? *la.dev : la.val;                               // uniform address: a scalar load
     st.a = __builtin_fabsf(st.lam);
     st.denom = st.a + 1e-15f;
-    int e = 1;
-    if (st.a > 1e-30f) e = __builtin_amdgcn_frexp_expf(st.a);
+    int e = __builtin_amdgcn_readfirstlane(st.a > 1e-30f ? __builtin_amdgcn_frexp_expf(st.a) : 1);
     e = e < -30 ? -30 : (e > 30 ? 30 : e);
     st.e2 = 2 * e;
-    st.s2 = __builtin_ldexpf(1.0f, -2 * e);
+    st.s2 = __builtin_bit_cast(float, (127 - 2 * e) << 23);           // 2^(-2e), built in scalar registers
     const bool match = la.n_expected == 0 || lam_n_fft(st.a) == n_launch;
     st.action = match ? kLamRun : kLamSkip;
     if (la.role & kLamQuiet) return st;
@@ -122,6 +124,7 @@ template <> struct FftPlan<1024> { static constexpr int R = 16, C = 4, PASSES = 
 template <> struct FftPlan<2048> { static constexpr int R = 32, C = 2, PASSES = 1, WAVES = 8, NBPRE = 40, MINW = 2; };
 template <> struct FftPlan<4096> { static constexpr int R = 64, C = 1, PASSES = 1, WAVES = 4, NBPRE = 8, MINW = 1; };
 
+constexpr int kRedBytes = 80;          // 8 + 8 partial sums, then the tangent scale (word 16) computed once per workgroup
 struct FftGeom {
     int N, R, C, G, FPW, PASSES, WAVES, NLOC, THREADS, SLOTS, MT, EX_STRIDE, SLOT_STRIDE_F2, NBPRE, MINW, LDS_BYTES, AUX_OFF, RED_OFF, WIN_LDS;
 };
@@ -153,12 +156,12 @@ template <int N> constexpr FftGeom geom()
     g.SLOT_STRIDE_F2 = slot_stride_f2(N, P::R, P::C);
     // LDS map: [FFT slots][aux: window table (phase 1) aliased with the half-tile exchange (phase 2)][8 sums]
     g.WIN_LDS = (N <= 2048) ? 1 : 0;                      // n_fft 4096 has no room: its window stays in global memory
-    const int xch = (g.WAVES == 8) ? 8 * 64 * 16 : 0;
+    const int xch = (g.WAVES == 8) ? 8 * 64 * 16 * g.MT : 0;
     const int win = g.WIN_LDS ? N * 8 : 0;
     g.AUX_OFF = g.SLOTS * g.SLOT_STRIDE_F2 * 8;
     g.RED_OFF = g.AUX_OFF + (xch > win ? xch : win);
-    // [8 sums (64 B)][tw2 table: R x C complex, the radix-C twiddles: every lane of a wave reads one of C values per p1]
-    g.LDS_BYTES = g.RED_OFF + 64 + ((P::C > 1 && N <= 2048) ? P::R * P::C * 8 : 0);
+    // [16 sums + tangent scale (kRedBytes)][tw2 table: R x C complex, the radix-C twiddles: every lane of a wave reads one of C values per p1]
+    g.LDS_BYTES = g.RED_OFF + kRedBytes + ((P::C > 1 && N <= 2048) ? P::R * P::C * 8 : 0);
     return g;
 }
 
@@ -183,6 +186,7 @@ struct FwdParams {
     unsigned flags;
     int remove_dc, normalize;
     int win_half;               // window support = middle half of n_fft (DSPEC: win_length = n_fft / 2)
+    int wgs_per_clip;           // ceil(tiles_per_clip / tiles per workgroup)
 };
 
 struct PrepParams {
@@ -193,7 +197,8 @@ struct PrepParams {
 };
 
 hipError_t launch_prep(const PrepParams& p, hipStream_t s);
-hipError_t launch_forward(int n_fft, int mode, const FwdParams& p, int grid, hipStream_t s);
+hipError_t launch_forward(int n_fft, int mode, int tiles_per_wg, const FwdParams& p, int grid, hipStream_t s);
+int forward_tiles_per_wg(int n_fft, int batch, int tiles_per_clip);          // 1 or 2: what launch_forward should be given
 int forward_lds_bytes(int n_fft);
 int forward_frames_per_tile(int n_fft, int mode);
 int forward_waves(int n_fft);              // waves per workgroup of the fused kernel for this n_fft

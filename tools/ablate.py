@@ -5,6 +5,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
+os.environ.setdefault("DMEL_LIB", os.path.join(ROOT, "differentiable-mel-spectrogram_amd", "build", "libdmel_hip_ablate.so"))
 import dmel_amd
 from dmel_amd import capi, synth
 sys.path.insert(0, ROOT)

@@ -68,3 +68,36 @@ for i, nm in enumerate(NAMES):
 start = st[:, 0, 0] - t_first
 print("workgroup start times (cycles after the first): p10 %d  median %d  p90 %d  max %d" %
       (np.percentile(start, 10), np.median(start), np.percentile(start, 90), start.max()))
+# first round (the workgroups the dispatcher places at once) against the later ones
+cut = np.sort(start)[min(len(start) - 1, 2 * 256 - 1)] if len(start) > 512 else start.max()
+for label, sel in (("round 1 (placed at launch)", start <= cut), ("later rounds", start > cut)):
+    if sel.sum() == 0:
+        continue
+    tt = tot[sel]
+    print(f"{label}: {sel.sum()} workgroups, wave lifetime median {np.median(tt):.0f} max {tt.max()}")
+    for i, nm in enumerate(NAMES):
+        v = d[sel][:, :, i]
+        print(f"    {nm:32s} median {np.median(v):8.0f}   p90 {np.percentile(v, 90):8.0f}")
+# placement: HW_ID bits (gfx9): wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13 (3 bits; gfx950 uses more SEs: take 16:13); XCC_ID 3:0
+raw = buf.reshape(4096, 8, SL)[:nwg, 0, :]
+hw, xcc = raw[:, 12].astype(np.int64), raw[:, 13].astype(np.int64) & 0xF
+cu, sh, se = (hw >> 8) & 0xF, (hw >> 12) & 1, (hw >> 13) & 0xF
+place = xcc * 10000 + se * 100 + sh * 50 + cu
+uniq = len(set(place.tolist()))
+print(f"placement: {uniq} distinct (xcc, se, sh, cu) over {nwg} workgroups; XCC of the first 16 workgroups: {xcc[:16].tolist()}")
+t0w = st[:, 0, 0]
+for x in range(int(xcc.max()) + 1):
+    sel = np.flatnonzero(xcc == x)
+    base = t0w[sel].min()
+    order = sel[np.argsort(t0w[sel])]
+    firsts = [(int(i), int(t0w[i] - base), int(place[i] % 10000)) for i in order[:10]]
+    print(f"  xcc {x}: {len(sel)} workgroups; first ten (blockIdx, start-cycles, se*100+sh*50+cu): {firsts}")
+    # per CU: start times of its workgroups
+    cus = {}
+    for i in sel:
+        cus.setdefault(int(place[i]), []).append((int(t0w[i] - base), int(i)))
+    ex = sorted(cus.items())[:3]
+    for c, lst in ex:
+        print(f"     cu {c % 10000}: {sorted(lst)}")
+end = st[:, :, 11].max(axis=1) - t_first
+print("workgroup end times: p10 %d  median %d  p90 %d  max %d" % (np.percentile(end, 10), np.median(end), np.percentile(end, 90), end.max()))
