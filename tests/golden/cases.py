@@ -104,6 +104,9 @@ def load(case) -> dict:
 PANNS_CFG = dict(n_classes=50, lambd=8000 * 0.035 / 6, n_mels=64, sr=8000, L=8000, hop=80, B=3, seed=31)
 
 
+NET_CLASSES, NET_SEED = 10, 47          # g11_nets: MelConvNet / MelLinearNet logits (make_golden.run_nets)
+
+
 def fill_state(net, seed=0):
     """Overwrite every floating tensor of ``net.state_dict()`` except ``spectrogram_layer.*`` with closed-form pseudo-random
     values keyed on the entry's name, so that the reference net (make_golden.py) and ours (tests) carry identical weights

@@ -204,6 +204,42 @@ def run_xgrad(models, tf, case):
     return dict(gx_lin=g_lin.numpy().astype(np.float32)[:keep], gx_log=g_log.numpy().astype(np.float32)[:keep])
 
 
+NET_CASES = (
+    # (fixture key, net class, case name, energy_normalize)
+    ("conv_g1_log", "MelConvNet", "g1_c1", True),
+    ("conv_g1_lin", "MelConvNet", "g1_c1", False),
+    ("linear_g1_log", "MelLinearNet", "g1_c1", True),
+    ("linear_g4_log", "MelLinearNet", "g4_esc_hop441", True),
+)
+
+
+def run_nets(models):
+    """f1: logits and s of the reference's own MelConvNet / MelLinearNet (models.py:58-78, 105-136) on the G1 and G4 inputs,
+    weights from cases.fill_state.  MelLinearNet applies F.dropout(p=0.2) with its default training=True on every call
+    (models.py:75): for a deterministic fixture torch.nn.functional.dropout is replaced by the identity while the reference
+    runs (the test does the same to our net); MelConvNet has no dropout."""
+    import torch.nn.functional as F
+    out = {}
+    orig = F.dropout
+    F.dropout = lambda x, *a, **k: x
+    try:
+        for key, cls, cname, en in NET_CASES:
+            case = C.BY_NAME[cname]
+            net = getattr(models, cls)(C.NET_CLASSES, torch.tensor(float(case["lambd"])), "cpu", case["n_mels"], case["sr"], case["L"],
+                                       hop_length=case["hop"], optimized=True, energy_normalize=en)
+            C.fill_state(net, seed=C.NET_SEED)
+            x = torch.from_numpy(C.make_input(case))
+            with torch.no_grad():
+                logits, sp = net(x)
+            out[key + "_logits"] = logits.numpy().astype(np.float32)
+            sp_np = sp.numpy().astype(np.float32)
+            idx = C.sample_index(case)
+            out[key + "_s"] = sp_np if idx is None else sp_np.reshape(-1)[idx]
+    finally:
+        F.dropout = orig
+    return out
+
+
 def run_net_keys(models):
     """state_dict keys + shapes of the reference's wrapping nets (models.py:58-136): the checkpoint contract."""
     import json
@@ -223,7 +259,7 @@ def main(argv):
         argv = [a for a in argv if a != "net_keys"]
         if len(argv) == 1 and "net_keys" in sys.argv:
             return
-    names = argv[1:] or [c["name"] for c in C.CASES] + ["g7_dspec"] + ["g8_fbgrad_" + n for n in FBGRAD_CASES] + ["g9_panns"] + ["g10_xgrad_" + n for n in XGRAD_CASES]
+    names = argv[1:] or [c["name"] for c in C.CASES] + ["g7_dspec"] + ["g8_fbgrad_" + n for n in FBGRAD_CASES] + ["g9_panns"] + ["g10_xgrad_" + n for n in XGRAD_CASES] + ["g11_nets"]
     for name in names:
         if name == "g7_dspec":
             out = run_dspec(models, tf)
@@ -231,6 +267,8 @@ def main(argv):
             out = run_xgrad(models, tf, C.BY_NAME[name[len("g10_xgrad_"):]])
         elif name == "g9_panns":
             out = run_panns(models)
+        elif name == "g11_nets":
+            out = run_nets(models)
         elif name.startswith("g8_fbgrad_"):
             out = run_fbgrad(models, tf, C.BY_NAME[name[len("g8_fbgrad_"):]])
         else:

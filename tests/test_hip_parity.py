@@ -790,3 +790,84 @@ def test_unusual_shapes_match_oracle(case):
             yi = _layer(case, log=log, trainable=False)(x.detach())
         oi = yi.cpu().numpy()
         assert (_log_err(oi, o_ref) if log else _rel_err(oi, o_ref)) <= TOL
+
+
+# ---- f1: logits of the caller nets against the reference's own (tests/golden/g11_nets.npz) --------------------------------
+@pytest.mark.parametrize("key,cls,cname,en", [("conv_g1_log", "MelConvNet", "g1_c1", True), ("conv_g1_lin", "MelConvNet", "g1_c1", False),
+                                              ("linear_g1_log", "MelLinearNet", "g1_c1", True),
+                                              ("linear_g4_log", "MelLinearNet", "g4_esc_hop441", True)])
+def test_caller_nets_match_reference_logits(key, cls, cname, en, monkeypatch):
+    """`(logits, s)` of our MelConvNet / MelLinearNet on the G1 / G4 inputs against the reference's own nets (models.py:58-78,
+    105-136) with the same closed-form weights; F.dropout is the identity on both sides (models.py:75 keeps it always on)."""
+    import os
+    import torch.nn.functional as F
+    from dmel_amd import nets
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "g11_nets.npz"))
+    monkeypatch.setattr(F, "dropout", lambda x, *a, **k: x)
+    case = C.BY_NAME[cname]
+    net = getattr(nets, cls)(C.NET_CLASSES, torch.tensor(float(case["lambd"])), "cuda:0", case["n_mels"], case["sr"], case["L"],
+                             hop_length=case["hop"], optimized=True, energy_normalize=en)
+    C.fill_state(net, seed=C.NET_SEED)
+    net = net.to("cuda:0")
+    x = torch.from_numpy(C.make_input(case)).to("cuda:0")
+    with torch.no_grad():
+        logits, s = net(x)
+    s_np = s.cpu().numpy()
+    idx = C.sample_index(case)
+    got_s = s_np if idx is None else s_np.reshape(-1)[idx]
+    if en:
+        assert _log_err(got_s, gold[key + "_s"]) <= TOL
+    else:
+        assert _rel_err(got_s, gold[key + "_s"]) <= TOL
+    ref = gold[key + "_logits"]
+    assert logits.shape == ref.shape
+    # logits are sums over thousands of spectrogram bins: 1e-4 on s bounds them by about 1e-4 of their scale
+    assert float(np.abs(logits.cpu().numpy() - ref).max()) <= 3e-4 * float(np.abs(ref).max()) + 1e-5
+
+
+def test_config5_training_step_front_end_share():
+    """BASELINE config 5 at full size: ESC-50-shaped clips (32 x 220500 @ 44.1 kHz, hop 441, 128 mels, lambd 256 -> n_fft 2048)
+    through MelConvNet, CrossEntropy, Adam with the two learning-rate groups of main.py:36-53.  The front end's kernels are
+    isolated with the library's HIP-event profiling: three launches per step (partial sums, fused forward, dot), a few
+    per cent of the step."""
+    from dmel_amd import nets, synth
+    B, L, sr, lam, hop, M, ncls = 32, 220500, 44100, 256.0, 441, 128, 50
+    torch.manual_seed(0)
+    net = nets.MelConvNet(ncls, torch.tensor(lam), "cuda:0", M, sr, L, hop_length=hop, optimized=True, energy_normalize=True).to("cuda:0")
+    opt = nets.make_optimizer(net, lr_model=1e-4, lr_tf=1.0)
+    loss_fn = torch.nn.CrossEntropyLoss()
+    x = torch.from_numpy(synth.waveforms(B, L, seed=0)).to("cuda:0")
+    y = (torch.arange(B, device="cuda:0") * 7) % ncls
+    losses = []
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        logits, s = net(x)
+        loss = loss_fn(logits, y)
+        loss.backward()
+        opt.step()
+        losses.append(loss.detach())
+        return s
+
+    for _ in range(3):
+        s = step()
+    torch.cuda.synchronize()
+    assert s.shape == (B, 1, M, L // hop + 1) and net.spectrogram_layer.plan_info()["n_fft"] == 2048
+    plan = net.spectrogram_layer._plan_for(torch.device("cuda:0"))
+    plan.set_profiling(True)
+    import time
+    n = 4
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    dt_ms = 1e3 * (time.perf_counter() - t0) / n
+    pr = plan.get_profile()
+    plan.set_profiling(False)
+    assert (pr["prep_launches"], pr["fwd_launches"], pr["bwd_launches"]) == (n, n, n)       # no guard launches: lambd is far from a boundary
+    front_ms = (pr["prep_ms"] + pr["fwd_ms"] + pr["bwd_ms"]) / n
+    assert front_ms < 0.5, front_ms                                  # ~0.14 ms measured (profiles/)
+    assert front_ms / dt_ms < 0.15, (front_ms, dt_ms)                # ~3 % measured: the CNN dominates the step
+    ls = [float(v) for v in losses]
+    assert all(np.isfinite(ls)) and ls[-1] < ls[1]          # the first Adam step overshoots (3.95 -> 68), then the loss falls
+    assert float(net.spectrogram_layer.lambd) != lam and net.spectrogram_layer.lambd_status()["error"] == 0

@@ -91,3 +91,27 @@ def test_load_cnn6_checkpoint_remaps_keys(tmp_path):
     assert torch.equal(net.spectrogram_model.conv_block3.conv1.weight, donor.conv_block3.conv1.weight)
     with pytest.raises(FileNotFoundError):
         panns.load_cnn6_checkpoint(net, str(tmp_path / "missing.pth"))
+
+
+# ---- f1: the reference's own logits (tests/golden/g11_nets.npz, make_golden.run_nets) ----------------------------------
+def test_net_heads_reproduce_reference_logits_on_cpu(monkeypatch):
+    """The heads of MelConvNet / MelLinearNet (stock torch ops on CPU) fed with the `s` the reference's own run produced give the
+    reference's logits: same closed-form weights (cases.fill_state), dropout replaced by the identity as in the capture."""
+    import numpy as np
+    import torch.nn.functional as F
+    import cases as C
+    from dmel_amd import nets
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "g11_nets.npz"))
+    monkeypatch.setattr(F, "dropout", lambda x, *a, **k: x)
+    case = C.BY_NAME["g1_c1"]
+    for key, cls, en in (("conv_g1_log", "MelConvNet", True), ("conv_g1_lin", "MelConvNet", False), ("linear_g1_log", "MelLinearNet", True)):
+        net = getattr(nets, cls)(C.NET_CLASSES, torch.tensor(float(case["lambd"])), "cpu", case["n_mels"], case["sr"], case["L"],
+                                 hop_length=case["hop"], optimized=True, energy_normalize=en)
+        C.fill_state(net, seed=C.NET_SEED)
+        s = torch.from_numpy(gold[key + "_s"])
+        net._features = lambda x, s=s: s                      # the front end needs the GPU: feed the reference's spectrogram
+        with torch.no_grad():
+            logits, s_out = net(torch.zeros(case["B"], case["L"]))
+        ref = torch.from_numpy(gold[key + "_logits"])
+        assert logits.shape == ref.shape and s_out is s
+        assert float((logits - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6, key
