@@ -88,6 +88,13 @@ struct dmel_plan {
     // are ordered across streams by `xev` (see order_after_last_stream): two streams through one plan serialise, never race.
     unsigned char* own_scratch = nullptr;
     int own_scratch_clips = 0;
+    // transforms beyond the LDS kernels (dmel_big.hip): chirp / filter tables per DFT length, twiddles per FFT length, the
+    // window table and the per-workgroup sequences in global memory
+    struct BigTab { int M = 0, logM = 0; float2* chirp = nullptr; float2* hbr = nullptr; };
+    std::map<int, BigTab> big_tabs;
+    std::map<int, float2*> big_tw;
+    float2* big_win = nullptr; size_t big_win_n = 0;
+    float2* big_z = nullptr; size_t big_z_n = 0;
     float* fbw = nullptr;          // workspace of dmel_backward_fb (spectrogram (B, F, T) + slice partials) and dmel_backward_x
     size_t fbw_floats = 0;         // (frame gradients (B, T, N)); grown on demand
     hipStream_t last_stream = nullptr;
@@ -179,7 +186,8 @@ dmel_status build_tables(dmel_plan* pl, int N, NfftTables** out)
         DMEL_HIP(hipMalloc(&tb.rowband, rowband.size() * sizeof(int2)));
         DMEL_HIP(hipMemcpy(tb.rowband, rowband.data(), rowband.size() * sizeof(int2), hipMemcpyHostToDevice));
     }
-    if (N > dmel::kMaxFastNfft) {
+    const bool is_pow2 = (N & (N - 1)) == 0;
+    if (N > dmel::kMaxFastNfft || !is_pow2) {
         std::vector<float> fbT((size_t)M * tb.F);
         std::vector<int2> band(M);
         for (int m = 0; m < M; ++m) {
@@ -364,6 +372,84 @@ dmel_status ensure_own_scratch(dmel_plan* pl, int batch, hipStream_t s, Scratch*
     return DMEL_OK;
 }
 
+// in-place radix-2 FFT in double precision (host: the transform of Bluestein's chirp filter, once per DFT length)
+void host_fft(std::vector<double>& re, std::vector<double>& im)
+{
+    const size_t n = re.size();
+    for (size_t i = 1, j = 0; i < n; ++i) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { std::swap(re[i], re[j]); std::swap(im[i], im[j]); }
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        const double ang = -2.0 * M_PI / (double)len;
+        for (size_t s0 = 0; s0 < n; s0 += len)
+            for (size_t k = 0; k < len / 2; ++k) {
+                const double wr = std::cos(ang * (double)k), wi = std::sin(ang * (double)k);
+                const size_t a = s0 + k, b = a + len / 2;
+                const double tr = re[b] * wr - im[b] * wi, ti = re[b] * wi + im[b] * wr;
+                re[b] = re[a] - tr; im[b] = im[a] - ti;
+                re[a] += tr; im[a] += ti;
+            }
+    }
+}
+
+// tables of the big path for DFT length N: twiddles of the power-of-two FFT behind it and, when N is not a power of two,
+// Bluestein's chirp c[n] = exp(-i pi n^2 / N) and the transform of its filter
+dmel_status big_tables_for(dmel_plan* pl, int N, dmel_plan::BigTab* out, const float2** tw)
+{
+    const bool pow2 = (N & (N - 1)) == 0;
+    int M = N;
+    if (!pow2) { M = 1; while (M < 2 * N - 1) M <<= 1; }
+    if (M > dmel::kMaxBigFft)
+        return fail(DMEL_ERR_UNSUPPORTED, "transform length " + std::to_string(N) + " needs an FFT of " + std::to_string(M) +
+                    " points; the HIP path stops at " + std::to_string(dmel::kMaxBigFft));
+    auto tit = pl->big_tw.find(M);
+    if (tit == pl->big_tw.end()) {
+        std::vector<float2> t((size_t)std::max(1, M / 2));
+        for (int k = 0; k < M / 2; ++k) {
+            const double th = -2.0 * M_PI * (double)k / (double)M;
+            t[k] = make_float2((float)std::cos(th), (float)std::sin(th));
+        }
+        float2* d = nullptr;
+        DMEL_HIP(hipMalloc(&d, t.size() * sizeof(float2)));
+        DMEL_HIP(hipMemcpy(d, t.data(), t.size() * sizeof(float2), hipMemcpyHostToDevice));
+        tit = pl->big_tw.emplace(M, d).first;
+    }
+    *tw = tit->second;
+    auto bit = pl->big_tabs.find(N);
+    if (bit == pl->big_tabs.end()) {
+        dmel_plan::BigTab bt;
+        bt.M = M; bt.logM = 0; while ((1 << bt.logM) < M) ++bt.logM;
+        if (!pow2) {
+            std::vector<float2> chirp(N);
+            std::vector<double> hr(M, 0.0), hi(M, 0.0);
+            for (int k = 0; k < N; ++k) {
+                const long long q = ((long long)k * k) % (2LL * N);        // k^2 mod 2N: the phase argument stays small
+                const double a = M_PI * (double)q / (double)N;
+                chirp[k] = make_float2((float)std::cos(a), (float)(-std::sin(a)));
+                hr[k] = std::cos(a); hi[k] = std::sin(a);
+                if (k) { hr[M - k] = std::cos(a); hi[M - k] = std::sin(a); }
+            }
+            host_fft(hr, hi);
+            std::vector<float2> hbr(M);
+            for (int j = 0; j < M; ++j) {
+                unsigned r = 0;
+                for (int bbit = 0; bbit < bt.logM; ++bbit) r |= ((unsigned)(j >> bbit) & 1u) << (bt.logM - 1 - bbit);
+                hbr[r] = make_float2((float)(hr[j] / M), (float)(hi[j] / M));     // position r of a DIF output holds bin brev(r) = j
+            }
+            DMEL_HIP(hipMalloc(&bt.chirp, chirp.size() * sizeof(float2)));
+            DMEL_HIP(hipMemcpy(bt.chirp, chirp.data(), chirp.size() * sizeof(float2), hipMemcpyHostToDevice));
+            DMEL_HIP(hipMalloc(&bt.hbr, hbr.size() * sizeof(float2)));
+            DMEL_HIP(hipMemcpy(bt.hbr, hbr.data(), hbr.size() * sizeof(float2), hipMemcpyHostToDevice));
+        }
+        bit = pl->big_tabs.emplace(N, bt).first;
+    }
+    *out = bit->second;
+    return DMEL_OK;
+}
+
 // One launch (plus, when needed, the partial-sum / window-table kernel in front of it) of the forward for a given n_fft.
 // `lam` says where lambd comes from and whether the kernels check it against N (dmel_kernels.h); `sc` is the scratch of
 // this call.  Shared by every entry point; the plan mutex is held by the caller.
@@ -371,13 +457,66 @@ dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dm
                              float* out, float* tangent, int mode, int remove_dc, const Scratch& sc, hipStream_t s, int win_half,
                              bool* sums_done)
 {
-    if (N < 1 || (N & (N - 1)))
-        return fail(DMEL_ERR_UNSUPPORTED, "n_fft = " + std::to_string(N) + " is not a power of two");
-    if (N > dmel::kMaxNfft)
-        return fail(DMEL_ERR_UNSUPPORTED, "n_fft = " + std::to_string(N) + " > " + std::to_string(dmel::kMaxNfft) + " is not supported by the HIP kernels");
+    if (N < 1) return fail(DMEL_ERR_UNSUPPORTED, "n_fft = " + std::to_string(N));
+    const bool pow2 = (N & (N - 1)) == 0;
+    const bool big = !pow2 || N > dmel::kMaxNfft;
+    if (big && (N & 1)) return fail(DMEL_ERR_UNSUPPORTED, "n_fft = " + std::to_string(N) + " is odd");
     NfftTables* tb = nullptr;
     dmel_status st = build_tables(pl, N, &tb);
     if (st != DMEL_OK) return st;
+    // the whole-clip window of the optimized=False branches is centred at L/2 as a real number inside its L = n_fft/2 entries
+    // (time_frequency.py:24), which torch.stft places (n_fft - L) / 2 = L/2 (integer) entries into the frame
+    const float center = win_half ? (float)((N / 2) / 2) + (float)(N / 2) / 2.0f : (float)N / 2.0f;
+    if (big) {
+        // ---- lengths the LDS kernels do not reach: global-memory FFT / Bluestein (dmel_big.hip) ------------------------
+        dmel_plan::BigTab bt;
+        const float2* tw = nullptr;
+        if ((st = big_tables_for(pl, N, &bt, &tw)) != DMEL_OK) return st;
+        if ((st = order_after_last_stream(pl, s)) != DMEL_OK) return st;          // window table and sequences are plan-owned
+        const bool pair = (mode == dmel::kInfer || mode == dmel::kSpec);
+        const long long units = (long long)batch * (pair ? (pl->T + 1) / 2 : pl->T);
+        const int grid = dmel::big_grid(units, bt.M);
+        const size_t need_z = dmel::big_uses_global(bt.M) ? (size_t)grid * bt.M : 0;
+        if ((size_t)N > pl->big_win_n || need_z > pl->big_z_n) {
+            if (is_capturing(s)) return fail(DMEL_ERR_INVALID_ARGUMENT, "workspace must grow but the stream is capturing: run one call eagerly first");
+            DMEL_HIP(hipDeviceSynchronize());
+            if ((size_t)N > pl->big_win_n) {
+                (void)hipFree(pl->big_win); pl->big_win = nullptr; pl->big_win_n = 0;
+                DMEL_HIP(hipMalloc(&pl->big_win, (size_t)N * sizeof(float2)));
+                pl->big_win_n = (size_t)N;
+            }
+            if (need_z > pl->big_z_n) {
+                (void)hipFree(pl->big_z); pl->big_z = nullptr; pl->big_z_n = 0;
+                DMEL_HIP(hipMalloc(&pl->big_z, need_z * sizeof(float2)));
+                pl->big_z_n = need_z;
+            }
+        }
+        const bool need_sums = remove_dc && !*sums_done;
+        const size_t m0 = prof_mark(pl, s);
+        {
+            dmel::PrepParams pp{};
+            pp.x = x; pp.psum = sc.psum; pp.win2 = pl->big_win;
+            pp.B = need_sums ? batch : 0; pp.L = pl->cfg.n_points; pp.nchunks = pl->nchunks; pp.chunk = pl->chunk;
+            pp.N = N; pp.normalize = pl->cfg.normalize_window; pp.win_half = win_half; pp.center = center;
+            pp.lam = lam; pp.lam.role = dmel::kLamQuiet;
+            DMEL_HIP(dmel::launch_prep(pp, s));
+            if (need_sums) *sums_done = true;
+        }
+        const size_t m1 = prof_mark(pl, s);
+        prof_span(pl, m0, m1, 0);
+        dmel::BigParams bp{};
+        bp.x = x; bp.out = out; bp.tangent = tangent; bp.psum = sc.psum; bp.win2 = pl->big_win;
+        bp.tw = tw; bp.chirp = bt.chirp; bp.hbr = bt.hbr; bp.zws = pl->big_z; bp.fbT = tb->fbT; bp.band = tb->band;
+        bp.B = batch; bp.L = pl->cfg.n_points; bp.T = pl->T; bp.hop = pl->cfg.hop_length; bp.M = pl->cfg.n_mels;
+        bp.nchunks = pl->nchunks; bp.N = N; bp.F = tb->F; bp.mode = mode; bp.Mfft = bt.M; bp.logM = bt.logM;
+        bp.inv_L = 1.0f / (float)pl->cfg.n_points; bp.eps = (float)eps; bp.flags = flags; bp.remove_dc = remove_dc; bp.lam = lam;
+        DMEL_HIP(dmel::launch_big(bp, s));
+        prof_span(pl, m1, prof_mark(pl, s), 1);
+        pl->info.n_fft = N; pl->info.n_freqs = tb->F; pl->info.n_time = pl->T;
+        pl->info.kernel_path = 3; pl->info.frames_per_tile = pair ? 2 : 1; pl->info.grid_fwd = grid;
+        pl->info.fb_blocks = 0; pl->info.fb_blocks_dense = 0; pl->info.lds_bytes = dmel::big_uses_global(bt.M) ? 0 : bt.M * 8;
+        return DMEL_OK;
+    }
 
     // The fused kernel builds its own window table (n_fft <= 2048) and, for clips up to 32768 samples, its
     // own clip mean; the prep kernel only runs for what is left: partial sums of long clips, the window
@@ -391,7 +530,7 @@ dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dm
         dmel::PrepParams pp{};
         pp.x = x; pp.psum = sc.psum; pp.win2 = sc.win;
         pp.B = need_sums ? batch : 0; pp.L = pl->cfg.n_points; pp.nchunks = pl->nchunks; pp.chunk = pl->chunk;
-        pp.N = need_window ? N : 0; pp.normalize = pl->cfg.normalize_window; pp.win_half = win_half;
+        pp.N = need_window ? N : 0; pp.normalize = pl->cfg.normalize_window; pp.win_half = win_half; pp.center = center;
         pp.lam = lam; pp.lam.role = dmel::kLamQuiet;
         DMEL_HIP(dmel::launch_prep(pp, s));
         if (need_sums) *sums_done = true;
@@ -521,7 +660,7 @@ void lam_decide(const dmel_plan* pl, bool capturing, int* n_fft, int* guards)
             if ((a + reach) * 6.0f >= (float)N + 1.0f) g |= 2;
         }
     }
-    if (2 * N > dmel::kMaxNfft) g &= ~2;
+    if (2 * N > dmel::kMaxBigFft) g &= ~2;
     if (N < 2) g &= ~1;
     *n_fft = N; *guards = g;
 }
@@ -642,6 +781,7 @@ dmel_status dmel_plan_create(const dmel_config* cfg, dmel_plan** plan)
     DMEL_HIP(dmel::forward_prepare_attributes());
     DMEL_HIP(dmel::long_prepare_attributes());
     DMEL_HIP(dmel::xgrad_prepare_attributes());
+    DMEL_HIP(dmel::big_prepare_attributes());
     dmel_plan* pl = new (std::nothrow) dmel_plan();
     if (!pl) return fail(DMEL_ERR_OUT_OF_MEMORY, "host allocation failed");
     pl->cfg = *cfg;
@@ -672,6 +812,9 @@ dmel_status dmel_plan_destroy(dmel_plan* plan)
     for (auto& kv : plan->tables) kv.second.release();
     for (hipEvent_t e : plan->ev_pool) (void)hipEventDestroy(e);
     (void)hipFree(plan->own_scratch); (void)hipFree(plan->fbw);
+    for (auto& kv : plan->big_tabs) { (void)hipFree(kv.second.chirp); (void)hipFree(kv.second.hbr); }
+    for (auto& kv : plan->big_tw) (void)hipFree(kv.second);
+    (void)hipFree(plan->big_win); (void)hipFree(plan->big_z);
     if (plan->host_words) (void)hipHostFree(plan->host_words);
     if (plan->xev) (void)hipEventDestroy(plan->xev);
     delete plan;
@@ -702,8 +845,6 @@ dmel_status dmel_forward_scratch(dmel_plan* plan, const float* x, int32_t batch,
     if (flags & DMEL_FLAG_FULL_WINDOW) {
         if (!plan) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
         const int L = plan->cfg.n_points;
-        if ((L & (L - 1)) || 2 * L > dmel::kMaxNfft)
-            return fail(DMEL_ERR_UNSUPPORTED, "DMEL_FLAG_FULL_WINDOW needs n_points to be a power of two <= " + std::to_string(dmel::kMaxNfft / 2));
         return run_forward(plan, x, batch, lambd, flags & ~DMEL_FLAG_FULL_WINDOW, eps, static_cast<float*>(out), tangent,
                            tangent ? dmel::kTrain : dmel::kInfer, 1, stream, 2 * L, 1, scratch);
     }
@@ -779,7 +920,7 @@ dmel_status dmel_forward_dev(dmel_plan* plan, const float* x, int32_t batch, con
     if (!capturing) {
         NfftTables* tb = nullptr;
         for (int n : {N, 2 * N, N / 2})
-            if (n >= 1 && n <= dmel::kMaxNfft && (st = build_tables(plan, n, &tb)) != DMEL_OK) return st;
+            if (n >= 1 && n <= dmel::kMaxBigFft && (st = build_tables(plan, n, &tb)) != DMEL_OK) return st;
     }
     int cand[3], nc = 0;
     cand[nc++] = N;
@@ -990,7 +1131,7 @@ dmel_status dmel_backward_x(dmel_plan* plan, const float* x, int32_t batch, floa
     dmel::PrepParams pp{};
     pp.x = x; pp.psum = sc.psum; pp.win2 = sc.win;
     pp.B = batch; pp.L = plan->cfg.n_points; pp.nchunks = plan->nchunks; pp.chunk = plan->chunk;
-    pp.N = N; pp.normalize = plan->cfg.normalize_window; pp.win_half = 0;
+    pp.N = N; pp.normalize = plan->cfg.normalize_window; pp.win_half = 0; pp.center = (float)N / 2.0f;
     pp.lam.val = lambd; pp.lam.role = dmel::kLamQuiet;
     DMEL_HIP(dmel::launch_prep(pp, s));
     dmel::XgradParams xp{};

@@ -1,0 +1,189 @@
+// dmel_big.hip -- the forward for transform lengths the LDS kernels do not reach:
+//   * the optimized branch with |lambd| > 2730 samples: n_fft = 32768, 65536, ... (time_frequency.py:39 accepts any lambd);
+//   * the constructor's default branch optimized=False on clips whose length is not a power of two (time_frequency.py:41,51:
+//     window = whole clip, n_fft = 2 * n_points, e.g. Audio-MNIST's 8000 samples -> n_fft 16000, search_spaces.py:64) and
+//     the DSPEC layer on such clips (models.py:171-200).
+// One workgroup of 1024 threads transforms one complex sequence (a frame and its lambd-tangent, or two frames), held in LDS
+// when it fits and in a per-workgroup slice of a global workspace otherwise (the radix-2 passes of dmel_ldsfft.h work on
+// either: a workgroup's own stores are visible to it after __syncthreads()).  A length that is not a power of two goes through
+// Bluestein's chirp-z identity  n k = (n^2 + k^2 - (k - n)^2) / 2:
+//     X[k] = c[k] * sum_n (x[n] c[n]) conj(c)[k - n],   c[n] = exp(-i pi n^2 / N)
+// i.e. one forward FFT of length M >= 2N - 1, a pointwise product with the precomputed transform of the chirp filter, and
+// one inverse FFT (run as a forward FFT on the conjugate).  The pairing pass and the band-limited mel stage are those of the
+// long-transform kernel (dmel_aux.hip).  A correctness path for sizes training rarely reaches, not a tuned one.
+#include "dmel_kernels.h"
+#include "dmel_ldsfft.h"
+
+namespace dmel {
+
+constexpr int kBigThreads = 1024;
+
+__device__ __forceinline__ float big_wave_sum(float v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);       // same tree on every lane and every run
+    return v;
+}
+
+template <bool GLOBAL_Z>
+__global__ void __launch_bounds__(kBigThreads) dmel_big_kernel(BigParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* Z = GLOBAL_Z ? p.zws + (size_t)blockIdx.x * p.Mfft : reinterpret_cast<float2*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = p.N, M = p.Mfft, F = p.F, sh = 32 - p.logM;
+    const bool blue = p.chirp != nullptr;
+    const bool pair = (p.mode == kInfer || p.mode == kSpec);
+    const bool spec_mode = (p.mode == kSpec || p.mode == kSpecTrain);
+    const int tiles = pair ? (p.T + 1) / 2 : p.T;
+    const long long units = (long long)p.B * tiles;
+
+    const LamState ls = lam_prologue(p.lam, N, blockIdx.x == 0 && tid == 0);
+    if (ls.action != kLamRun) {
+        if (ls.action == kLamPoison) {           // no launch of this forward matched the device lambd (dmel_kernels.h)
+            const int rows = spec_mode ? F : p.M;
+            const long long total = (long long)p.B * rows * p.T;
+            for (long long o = (long long)blockIdx.x * kBigThreads + tid; o < total; o += (long long)gridDim.x * kBigThreads) {
+                if (p.flags & 4u) reinterpret_cast<unsigned short*>(p.out)[o] = 0x7fc0u; else p.out[o] = __builtin_nanf("");
+                if (p.tangent) p.tangent[o] = __builtin_nanf("");
+            }
+        }
+        return;
+    }
+    const float htan = 0.5f * lam_tangent_scale(ls);
+    // position of bin k inside Z: natural order after the Bluestein round trip, bit-reversed after a single DIF transform
+    auto pos = [&](int k) -> unsigned { return blue ? (unsigned)k : (M > 1 ? __brev((unsigned)k) >> sh : 0u); };
+
+    for (long long unit = blockIdx.x; unit < units; unit += gridDim.x) {
+        const int b = (int)(unit / tiles), tile = (int)(unit % tiles);
+        const int tA = pair ? 2 * tile : tile, tB = tA + 1;
+        const float* xb = p.x + (size_t)b * p.L;
+        float mean = 0.f;
+        if (p.remove_dc) {
+            double s = 0.0;
+            for (int c = 0; c < p.nchunks; ++c) s += (double)p.psum[(size_t)b * p.nchunks + c];
+            mean = (float)(s * (double)p.inv_L);
+        }
+        __syncthreads();                                   // the previous unit's readers are done with Z
+        for (int n = tid; n < M; n += kBigThreads) {
+            float2 z = make_float2(0.f, 0.f);
+            if (n < N) {
+                const long long ia = (long long)tA * p.hop - N / 2 + n;
+                const float va = (ia >= 0 && ia < p.L) ? (xb[ia] - mean) : 0.f;      // zero padding after the DC removal
+                const float2 wd = p.win2[n];
+                if (pair) {
+                    const long long ib = ia + p.hop;
+                    const float vb = (tB < p.T && ib >= 0 && ib < p.L) ? (xb[ib] - mean) : 0.f;
+                    z = make_float2(va * wd.x, vb * wd.x);
+                } else {
+                    z = make_float2(va * wd.x, va * wd.y);
+                }
+                if (blue) z = c_mul(z, p.chirp[n]);
+            }
+            Z[n] = z;
+        }
+        __syncthreads();
+        lds_fft_dif<kBigThreads>(Z, M, p.logM, tid, [&](int k) { return p.tw[k]; });
+        if (blue) {
+            // Y H / M at the bit-reversed positions the DIF left, conjugated: a forward DIT of that is the conjugate of the
+            // inverse transform, in natural order
+            for (int i = tid; i < M; i += kBigThreads) {
+                const float2 v = c_mul(Z[i], p.hbr[i]);
+                Z[i] = make_float2(v.x, -v.y);
+            }
+            __syncthreads();
+            lds_fft_dit<kBigThreads>(Z, M, p.logM, tid, [&](int k) { return p.tw[k]; });
+            for (int k = tid; k < N; k += kBigThreads) {
+                const float2 v = Z[k];
+                Z[k] = c_mul(make_float2(v.x, -v.y), p.chirp[k]);
+            }
+            __syncthreads();
+        }
+        // pairing pass (see dmel_fwd.hip): PD[k] = (|S|^2, Im(conj S * D)) or (|S|^2, |D|^2), in place at pos(k);
+        // the two addresses a thread touches belong to no other thread
+        for (int k = tid; k <= (N >> 1); k += kBigThreads) {
+            const unsigned ak = pos(k), an = pos((N - k) % N);
+            const float2 zk = Z[ak], zn = Z[an];
+            const float sx = zk.x + zn.x, sy = zk.y - zn.y, dx = zk.x - zn.x, dy = zk.y + zn.y;
+            Z[ak] = pair ? make_float2(fmaf(sx, sx, sy * sy), fmaf(dx, dx, dy * dy))
+                         : make_float2(fmaf(sx, sx, sy * sy), fmaf(sx, dy, -(sy * dx)));
+        }
+        __syncthreads();
+        if (spec_mode) {
+            for (int k = tid; k < F; k += kBigThreads) {
+                const float2 pd = Z[pos(k)];
+                const size_t o = ((size_t)b * F + k) * p.T;
+                if (p.mode == kSpec) {
+                    p.out[o + tA] = 0.25f * pd.x;
+                    if (tB < p.T) p.out[o + tB] = 0.25f * pd.y;
+                } else {
+                    p.out[o + tA] = 0.25f * pd.x;
+                    if (p.tangent) p.tangent[o + tA] = htan * pd.y;
+                }
+            }
+            continue;
+        }
+        const bool do_log = (p.flags & 1u) != 0;
+        for (int m = wave; m < p.M; m += kBigThreads / 64) {
+            const int2 bd = p.band[m];
+            const float* fr = p.fbT + (size_t)m * F;
+            float s0 = 0.f, s1 = 0.f;
+            for (int k = bd.x + lane; k < bd.y; k += 64) {
+                const float c = fr[k];
+                const float2 pd = Z[pos(k)];
+                s0 = fmaf(c, pd.x, s0);
+                s1 = fmaf(c, pd.y, s1);
+            }
+            s0 = big_wave_sum(s0);
+            s1 = big_wave_sum(s1);
+            if (lane != 0) continue;
+            const size_t o = ((size_t)b * p.M + m) * p.T;
+            const bool out_bf16 = (p.flags & 4u) != 0;
+            auto put = [&](int t, float v) { if (out_bf16) reinterpret_cast<unsigned short*>(p.out)[o + t] = bf16_bits(v); else p.out[o + t] = v; };
+            if (pair) {
+                const float ma = 0.25f * s0, mb = 0.25f * s1;
+                put(tA, do_log ? logf(ma + p.eps) : ma);
+                if (tB < p.T) put(tB, do_log ? logf(mb + p.eps) : mb);
+            } else {
+                const float mel = 0.25f * s0, dmel = htan * s1;
+                if (do_log) {
+                    const float me = mel + p.eps;
+                    put(tA, logf(me));
+                    if (p.tangent) p.tangent[o + tA] = dmel / me;
+                } else {
+                    put(tA, mel);
+                    if (p.tangent) p.tangent[o + tA] = dmel;
+                }
+            }
+        }
+    }
+}
+
+constexpr int kBigLdsMax = 16384;          // complex entries: 128 KB
+
+hipError_t big_prepare_attributes()
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(dmel_big_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               kBigLdsMax * (int)sizeof(float2));
+}
+
+bool big_uses_global(int m_fft) { return m_fft > kBigLdsMax; }
+
+// workgroups of one launch: every unit its own workgroup while the sequence fits LDS, a bounded number of persistent ones
+// (each owns m_fft complex words of the workspace) otherwise
+int big_grid(long long units, int m_fft)
+{
+    const long long cap = big_uses_global(m_fft) ? (m_fft > 65536 ? 256 : 1024) : 0x7fffffffLL;
+    return (int)(units < cap ? (units > 0 ? units : 1) : cap);
+}
+
+hipError_t launch_big(const BigParams& p, hipStream_t s)
+{
+    const bool pair = (p.mode == kInfer || p.mode == kSpec);
+    const long long units = (long long)p.B * (pair ? (p.T + 1) / 2 : p.T);
+    const int grid = big_grid(units, p.Mfft);
+    if (big_uses_global(p.Mfft)) hipLaunchKernelGGL(dmel_big_kernel<true>, dim3((unsigned)grid), dim3(kBigThreads), 0, s, p);
+    else hipLaunchKernelGGL(dmel_big_kernel<false>, dim3((unsigned)grid), dim3(kBigThreads), (size_t)p.Mfft * sizeof(float2), s, p);
+    return hipGetLastError();
+}
+
+}  // namespace dmel

@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(kThreads) dmel_prep_kernel(PrepParams p)
         const double s2 = (double)ls.s2;
         double s_ww = 0.0, s_wd = 0.0;
         for (int n = tid; n < p.N; n += kThreads) {
-            const float d = (float)n - (float)p.N / 2.0f;
+            const float d = (float)n - p.center;
             const float t = d / denom;
             float w = expf(-0.5f * (t * t));
             if (p.win_half && (n < p.N / 4 || n >= 3 * p.N / 4)) w = 0.f;
@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(kThreads) dmel_prep_kernel(PrepParams p)
         const double nrm = sqrt(ww);
         for (int n = tid; n < p.N; n += kThreads) {
             const double w = (double)p.win2[n].x;
-            const float d = (float)n - (float)p.N / 2.0f;
+            const float d = (float)n - p.center;
             const double dwe = w * (double)d * (double)d * s2;       // recomputed in fp64 (the table holds it rounded)
             p.win2[n] = make_float2((float)(w / nrm), (float)(dwe / nrm - w * wd / (nrm * nrm * nrm)));
         }

@@ -194,6 +194,8 @@ struct PrepParams {
     int B, L, nchunks, chunk, N, normalize;
     LamArgs lam;      // the window block reads lambd itself (role 0: it neither reports nor poisons)
     int win_half;
+    float center;     // the window's centre in table coordinates: N/2, or (L/2 as an integer) + L/2 for the whole-clip window of an
+                      // odd clip length L placed in an n_fft = 2L frame (time_frequency.py:24 centres at L/2 as a real number)
 };
 
 hipError_t launch_prep(const PrepParams& p, hipStream_t s);
@@ -226,6 +228,25 @@ struct LongParams {
 };
 hipError_t launch_long(const LongParams& p, hipStream_t s);
 hipError_t long_prepare_attributes();
+
+// transforms beyond the LDS kernels: power-of-two n_fft > 16384 (global-memory FFT) and lengths that are not powers of two
+// (Bluestein), dmel_big.hip
+constexpr int kMaxBigFft = 262144;     // largest power-of-two FFT of that path (n_fft itself, or >= 2 n_fft - 1 for Bluestein)
+struct BigParams {
+    const float* x; float* out; float* tangent; const float* psum; const float2* win2;
+    const float2* tw;        // (Mfft/2): exp(-2 pi i k / Mfft)
+    const float2* chirp;     // (N): exp(-i pi n^2 / N), or nullptr when N is a power of two (then Mfft == N)
+    const float2* hbr;       // (Mfft): transform of the chirp filter / Mfft at the bit-reversed positions of a DIF transform
+    float2* zws;             // workspace, Mfft complex words per workgroup, when the sequence does not fit LDS
+    const float* fbT; const int2* band;
+    int B, L, T, hop, M, nchunks, N, F, mode, Mfft, logM;
+    float inv_L, eps; unsigned flags; int remove_dc;
+    LamArgs lam;
+};
+hipError_t launch_big(const BigParams& p, hipStream_t s);
+hipError_t big_prepare_attributes();
+bool big_uses_global(int m_fft);
+int big_grid(long long units, int m_fft);
 
 // gradient w.r.t. the waveform (dmel_xgrad.hip)
 struct XgradParams {

@@ -251,15 +251,13 @@ class MelSpectrogramLayer(nn.Module):
         if n_points != self.n_points:
             # the reference fails here too (RuntimeError from the slice-assign at models.py:54)
             raise RuntimeError(f"input has {n_points} points, the layer was built for n_points={self.n_points}")
-        if not self.optimized and (n_points & (n_points - 1) or n_points > capi.MAX_NFFT // 2):
-            raise NotImplementedError(
-                "optimized=False (window = whole signal, n_fft = 2*n_points; time_frequency.py:41,51) runs on the HIP path "
-                f"only for power-of-two n_points <= {capi.MAX_NFFT // 2}; construct the layer with optimized=True as all mel "
-                "experiments do (search_spaces.py:11,44)")
         if not x.is_cuda:
             raise RuntimeError("dmel_amd runs on MI355X only: x must be a CUDA/HIP tensor (no CPU fallback)")
         if x.requires_grad and not self.optimized:
             raise NotImplementedError("gradient w.r.t. the waveform is implemented for optimized=True only")
+        if self.mel_fb is not None and not self.optimized and (n_points & (n_points - 1) or 2 * n_points > capi.MAX_NFFT):
+            raise NotImplementedError("a learnable filterbank with optimized=False needs a power-of-two n_points <= "
+                                      f"{capi.MAX_NFFT // 2} (its gradient kernel runs on the power-of-two transforms only)")
         if self.lambd.device != x.device:
             raise RuntimeError(f"lambd is on {self.lambd.device} but x is on {x.device}; call layer.to(x.device)")
         # dtype / layout conversions only when needed (each no-op torch call still costs ~2 us of host time); when x requires
@@ -335,7 +333,8 @@ class SpectrogramLayer(nn.Module):
     Signature-compatible with the reference (models.py:171-200):
         SpectrogramLayer(init_lambd, device='cpu', optimized=False, size=(512, 1024), hop_length=1, normalize_window=False)
     ``optimized=False``: window = whole signal, n_fft = 2*n_points (time_frequency.py:41,51), output
-    ``(B, 1, n_points + 1, n_points // hop_length + 1)``; n_points must be a power of two <= 8192.
+    ``(B, 1, n_points + 1, n_points // hop_length + 1)``; any n_points (a length that is not a power of two takes the
+    chirp-z path of csrc/dmel_big.hip).
     ``optimized=True``: n_fft = next_pow2(int(6*|lambd|)) and the output must have the shape ``size``.
     """
 
@@ -371,9 +370,7 @@ class SpectrogramLayer(nn.Module):
             if tuple(self.size) != expect:     # the reference's slice-assign at models.py:198 fails the same way
                 raise RuntimeError(f"size={tuple(self.size)} but the spectrogram is {expect}")
         else:
-            n_fft, half = 2 * n_points, True
-            if n_fft & (n_fft - 1) or n_fft > capi.MAX_NFFT or n_fft < 2:
-                raise NotImplementedError(f"optimized=False needs n_points to be a power of two <= {capi.MAX_NFFT // 2} on the HIP path, got {n_points}")
+            n_fft, half = 2 * n_points, True      # any clip length: powers of two on the FFT kernels, the rest through Bluestein
         key = (x.device.index, n_points)
         plan = self._plans.get(key)
         if plan is None:

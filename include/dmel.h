@@ -33,7 +33,8 @@ extern "C" {
 typedef enum dmel_status {
     DMEL_OK = 0,
     DMEL_ERR_INVALID_ARGUMENT = 1,  /* bad shape / null pointer / negative size          */
-    DMEL_ERR_UNSUPPORTED = 2,       /* n_fft outside [1, 16384] for the HIP kernels       */
+    DMEL_ERR_UNSUPPORTED = 2,       /* a transform that needs an FFT of more than 262144 points (|lambd| > 43690, or an
+                                       optimized=False clip longer than 65536 samples); optional gradients: n_fft > 16384 */
     DMEL_ERR_HIP = 3,               /* a HIP runtime call failed (message has the detail) */
     DMEL_ERR_NO_DEVICE = 4,         /* no gfx950 device visible                           */
     DMEL_ERR_OUT_OF_MEMORY = 5,
@@ -57,7 +58,8 @@ typedef struct dmel_plan dmel_plan;
 /* Flags for dmel_forward */
 #define DMEL_FLAG_LOG 1u       /* fuse out = log(mel + eps)                        models.py:73 */
 #define DMEL_FLAG_FULL_WINDOW 2u /* the layer's optimized=False branch: window = whole clip, n_fft = 2*n_points
-                                  (time_frequency.py:41,51); n_points must be a power of two <= 8192     */
+                                  (time_frequency.py:41,51); any n_points (powers of two up to 8192 on the FFT kernels,
+                                  everything else through the global-memory / chirp-z path)                */
 #define DMEL_FLAG_OUT_BF16 4u   /* dmel_forward writes `out` as bf16 (round to nearest even of the fp32 result; BASELINE
                                   config 2 "bf16 activations / fp32 grad"): half the output bytes.  The arithmetic, the
                                   tangent and d lambd stay fp32.  The reference's output is fp32 (models.py:36).          */
@@ -221,7 +223,7 @@ dmel_status dmel_spectrogram(dmel_plan* plan, const float* x, int32_t batch, flo
  *   n_fft   0: derive from lambd (optimized branch, :39); otherwise the transform length to use --
  *           the non-optimized branch (:41,:51) is n_fft = 2 * n_points with DMEL_SPEC_HALF_WINDOW
  *           (torch.stft zero-pads the win_length = n_points window to n_fft on both sides).
- *           Must be a power of two <= 16384.
+ *           Any even length (powers of two up to 16384 on the LDS kernels).
  *   spec, tangent   device, (batch, n_fft/2+1, n_time) fp32; tangent may be NULL.
  */
 #define DMEL_SPEC_REMOVE_DC 1u      /* models.py:187: x[idx] - mean(x[idx])                          */

@@ -186,6 +186,69 @@ static void fft_c2c(double* re, double* im, int n, const double* cs, const doubl
     }
 }
 
+/* DFT of any length, fp64: radix-2 when n is a power of two, Bluestein's chirp-z otherwise (torch.stft accepts any n_fft;
+ * the optimized=False branches use n_fft = 2 * n_points, time_frequency.py:51).  One plan per transform length, shared
+ * read-only by the threads; each thread brings its own work arrays of plan->m doubles. */
+typedef struct {
+    int n, m, pow2;
+    double *cs, *sn;          /* radix-2 tables of length m (or n when pow2) */
+    double *cr, *ci;          /* chirp exp(-i pi k^2 / n), k < n */
+    double *hr, *hi;          /* FFT_m of the wrapped conjugate chirp, divided by m */
+} dft_plan;
+
+static void dft_plan_free(dft_plan* p)
+{
+    free(p->cs); free(p->sn); free(p->cr); free(p->ci); free(p->hr); free(p->hi);
+    memset(p, 0, sizeof(*p));
+}
+
+static int dft_plan_init(dft_plan* p, int n)
+{
+    memset(p, 0, sizeof(*p));
+    p->n = n;
+    p->pow2 = (n & (n - 1)) == 0;
+    p->m = n;
+    if (!p->pow2) { p->m = 1; while (p->m < 2 * n - 1) p->m <<= 1; }
+    const int m = p->m;
+    p->cs = (double*)malloc(sizeof(double) * (size_t)m);
+    p->sn = (double*)malloc(sizeof(double) * (size_t)m);
+    if (!p->cs || !p->sn) { dft_plan_free(p); return DMEL_ORACLE_ENOMEM; }
+    for (int k = 0; k < m; ++k) { p->cs[k] = cos(2.0 * M_PI * k / m); p->sn[k] = sin(2.0 * M_PI * k / m); }
+    if (p->pow2) return DMEL_ORACLE_OK;
+    p->cr = (double*)malloc(sizeof(double) * (size_t)n); p->ci = (double*)malloc(sizeof(double) * (size_t)n);
+    p->hr = (double*)calloc((size_t)m, sizeof(double)); p->hi = (double*)calloc((size_t)m, sizeof(double));
+    if (!p->cr || !p->ci || !p->hr || !p->hi) { dft_plan_free(p); return DMEL_ORACLE_ENOMEM; }
+    for (int k = 0; k < n; ++k) {
+        const long long q = ((long long)k * k) % (2LL * n);          /* k^2 mod 2n keeps the phase argument small */
+        const double a = M_PI * (double)q / (double)n;
+        p->cr[k] = cos(a); p->ci[k] = -sin(a);
+        p->hr[k] = cos(a); p->hi[k] = sin(a);                         /* conj chirp at +k ... */
+        if (k) { p->hr[m - k] = cos(a); p->hi[m - k] = sin(a); }      /* ... and at -k */
+    }
+    fft_c2c(p->hr, p->hi, m, p->cs, p->sn);
+    for (int k = 0; k < m; ++k) { p->hr[k] /= m; p->hi[k] /= m; }
+    return DMEL_ORACLE_OK;
+}
+
+/* in place on (re, im), n entries; wr, wi: work arrays of plan->m doubles (unused when n is a power of two) */
+static void dft_run(const dft_plan* p, double* re, double* im, double* wr, double* wi)
+{
+    if (p->pow2) { fft_c2c(re, im, p->n, p->cs, p->sn); return; }
+    const int n = p->n, m = p->m;
+    for (int k = 0; k < n; ++k) { wr[k] = re[k] * p->cr[k] - im[k] * p->ci[k]; wi[k] = re[k] * p->ci[k] + im[k] * p->cr[k]; }
+    for (int k = n; k < m; ++k) { wr[k] = 0.0; wi[k] = 0.0; }
+    fft_c2c(wr, wi, m, p->cs, p->sn);
+    for (int k = 0; k < m; ++k) {                 /* conj(Y H / m): the inverse transform as a forward one */
+        const double a = wr[k] * p->hr[k] - wi[k] * p->hi[k], b = wr[k] * p->hi[k] + wi[k] * p->hr[k];
+        wr[k] = a; wi[k] = -b;
+    }
+    fft_c2c(wr, wi, m, p->cs, p->sn);
+    for (int k = 0; k < n; ++k) {                 /* conj back, times the chirp */
+        const double a = wr[k], b = -wi[k];
+        re[k] = a * p->cr[k] - b * p->ci[k]; im[k] = a * p->ci[k] + b * p->cr[k];
+    }
+}
+
 /*
  * Forward of the layer (+ optional fused log) and, if `tangent` != NULL, the forward-mode
  * derivative d out / d lambd_raw of every output element.
@@ -212,14 +275,12 @@ int dmel_oracle_forward(const float* x, int B, int L, float lambd_raw, int hop, 
 }
 
 /* optimized = 0: the layer's default branch (models.py:15 optimized=False -> time_frequency.py:41,51):
- * window length = L (normalised over L), n_fft = 2L, window zero-padded to n_fft by torch.stft.
- * L must be a power of two here (radix-2 FFT). */
+ * window length = L (normalised over L), n_fft = 2L, window zero-padded to n_fft by torch.stft; any L (dft_run). */
 int dmel_oracle_forward_ex(const float* x, int B, int L, float lambd_raw, int hop, int n_mels,
                            int sample_rate, double f_min, double f_max, int normalize_window,
                            int apply_log, double eps, int optimized, float* out, float* tangent)
 {
     if (!x || !out || B < 0 || L < 1 || hop < 1 || n_mels < 1 || sample_rate < 2) return DMEL_ORACLE_EINVAL;
-    if (!optimized && (L & (L - 1))) return DMEL_ORACLE_EINVAL;
     const int N = optimized ? dmel_oracle_n_fft(lambd_raw) : 2 * L;
     const int F = N / 2 + 1;
     const int T = L / hop + 1;
@@ -230,13 +291,13 @@ int dmel_oracle_forward_ex(const float* x, int B, int L, float lambd_raw, int ho
     float* w = (float*)malloc(sizeof(float) * (size_t)N);
     double* dw = (double*)malloc(sizeof(double) * (size_t)N);
     float* fb = (float*)malloc(sizeof(float) * (size_t)F * n_mels);
-    double* cs = (double*)malloc(sizeof(double) * (size_t)N);
-    double* sn = (double*)malloc(sizeof(double) * (size_t)N);
     int* flo = (int*)malloc(sizeof(int) * (size_t)n_mels);
     int* fhi = (int*)malloc(sizeof(int) * (size_t)n_mels);
     float* mean = (float*)malloc(sizeof(float) * (size_t)(B > 0 ? B : 1));
-    int rc = DMEL_ORACLE_OK;
-    if (!w || !dw || !fb || !cs || !sn || !flo || !fhi || !mean) { rc = DMEL_ORACLE_ENOMEM; goto done; }
+    dft_plan plan;
+    int rc = dft_plan_init(&plan, N);
+    if (rc) { free(w); free(dw); free(fb); free(flo); free(fhi); free(mean); return rc; }
+    if (!w || !dw || !fb || !flo || !fhi || !mean) { rc = DMEL_ORACLE_ENOMEM; goto done; }
 
     if (optimized) {
         dmel_oracle_window(lambd_raw, N, normalize_window, w, dw);
@@ -247,7 +308,6 @@ int dmel_oracle_forward_ex(const float* x, int B, int L, float lambd_raw, int ho
     }
     rc = dmel_oracle_mel_fbanks(F, f_min, f_max, n_mels, sample_rate, fb);
     if (rc) goto done;
-    for (int k = 0; k < N; ++k) { cs[k] = cos(2.0 * M_PI * k / N); sn[k] = sin(2.0 * M_PI * k / N); }
     /* support of each mel column (the matrix is banded; skipping exact zeros changes nothing) */
     for (int m = 0; m < n_mels; ++m) {
         int lo = F, hi = -1;
@@ -267,10 +327,12 @@ int dmel_oracle_forward_ex(const float* x, int B, int L, float lambd_raw, int ho
         double* im = (double*)malloc(sizeof(double) * (size_t)N);
         double* P = (double*)malloc(sizeof(double) * (size_t)F);
         double* D = (double*)malloc(sizeof(double) * (size_t)F);
+        double* wr = (double*)malloc(sizeof(double) * (size_t)plan.m);
+        double* wi = (double*)malloc(sizeof(double) * (size_t)plan.m);
 #pragma omp for schedule(static) collapse(2)
         for (int b = 0; b < B; ++b) {
             for (int t = 0; t < T; ++t) {
-                if (!re || !im || !P || !D) continue;
+                if (!re || !im || !P || !D || !wr || !wi) continue;
                 const float* xb = x + (size_t)b * L;
                 /* frame t covers padded samples [t*hop, t*hop+N) = original [t*hop-pad, ...) */
                 for (int n = 0; n < N; ++n) {
@@ -279,11 +341,11 @@ int dmel_oracle_forward_ex(const float* x, int B, int L, float lambd_raw, int ho
                     re[n] = (double)(v * w[n]);         /* torch.stft: fp32 frame * fp32 window */
                     im[n] = (double)v * dw[n];          /* packed second real signal: x~ * w'   */
                 }
-                fft_c2c(re, im, N, cs, sn);
+                dft_run(&plan, re, im, wr, wi);
                 /* Z = FFT(a + i b), a = x~ w, b = x~ w'.  X = FFT(a), X' = FFT(b):
                  *   X[k] = (Z[k] + conj Z[N-k]) / 2,  X'[k] = (Z[k] - conj Z[N-k]) / (2i)      */
                 for (int k = 0; k < F; ++k) {
-                    int nk = (N - k) & (N - 1);
+                    int nk = (N - k) % N;
                     double sr = re[k] + re[nk], si = im[k] - im[nk];
                     double dr = re[k] - re[nk], di = im[k] + im[nk];
                     double xr = 0.5 * sr, xi = 0.5 * si;        /* X  */
@@ -310,10 +372,11 @@ int dmel_oracle_forward_ex(const float* x, int B, int L, float lambd_raw, int ho
                 }
             }
         }
-        free(re); free(im); free(P); free(D);
+        free(re); free(im); free(P); free(D); free(wr); free(wi);
     }
 done:
-    free(w); free(dw); free(fb); free(cs); free(sn); free(flo); free(fhi); free(mean);
+    dft_plan_free(&plan);
+    free(w); free(dw); free(fb); free(flo); free(fhi); free(mean);
     return rc;
 }
 
@@ -497,21 +560,6 @@ int dmel_oracle_xgrad(const float* x, int B, int L, float lambd_raw, int hop, in
     return rc;
 }
 
-/* naive DFT for transform lengths that are not powers of two (non-optimized DSPEC with arbitrary n_points) */
-static void dft_c2c(const double* re, const double* im, int n, double* ore, double* oim)
-{
-    for (int k = 0; k < n; ++k) {
-        double sr = 0.0, si = 0.0;
-        for (int t = 0; t < n; ++t) {
-            double a = -2.0 * M_PI * (double)(((long long)k * t) % n) / (double)n;
-            double c = cos(a), s = sin(a);
-            sr += re[t] * c - im[t] * s;
-            si += re[t] * s + im[t] * c;
-        }
-        ore[k] = sr; oim[k] = si;
-    }
-}
-
 /*
  * DSPEC: models.SpectrogramLayer.forward (models.py:171-200) with optimized=False:
  *   window_length = len(x) = L (time_frequency.py:41), window centred at L/2 (:24), n_fft = 2L (:51),
@@ -524,21 +572,19 @@ int dmel_oracle_dspec(const float* x, int B, int L, float lambd_raw, int hop, in
 {
     if (!x || !spec || B < 0 || L < 1 || hop < 1) return DMEL_ORACLE_EINVAL;
     const int N = 2 * L, F = L + 1, T = L / hop + 1, padw = (N - L) / 2;
-    const int pow2 = (N & (N - 1)) == 0;
     const double sgn = (lambd_raw > 0) - (lambd_raw < 0);
     float* g = (float*)malloc(sizeof(float) * (size_t)L);
     double* dg = (double*)malloc(sizeof(double) * (size_t)L);
-    double* cs = (double*)malloc(sizeof(double) * (size_t)N);
-    double* sn = (double*)malloc(sizeof(double) * (size_t)N);
-    if (!g || !dg || !cs || !sn) { free(g); free(dg); free(cs); free(sn); return DMEL_ORACLE_ENOMEM; }
+    dft_plan plan;
+    int prc = dft_plan_init(&plan, N);
+    if (prc || !g || !dg) { free(g); free(dg); if (!prc) dft_plan_free(&plan); return DMEL_ORACLE_ENOMEM; }
     dmel_oracle_window(lambd_raw, L, normalize_window, g, dg);
-    for (int k = 0; k < N; ++k) { cs[k] = cos(2.0 * M_PI * k / N); sn[k] = sin(2.0 * M_PI * k / N); }
 #pragma omp parallel
     {
         double* re = (double*)malloc(sizeof(double) * (size_t)N);
         double* im = (double*)malloc(sizeof(double) * (size_t)N);
-        double* ore = (double*)malloc(sizeof(double) * (size_t)N);
-        double* oim = (double*)malloc(sizeof(double) * (size_t)N);
+        double* ore = (double*)malloc(sizeof(double) * (size_t)plan.m);
+        double* oim = (double*)malloc(sizeof(double) * (size_t)plan.m);
 #pragma omp for schedule(static)
         for (int b = 0; b < B; ++b) {
             const float* xb = x + (size_t)b * L;
@@ -554,8 +600,7 @@ int dmel_oracle_dspec(const float* x, int B, int L, float lambd_raw, int hop, in
                     else { re[n] = 0.0; im[n] = 0.0; }
                 }
                 double *zr = re, *zi = im;
-                if (pow2) fft_c2c(re, im, N, cs, sn);
-                else { dft_c2c(re, im, N, ore, oim); zr = ore; zi = oim; }
+                dft_run(&plan, re, im, ore, oim);
                 for (int k = 0; k < F; ++k) {
                     int nk = (N - k) % N;
                     double sr = zr[k] + zr[nk], sim = zi[k] - zi[nk];
@@ -569,6 +614,7 @@ int dmel_oracle_dspec(const float* x, int B, int L, float lambd_raw, int hop, in
         }
         free(re); free(im); free(ore); free(oim);
     }
-    free(g); free(dg); free(cs); free(sn);
+    dft_plan_free(&plan);
+    free(g); free(dg);
     return DMEL_ORACLE_OK;
 }

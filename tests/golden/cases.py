@@ -60,6 +60,12 @@ CASES = [
     # the constructor's default branch optimized=False (models.py:15): window = whole signal, n_fft = 2*n_points
     _case("g7_mel_nonopt_256", 3, 256, 8000, 12.0, 16, 20, seed=22, optimized=False),
     _case("g7_mel_nonopt_1024n", 2, 1024, 16000, 70.0, 64, 64, seed=23, optimized=False, normalize_window=True),
+    # ... on clip lengths that are not powers of two: Audio-MNIST's 8000 samples (search_spaces.py:64) -> n_fft 16000, an odd length
+    _case("g7_mel_nonopt_8000", 2, 8000, 8000, 300.0, 80, 64, seed=24, optimized=False),
+    _case("g7_mel_nonopt_601", 2, 601, 8000, 50.0, 20, 24, seed=25, optimized=False, normalize_window=True),
+    # lambd beyond 2730 samples: n_fft 32768 and 65536
+    _case("g5_n32768", 2, 40000, 8000, 2800.0, 2000, 64, seed=26),
+    _case("g5_n65536", 1, 66000, 8000, 6000.0, 6000, 64, seed=27),
 ]
 
 BY_NAME = {c["name"]: c for c in CASES}

@@ -116,10 +116,11 @@ def run_case(models, tf, case):
     return out
 
 
-def run_dspec(models, tf):
-    """G7: DSPEC non-optimized layer (models.py:171-200), L=128, hop=1, lambd=6.38."""
+def run_dspec(models, tf, L=128):
+    """G7: DSPEC non-optimized layer (models.py:171-200), hop=1, lambd=6.38; L=128 is the reference's own use, L=100 a clip
+    length that is not a power of two (n_fft = 200)."""
     from dmel_amd import synth
-    x = torch.from_numpy(synth.waveforms(2, 128, seed=77, scale=1.0))
+    x = torch.from_numpy(synth.waveforms(2, L, seed=77, scale=1.0))
     layer = models.SpectrogramLayer(torch.tensor(6.38), optimized=False, hop_length=1)
     s = layer(x)
     g = torch.from_numpy(synth.cotangent(tuple(s.shape), seed=78))
@@ -259,10 +260,12 @@ def main(argv):
         argv = [a for a in argv if a != "net_keys"]
         if len(argv) == 1 and "net_keys" in sys.argv:
             return
-    names = argv[1:] or [c["name"] for c in C.CASES] + ["g7_dspec"] + ["g8_fbgrad_" + n for n in FBGRAD_CASES] + ["g9_panns"] + ["g10_xgrad_" + n for n in XGRAD_CASES] + ["g11_nets"]
+    names = argv[1:] or [c["name"] for c in C.CASES] + ["g7_dspec", "g7_dspec_100"] + ["g8_fbgrad_" + n for n in FBGRAD_CASES] + ["g9_panns"] + ["g10_xgrad_" + n for n in XGRAD_CASES] + ["g11_nets"]
     for name in names:
         if name == "g7_dspec":
             out = run_dspec(models, tf)
+        elif name == "g7_dspec_100":
+            out = run_dspec(models, tf, L=100)
         elif name.startswith("g10_xgrad_"):
             out = run_xgrad(models, tf, C.BY_NAME[name[len("g10_xgrad_"):]])
         elif name == "g9_panns":

@@ -81,6 +81,11 @@ def test_matches_reference_golden(case):
             _, t_ref = O.forward(x32, case["lambd"], case["hop"], case["n_mels"], case["sr"], case["f_min"], case["f_max"],
                                  case["normalize_window"], apply_log=log, optimized=case["optimized"])
             assert abs(got_d - exp_d) <= _dlam_tol(exp_d, g_np, t_ref), (got_d, exp_d)
+            # north_star's bar is a plain relative 1e-4: wherever the sum is not dominated by cancellation (|d lambd| more than
+            # 1e-3 of sum |g t|: every noise fixture) it is asserted as such, without the floor term of _dlam_tol
+            cancel = float(np.abs(g_np.astype(np.float64) * t_ref.astype(np.float64)).sum())
+            if abs(exp_d) > 1e-3 * cancel:
+                assert abs(got_d - exp_d) <= TOL * abs(exp_d), (case["name"], got_d, exp_d, abs(got_d - exp_d) / abs(exp_d))
 
 
 @pytest.mark.parametrize("name", ["g1_c1", "g2_c2", "g5_n128", "g5_n4096", "g6_n256_ragged", "g6_n64", "g6_n32",
@@ -197,12 +202,10 @@ def test_error_behaviour():
         layer(torch.zeros(case["L"], device="cuda:0"))
     with pytest.raises(RuntimeError):
         layer(torch.zeros(2, case["L"]))      # CPU tensor: no fallback
-    big = _layer(dict(case, lambd=2800.0))    # n_fft 32768 > 16384
-    with pytest.raises(RuntimeError, match="not supported by the HIP kernels"):
+    big = _layer(dict(case, lambd=50000.0), trainable=False)    # n_fft 524288: beyond the 262144-point FFT of the big path
+    big.lambd_sync = True
+    with pytest.raises(RuntimeError, match="the HIP path stops at"):
         big(torch.zeros(1, case["L"], device="cuda:0"))
-    slow = MelSpectrogramLayer(torch.tensor(64.0), 64, case["L"], 16000, hop_length=256, optimized=False).to("cuda:0")
-    with pytest.raises(NotImplementedError):     # optimized=False needs a power-of-two clip <= 8192 on the HIP path
-        slow(torch.zeros(1, case["L"], device="cuda:0"))
     # empty batch and non-contiguous / fp64 input are fine
     assert layer(torch.zeros(0, case["L"], device="cuda:0")).shape == (0, 1, case["n_mels"], case["L"] // case["hop"] + 1)
     x = torch.from_numpy(C.make_input(case)).to("cuda:0")
@@ -342,8 +345,30 @@ def test_dspec_layer_matches_reference_and_oracle():
         (out * torch.from_numpy(gn).to("cuda:0")).sum().backward()
         ref = O.backward(gn, rt)
         assert abs(float(lay.lambd.grad) - ref) <= _dlam_tol(ref, gn, rt)
-    with pytest.raises(NotImplementedError):
-        SpectrogramLayer(torch.tensor(5.0), optimized=False).to("cuda:0")(torch.zeros(1, 100, device="cuda:0"))
+    # clip lengths that are not powers of two (n_fft = 2L through the chirp-z path): the reference's own output at L = 100,
+    # the oracle at an odd length and at Audio-MNIST's 8000 samples (n_fft 16000: the sequence lives in global memory)
+    gold100 = np.load(os.path.join(os.path.dirname(__file__), "golden", "g7_dspec_100.npz"))
+    x100 = synth.waveforms(2, 100, seed=77, scale=1.0)
+    lay = SpectrogramLayer(torch.tensor(6.38), optimized=False, hop_length=1).to("cuda:0")
+    s100 = lay(torch.from_numpy(x100).to("cuda:0"))
+    # single FFT bins (no mel averaging) meet the fp32 noise floor of a chirp-z transform earlier than mel bands do: measured
+    # against a floor of 1e-5 of the loudest bin, as test_spectrogram_stage does (torch's own fp32 stft is 1.2e-4 off the fp64
+    # oracle at a floor of 1e-6)
+    assert s100.shape == (2, 1, 101, 101) and _rel_err(s100.detach().cpu().numpy(), gold100["spec"], floor=1e-5) <= TOL
+    g100 = synth.cotangent(tuple(s100.shape), seed=78)
+    (s100 * torch.from_numpy(g100).to("cuda:0")).sum().backward()
+    _, rt100 = O.dspec(x100, 6.38, hop=1)
+    assert abs(float(lay.lambd.grad) - float(gold100["dlam_lin"])) <= _dlam_tol(float(gold100["dlam_lin"]), g100, rt100)
+    for L, hop, lam, norm in ((77, 5, 9.0, True), (8000, 400, 300.0, False)):
+        xn = synth.waveforms(2, L, seed=L, scale=1.0)
+        lay = SpectrogramLayer(torch.tensor(lam), optimized=False, hop_length=hop, normalize_window=norm).to("cuda:0")
+        out = lay(torch.from_numpy(xn).to("cuda:0"))
+        rs, rt = O.dspec(xn, lam, hop=hop, normalize_window=norm)
+        assert out.shape == rs.shape and _rel_err(out.detach().cpu().numpy(), rs, floor=1e-5) <= TOL
+        gn = synth.cotangent(rs.shape, seed=L + 1)
+        (out * torch.from_numpy(gn).to("cuda:0")).sum().backward()
+        ref = O.backward(gn, rt)
+        assert abs(float(lay.lambd.grad) - ref) <= _dlam_tol(ref, gn, rt)
     # optimized branch: the mel layer's STFT without the filterbank; size must equal (F, T)
     case = C.BY_NAME["g5_n128"]
     xo = C.make_input(case).astype(np.float32)

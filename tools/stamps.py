@@ -17,7 +17,7 @@ NAMES = ["start->loads issued", "window table + clip mean", "samples arrive, win
          "radix-R #2", "twiddle + radix-C + Z store", "barrier wait", "MFMA loops", "half-tile exchange", "epilogue"]
 
 if sys.argv[1] == "build":
-    srcs = [os.path.join(PKG, "csrc", f) for f in ("dmel_fwd.hip", "dmel_aux.hip", "dmel_xgrad.hip", "dmel_api.cpp", "dmel_comm.cpp")]
+    srcs = [os.path.join(PKG, "csrc", f) for f in ("dmel_fwd.hip", "dmel_aux.hip", "dmel_big.hip", "dmel_xgrad.hip", "dmel_api.cpp", "dmel_comm.cpp")]
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-DDMEL_STAMPS", "-shared", "-o", LIB]
     for s in srcs:
         cmd += ["-x", "hip", s]
