@@ -32,7 +32,7 @@ SYMBOLS = (
     "dmel_forward", "dmel_backward", "dmel_backward_ex", "dmel_backward_fb", "dmel_backward_x", "dmel_spectrogram", "dmel_plan_get_info",
     "dmel_plan_set_profiling", "dmel_plan_get_profile", "dmel_spectrogram_ex",
     "dmel_comm_unique_id", "dmel_comm_create", "dmel_comm_destroy", "dmel_comm_allreduce_async", "dmel_comm_wait",
-    "dmel_comm_allreduce", "dmel_scratch_bytes", "dmel_forward_scratch", "dmel_forward_dev", "dmel_backward_scratch", "dmel_plan_get_config",
+    "dmel_comm_allreduce", "dmel_scratch_bytes", "dmel_plan_set_filterbank_dev", "dmel_forward_scratch", "dmel_forward_dev", "dmel_backward_scratch", "dmel_plan_get_config",
     "dmel_plan_lambd_status", "dmel_plan_set_tracking", "dmel_plan_lambd_reset",
 )
 TORCH_LIB_PATH = os.path.join(_PKG_DIR, "libdmel_torch.so")
@@ -132,6 +132,8 @@ def load():
     L.dmel_plan_set_profiling.restype = C.c_int
     L.dmel_plan_get_profile.argtypes = [vp, C.POINTER(DmelProfile)]
     L.dmel_plan_get_profile.restype = C.c_int
+    L.dmel_plan_set_filterbank_dev.argtypes = [vp, C.c_int32, vp, vp]
+    L.dmel_plan_set_filterbank_dev.restype = C.c_int
     L.dmel_scratch_bytes.argtypes = [vp, C.c_int32]
     L.dmel_scratch_bytes.restype = C.c_size_t
     L.dmel_forward_scratch.argtypes = [vp, vp, C.c_int32, C.c_float, C.c_uint32, C.c_double, vp, vp, vp, vp]
@@ -304,6 +306,10 @@ class Plan:
         if fb.shape != (n_fft_ // 2 + 1, self.n_mels):
             raise ValueError(f"filterbank must be ({n_fft_ // 2 + 1}, {self.n_mels}), got {fb.shape}")
         _check(load().dmel_plan_set_filterbank(self._h, int(n_fft_), fb.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def set_filterbank_dev(self, n_fft_: int, fb_ptr: int, stream: int):
+        """(n_fft/2+1, n_mels) fp32 row-major DEVICE matrix -> the plan's tables, on ``stream`` (no host copy, no sync)."""
+        _check(load().dmel_plan_set_filterbank_dev(self._h, int(n_fft_), fb_ptr, stream))
 
     def set_profiling(self, enable: bool):
         _check(load().dmel_plan_set_profiling(self._h, int(bool(enable))))

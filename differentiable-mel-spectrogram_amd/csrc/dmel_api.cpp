@@ -84,6 +84,7 @@ struct dmel_plan {
     double f_max = 0;
     std::map<int, NfftTables> tables;
     std::map<int, std::vector<float>> custom_fb;
+    std::map<int, bool> dense_dev;     // n_fft whose tables have the dense structure and get their values from the device
     // Plan-owned scratch of the entry points that take none from the caller (layout: dmel_scratch_bytes).  Calls that use it
     // are ordered across streams by `xev` (see order_after_last_stream): two streams through one plan serialise, never race.
     unsigned char* own_scratch = nullptr;
@@ -159,7 +160,9 @@ dmel_status build_tables(dmel_plan* pl, int N, NfftTables** out)
     const int M = pl->cfg.n_mels;
     std::vector<float> fb((size_t)tb.F * M);
     auto cit = pl->custom_fb.find(N);
-    if (cit != pl->custom_fb.end()) {
+    if (pl->dense_dev.count(N)) {
+        std::fill(fb.begin(), fb.end(), 1.0f);        // structure only: every block present; dmel_plan_set_filterbank_dev fills the values
+    } else if (cit != pl->custom_fb.end()) {
         fb = cit->second;
     } else {
         dmel_status st = dmel_mel_fbanks_host(tb.F, pl->cfg.f_min, pl->f_max, M, pl->cfg.sample_rate, fb.data());
@@ -830,12 +833,45 @@ dmel_status dmel_plan_set_filterbank(dmel_plan* plan, int32_t n_fft, const float
     DMEL_HIP(hipDeviceSynchronize());     // tables of this n_fft may be in use by queued kernels
     auto it = plan->tables.find(n_fft);
     if (it != plan->tables.end()) { it->second.release(); plan->tables.erase(it); }
+    plan->dense_dev.erase(n_fft);
     if (fb) {
         const size_t n = (size_t)(n_fft / 2 + 1) * plan->cfg.n_mels;
         plan->custom_fb[n_fft] = std::vector<float>(fb, fb + n);
     } else {
         plan->custom_fb.erase(n_fft);
     }
+    return DMEL_OK;
+}
+
+dmel_status dmel_plan_set_filterbank_dev(dmel_plan* plan, int32_t n_fft, const float* fb_dev, void* stream)
+{
+    if (!plan || !fb_dev) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan / fb_dev is NULL");
+    if (n_fft < 1 || n_fft > dmel::kMaxNfft || (n_fft & (n_fft - 1)))
+        return fail(DMEL_ERR_INVALID_ARGUMENT, "n_fft must be a power of two in [1, 16384]");
+    std::lock_guard<std::mutex> lock(plan->mu);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (!plan->dense_dev.count(n_fft)) {
+        // first use for this n_fft: the tables get the dense structure (every 4x16 block present) once; from then on an update is
+        // one small kernel on the caller's stream, no host copy and no synchronisation
+        if (is_capturing(s)) return fail(DMEL_ERR_INVALID_ARGUMENT, "first dmel_plan_set_filterbank_dev for an n_fft builds tables: call it once before capturing");
+        DMEL_HIP(hipDeviceSynchronize());
+        auto it = plan->tables.find(n_fft);
+        if (it != plan->tables.end()) { it->second.release(); plan->tables.erase(it); }
+        plan->custom_fb.erase(n_fft);
+        plan->dense_dev[n_fft] = true;
+    }
+    NfftTables* tb = nullptr;
+    dmel_status st = build_tables(plan, n_fft, &tb);
+    if (st != DMEL_OK) return st;
+    dmel::RepackParams rp{};
+    rp.fb = fb_dev; rp.ent_b = tb->ent_b; rp.ent_pre = tb->ent_pre; rp.tile_ranges = tb->tile_ranges;
+    rp.fb_dense = tb->fb_dense; rp.fbT = tb->fbT; rp.F = tb->F; rp.M = plan->cfg.n_mels;
+    const bool fast = n_fft >= dmel::kMinFastNfft && n_fft <= dmel::kMaxFastNfft;
+    const int waves = fast ? dmel::forward_waves(n_fft) : 0;
+    rp.runs = fast ? tb->groups * waves * 2 : 0;
+    rp.runs_group0 = waves * 2;
+    rp.nbpre = fast ? dmel::forward_nbpre(n_fft) : 0;
+    DMEL_HIP(dmel::launch_repack(rp, s));
     return DMEL_OK;
 }
 

@@ -113,6 +113,38 @@ hipError_t launch_dot(const void* g, int g_bf16, const float* t, long long count
     return hipGetLastError();
 }
 
+// ---- filterbank tables from a device matrix -----------------------------------------------------------------
+// grid.x = runs (one (group, wave, run) entry of tile_ranges each) + 1: the last workgroup copies / transposes the matrix
+__global__ void __launch_bounds__(256) dmel_repack_kernel(RepackParams p)
+{
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x == p.runs) {
+        const long long n = (long long)p.F * p.M;
+        for (long long i = tid; i < n; i += 256) {
+            const float v = p.fb[i];
+            p.fb_dense[i] = v;
+            if (p.fbT) { const int f = (int)(i / p.M), m = (int)(i % p.M); p.fbT[(size_t)m * p.F + f] = v; }
+        }
+        return;
+    }
+    const int run = blockIdx.x;
+    const int4 tr = p.tile_ranges[run];                 // (first k-step, #k-steps, offset into ent_b, mel tile)
+    if (tr.y <= 0 || tr.w < 0) return;
+    for (int i = tid; i < tr.y * 64; i += 256) {
+        const int ks = tr.x + i / 64, l = i % 64;
+        const int f = 4 * ks + (l >> 4), m = 16 * tr.w + (l & 15);
+        const float v = (f < p.F && m < p.M) ? p.fb[(size_t)f * p.M + m] : 0.f;
+        p.ent_b[tr.z + i] = v;
+        if (run < p.runs_group0 && i / 64 < p.nbpre) p.ent_pre[((size_t)run * p.nbpre + i / 64) * 64 + l] = v;
+    }
+}
+
+hipError_t launch_repack(const RepackParams& p, hipStream_t s)
+{
+    hipLaunchKernelGGL(dmel_repack_kernel, dim3((unsigned)(p.runs + 1)), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
 // ---- direct-DFT forward ------------------------------------------------------------------------
 // one workgroup per frame; dynamic LDS: a[N], b[N], P[F], D[F]
 __global__ void __launch_bounds__(128) dmel_naive_kernel(NaiveParams p)

@@ -281,6 +281,17 @@ struct FbGradParams {
 };
 hipError_t launch_fbgrad(const FbGradParams& p, hipStream_t s);
 
+// device-side refresh of every table that holds filterbank VALUES from an (F, M) fp32 device matrix, for tables built with the
+// dense structure (all 4x16 blocks present): what a trainable filterbank needs after each optimizer step
+struct RepackParams {
+    const float* fb;            // (F, M) row-major, device
+    float* ent_b; float* ent_pre; const int4* tile_ranges;
+    float* fb_dense;            // (F, M) copy for the kernels that read the matrix as it is
+    float* fbT;                 // (M, F) transposed copy (long / big transforms) or nullptr
+    int F, M, runs, nbpre, runs_group0;
+};
+hipError_t launch_repack(const RepackParams& p, hipStream_t s);
+
 // g: fp32, or bf16 when g_bf16 != 0 (the gradient of a bf16 output); t (the tangent) is always fp32
 hipError_t launch_dot(const void* g, int g_bf16, const float* t, long long count, int accumulate, double* partials,
                       unsigned* counter, int max_partials, float* result, hipStream_t s);

@@ -284,12 +284,14 @@ class MelSpectrogramLayer(nn.Module):
                                    "a learnable filterbank is tied to one n_fft")
             if fb.device != x.device:
                 raise RuntimeError(f"mel_fb is on {fb.device} but x is on {x.device}; call layer.to(x.device)")
-            key = (fb._version, fb.data_ptr(), n)
-            idx = x.device.index if x.device.index is not None else torch.cuda.current_device()
-            if fb.requires_grad or self._fb_synced.get(idx) != key:      # a trainable bank changes every step
-                with _on_device(x.device):
-                    plan.set_filterbank(n, fb.detach().to(torch.float32).cpu().numpy())      # host rebuild of the block tables
-                self._fb_synced[idx] = key
+            # the plan's tables are refreshed from the parameter's storage by one small kernel on the current stream at every
+            # forward (no host copy, no synchronisation: the matrix changes at every optimizer step, and writes through
+            # .data leave no trace to ask torch about)
+            fbd = fb.detach()
+            if fbd.dtype != torch.float32 or not fbd.is_contiguous():
+                fbd = fbd.to(torch.float32).contiguous()
+            with _on_device(x.device):
+                plan.set_filterbank_dev(n, fbd.data_ptr(), _stream_ptr(x.device))
         return _DmelFunction.apply(xf, self.lambd, plan, lam_host, self.log, self.eps, not self.optimized, fb, self.out_dtype)
 
     def extra_repr(self):

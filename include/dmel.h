@@ -100,6 +100,12 @@ dmel_status dmel_plan_get_config(const dmel_plan* plan, dmel_config* cfg);
  * HTK table.  Pass fb = NULL to return to the built-in table. */
 dmel_status dmel_plan_set_filterbank(dmel_plan* plan, int32_t n_fft, const float* fb);
 
+/* The same from a DEVICE matrix (a trainable filterbank after an optimizer step): the first call for an n_fft rebuilds that
+ * n_fft's tables with the dense structure (every 4x16 block multiplied; one device synchronisation), every later call is one
+ * small kernel on `stream` that refreshes the values -- no host copy, no synchronisation, capturable.  Return to the built-in
+ * table with dmel_plan_set_filterbank(plan, n_fft, NULL). */
+dmel_status dmel_plan_set_filterbank_dev(dmel_plan* plan, int32_t n_fft, const float* fb_dev, void* stream);
+
 /*
  * MelSpectrogramLayer.forward (models.py:33-56) [+ models.py:73 when DMEL_FLAG_LOG]:
  * DC removal, Gaussian-windowed STFT (center=True, zero padding), |.|^2, mel contraction.

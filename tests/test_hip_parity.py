@@ -528,11 +528,50 @@ def test_learnable_filterbank_layer():
     lay._plan_for(x.device).spectrogram(x.data_ptr(), case["B"], case["lambd"], spec.data_ptr(), torch.cuda.current_stream().cuda_stream, remove_dc=True)
     ref2 = torch.log(torch.einsum("bft,fm->bmt", spec.double(), lay.mel_fb.detach().double()) + 1e-10).unsqueeze(1)
     assert float((y2.double() - ref2).abs().max()) <= TOL
+    # ... and so is a write through .data (no version bump): the tables are refreshed from the storage at every forward
+    lay.mel_fb.data.mul_(1.25)
+    y3 = lay(x).detach()
+    ref3 = torch.log(torch.einsum("bft,fm->bmt", spec.double(), lay.mel_fb.detach().double()) + 1e-10).unsqueeze(1)
+    assert float((y3.double() - ref3).abs().max()) <= TOL and not torch.equal(y3, y2)
     # the bank is tied to its n_fft
     with torch.no_grad():
         lay.lambd.fill_(3.0 * float(case["lambd"]))
     with pytest.raises(RuntimeError, match="tied to one n_fft"):
         lay(x)
+
+
+@pytest.mark.parametrize("name", ["g1_c1", "g2_c2", "g5_n128", "g6_n32", "g5_n4096"])
+def test_filterbank_from_device_equals_filterbank_from_host(name):
+    """dmel_plan_set_filterbank_dev (one small kernel on the stream, no host copy, no synchronisation) fills the same tables as
+    dmel_plan_set_filterbank builds on the host: identical outputs, bit for bit, for a dense random matrix."""
+    from dmel_amd import capi
+    case = C.BY_NAME[name]
+    x = torch.from_numpy(C.make_input(case).astype(np.float32)).to("cuda:0")
+    n = capi.n_fft(case["lambd"])
+    fb = torch.rand((n // 2 + 1, case["n_mels"]), device="cuda:0") + 0.01
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for dev in (False, True):
+        plan = capi.Plan(case["L"], case["hop"], case["n_mels"], case["sr"])
+        if dev:
+            plan.set_filterbank_dev(n, fb.data_ptr(), st)
+        else:
+            plan.set_filterbank(n, fb.cpu().numpy())
+        out = torch.empty(C.out_shape(case), device="cuda:0"); tan = torch.empty_like(out)
+        plan.forward(x.data_ptr(), case["B"], case["lambd"], out.data_ptr(), tan.data_ptr(), True, 1e-10, st)
+        if dev:                                   # a second matrix through the same plan: only the repack kernel runs
+            fb2 = fb * 0.5
+            plan.set_filterbank_dev(n, fb2.data_ptr(), st)
+            out2 = torch.empty_like(out)
+            plan.forward(x.data_ptr(), case["B"], case["lambd"], out2.data_ptr(), None, False, 1e-10, st)
+            out1 = torch.empty_like(out)
+            plan.set_filterbank_dev(n, fb.data_ptr(), st)
+            plan.forward(x.data_ptr(), case["B"], case["lambd"], out1.data_ptr(), None, False, 1e-10, st)
+            torch.cuda.synchronize()
+            assert torch.equal(out2, 0.5 * out1)  # the contraction is linear in the matrix, and halving is exact
+        torch.cuda.synchronize()
+        outs.append((out, tan))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
 def test_backward_fb_rejects_bad_arguments():
