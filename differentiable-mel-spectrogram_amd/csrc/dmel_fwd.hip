@@ -235,7 +235,7 @@ __device__ __forceinline__ int clampi(int v, int hi) { return v < 0 ? 0 : (v > h
 #ifdef DMEL_STAMPS
 // Diagnostic build only (tools/stamps.py): s_memtime stamps of every wave at the phase boundaries of the
 // fused kernel, kept in a buffer nothing else reads.  Never compiled into libdmel_hip.so.
-constexpr int kStampSlots = 16;
+constexpr int kStampSlots = 32;     // 0-2 prologue, 12-13 placement, 3-11 tile 0, 16 + (2..11) tile 1 (2 = tile start)
 __device__ unsigned long long g_stamps[4096 * 8 * kStampSlots];
 __device__ __forceinline__ void stamp(int wgid, int wave, int lane, int idx)
 {
@@ -536,6 +536,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
         constexpr int ti = decltype(tt)::value;
         if (ti > 0 && tile0 + ti >= p.tiles_per_clip) return;          // the clip has no such tile (same answer in every wave)
         const int t0 = (tile0 + ti) * FPT;
+        if constexpr (ti > 0) STAMP(16 * ti + 2);   // previous tile's epilogue issued, this tile begins
         if constexpr (ti > 0) {
             // the FFT slots (every wave has read the previous tile's spectra before the barriers of its phase 2 or the one
             // here) and the window table / half-tile exchange region are used again
@@ -603,9 +604,9 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                         }
                     });
                 }
-                STAMP(3);   // samples arrived, windowed
+                STAMP(16 * ti + 3);   // samples arrived, windowed
                 fft_reg<R>(z);
-                STAMP(4);   // radix-R #1
+                STAMP(16 * ti + 4);   // radix-R #1
                 // twiddle w_N^(lg*q), transposition through LDS: S[q][lg]
                 static_for<0, R>([&](auto qq) {
                     constexpr int q = decltype(qq)::value;
@@ -623,7 +624,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                 });
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                STAMP(5);   // twiddle + LDS transposition
+                STAMP(16 * ti + 5);   // twiddle + LDS transposition
                 // the radix-C twiddles w_G^(r*p1) are requested before the second radix-R stage, not one by one inside the
                 // cross-lane stage (each read there was waited for on the spot)
                 float2 tw2r[R];
@@ -635,7 +636,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 fft_reg<R>(u);
-                STAMP(6);   // radix-R #2
+                STAMP(16 * ti + 6);   // radix-R #2
                 // twiddle w_G^(r*p1), radix-C across adjacent lanes, spectrum to LDS in natural order
                 const v2f rot_f = splat((C == 4 && r == 3) ? 0.f : 1.f);
                 const v2f rot_e = (C == 4 && r == 3) ? v2f{1.f, -1.f} : v2f{0.f, 0.f};
@@ -707,9 +708,9 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                 });
             });
         }
-        STAMP(7);   // twiddle + cross-lane radix-C + spectrum to LDS + pairing pass
+        STAMP(16 * ti + 7);   // twiddle + cross-lane radix-C + spectrum to LDS + pairing pass
         __syncthreads();
-        STAMP(8);   // barrier
+        STAMP(16 * ti + 8);   // barrier
 #ifdef DMEL_ABLATE
         if (dbg_skip_gemm) { if (tid == 0 && lds[0].x == 12345.678f) p.out[0] = 0.f; return; }
 #endif
@@ -790,6 +791,8 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                         // k-steps whose B fragments are already in registers
                         static_for<0, NBPRE / 4>([&](auto qq) {
                             constexpr int i = decltype(qq)::value * 4;
+                            // (running the padding groups too, branch-free on zero fragments, was measured: 24.6 against 21.9 us at
+                            // config 2 -- the matrix pipe of a SIMD serialises the four waves that reach this phase together)
                             if (i < nks) group4(ks0 + i, bpre[loc][i], bpre[loc][i + 1], bpre[loc][i + 2], bpre[loc][i + 3]);
                         });
                     }
@@ -805,7 +808,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                         }
                     }
                 });
-                STAMP(9);   // MFMA loops
+                STAMP(16 * ti + 9);   // MFMA loops
                 // ---- epilogue: accumulators -> (B,1,M,T) ------------------------------------------
                 const bool do_log = (p.flags & 1u) != 0;
                 const bool out_bf16 = (p.flags & 4u) != 0;
@@ -821,7 +824,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                     if (p.groups > 1) __syncthreads();
                     tile_of[1] = -1;
                 }
-                STAMP(10);  // half-tile exchange
+                STAMP(16 * ti + 10);  // half-tile exchange
 #ifdef DMEL_ABLATE
                 if (p.flags & 0x400u) continue;                        // timing ablation: skip the epilogue
 #endif
@@ -888,7 +891,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                         }
                     });
                 });
-                STAMP(11);  // epilogue stores issued
+                STAMP(16 * ti + 11);  // epilogue stores issued
             }
         }
     });

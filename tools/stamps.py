@@ -49,13 +49,15 @@ torch.cuda.synchronize()
 info = plan.info()
 nwg = min(info["grid_fwd"], 4096)
 waves = 8 if info["n_fft"] in (1024, 2048) else 4
-SL = 16
+SL = 32
 buf = np.zeros(4096 * 8 * SL, dtype=np.uint64)
 L_ = capi.load()
 L_.dmel_debug_read_stamps.argtypes = [C.c_void_p, C.c_int]
 rc = L_.dmel_debug_read_stamps(buf.ctypes.data, buf.size)
 assert rc == 0, rc
-st = buf.reshape(4096, 8, SL)[:nwg, :waves, :12].astype(np.int64)
+full = buf.reshape(4096, 8, SL)[:nwg, :waves, :].astype(np.int64)
+st = full[:, :, :12]
+two_tiles = bool((full[:, :, 16 + 11] != 0).any())
 t_first = st[:, :, 0].min()
 print(f"{name}: n_fft {info['n_fft']}, {nwg} workgroups x {waves} waves; kernel span (first start -> last end) "
       f"{(st[:, :, 11].max() - t_first)} cycles")
@@ -99,5 +101,16 @@ for x in range(int(xcc.max()) + 1):
     ex = sorted(cus.items())[:3]
     for c, lst in ex:
         print(f"     cu {c % 10000}: {sorted(lst)}")
+if two_tiles:
+    # second tile of two-tile workgroups: slots 16 + (2 .. 11); slot 18 = the tile begins (tile 0's epilogue stores are issued)
+    t2 = np.concatenate([full[:, :, 11:12], full[:, :, 18:28]], axis=2)
+    ok = (full[:, :, 27] != 0)
+    d2 = np.diff(t2, axis=2)
+    life2 = (full[:, :, 27] - full[:, :, 0])[ok]
+    print(f"two tiles per workgroup: wave lifetime over both tiles median {np.median(life2):.0f} max {life2.max()} cycles")
+    labels = ["tile 0 epilogue issued -> tile 1 begins", "barriers between the tiles, window rewrite, samples arrive, window"] + NAMES[3:]
+    for i, nm in enumerate(labels):
+        v = d2[:, :, i][ok]
+        print(f"    tile 1: {nm:68s} median {np.median(v):8.0f}   p90 {np.percentile(v, 90):8.0f}")
 end = st[:, :, 11].max(axis=1) - t_first
 print("workgroup end times: p10 %d  median %d  p90 %d  max %d" % (np.percentile(end, 10), np.median(end), np.percentile(end, 90), end.max()))
