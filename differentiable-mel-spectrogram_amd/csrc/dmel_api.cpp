@@ -595,13 +595,25 @@ dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dm
     return DMEL_OK;
 }
 
+// a plan's tables and scratch live on the device it was created on: launching from a thread whose current device is another
+// one would run the kernels there, on pointers that mean nothing there
+dmel_status check_device(const dmel_plan* pl)
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return fail(DMEL_ERR_NO_DEVICE, "no current HIP device"); }
+    if (dev != pl->device)
+        return fail(DMEL_ERR_INVALID_ARGUMENT, "the plan belongs to device " + std::to_string(pl->device) + " but the current device is " +
+                    std::to_string(dev) + " (hipSetDevice / torch.cuda.device before the call)");
+    return DMEL_OK;
+}
+
 dmel_status check_forward_args(dmel_plan* pl, const float* x, int batch, const void* out)
 {
     if (!pl) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
     if (batch < 0) return fail(DMEL_ERR_INVALID_ARGUMENT, "batch < 0");
     if (batch > 0 && (!x || !out)) return fail(DMEL_ERR_INVALID_ARGUMENT, "x / out is NULL");
     if (batch > 65534) return fail(DMEL_ERR_INVALID_ARGUMENT, "batch > 65534 (split the call)");
-    return DMEL_OK;
+    return check_device(pl);
 }
 
 // lambd by value (the host has read it, as time_frequency.py:39 does): one launch, plan-owned scratch unless given.
@@ -1058,6 +1070,7 @@ dmel_status dmel_backward_scratch(dmel_plan* plan, const void* grad_out, int32_t
         return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_backward: bad arguments");
     if (grad_dtype != DMEL_DTYPE_F32 && grad_dtype != DMEL_DTYPE_BF16)
         return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_backward: grad_dtype must be DMEL_DTYPE_F32 or DMEL_DTYPE_BF16");
+    { dmel_status sd = check_device(plan); if (sd != DMEL_OK) return sd; }
     std::lock_guard<std::mutex> lock(plan->mu);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     Scratch sc;
