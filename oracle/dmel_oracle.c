@@ -25,6 +25,10 @@
  *   d/d mel_fb, d/d x    autograd through models.py:38-53 with the bank / the waveform made a leaf
  *                                                      (dmel_oracle_fbgrad, dmel_oracle_xgrad)
  *   DSPEC layer          models.py:171-200             dmel_oracle_dspec
+ *   optimized=False      time_frequency.py:41,51       window = whole clip, n_fft = 2 * n_points for ANY clip length: a
+ *                                                      length that is not a power of two is transformed by Bluestein's
+ *                                                      chirp-z identity in fp64 (dft_run), pinned by the reference's own
+ *                                                      outputs at n_points 8000, 601 and 100 (torch.stft takes any n_fft)
  *
  * Pinning: tests/test_oracle_golden.py checks every function here against the fixtures in
  * tests/golden/NAME.npz, which tests/golden/make_golden.py captured from the reference's own

@@ -89,14 +89,16 @@ def test_window_centre_is_n_over_2():
     assert np.abs(num - dw).max() < 5e-5
 
 
-def test_dspec_oracle_matches_reference():
-    """G7: the reference's non-optimized SpectrogramLayer (models.py:171-200), L = 128, hop = 1, lambd = 6.38."""
+@pytest.mark.parametrize("L,fixture", [(128, "g7_dspec.npz"), (100, "g7_dspec_100.npz")])
+def test_dspec_oracle_matches_reference(L, fixture):
+    """G7: the reference's non-optimized SpectrogramLayer (models.py:171-200), hop = 1, lambd = 6.38, at L = 128 (the reference's
+    own use) and L = 100 (n_fft = 200: not a power of two, the oracle's chirp-z transform)."""
     import os
     from dmel_amd import synth
-    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "g7_dspec.npz"))
-    x = synth.waveforms(2, 128, seed=77, scale=1.0)
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", fixture))
+    x = synth.waveforms(2, L, seed=77, scale=1.0)
     spec, tan = O.dspec(x, 6.38, hop=1)
-    assert spec.shape == gold["spec"].shape == (2, 1, 129, 129)
+    assert spec.shape == gold["spec"].shape == (2, 1, L + 1, L + 1)
     scale = np.maximum(np.abs(gold["spec"]), 1e-6 * gold["spec"].max())
     assert float((np.abs(spec - gold["spec"]) / scale).max()) <= TOL
     g = synth.cotangent(spec.shape, seed=78)
