@@ -12,6 +12,9 @@
 //            Two real sequences ride in one complex FFT: (x~ w, x~ dw/dlambd) when the tangent is
 //            wanted (training), two neighbouring frames otherwise.  The pairing pass separates them
 //            once per bin and leaves PD[k] = (|X|^2, d|X|^2/dlambd) (or the two frames' |X|^2) in LDS.
+//            n_fft 2048 and 4096 use the compact layout (FftPlan::BPERM / SPLIT): the transposition moves one
+//            plane of floats at a time and the pairing pass gets Z[N-k] from the lane that holds it
+//            (ds_bpermute_b32), so a frame in flight needs N*4 bytes of LDS instead of N*8.
 //   phase 2 (MFMA): the mel contraction of models.py:53.  A operands are plain reads of PD,
 //            B fragments are the non-zero 4x16 blocks of the filterbank (prefetched into registers
 //            before phase 1), v_mfma_f32_16x16x4_f32 accumulates exact fp32.  With 4 waves each wave
@@ -290,6 +293,11 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
     float2* tw2l = reinterpret_cast<float2*>(smem_raw + g.RED_OFF + kRedBytes);
     // the half-tile exchange of phase 2 (8 waves) lives where the window table does: a second tile needs the table back
     constexpr bool WIN_ALIASED = WIN_LDS && WAVES == 8;
+    // compact layouts (dmel_kernels.h): pairing pass through ds_bpermute, transposition one plane at a time, half window table
+    constexpr bool BPERM = g.BPERM != 0, SPLIT = g.SPLIT != 0, WIN_SYM = g.WIN_SYM != 0;
+    static_assert(!BPERM || (G == 64 && PASSES == 1), "the bpermute pairing pass assumes one frame per wave");
+    static_assert(!SPLIT || BPERM, "a one-plane slot cannot hold the whole spectrum");
+    static_assert(!WIN_SYM || G == 64, "half window table: one frame per wave");
     constexpr int WPT = (N / 2 + THREADS - 1) / THREADS;       // window entries a thread computes (and keeps when TPW > 1)
 
     const int tid = threadIdx.x;
@@ -445,7 +453,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                     wtab[n] = wkeep[wi];
                     // the half-length window of torch.stft sits at [N/4, 3N/4): its mirror image stops one entry short
                     const bool has_mirror = n > 0 && !(p.win_half && n <= N / 4);
-                    if (n > 0) wtab[N - n] = has_mirror ? wkeep[wi] : make_float2(0.f, 0.f);
+                    if constexpr (!WIN_SYM) { if (n > 0) wtab[N - n] = has_mirror ? wkeep[wi] : make_float2(0.f, 0.f); }
                     const float mult = has_mirror ? 2.f : 1.f;
                     s_ww += mult * (w * w); s_wd += mult * (w * dw);
                 }
@@ -462,7 +470,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                 for (int q = 0; q < WAVES; ++q) { ww += red[q]; wd += red[8 + q]; }
                 __syncthreads();
                 const float inv = 1.0f / sqrtf(ww);
-                for (int n = tid; n < N; n += THREADS) {
+                for (int n = tid; n < (WIN_SYM ? N / 2 + 1 : N); n += THREADS) {
                     const float2 e = wtab[n];
                     wtab[n] = make_float2(e.x * inv, e.y * inv - e.x * wd * inv * inv * inv);
                 }
@@ -553,7 +561,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                     const int n = tid + THREADS * wi;
                     if (n < N / 2) {
                         wtab[n] = wkeep[wi];
-                        if (n > 0) wtab[N - n] = (p.win_half && n <= N / 4) ? make_float2(0.f, 0.f) : wkeep[wi];
+                        if constexpr (!WIN_SYM) { if (n > 0) wtab[N - n] = (p.win_half && n <= N / 4) ? make_float2(0.f, 0.f) : wkeep[wi]; }
                     }
                 });
                 if (tid == 0) wtab[N / 2] = wmid;
@@ -574,17 +582,24 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                 v2f z[R];
                 // window entries of this lane: one base register + compile-time offsets (ds_read_b64 offset:512a)
                 int wbyte = (WIN_LDS ? g.AUX_OFF : 0) + lg * 8;
-                asm volatile("" : "+v"(wbyte));
-                auto wload = [&](int a) -> v2f {
+                int wbyte_m = g.AUX_OFF + (G - lg) * 8;                      // half table: entry N - n of n = lg + G a, a >= R/2
+                asm volatile("" : "+v"(wbyte), "+v"(wbyte_m));
+                auto wload = [&](auto aa_) -> v2f {
+                    constexpr int a = decltype(aa_)::value;
                     float2 wd2;                                              // (w[n], dw[n] / d|lambd| * scale)
-                    if constexpr (WIN_LDS) wd2 = *reinterpret_cast<const float2*>(smem_raw + wbyte + G * 8 * a);
+                    if constexpr (WIN_SYM && a >= R / 2) {
+                        wd2 = *reinterpret_cast<const float2*>(smem_raw + wbyte_m + G * 8 * (R - 1 - a));
+                        // the half-length window of torch.stft covers [N/4, 3N/4): entry 3N/4 is zero, its mirror image is not
+                        if constexpr (a == 3 * R / 4) { if (p.win_half && lg == 0) wd2 = make_float2(0.f, 0.f); }
+                    }
+                    else if constexpr (WIN_LDS) wd2 = *reinterpret_cast<const float2*>(smem_raw + wbyte + G * 8 * a);
                     else wd2 = *reinterpret_cast<const float2*>(reinterpret_cast<const unsigned char*>(p.win2) + wbyte + G * 8 * a);
                     return v2f{wd2.x, wd2.y};
                 };
                 if (inside_w) {
                     static_for<0, R>([&](auto aa) {
                         constexpr int a = decltype(aa)::value;
-                        const v2f wd = wload(a);
+                        const v2f wd = wload(aa);
                         const float va = xa[ti][pass][a] - mean;
                         if constexpr (!PAIR) z[a] = splat(va) * wd;
                         else z[a] = v2f{va, xb2[ti][pass][a] - mean} * wd.xx;
@@ -593,7 +608,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                     static_for<0, R>([&](auto aa) {
                         constexpr int a = decltype(aa)::value;
                         const int n = lg + G * a;
-                        const v2f wd = wload(a);
+                        const v2f wd = wload(aa);
                         const int ia = f0 + n;
                         const float va = ((ia >= 0) && (ia < p.L)) ? xa[ti][pass][a] - mean : 0.f;
                         if constexpr (!PAIR) z[a] = splat(va) * wd;
@@ -608,31 +623,74 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                 fft_reg<R>(z);
                 STAMP(16 * ti + 4);   // radix-R #1
                 // twiddle w_N^(lg*q), transposition through LDS: S[q][lg]
-                static_for<0, R>([&](auto qq) {
-                    constexpr int q = decltype(qq)::value;
-                    v2f v = z[bitrev(q, LB)];
-                    if constexpr (q != 0) v = cmul(v, p.tw1[q * G + lg]);
-                    sl[q * EXS + lg] = v;
-                });
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 v2f u[R];
-                static_for<0, R>([&](auto bb) {
-                    constexpr int bi = decltype(bb)::value;
-                    u[bi] = sl[qp * EXS + r + C * bi];
-                });
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+                if constexpr (!SPLIT) {
+                    static_for<0, R>([&](auto qq) {
+                        constexpr int q = decltype(qq)::value;
+                        v2f v = z[bitrev(q, LB)];
+                        if constexpr (q != 0) v = cmul(v, p.tw1[q * G + lg]);
+                        sl[q * EXS + lg] = v;
+                    });
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    static_for<0, R>([&](auto bb) {
+                        constexpr int bi = decltype(bb)::value;
+                        u[bi] = sl[qp * EXS + r + C * bi];
+                    });
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                } else {
+                    // one plane of N floats: real parts through, then imaginary parts (LDS executes a wave's accesses in order, so
+                    // the second set of writes cannot overtake the first set of reads)
+                    float* slf = reinterpret_cast<float*>(sl);
+                    static_for<0, R>([&](auto qq) {
+                        constexpr int q = decltype(qq)::value;
+                        v2f v = z[bitrev(q, LB)];
+                        if constexpr (q != 0) v = cmul(v, p.tw1[q * G + lg]);
+                        z[bitrev(q, LB)] = v;
+                        slf[q * EXS + lg] = v.x;
+                    });
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    float ure[R];
+                    static_for<0, R>([&](auto bb) {
+                        constexpr int bi = decltype(bb)::value;
+                        ure[bi] = slf[qp * EXS + r + C * bi];
+                    });
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    static_for<0, R>([&](auto qq) {
+                        constexpr int q = decltype(qq)::value;
+                        slf[q * EXS + lg] = z[bitrev(q, LB)].y;
+                    });
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    static_for<0, R>([&](auto bb) {
+                        constexpr int bi = decltype(bb)::value;
+                        u[bi] = v2f{ure[bi], slf[qp * EXS + r + C * bi]};
+                    });
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
                 STAMP(16 * ti + 5);   // twiddle + LDS transposition
                 // the radix-C twiddles w_G^(r*p1) are requested before the second radix-R stage, not one by one inside the
                 // cross-lane stage (each read there was waited for on the spot)
+                // (R = 32: in chunks of 8, the next chunk requested while one is used -- all 31 at once cost 62 registers on top of
+                // the 64 of the transform)
+                constexpr int TWC = (R > 16) ? 8 : R;
                 float2 tw2r[R];
-                if constexpr (C > 1) {
-                    static_for<1, R>([&](auto pp1) {
+                auto tw2_fetch = [&](auto cc) {
+                    constexpr int c0 = decltype(cc)::value;
+                    static_for<(c0 == 0 ? 1 : c0), (c0 + TWC < R ? c0 + TWC : R)>([&](auto pp1) {
                         constexpr int p1 = decltype(pp1)::value;
                         if constexpr (TW2_LDS) tw2r[p1] = tw2l[p1 * C + r]; else tw2r[p1] = p.tw2[p1 * C + r];
                     });
+                };
+                if constexpr (C > 1) {
+                    tw2_fetch(IC<0>{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 fft_reg<R>(u);
@@ -640,8 +698,14 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                 // twiddle w_G^(r*p1), radix-C across adjacent lanes, spectrum to LDS in natural order
                 const v2f rot_f = splat((C == 4 && r == 3) ? 0.f : 1.f);
                 const v2f rot_e = (C == 4 && r == 3) ? v2f{1.f, -1.f} : v2f{0.f, 0.f};
+                v2f zr[BPERM ? R : 1];                                   // Z[qp + R p1 + R R p2] of this lane, by p1
                 static_for<0, R>([&](auto pp1) {
                     constexpr int p1 = decltype(pp1)::value;
+                    if constexpr (C > 1 && TWC < R && p1 % TWC == 0 && p1 + TWC < R) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        tw2_fetch(IC<p1 + TWC>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     v2f v = u[bitrev(p1, LB)];
                     int p2 = 0;
                     if constexpr (C > 1) {
@@ -659,9 +723,61 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                         v = __builtin_elementwise_fma(splat(((r & 1) == 0) ? 1.f : -1.f), t, o);
                         p2 = ((r & 1) << 1) | (r >> 1);
                     }
-                    const int k = qp + R * p1 + R * R * p2;
-                    sl[z_index<R, C>(k)] = v;
+                    if constexpr (BPERM) zr[p1] = v;
+                    else {
+                        const int k = qp + R * p1 + R * R * p2;
+                        sl[z_index<R, C>(k)] = v;
+                    }
                 });
+                if constexpr (BPERM) {
+                    // ---- pairing pass without the spectrum in LDS.  Z[N-k] of k = qp + R p1 + R^2 p2 is Z[qp' + R p1' + R^2 p2'] with
+                    //   qp > 0:            qp' = R - qp, p1' = R - 1 - p1,  p2' = C - 1 - p2
+                    //   qp = 0, p1 > 0:    qp' = 0,      p1' = R - p1,      p2' = C - 1 - p2
+                    //   qp = 0, p1 = 0:    qp' = 0,      p1' = 0,           p2' = (C - p2) mod C
+                    // i.e. one fixed partner lane (two for the four lanes with qp = 0) and a register index that depends on p1 only:
+                    // each lane offers the register its partner wants (a select between the two cases) and ds_bpermute_b32 hands
+                    // it over -- LDS crossbar, no LDS storage.  Rounds p1 < R/2 meet every pair {k, N-k} exactly once (the partner
+                    // register is >= R/2), one more round covers p1 = R/2 on the qp = 0 lanes.  PD is symmetric in k <-> N-k, so
+                    // the lane that holds the upper bin writes PD[N-k]; only PD[0..N/2] exists in LDS, over the transposition plane.
+                    constexpr int PADC = (C > 1) ? 4 : 0, RR = R * R;
+                    auto lane_of_p2 = [](int v) { return C == 4 ? (((v & 1) << 1) | (v >> 1)) : v; };
+                    const int p2 = lane_of_p2(r);                              // (the digit reversal is its own inverse)
+                    const bool q0 = (qp == 0);
+                    const bool dir_a = (2 * p2 < C);                             // this lane's bins are <= N/2: it writes PD[k], else PD[N-k]
+                    const int p2m = C - 1 - p2;
+                    const int pull1 = (((R - qp) & (R - 1)) * C + lane_of_p2(p2m)) * 4;
+                    const int pull0 = q0 ? lane_of_p2((C - p2) % C) * 4 : pull1;
+                    const int slot_b = slot * (SS * 8);
+                    const int base_a = slot_b + (qp + (RR + PADC) * p2) * 8;
+                    const int base_b = slot_b + ((R - qp) + R * (R - 1) + (RR + PADC) * p2m) * 8;
+                    const int obase = dir_a ? base_a : base_b;
+                    const int ostep = dir_a ? R * 8 : -R * 8;
+                    const bool nyq = q0 && (2 * p2 == C);                        // k = N/2 (C > 1: round 0; C = 1: the extra round)
+                    const int addr0 = nyq ? slot_b + (N / 2 + PADC * (C / 2)) * 8 : obase;
+                    const bool w0 = dir_a || !q0 || nyq;
+                    static_for<0, R / 2 + 1>([&](auto pp1) {
+                        constexpr int p1 = decltype(pp1)::value;
+                        constexpr int s_a = (p1 == R / 2) ? R / 2 : (R - 1 - p1);        // what a partner with qp > 0 wants
+                        constexpr int s_b = (p1 == R / 2) ? R / 2 : ((R - p1) % R);      // ... with qp = 0
+                        // (component by component: a scalar-condition select of two ext vectors lost its second lane here)
+                        const float send_x = (s_a == s_b) ? zr[s_a].x : (q0 ? zr[s_b].x : zr[s_a].x);
+                        const float send_y = (s_a == s_b) ? zr[s_a].y : (q0 ? zr[s_b].y : zr[s_a].y);
+                        const int pull = (p1 == 0) ? pull0 : pull1;
+                        const int got_x = __builtin_amdgcn_ds_bpermute(pull, __builtin_bit_cast(int, send_x));
+                        const int got_y = __builtin_amdgcn_ds_bpermute(pull, __builtin_bit_cast(int, send_y));
+                        const v2f zn = v2f{__builtin_bit_cast(float, got_x), __builtin_bit_cast(float, got_y)};
+                        const v2f zk = zr[p1];
+                        const float sx = zk.x + zn.x, sy = zk.y - zn.y, dx = zk.x - zn.x, dy = zk.y + zn.y;
+                        v2f pdv;
+                        if constexpr (!PAIR) pdv = v2f{fmaf(sx, sx, sy * sy), fmaf(sx, dy, -(sy * dx))};
+                        else pdv = v2f{fmaf(sx, sx, sy * sy), fmaf(dx, dx, dy * dy)};
+                        if constexpr (p1 == 0) { if (w0) *reinterpret_cast<v2f*>(smem_raw + addr0) = pdv; }
+                        else if constexpr (p1 < R / 2) *reinterpret_cast<v2f*>(smem_raw + obase + ostep * p1) = pdv;
+                        else { if (q0 && dir_a) *reinterpret_cast<v2f*>(smem_raw + base_a + R * 8 * (R / 2)) = pdv; }
+                    });
+                    // the filterbank fragments of phase 2: requested once the spectrum registers are dead
+                    if constexpr (pass == PASSES - 1) { __builtin_amdgcn_sched_barrier(0); fetch_bpre(); }
+                } else {
                 // the filterbank fragments of phase 2 are requested here: the registers of the FFT are free, and the pairing
                 // pass plus the barrier behind it cover the round trip
                 if constexpr (pass == PASSES - 1) { fetch_bpre(); __builtin_amdgcn_sched_barrier(0); }
@@ -706,6 +822,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                     v2f* dst = reinterpret_cast<v2f*>(smem_raw + zb + (ck + PADC * (ck / RR)) * 8);
                     if (i < NPAIR - 1 || lg == 0) *dst = pd[i];          // the last round holds only the Nyquist bin
                 });
+                }
             });
         }
         STAMP(16 * ti + 7);   // twiddle + cross-lane radix-C + spectrum to LDS + pairing pass
@@ -906,7 +1023,7 @@ template <int N, int MODE, int TPW> static hipError_t launch_one(const FwdParams
 }
 
 // two tiles per workgroup are built for the sizes whose launches are large enough to use them (forward_tiles_per_wg)
-template <int N> constexpr bool has_tpw2() { return N >= 256 && N <= 2048; }
+template <int N> constexpr bool has_tpw2() { return N >= 256 && N <= 1024; }
 
 template <int N> static hipError_t launch_n(int mode, int tpw, const FwdParams& p, int grid, hipStream_t s)
 {
@@ -977,7 +1094,7 @@ int forward_frames_per_tile(int n_fft, int mode)
 // are used when that model says the launch gets shorter -- e.g. not for 5 rounds becoming 3 double ones (config 3).
 int forward_tiles_per_wg(int n_fft, int batch, int tiles_per_clip)
 {
-    if (n_fft < 256 || n_fft > 2048 || tiles_per_clip < 2 || batch < 1) return 1;
+    if (n_fft < 256 || n_fft > 1024 || tiles_per_clip < 2 || batch < 1) return 1;
     const int lds = forward_lds_bytes(n_fft);
     const long long resident = 256LL * (lds > 0 && 163840 / lds > 0 ? 163840 / lds : 1);
     const long long wg1 = (long long)batch * tiles_per_clip, wg2 = (long long)batch * ((tiles_per_clip + 1) / 2);

@@ -115,28 +115,34 @@ __device__ __forceinline__ float lam_tangent_scale(const LamState& st)
 // the first half of tile w and the second half of tile 7-w (exchanged through 8 KB of LDS), which
 // evens out the HTK bands that widen with frequency.
 template <int N> struct FftPlan;
-template <> struct FftPlan<32>   { static constexpr int R = 4,  C = 2, PASSES = 1, WAVES = 4, NBPRE = 4, MINW = 4; };
-template <> struct FftPlan<64>   { static constexpr int R = 8,  C = 1, PASSES = 1, WAVES = 4, NBPRE = 4, MINW = 4; };
-template <> struct FftPlan<128>  { static constexpr int R = 8,  C = 2, PASSES = 1, WAVES = 4, NBPRE = 8, MINW = 4; };
-template <> struct FftPlan<256>  { static constexpr int R = 16, C = 1, PASSES = 1, WAVES = 4, NBPRE = 12, MINW = 4; };
-template <> struct FftPlan<512>  { static constexpr int R = 16, C = 2, PASSES = 1, WAVES = 4, NBPRE = 20, MINW = 4; };
-template <> struct FftPlan<1024> { static constexpr int R = 16, C = 4, PASSES = 1, WAVES = 8, NBPRE = 20, MINW = 4; };
-template <> struct FftPlan<2048> { static constexpr int R = 32, C = 2, PASSES = 1, WAVES = 8, NBPRE = 40, MINW = 2; };
-template <> struct FftPlan<4096> { static constexpr int R = 64, C = 1, PASSES = 1, WAVES = 4, NBPRE = 8, MINW = 1; };
+// BPERM: the pairing pass takes Z[N-k] from the lane that holds it with ds_bpermute_b32 instead of storing the whole spectrum
+// to LDS and reading it back mirrored; only PD[0..N/2] is ever stored.  SPLIT: the transposition between the two radix-R stages
+// moves the real and the imaginary parts one after the other through ONE plane of N floats; together with BPERM and a
+// half-length (symmetric) window table a frame in flight needs N*4 bytes of LDS instead of N*8 (n_fft 2048: two workgroups
+// per CU instead of one).
+template <> struct FftPlan<32>   { static constexpr int R = 4,  C = 2, PASSES = 1, WAVES = 4, NBPRE = 4, MINW = 4, BPERM = 0, SPLIT = 0; };
+template <> struct FftPlan<64>   { static constexpr int R = 8,  C = 1, PASSES = 1, WAVES = 4, NBPRE = 4, MINW = 4, BPERM = 0, SPLIT = 0; };
+template <> struct FftPlan<128>  { static constexpr int R = 8,  C = 2, PASSES = 1, WAVES = 4, NBPRE = 8, MINW = 4, BPERM = 0, SPLIT = 0; };
+template <> struct FftPlan<256>  { static constexpr int R = 16, C = 1, PASSES = 1, WAVES = 4, NBPRE = 12, MINW = 4, BPERM = 0, SPLIT = 0; };
+template <> struct FftPlan<512>  { static constexpr int R = 16, C = 2, PASSES = 1, WAVES = 4, NBPRE = 20, MINW = 4, BPERM = 0, SPLIT = 0; };
+template <> struct FftPlan<1024> { static constexpr int R = 16, C = 4, PASSES = 1, WAVES = 8, NBPRE = 20, MINW = 4, BPERM = 0, SPLIT = 0; };
+template <> struct FftPlan<2048> { static constexpr int R = 32, C = 2, PASSES = 1, WAVES = 8, NBPRE = 40, MINW = 4, BPERM = 1, SPLIT = 1; };
+template <> struct FftPlan<4096> { static constexpr int R = 64, C = 1, PASSES = 1, WAVES = 8, NBPRE = 40, MINW = 2, BPERM = 1, SPLIT = 1; };
 
 constexpr int kRedBytes = 80;          // 8 + 8 partial sums, then the tangent scale (word 16) computed once per workgroup
 struct FftGeom {
     int N, R, C, G, FPW, PASSES, WAVES, NLOC, THREADS, SLOTS, MT, EX_STRIDE, SLOT_STRIDE_F2, NBPRE, MINW, LDS_BYTES, AUX_OFF, RED_OFF, WIN_LDS;
+    int BPERM, SPLIT, WIN_SYM;
 };
 
 constexpr int ex_stride(int G, int C) { return G + (G >= 32 ? C : 1); }
 constexpr int z_index_host(int k, int R, int C) { return C == 1 ? k : k + (k / (R * R)) * 4; }
-constexpr int slot_stride_f2(int N, int R, int C)
+constexpr int slot_stride_f2(int N, int R, int C, int bperm = 0, int split = 0)
 {
     const int G = N / R;
-    const int a = R * ex_stride(G, C);
-    const int b = z_index_host(N - 1, R, C) + 1;
-    const int need = (a > b ? a : b) * 8;
+    const int a = R * ex_stride(G, C) * (split ? 4 : 8);                           // transposition: complex entries, or one plane of floats
+    const int b = (z_index_host(bperm ? N / 2 : N - 1, R, C) + 1) * 8;             // spectrum Z[0..N-1], or only PD[0..N/2]
+    const int need = a > b ? a : b;
     // = 48 bytes (mod 128).  The A operands of phase 2 are read with ds_read_b32 / ds_read2_b32, which bank modulo 32 dwords
     // (128 B) in two 32-lane groups: each group touches 16 B per slot, so the 8 slots must start 16 B apart modulo 128
     // (a stride = 32 mod 256 put slots s and s+4 on the same banks: 2-way conflicts, SQ_LDS_BANK_CONFLICT = 25 % of the
@@ -153,11 +159,14 @@ template <int N> constexpr FftGeom geom()
     g.SLOTS = g.WAVES * g.FPW * g.PASSES;
     g.MT = g.SLOTS >= 8 ? g.SLOTS / 8 : 1;
     g.EX_STRIDE = ex_stride(g.G, g.C);
-    g.SLOT_STRIDE_F2 = slot_stride_f2(N, P::R, P::C);
+    g.BPERM = P::BPERM; g.SPLIT = P::SPLIT;
+    g.SLOT_STRIDE_F2 = slot_stride_f2(N, P::R, P::C, P::BPERM, P::SPLIT);
     // LDS map: [FFT slots][aux: window table (phase 1) aliased with the half-tile exchange (phase 2)][8 sums]
     g.WIN_LDS = (N <= 2048) ? 1 : 0;                      // n_fft 4096 has no room: its window stays in global memory
     const int xch = (g.WAVES == 8) ? 8 * 64 * 16 * g.MT : 0;
-    const int win = g.WIN_LDS ? N * 8 : 0;
+    // the Gaussian window is symmetric about N/2: the compact layout keeps entries 0..N/2 only
+    g.WIN_SYM = (g.WIN_LDS && P::SPLIT) ? 1 : 0;
+    const int win = g.WIN_LDS ? (g.WIN_SYM ? (N / 2 + 1) * 8 : N * 8) : 0;
     g.AUX_OFF = g.SLOTS * g.SLOT_STRIDE_F2 * 8;
     g.RED_OFF = g.AUX_OFF + (xch > win ? xch : win);
     // [16 sums + tangent scale (kRedBytes)][tw2 table: R x C complex, the radix-C twiddles: every lane of a wave reads one of C values per p1]
