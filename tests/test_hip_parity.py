@@ -116,7 +116,7 @@ def test_matches_oracle_elementwise(name):
         assert float(np.abs(t - t_ref).max()) / tscale <= TOL
 
 
-@pytest.mark.parametrize("name", ["g1_c1", "g2_c2", "g6_n256_ragged", "g5_n128", "g6_n32"])
+@pytest.mark.parametrize("name", ["g1_c1", "g2_c2", "g6_n256_ragged", "g5_n128", "g6_n32", "g6_n2048_short", "g3_c3", "g5_n4096"])
 def test_inference_path_equals_training_path(name):
     """Without a trainable lambd two frames share one FFT; results must agree with the tangent-carrying kernel."""
     case = C.BY_NAME[name]
@@ -128,7 +128,7 @@ def test_inference_path_equals_training_path(name):
     assert float((a.detach() - b).abs().max()) <= 2e-5
 
 
-@pytest.mark.parametrize("name", ["g1_c1", "g2_c2", "g5_n128", "g6_n256_ragged", "g6_n2048_short"])
+@pytest.mark.parametrize("name", ["g1_c1", "g2_c2", "g5_n128", "g6_n256_ragged", "g6_n2048_short", "g5_n4096"])
 def test_spectrogram_stage(name):
     """Framing + window + FFT + |.|^2 alone (time_frequency.py:32-58) against the oracle."""
     case = C.BY_NAME[name]
@@ -334,7 +334,9 @@ def test_dspec_layer_matches_reference_and_oracle():
     exp_d = float(gold["dlam_lin"])
     assert abs(float(layer.lambd.grad) - exp_d) <= _dlam_tol(exp_d, g_np, ref_t)
     # normalised window, other hop, power-of-two lengths from 16 to 1024
-    for L, hop, lam, norm in ((16, 1, 2.5, False), (64, 3, 5.0, True), (256, 8, 20.0, False), (1024, 64, 90.0, True)):
+    # (n_fft = 2L: 2048 and 4096 run the compact layout of the fused kernel with the half-length window)
+    for L, hop, lam, norm in ((16, 1, 2.5, False), (64, 3, 5.0, True), (256, 8, 20.0, False), (1024, 64, 90.0, True),
+                              (1024, 100, -70.0, False), (2048, 128, 200.0, True)):
         xn = synth.waveforms(3, L, seed=L, scale=1.0)
         lay = SpectrogramLayer(torch.tensor(lam), optimized=False, hop_length=hop, normalize_window=norm).to("cuda:0")
         out = lay(torch.from_numpy(xn).to("cuda:0"))
@@ -648,6 +650,24 @@ def test_full_window_branch_up_to_8192_points():
     assert _log_err(y.detach().cpu().numpy(), y_ref) <= TOL
 
 
+def test_full_window_branch_on_the_compact_layout():
+    """optimized=False at n_points 2048: n_fft 4096 on the fused kernel's compact layout, half-length window from the prep kernel."""
+    case = dict(C.BY_NAME["g7_mel_nonopt_1024n"], name="nonopt_2048", L=2048, lambd=-150.0, hop=100, normalize_window=True)
+    x_np = C.make_input(case).astype(np.float32)
+    g_np = C.make_cotangent(case)
+    for log in (False, True):
+        layer = _layer(case, log=log)
+        y = layer(torch.from_numpy(x_np).to("cuda:0"))
+        assert layer.plan_info()["kernel_path"] == 0 and layer.plan_info()["n_fft"] == 4096
+        (y * torch.from_numpy(g_np).to("cuda:0")).sum().backward()
+        y_ref, t_ref = O.forward(x_np, case["lambd"], case["hop"], case["n_mels"], case["sr"], case["f_min"], case["f_max"],
+                                 case["normalize_window"], apply_log=log, optimized=False)
+        o = y.detach().cpu().numpy()
+        assert (_log_err(o, y_ref) if log else _rel_err(o, y_ref)) <= TOL
+        exp_d = O.backward(g_np, t_ref)
+        assert abs(float(layer.lambd.grad) - exp_d) <= _dlam_tol(exp_d, g_np, t_ref)
+
+
 # ---- bf16 activations (BASELINE config 2: "bf16 activations / fp32 grad") ----------------------------------------
 @pytest.mark.parametrize("name", ["g1_c1", "g2_c2", "g6_n256_ragged", "g6_n32"])
 def test_bf16_output_is_the_rounded_fp32_output(name):
@@ -828,6 +848,9 @@ ODD_SHAPES = [
     dict(C.BY_NAME["g1_c1"], name="many_mels", B=2, L=16000, lambd=170.0, hop=400, n_mels=200),             # two mel groups, n_fft 1024
     dict(C.BY_NAME["g1_c1"], name="many_mels_2048", B=1, L=16000, lambd=300.0, hop=800, n_mels=300),
     dict(C.BY_NAME["g1_c1"], name="short_clip", B=4, L=37, lambd=10.0, hop=5, n_mels=8),                    # clip shorter than n_fft 64
+    # compact LDS layout (n_fft 2048 / 4096): negative lambd, normalised window, frame count not a multiple of the tile
+    dict(C.BY_NAME["g1_c1"], name="compact_2048_neg_norm", B=3, L=12345, lambd=-260.0, hop=333, n_mels=80, normalize_window=True),
+    dict(C.BY_NAME["g1_c1"], name="compact_4096_norm", B=2, L=30011, lambd=500.0, hop=1001, n_mels=64, normalize_window=True),
 ]
 
 
@@ -848,7 +871,8 @@ def test_unusual_shapes_match_oracle(case):
         assert (_log_err(o, o_ref) if log else _rel_err(o, o_ref)) <= TOL
         exp_d = O.backward(g_np, t_ref)
         assert abs(float(layer.lambd.grad) - exp_d) <= _dlam_tol(exp_d, g_np, t_ref)
-        ref_x = O.backward_x(x_np, case["lambd"], case["hop"], case["sr"], g_np, o if log else None, case["f_min"], case["f_max"])
+        ref_x = O.backward_x(x_np, case["lambd"], case["hop"], case["sr"], g_np, o if log else None, case["f_min"], case["f_max"],
+                             case["normalize_window"])
         assert _gx_err(x.grad.cpu().numpy(), ref_x) <= TOL
         with torch.no_grad():
             yi = _layer(case, log=log, trainable=False)(x.detach())
