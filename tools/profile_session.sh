@@ -14,4 +14,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --steps 30 --warmup 5 --mode eager --no-cpu-baseline --no-other-configs > $OUT/write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $OUT/sq1 -- python3 bench.py --steps 30 --warmup 5 --mode eager --no-cpu-baseline --no-other-configs > $OUT/sq1.log 2>&1
 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/sq2 -- python3 bench.py --steps 30 --warmup 5 --mode eager --no-cpu-baseline --no-other-configs > $OUT/sq2.log 2>&1
-ls -R $OUT | head -50
+# the n_fft 2048 kernel (configs 3 and 5): kernel trace of plain launch trains (registers, LDS, duration per dispatch)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_c3 -- python3 tools/ktime.py c3 train 60 > $OUT/kt_c3.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_c5 -- python3 tools/ktime.py c5 train 60 > $OUT/kt_c5.log 2>&1
+ls -R $OUT | head -60

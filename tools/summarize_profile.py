@@ -42,6 +42,25 @@ for k in sorted({r["Kernel_Name"] for r in rows}):
                      lds=r0.get("LDS_Block_Size"), scratch=r0.get("Scratch_Size"), wg=r0.get("Workgroup_Size", r0.get("Workgroup_Size_X")), grid=r0.get("Grid_Size", r0.get("Grid_Size_X"))))
 json.dump(summ, open(os.path.join(out, f"{tag}_kernel_trace_summary_c2.json"), "w"), indent=1)
 
+# configs 3 and 5 (n_fft 2048): per-kernel summary of the launch trains of tools/ktime.py
+other = {}
+for cfg in ("c3", "c5"):
+    hits = glob.glob(os.path.join(src, f"kt_{cfg}/**/*_kernel_trace.csv"), recursive=True)
+    if len(hits) != 1:
+        continue
+    rws = list(csv.DictReader(open(hits[0])))
+    lst = []
+    for k in sorted({r["Kernel_Name"] for r in rws if "dmel" in r["Kernel_Name"]}):
+        rs = [r for r in rws if r["Kernel_Name"] == k]
+        d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rs]
+        r0 = rs[0]
+        lst.append(dict(kernel=short(k)[:110], calls=len(d), avg_ns=round(statistics.mean(d), 1), median_ns=statistics.median(d), min_ns=min(d),
+                        vgpr=r0.get("VGPR_Count"), lds=r0.get("LDS_Block_Size"), scratch=r0.get("Scratch_Size"),
+                        wg=r0.get("Workgroup_Size", r0.get("Workgroup_Size_X")), grid=r0.get("Grid_Size", r0.get("Grid_Size_X"))))
+    other[cfg] = lst
+if other:
+    json.dump(other, open(os.path.join(out, f"{tag}_kernel_trace_summary_c3_c5.json"), "w"), indent=1)
+
 # one steady-state step of the timed region (graph replay): kernels in issue order with gaps
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 def tight(i):      # forward, dot and the optimizer's kernels back to back: a graph replay, not the eagerly issued trial
@@ -117,6 +136,7 @@ json.dump(sqj, open(os.path.join(out, f"{tag}_pmc_sq_c2.json"), "w"), indent=1)
 bench["roofline"]["traffic"] = traffic
 json.dump(bench, open(os.path.join(out, f"{tag}_bench_c2.json"), "w"), indent=1)
 print(json.dumps([s_ for s_ in summ if "dmel" in s_["kernel"]], indent=1))
+print(json.dumps(other, indent=1))
 print(json.dumps(hbm["c2"], indent=1))
 print(json.dumps(sqj["per_wave"]), json.dumps(sqj["shares_of_wave_cycles"]))
 print({k: bench[k] for k in ("value", "ms_per_step")}, bench["module_step"])
