@@ -208,13 +208,7 @@ dmel_status build_tables(dmel_plan* pl, int N, NfftTables** out)
         DMEL_HIP(hipMemcpy(tb.band, band.data(), band.size() * sizeof(int2), hipMemcpyHostToDevice));
     } else if (N >= dmel::kMinFastNfft) {
         int R = 0, C = 0;
-        switch (N) {
-            case 32: R = 4; C = 2; break;   case 64: R = 8; C = 1; break;
-            case 128: R = 8; C = 2; break;  case 256: R = 16; C = 1; break;
-            case 512: R = 16; C = 2; break; case 1024: R = 16; C = 4; break;
-            case 2048: R = 32; C = 2; break; case 4096: R = 64; C = 1; break;
-            default: return fail(DMEL_ERR_UNSUPPORTED, "n_fft has no FFT plan");
-        }
+        if (!dmel::forward_plan_rc(N, &R, &C)) return fail(DMEL_ERR_UNSUPPORTED, "n_fft has no FFT plan");
         const int G = N / R;
         std::vector<float2> tw1((size_t)R * G), tw2((size_t)R * C);
         for (int q = 0; q < R; ++q)
@@ -555,22 +549,6 @@ dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dm
         pl->info.fb_blocks = 0; pl->info.fb_blocks_dense = 0; pl->info.lds_bytes = (2 * N + 2 * tb->F) * 4;
         return DMEL_OK;
     }
-    if (N > dmel::kMaxFastNfft) {
-        dmel::LongParams lp{};
-        lp.x = x; lp.out = out; lp.tangent = tangent; lp.psum = sc.psum; lp.win2 = sc.win;
-        lp.tw = tb->tw_long; lp.fbT = tb->fbT; lp.band = tb->band;
-        lp.B = batch; lp.L = pl->cfg.n_points; lp.T = pl->T; lp.hop = pl->cfg.hop_length; lp.M = pl->cfg.n_mels;
-        lp.nchunks = pl->nchunks; lp.N = N; lp.F = tb->F; lp.mode = mode;
-        lp.logN = 0; while ((1 << lp.logN) < N) ++lp.logN;
-        lp.inv_L = inv_L; lp.eps = (float)eps; lp.flags = flags; lp.remove_dc = remove_dc; lp.lam = lam;
-        DMEL_HIP(dmel::launch_long(lp, s));
-        prof_span(pl, m1, prof_mark(pl, s), 1);
-        const bool pair = (mode == dmel::kInfer || mode == dmel::kSpec);
-        pl->info.kernel_path = 2; pl->info.frames_per_tile = pair ? 2 : 1;
-        pl->info.grid_fwd = batch * (pair ? (pl->T + 1) / 2 : pl->T);
-        pl->info.fb_blocks = 0; pl->info.fb_blocks_dense = 0; pl->info.lds_bytes = N * 8;
-        return DMEL_OK;
-    }
     dmel::FwdParams fp{};
     fp.x = x; fp.out = out; fp.tangent = tangent; fp.psum = (remove_dc && !kernel_mean) ? sc.psum : nullptr; fp.win2 = sc.win;
     fp.tw1 = tb->tw1; fp.tw2 = tb->tw2; fp.ent_b = tb->ent_b; fp.tile_ranges = tb->tile_ranges; fp.ent_b_floats = tb->ent_b_floats; fp.ent_pre = tb->ent_pre;
@@ -583,7 +561,7 @@ dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dm
     fp.remove_dc = remove_dc; fp.normalize = pl->cfg.normalize_window; fp.win_half = win_half;
     static const int force_tpw = std::getenv("DMEL_TILES_PER_WG") ? std::atoi(std::getenv("DMEL_TILES_PER_WG")) : 0;   // diagnostics
     int tpw = dmel::forward_tiles_per_wg(N, batch, fp.tiles_per_clip);
-    if (force_tpw == 1 || (force_tpw == 2 && N >= 256 && N <= 2048)) tpw = force_tpw;
+    if (force_tpw == 1 || (force_tpw == 2 && N >= 256 && N <= 1024)) tpw = force_tpw;
     fp.wgs_per_clip = (fp.tiles_per_clip + tpw - 1) / tpw;
     const long long grid = (long long)batch * fp.wgs_per_clip;
     if (grid > 0x7fffffffLL) return fail(DMEL_ERR_INVALID_ARGUMENT, "too many tiles for one launch");
@@ -794,7 +772,6 @@ dmel_status dmel_plan_create(const dmel_config* cfg, dmel_plan** plan)
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(DMEL_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", libdmel_hip is built for gfx950 only");
     DMEL_HIP(dmel::forward_prepare_attributes());
-    DMEL_HIP(dmel::long_prepare_attributes());
     DMEL_HIP(dmel::xgrad_prepare_attributes());
     DMEL_HIP(dmel::big_prepare_attributes());
     dmel_plan* pl = new (std::nothrow) dmel_plan();

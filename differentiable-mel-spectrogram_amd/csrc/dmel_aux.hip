@@ -236,154 +236,6 @@ hipError_t launch_naive(const NaiveParams& p, hipStream_t s)
     return hipGetLastError();
 }
 
-// ---- long transforms -----------------------------------------------------------------------------
-// n_fft 8192 and 16384 (|lambd| > 682.6 samples: windows of 0.5 s and more) do not fit the register-resident wave FFT.
-// One workgroup of 1024 threads transforms one complex sequence of N points held in LDS (128 KB at N = 16384): in-place
-// decimation in frequency with the radix-2 stages fused in pairs (dmel_ldsfft.h),
-// spectrum left in bit-reversed order and read back through __brev.  Same packing as the fused kernel: training mode transforms x~ w + i x~ w' (one frame and its
-// lambd-tangent), inference / spectrogram modes transform two frames at once; the pairing pass is identical.  The
-// mel stage is a band-limited dot product per mel band (one wave per band, fixed-order reduction).  A correctness
-// path for rarely reached sizes, not a tuned one.
-constexpr int kLongThreads = 1024;
-
-__device__ __forceinline__ float wave_sum_shfl(float v)
-{
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);       // same tree on every lane and every run
-    return v;
-}
-
-template <bool TWLDS>
-__global__ void __launch_bounds__(kLongThreads) dmel_long_kernel(LongParams p)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float2* Z = reinterpret_cast<float2*>(smem_raw);
-    float2* twl = Z + p.N;                 // TWLDS: the twiddle table sits behind the sequence (small n_fft only, see launch_long)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int N = p.N, F = p.F, sh = 32 - p.logN;
-    const bool pair = (p.mode == kInfer || p.mode == kSpec);
-    const int tiles = pair ? (p.T + 1) / 2 : p.T;
-    const int b = blockIdx.x / tiles, tile = blockIdx.x % tiles;
-    const int tA = pair ? 2 * tile : tile, tB = tA + 1;
-    const float* xb = p.x + (size_t)b * p.L;
-    const LamState ls = lam_prologue(p.lam, N, blockIdx.x == 0 && tid == 0);
-    if (ls.action != kLamRun) {
-        if (ls.action == kLamPoison) {           // no launch of this forward matched the device lambd (dmel_kernels.h)
-            const int rows = (p.mode == kSpec || p.mode == kSpecTrain) ? F : p.M;
-            for (int rr = tid; rr < rows; rr += kLongThreads) {
-                const size_t o = ((size_t)b * rows + rr) * p.T;
-                for (int tt = tA; tt <= (pair ? tB : tA) && tt < p.T; ++tt) {
-                    if (p.flags & 4u) reinterpret_cast<unsigned short*>(p.out)[o + tt] = 0x7fc0u; else p.out[o + tt] = __builtin_nanf("");
-                    if (p.tangent) p.tangent[o + tt] = __builtin_nanf("");
-                }
-            }
-        }
-        return;
-    }
-    const float htan = 0.5f * lam_tangent_scale(ls);
-    float mean = 0.f;
-    if (p.remove_dc) {
-        double s = 0.0;
-        for (int c = 0; c < p.nchunks; ++c) s += (double)p.psum[(size_t)b * p.nchunks + c];
-        mean = (float)(s * (double)p.inv_L);
-    }
-    for (int n = tid; n < N; n += kLongThreads) {
-        const long long ia = (long long)tA * p.hop - N / 2 + n;
-        const float va = (ia >= 0 && ia < p.L) ? (xb[ia] - mean) : 0.f;      // zero padding after the DC removal
-        const float2 wd = p.win2[n];
-        if (pair) {
-            const long long ib = ia + p.hop;
-            const float vb = (tB < p.T && ib >= 0 && ib < p.L) ? (xb[ib] - mean) : 0.f;
-            Z[n] = make_float2(va * wd.x, vb * wd.x);
-        } else {
-            Z[n] = make_float2(va * wd.x, va * wd.y);
-        }
-    }
-    if (TWLDS) for (int k = tid; k < (N >> 1); k += kLongThreads) twl[k] = p.tw[k];
-    __syncthreads();
-    if (TWLDS) lds_fft_dif<kLongThreads>(Z, N, p.logN, tid, [&](int k) { return twl[k]; });
-    else lds_fft_dif<kLongThreads>(Z, N, p.logN, tid, [&](int k) { return p.tw[k]; });
-    // pairing pass (see dmel_fwd.hip): PD[k] = (|S|^2, Im(conj S * D)) or (|S|^2, |D|^2), in place at Z[brev(k)];
-    // the two addresses a thread touches belong to no other thread
-    for (int k = tid; k <= (N >> 1); k += kLongThreads) {
-        const unsigned ak = __brev((unsigned)k) >> sh, an = __brev((unsigned)((N - k) & (N - 1))) >> sh;
-        const float2 zk = Z[ak], zn = Z[an];
-        const float sx = zk.x + zn.x, sy = zk.y - zn.y, dx = zk.x - zn.x, dy = zk.y + zn.y;
-        Z[ak] = pair ? make_float2(fmaf(sx, sx, sy * sy), fmaf(dx, dx, dy * dy))
-                     : make_float2(fmaf(sx, sx, sy * sy), fmaf(sx, dy, -(sy * dx)));
-    }
-    __syncthreads();
-    if (p.mode == kSpec || p.mode == kSpecTrain) {
-        for (int k = tid; k < F; k += kLongThreads) {
-            const float2 pd = Z[__brev((unsigned)k) >> sh];
-            const size_t o = ((size_t)b * F + k) * p.T;
-            if (p.mode == kSpec) {
-                p.out[o + tA] = 0.25f * pd.x;
-                if (tB < p.T) p.out[o + tB] = 0.25f * pd.y;
-            } else {
-                p.out[o + tA] = 0.25f * pd.x;
-                if (p.tangent) p.tangent[o + tA] = htan * pd.y;
-            }
-        }
-        return;
-    }
-    const bool do_log = (p.flags & 1u) != 0;
-    for (int m = wave; m < p.M; m += kLongThreads / 64) {
-        const int2 bd = p.band[m];
-        const float* fr = p.fbT + (size_t)m * F;
-        float s0 = 0.f, s1 = 0.f;
-        for (int k = bd.x + lane; k < bd.y; k += 64) {
-            const float c = fr[k];
-            const float2 pd = Z[__brev((unsigned)k) >> sh];
-            s0 = fmaf(c, pd.x, s0);
-            s1 = fmaf(c, pd.y, s1);
-        }
-        s0 = wave_sum_shfl(s0);
-        s1 = wave_sum_shfl(s1);
-        if (lane != 0) continue;
-        const size_t o = ((size_t)b * p.M + m) * p.T;
-        const bool out_bf16 = (p.flags & 4u) != 0;
-        auto put = [&](int t, float v) { if (out_bf16) reinterpret_cast<unsigned short*>(p.out)[o + t] = bf16_bits(v); else p.out[o + t] = v; };
-        if (pair) {
-            const float ma = 0.25f * s0, mb = 0.25f * s1;
-            put(tA, do_log ? logf(ma + p.eps) : ma);
-            if (tB < p.T) put(tB, do_log ? logf(mb + p.eps) : mb);
-        } else {
-            const float mel = 0.25f * s0, dmel = htan * s1;
-            if (do_log) {
-                const float me = mel + p.eps;
-                put(tA, logf(me));
-                if (p.tangent) p.tangent[o + tA] = dmel / me;
-            } else {
-                put(tA, mel);
-                if (p.tangent) p.tangent[o + tA] = dmel;
-            }
-        }
-    }
-}
-
-hipError_t long_prepare_attributes()
-{
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dmel_long_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       kMaxNfft * (int)sizeof(float2));
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(dmel_long_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 12);
-}
-
-hipError_t launch_long(const LongParams& p, hipStream_t s)
-{
-    const bool pair = (p.mode == kInfer || p.mode == kSpec);
-    const long long tiles = pair ? (p.T + 1) / 2 : p.T;
-    const long long grid = tiles * p.B;
-    if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
-    // the twiddle table goes to LDS only where that does not cost a resident workgroup: at n_fft 8192 it would (64 + 32 KB:
-    // one workgroup per CU instead of two; measured 5 % slower), at 16384 it does not fit
-    if (p.N <= 4096)
-        hipLaunchKernelGGL(dmel_long_kernel<true>, dim3((unsigned)grid), dim3(kLongThreads), (size_t)p.N * 12, s, p);
-    else
-        hipLaunchKernelGGL(dmel_long_kernel<false>, dim3((unsigned)grid), dim3(kLongThreads), (size_t)p.N * sizeof(float2), s, p);
-    return hipGetLastError();
-}
-
 // ---- filterbank gradient ----------------------------------------------------------------------
 // grad_fb = sum over clips of  spec_b (F x T) * gm_b^T (T x M): per clip a small GEMM whose K dimension (time) is
 // contiguous in both operands.  One workgroup owns a 32 (freq) x 128 (mel) tile of grad_fb for one slice of the

@@ -294,10 +294,14 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
     // the half-tile exchange of phase 2 (8 waves) lives where the window table does: a second tile needs the table back
     constexpr bool WIN_ALIASED = WIN_LDS && WAVES == 8;
     // compact layouts (dmel_kernels.h): pairing pass through ds_bpermute, transposition one plane at a time, half window table
-    constexpr bool BPERM = g.BPERM != 0, SPLIT = g.SPLIT != 0, WIN_SYM = g.WIN_SYM != 0;
+    constexpr bool BPERM = g.PAIRING == kPairBperm, PLANE = g.PAIRING == kPairPlane, SPLIT = g.SPLIT != 0, WIN_SYM = g.WIN_SYM != 0;
+    constexpr bool KEEPZ = BPERM || PLANE;                      // the spectrum stays in registers until the pairing pass
+    constexpr int WPF = g.WPF;                                  // waves per frame (n_fft 8192: 2, 16384: 4)
     static_assert(!BPERM || (G == 64 && PASSES == 1), "the bpermute pairing pass assumes one frame per wave");
-    static_assert(!SPLIT || BPERM, "a one-plane slot cannot hold the whole spectrum");
+    static_assert(!SPLIT || KEEPZ, "a one-plane slot cannot hold the whole spectrum");
     static_assert(!WIN_SYM || G == 64, "half window table: one frame per wave");
+    static_assert(WPF == 1 || (PLANE && SPLIT && PASSES == 1 && !WIN_LDS), "frames spread over several waves exchange through planes");
+    static_assert(!PLANE || G >= 64, "plane pairing: whole waves per frame");
     constexpr int WPT = (N / 2 + THREADS - 1) / THREADS;       // window entries a thread computes (and keeps when TPW > 1)
 
     const int tid = threadIdx.x;
@@ -363,8 +367,20 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
         }
     };
 
-    const int j = lane / G, lg = lane % G;
+    // lane of this thread inside its frame: part of a wave (G < 64), the wave, or one of WPF waves
+    const int j = (WPF > 1) ? 0 : lane / G;
+    const int lg = (WPF > 1) ? (wave % WPF) * 64 + lane : lane % G;
     const int qp = lg / C, r = lg % C;
+    // exchange among the lanes of one frame: a wave-level fence, or a workgroup barrier when the frame has several waves
+    // (every wave of the workgroup runs the same sequence of them)
+    auto sync_frame = [&]() {
+        if constexpr (WPF > 1) __syncthreads();
+        else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    };
 
     // ---- samples: one register set per tile of the workgroup; tile ti + 1 is requested while tile ti is transformed.
     // Frames that lie wholly inside the clip (all but the first/last few) use plain offsets; the others clamp every index
@@ -378,7 +394,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
         const int t0 = (tile0 + ti) * FPT;
         static_for<0, PASSES>([&](auto pp) {
             constexpr int pass = decltype(pp)::value;
-            const int slot = pass * (WAVES * FPW) + wave * FPW + j;
+            const int slot = (WPF > 1) ? wave / WPF : pass * (WAVES * FPW) + wave * FPW + j;
             const int tA = PAIR ? (t0 + 2 * slot) : (t0 + slot);
             const int f0 = tA * p.hop - N / 2;                       // first sample of frame tA
             const int f1 = PAIR ? f0 + p.hop : f0;
@@ -572,7 +588,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
         if (!dbg_skip_fft) {
             static_for<0, PASSES>([&](auto pp) {
                 constexpr int pass = decltype(pp)::value;
-                const int slot = pass * (WAVES * FPW) + wave * FPW + j;
+                const int slot = (WPF > 1) ? wave / WPF : pass * (WAVES * FPW) + wave * FPW + j;
                 v2f* sl = lds + slot * SS;
                 const int tA = PAIR ? (t0 + 2 * slot) : (t0 + slot);
                 const int f0 = tA * p.hop - N / 2;                       // first sample of frame tA
@@ -651,29 +667,23 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                         z[bitrev(q, LB)] = v;
                         slf[q * EXS + lg] = v.x;
                     });
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    sync_frame();
                     float ure[R];
                     static_for<0, R>([&](auto bb) {
                         constexpr int bi = decltype(bb)::value;
                         ure[bi] = slf[qp * EXS + r + C * bi];
                     });
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
+                    sync_frame();
                     static_for<0, R>([&](auto qq) {
                         constexpr int q = decltype(qq)::value;
                         slf[q * EXS + lg] = z[bitrev(q, LB)].y;
                     });
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    sync_frame();
                     static_for<0, R>([&](auto bb) {
                         constexpr int bi = decltype(bb)::value;
                         u[bi] = v2f{ure[bi], slf[qp * EXS + r + C * bi]};
                     });
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
+                    sync_frame();
                 }
                 STAMP(16 * ti + 5);   // twiddle + LDS transposition
                 // the radix-C twiddles w_G^(r*p1) are requested before the second radix-R stage, not one by one inside the
@@ -698,7 +708,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                 // twiddle w_G^(r*p1), radix-C across adjacent lanes, spectrum to LDS in natural order
                 const v2f rot_f = splat((C == 4 && r == 3) ? 0.f : 1.f);
                 const v2f rot_e = (C == 4 && r == 3) ? v2f{1.f, -1.f} : v2f{0.f, 0.f};
-                v2f zr[BPERM ? R : 1];                                   // Z[qp + R p1 + R R p2] of this lane, by p1
+                v2f zr[KEEPZ ? R : 1];                                   // Z[qp + R p1 + R R p2] of this lane, by p1
                 static_for<0, R>([&](auto pp1) {
                     constexpr int p1 = decltype(pp1)::value;
                     if constexpr (C > 1 && TWC < R && p1 % TWC == 0 && p1 + TWC < R) {
@@ -723,13 +733,13 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                         v = __builtin_elementwise_fma(splat(((r & 1) == 0) ? 1.f : -1.f), t, o);
                         p2 = ((r & 1) << 1) | (r >> 1);
                     }
-                    if constexpr (BPERM) zr[p1] = v;
+                    if constexpr (KEEPZ) zr[p1] = v;
                     else {
                         const int k = qp + R * p1 + R * R * p2;
                         sl[z_index<R, C>(k)] = v;
                     }
                 });
-                if constexpr (BPERM) {
+                if constexpr (KEEPZ) {
                     // ---- pairing pass without the spectrum in LDS.  Z[N-k] of k = qp + R p1 + R^2 p2 is Z[qp' + R p1' + R^2 p2'] with
                     //   qp > 0:            qp' = R - qp, p1' = R - 1 - p1,  p2' = C - 1 - p2
                     //   qp = 0, p1 > 0:    qp' = 0,      p1' = R - p1,      p2' = C - 1 - p2
@@ -747,6 +757,27 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                     const int p2m = C - 1 - p2;
                     const int pull1 = (((R - qp) & (R - 1)) * C + lane_of_p2(p2m)) * 4;
                     const int pull0 = q0 ? lane_of_p2((C - p2) % C) * 4 : pull1;
+                    // PLANE (frames of several waves): the partner lane may sit in another wave, so Z[N-k] goes through one plane
+                    // of floats in the frame's slot, indexed k + PLANE_PAD (k / R^2): real parts written, read mirrored, then the
+                    // imaginary parts through the same plane.  Mirror index of (qp, p1, p2): the partner's own index, linear in p1.
+                    constexpr int PP = g.PLANE_PAD;
+                    float* plane = reinterpret_cast<float*>(sl);
+                    const int pidx = qp + (RR + PP) * p2;                              // + R p1
+                    const int midx = (R - qp) + R * (R - 1) + (RR + PP) * p2m;         // - R p1   (qp = 0: R - qp = R, no wrap)
+                    const int midx0 = q0 ? (RR + PP) * ((C - p2) % C) : midx;         // p1 = 0
+                    float znx[PLANE ? R / 2 + 1 : 1];
+                    if constexpr (PLANE) {
+                        static_for<0, R>([&](auto pp1) { constexpr int p1 = decltype(pp1)::value; plane[pidx + R * p1] = zr[p1].x; });
+                        sync_frame();
+                        static_for<0, R / 2 + 1>([&](auto pp1) {
+                            constexpr int p1 = decltype(pp1)::value;
+                            znx[p1] = plane[(p1 == 0) ? midx0 : midx - R * p1];
+                        });
+                        sync_frame();
+                        static_for<0, R>([&](auto pp1) { constexpr int p1 = decltype(pp1)::value; plane[pidx + R * p1] = zr[p1].y; });
+                        sync_frame();
+                    }
+                    v2f pdk[PLANE ? R / 2 + 1 : 1];                                    // PLANE: PD overwrites the plane, after everyone has read it
                     const int slot_b = slot * (SS * 8);
                     const int base_a = slot_b + (qp + (RR + PADC) * p2) * 8;
                     const int base_b = slot_b + ((R - qp) + R * (R - 1) + (RR + PADC) * p2m) * 8;
@@ -762,19 +793,34 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                         // (component by component: a scalar-condition select of two ext vectors lost its second lane here)
                         const float send_x = (s_a == s_b) ? zr[s_a].x : (q0 ? zr[s_b].x : zr[s_a].x);
                         const float send_y = (s_a == s_b) ? zr[s_a].y : (q0 ? zr[s_b].y : zr[s_a].y);
-                        const int pull = (p1 == 0) ? pull0 : pull1;
-                        const int got_x = __builtin_amdgcn_ds_bpermute(pull, __builtin_bit_cast(int, send_x));
-                        const int got_y = __builtin_amdgcn_ds_bpermute(pull, __builtin_bit_cast(int, send_y));
-                        const v2f zn = v2f{__builtin_bit_cast(float, got_x), __builtin_bit_cast(float, got_y)};
+                        v2f zn;
+                        if constexpr (PLANE) {
+                            zn = v2f{znx[p1], plane[(p1 == 0) ? midx0 : midx - R * p1]};
+                        } else {
+                            const int pull = (p1 == 0) ? pull0 : pull1;
+                            const int got_x = __builtin_amdgcn_ds_bpermute(pull, __builtin_bit_cast(int, send_x));
+                            const int got_y = __builtin_amdgcn_ds_bpermute(pull, __builtin_bit_cast(int, send_y));
+                            zn = v2f{__builtin_bit_cast(float, got_x), __builtin_bit_cast(float, got_y)};
+                        }
                         const v2f zk = zr[p1];
                         const float sx = zk.x + zn.x, sy = zk.y - zn.y, dx = zk.x - zn.x, dy = zk.y + zn.y;
                         v2f pdv;
                         if constexpr (!PAIR) pdv = v2f{fmaf(sx, sx, sy * sy), fmaf(sx, dy, -(sy * dx))};
                         else pdv = v2f{fmaf(sx, sx, sy * sy), fmaf(dx, dx, dy * dy)};
-                        if constexpr (p1 == 0) { if (w0) *reinterpret_cast<v2f*>(smem_raw + addr0) = pdv; }
+                        if constexpr (PLANE) pdk[p1] = pdv;
+                        else if constexpr (p1 == 0) { if (w0) *reinterpret_cast<v2f*>(smem_raw + addr0) = pdv; }
                         else if constexpr (p1 < R / 2) *reinterpret_cast<v2f*>(smem_raw + obase + ostep * p1) = pdv;
                         else { if (q0 && dir_a) *reinterpret_cast<v2f*>(smem_raw + base_a + R * 8 * (R / 2)) = pdv; }
                     });
+                    if constexpr (PLANE) {
+                        sync_frame();
+                        static_for<0, R / 2 + 1>([&](auto pp1) {
+                            constexpr int p1 = decltype(pp1)::value;
+                            if constexpr (p1 == 0) { if (w0) *reinterpret_cast<v2f*>(smem_raw + addr0) = pdk[p1]; }
+                            else if constexpr (p1 < R / 2) *reinterpret_cast<v2f*>(smem_raw + obase + ostep * p1) = pdk[p1];
+                            else { if (q0 && dir_a) *reinterpret_cast<v2f*>(smem_raw + base_a + R * 8 * (R / 2)) = pdk[p1]; }
+                        });
+                    }
                     // the filterbank fragments of phase 2: requested once the spectrum registers are dead
                     if constexpr (pass == PASSES - 1) { __builtin_amdgcn_sched_barrier(0); fetch_bpre(); }
                 } else {
@@ -1059,8 +1105,23 @@ hipError_t launch_forward(int n_fft, int mode, int tpw, const FwdParams& p, int 
         case 1024: return launch_n<1024>(mode, tpw, p, grid, s);
         case 2048: return launch_n<2048>(mode, tpw, p, grid, s);
         case 4096: return launch_n<4096>(mode, tpw, p, grid, s);
+        case 8192: return launch_n<8192>(mode, tpw, p, grid, s);
+        case 16384: return launch_n<16384>(mode, tpw, p, grid, s);
     }
     return hipErrorInvalidValue;
+}
+
+// (R, C) of the plan for n_fft: the host builds the twiddle tables from these
+bool forward_plan_rc(int n_fft, int* R, int* C)
+{
+    switch (n_fft) {
+        case 32: *R = geom<32>().R; *C = geom<32>().C; return true;       case 64: *R = geom<64>().R; *C = geom<64>().C; return true;
+        case 128: *R = geom<128>().R; *C = geom<128>().C; return true;    case 256: *R = geom<256>().R; *C = geom<256>().C; return true;
+        case 512: *R = geom<512>().R; *C = geom<512>().C; return true;    case 1024: *R = geom<1024>().R; *C = geom<1024>().C; return true;
+        case 2048: *R = geom<2048>().R; *C = geom<2048>().C; return true; case 4096: *R = geom<4096>().R; *C = geom<4096>().C; return true;
+        case 8192: *R = geom<8192>().R; *C = geom<8192>().C; return true; case 16384: *R = geom<16384>().R; *C = geom<16384>().C; return true;
+    }
+    return false;
 }
 
 template <int N> static constexpr int lds_of() { return geom<N>().LDS_BYTES; }
@@ -1071,6 +1132,7 @@ int forward_lds_bytes(int n_fft)
         case 32: return lds_of<32>(); case 64: return lds_of<64>(); case 128: return lds_of<128>();
         case 256: return lds_of<256>(); case 512: return lds_of<512>(); case 1024: return lds_of<1024>();
         case 2048: return lds_of<2048>(); case 4096: return lds_of<4096>();
+        case 8192: return lds_of<8192>(); case 16384: return lds_of<16384>();
     }
     return -1;
 }
@@ -1083,6 +1145,7 @@ int forward_frames_per_tile(int n_fft, int mode)
         case 128: slots = geom<128>().SLOTS; break; case 256: slots = geom<256>().SLOTS; break;
         case 512: slots = geom<512>().SLOTS; break; case 1024: slots = geom<1024>().SLOTS; break;
         case 2048: slots = geom<2048>().SLOTS; break; case 4096: slots = geom<4096>().SLOTS; break;
+        case 8192: slots = geom<8192>().SLOTS; break; case 16384: slots = geom<16384>().SLOTS; break;
     }
     if (slots < 0) return -1;
     return (mode == kTrain || mode == kSpecTrain) ? slots : 2 * slots;
@@ -1108,6 +1171,7 @@ int forward_waves(int n_fft)
         case 32: return geom<32>().WAVES; case 64: return geom<64>().WAVES; case 128: return geom<128>().WAVES;
         case 256: return geom<256>().WAVES; case 512: return geom<512>().WAVES; case 1024: return geom<1024>().WAVES;
         case 2048: return geom<2048>().WAVES; case 4096: return geom<4096>().WAVES;
+        case 8192: return geom<8192>().WAVES; case 16384: return geom<16384>().WAVES;
     }
     return -1;
 }
@@ -1118,6 +1182,7 @@ int forward_nbpre(int n_fft)
         case 32: return geom<32>().NBPRE; case 64: return geom<64>().NBPRE; case 128: return geom<128>().NBPRE;
         case 256: return geom<256>().NBPRE; case 512: return geom<512>().NBPRE; case 1024: return geom<1024>().NBPRE;
         case 2048: return geom<2048>().NBPRE; case 4096: return geom<4096>().NBPRE;
+        case 8192: return geom<8192>().NBPRE; case 16384: return geom<16384>().NBPRE;
     }
     return -1;
 }
@@ -1153,7 +1218,9 @@ hipError_t forward_prepare_attributes()
     if ((e = set_attr_n<512>()) != hipSuccess) return e;
     if ((e = set_attr_n<1024>()) != hipSuccess) return e;
     if ((e = set_attr_n<2048>()) != hipSuccess) return e;
-    return set_attr_n<4096>();
+    if ((e = set_attr_n<4096>()) != hipSuccess) return e;
+    if ((e = set_attr_n<8192>()) != hipSuccess) return e;
+    return set_attr_n<16384>();
 }
 
 }  // namespace dmel

@@ -8,8 +8,8 @@ namespace dmel {
 constexpr int kWave = 64;
 constexpr int kThreads = 256;          // prep / dot kernels
 constexpr int kMaxChunks = 64;         // partial sums per clip for the DC removal
-constexpr int kMaxFastNfft = 4096;     // largest transform of the fused wave-FFT kernel
-constexpr int kMaxNfft = 16384;        // largest transform overall: above kMaxFastNfft the one-frame-per-workgroup LDS FFT runs
+constexpr int kMaxFastNfft = 16384;    // largest transform of the fused wave-FFT kernel (8192 and 16384: two / four waves per frame)
+constexpr int kMaxNfft = 16384;        // largest power-of-two transform held in LDS; beyond it (and for other lengths) dmel_big.hip
 constexpr int kMinFastNfft = 32;       // below this the direct-DFT kernel runs
 
 // fp32 -> bf16 bits, round to nearest even (v_cvt_pk_bf16_f32 on gfx950); outputs only, the arithmetic stays fp32
@@ -115,33 +115,41 @@ __device__ __forceinline__ float lam_tangent_scale(const LamState& st)
 // the first half of tile w and the second half of tile 7-w (exchanged through 8 KB of LDS), which
 // evens out the HTK bands that widen with frequency.
 template <int N> struct FftPlan;
-// BPERM: the pairing pass takes Z[N-k] from the lane that holds it with ds_bpermute_b32 instead of storing the whole spectrum
-// to LDS and reading it back mirrored; only PD[0..N/2] is ever stored.  SPLIT: the transposition between the two radix-R stages
-// moves the real and the imaginary parts one after the other through ONE plane of N floats; together with BPERM and a
-// half-length (symmetric) window table a frame in flight needs N*4 bytes of LDS instead of N*8 (n_fft 2048: two workgroups
-// per CU instead of one).
-template <> struct FftPlan<32>   { static constexpr int R = 4,  C = 2, PASSES = 1, WAVES = 4, NBPRE = 4, MINW = 4, BPERM = 0, SPLIT = 0; };
-template <> struct FftPlan<64>   { static constexpr int R = 8,  C = 1, PASSES = 1, WAVES = 4, NBPRE = 4, MINW = 4, BPERM = 0, SPLIT = 0; };
-template <> struct FftPlan<128>  { static constexpr int R = 8,  C = 2, PASSES = 1, WAVES = 4, NBPRE = 8, MINW = 4, BPERM = 0, SPLIT = 0; };
-template <> struct FftPlan<256>  { static constexpr int R = 16, C = 1, PASSES = 1, WAVES = 4, NBPRE = 12, MINW = 4, BPERM = 0, SPLIT = 0; };
-template <> struct FftPlan<512>  { static constexpr int R = 16, C = 2, PASSES = 1, WAVES = 4, NBPRE = 20, MINW = 4, BPERM = 0, SPLIT = 0; };
-template <> struct FftPlan<1024> { static constexpr int R = 16, C = 4, PASSES = 1, WAVES = 8, NBPRE = 20, MINW = 4, BPERM = 0, SPLIT = 0; };
-template <> struct FftPlan<2048> { static constexpr int R = 32, C = 2, PASSES = 1, WAVES = 8, NBPRE = 40, MINW = 4, BPERM = 1, SPLIT = 1; };
-template <> struct FftPlan<4096> { static constexpr int R = 64, C = 1, PASSES = 1, WAVES = 8, NBPRE = 40, MINW = 2, BPERM = 1, SPLIT = 1; };
+// PAIRING: how the pairing pass gets Z[N-k].  0: the whole spectrum is stored to LDS and read back mirrored.  1 (kPairBperm):
+// from the lane that holds it, with ds_bpermute_b32; only PD[0..N/2] is ever stored.  2 (kPairPlane, frames spread over several
+// waves): through one plane of N floats, real parts first, imaginary parts second.  SPLIT: the transposition between the two
+// radix-R stages moves the real and the imaginary parts one after the other through ONE plane of N floats; together with
+// PAIRING != 0 and a half-length (symmetric) window table a frame in flight needs N*4 bytes of LDS instead of N*8 (n_fft 2048:
+// two workgroups per CU instead of one).
+// G = N / R lanes work on one frame: a part of a wave (G < 64: 64/G frames per wave), one wave, or G/64 waves (n_fft 8192,
+// 16384: the exchanges between them are workgroup barriers instead of wave barriers).
+constexpr int kPairLds = 0, kPairBperm = 1, kPairPlane = 2;
+template <> struct FftPlan<32>   { static constexpr int R = 4,  C = 2, PASSES = 1, WAVES = 4, NBPRE = 4, MINW = 4, PAIRING = 0, SPLIT = 0; };
+template <> struct FftPlan<64>   { static constexpr int R = 8,  C = 1, PASSES = 1, WAVES = 4, NBPRE = 4, MINW = 4, PAIRING = 0, SPLIT = 0; };
+template <> struct FftPlan<128>  { static constexpr int R = 8,  C = 2, PASSES = 1, WAVES = 4, NBPRE = 8, MINW = 4, PAIRING = 0, SPLIT = 0; };
+template <> struct FftPlan<256>  { static constexpr int R = 16, C = 1, PASSES = 1, WAVES = 4, NBPRE = 12, MINW = 4, PAIRING = 0, SPLIT = 0; };
+template <> struct FftPlan<512>  { static constexpr int R = 16, C = 2, PASSES = 1, WAVES = 4, NBPRE = 20, MINW = 4, PAIRING = 0, SPLIT = 0; };
+template <> struct FftPlan<1024> { static constexpr int R = 16, C = 4, PASSES = 1, WAVES = 8, NBPRE = 20, MINW = 4, PAIRING = 0, SPLIT = 0; };
+template <> struct FftPlan<2048> { static constexpr int R = 32, C = 2, PASSES = 1, WAVES = 8, NBPRE = 40, MINW = 4, PAIRING = 1, SPLIT = 1; };
+// (4096 as two waves per frame, R = 32, C = 4, two workgroups per CU: 291 us against 184 at the reference's ESC-50 shape --
+// the workgroup barriers of a shared frame cost more than the occupancy gives)
+template <> struct FftPlan<4096> { static constexpr int R = 64, C = 1, PASSES = 1, WAVES = 8, NBPRE = 40, MINW = 2, PAIRING = 1, SPLIT = 1; };
+template <> struct FftPlan<8192> { static constexpr int R = 64, C = 2, PASSES = 1, WAVES = 8, NBPRE = 40, MINW = 2, PAIRING = 2, SPLIT = 1; };
+template <> struct FftPlan<16384> { static constexpr int R = 64, C = 4, PASSES = 1, WAVES = 8, NBPRE = 40, MINW = 2, PAIRING = 2, SPLIT = 1; };
 
 constexpr int kRedBytes = 80;          // 8 + 8 partial sums, then the tangent scale (word 16) computed once per workgroup
 struct FftGeom {
     int N, R, C, G, FPW, PASSES, WAVES, NLOC, THREADS, SLOTS, MT, EX_STRIDE, SLOT_STRIDE_F2, NBPRE, MINW, LDS_BYTES, AUX_OFF, RED_OFF, WIN_LDS;
-    int BPERM, SPLIT, WIN_SYM;
+    int PAIRING, SPLIT, WIN_SYM, WPF, PLANE_PAD;
 };
 
 constexpr int ex_stride(int G, int C) { return G + (G >= 32 ? C : 1); }
 constexpr int z_index_host(int k, int R, int C) { return C == 1 ? k : k + (k / (R * R)) * 4; }
-constexpr int slot_stride_f2(int N, int R, int C, int bperm = 0, int split = 0)
+constexpr int slot_stride_f2(int N, int R, int C, int pairing = 0, int split = 0)
 {
     const int G = N / R;
     const int a = R * ex_stride(G, C) * (split ? 4 : 8);                           // transposition: complex entries, or one plane of floats
-    const int b = (z_index_host(bperm ? N / 2 : N - 1, R, C) + 1) * 8;             // spectrum Z[0..N-1], or only PD[0..N/2]
+    const int b = (z_index_host(pairing ? N / 2 : N - 1, R, C) + 1) * 8;           // spectrum Z[0..N-1], or only PD[0..N/2]
     const int need = a > b ? a : b;
     // = 48 bytes (mod 128).  The A operands of phase 2 are read with ds_read_b32 / ds_read2_b32, which bank modulo 32 dwords
     // (128 B) in two 32-lane groups: each group touches 16 B per slot, so the 8 slots must start 16 B apart modulo 128
@@ -154,13 +162,17 @@ template <int N> constexpr FftGeom geom()
 {
     using P = FftPlan<N>;
     FftGeom g{};
-    g.N = N; g.R = P::R; g.C = P::C; g.G = N / P::R; g.FPW = kWave / g.G; g.PASSES = P::PASSES;
+    g.N = N; g.R = P::R; g.C = P::C; g.G = N / P::R; g.PASSES = P::PASSES;
+    g.WPF = g.G > kWave ? g.G / kWave : 1;                // waves per frame
+    g.FPW = g.G > kWave ? 1 : kWave / g.G;                // frames per wave (1 when a frame has several waves: see SLOTS)
     g.WAVES = P::WAVES; g.NLOC = 2; g.THREADS = kWave * P::WAVES; g.NBPRE = P::NBPRE; g.MINW = P::MINW;
-    g.SLOTS = g.WAVES * g.FPW * g.PASSES;
+    g.SLOTS = g.WAVES * g.FPW * g.PASSES / g.WPF;
+    // the pairing plane is indexed by k + PLANE_PAD * (k / R^2): the C lanes of a quad write to different banks
+    g.PLANE_PAD = P::C > 1 ? 64 / P::C : 0;
     g.MT = g.SLOTS >= 8 ? g.SLOTS / 8 : 1;
     g.EX_STRIDE = ex_stride(g.G, g.C);
-    g.BPERM = P::BPERM; g.SPLIT = P::SPLIT;
-    g.SLOT_STRIDE_F2 = slot_stride_f2(N, P::R, P::C, P::BPERM, P::SPLIT);
+    g.PAIRING = P::PAIRING; g.SPLIT = P::SPLIT;
+    g.SLOT_STRIDE_F2 = slot_stride_f2(N, P::R, P::C, P::PAIRING, P::SPLIT);
     // LDS map: [FFT slots][aux: window table (phase 1) aliased with the half-tile exchange (phase 2)][8 sums]
     g.WIN_LDS = (N <= 2048) ? 1 : 0;                      // n_fft 4096 has no room: its window stays in global memory
     const int xch = (g.WAVES == 8) ? 8 * 64 * 16 * g.MT : 0;
@@ -214,6 +226,7 @@ int forward_lds_bytes(int n_fft);
 int forward_frames_per_tile(int n_fft, int mode);
 int forward_waves(int n_fft);              // waves per workgroup of the fused kernel for this n_fft
 int forward_nbpre(int n_fft);              // k-steps per run kept in registers (layout of FwdParams::ent_pre)
+bool forward_plan_rc(int n_fft, int* R, int* C);   // radix per lane and cross-lane radix of the plan (layout of tw1 / tw2)
 hipError_t forward_prepare_attributes();   // raises the dynamic-LDS limit of every instantiation once
 
 // direct-DFT kernel for n_fft < 32 (and as an on-device cross-check of the fast path)
@@ -225,18 +238,6 @@ struct NaiveParams {
 };
 hipError_t launch_naive(const NaiveParams& p, hipStream_t s);
 
-// long transforms (4096 < n_fft <= 16384, |lambd| up to 2730 samples): one workgroup per frame (pair), radix-2 FFT in LDS
-struct LongParams {
-    const float* x; float* out; float* tangent; const float* psum; const float2* win2;
-    const float2* tw;        // (N/2): exp(-2 pi i k / N)
-    const float* fbT;        // (M, F): filterbank transposed, so that one band is contiguous
-    const int2* band;        // (M): [first, last+1) non-zero rows of every filterbank column
-    int B, L, T, hop, M, nchunks, N, F, mode, logN;
-    float inv_L, eps; unsigned flags; int remove_dc;
-    LamArgs lam;
-};
-hipError_t launch_long(const LongParams& p, hipStream_t s);
-hipError_t long_prepare_attributes();
 
 // transforms beyond the LDS kernels: power-of-two n_fft > 16384 (global-memory FFT) and lengths that are not powers of two
 // (Bluestein), dmel_big.hip

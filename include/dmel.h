@@ -268,7 +268,7 @@ typedef struct dmel_plan_info {
     int32_t fb_blocks;         /* non-zero 4x16 filterbank blocks fed to the MFMA loop      */
     int32_t fb_blocks_dense;   /* the same count for a dense matrix                         */
     int32_t lds_bytes;         /* dynamic LDS of the fused kernel                           */
-    int32_t kernel_path;       /* 0 = wave-FFT + MFMA kernel, 1 = direct-DFT kernel (n_fft < 32), 2 = LDS FFT (n_fft > 4096) */
+    int32_t kernel_path;       /* 0 = wave-FFT + MFMA kernel (32 <= n_fft <= 16384), 1 = direct-DFT kernel (n_fft < 32), 3 = global-memory FFT / chirp-z (dmel_big.hip) */
 } dmel_plan_info;
 dmel_status dmel_plan_get_info(const dmel_plan* plan, dmel_plan_info* info);
 
