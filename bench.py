@@ -457,11 +457,12 @@ def _flush_c_stdio():
 
 
 def other_configs(torch, capi, synth, dev, kernel_times):
-    """BASELINE configs 3 and 5 (both n_fft 2048), not bench lines of their own: kernel times of the forward + dot through the
-    C ABI and the same roofline accounting, plus config 5's front end isolated inside a real MelConvNet training step."""
+    """BASELINE configs 3 and 5 (both n_fft 2048) and the shapes of the reference's own experiments, not bench lines of their own:
+    kernel times of the forward + dot through the C ABI and the same roofline accounting, plus config 5's front end isolated
+    inside a real MelConvNet training step."""
     res = {}
-    for name in ("c3", "c5"):
-        B, L, sr, lam, hop, M = CONFIGS[name]
+
+    def one(name, B, L, sr, lam, hop, M):
         T = L // hop + 1
         x = torch.from_numpy(synth.waveforms(B, L, seed=7)).to(dev)
         g = torch.from_numpy(synth.cotangent((B, 1, M, T), seed=8)).to(dev)
@@ -472,15 +473,28 @@ def other_configs(torch, capi, synth, dev, kernel_times):
         info = plan.info()
         fwd_us, _, prep_us, bwd_us, step_us = kernel_times(plan, x, g, out, tan, dl, lam, out.numel(), B, False)
         alg = 4 * (B * L + 2 * B * M * T)
-        res[name] = {"workload": f"batch {B} x {L} @ {sr} Hz, n_fft {info['n_fft']} (lambd {lam}), hop {hop}, n_mels {M}",
-                     "frames_per_step": B * T, "step_us": round(step_us, 2), "frames_per_s": round(B * T / (step_us * 1e-6), 1),
-                     "kernels_us": {"prep_partial_sums": round(prep_us, 2), "fused_forward": round(fwd_us, 2), "backward_dot": round(bwd_us, 2)},
-                     "roofline": {"bound": "hbm", "kernel": f"dmel_fwd_kernel<{info['n_fft']},train>",
-                                  "achieved": round(alg / (fwd_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": round(alg / (fwd_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": alg,
-                                  "avg_launch_us": round(fwd_us, 2), "traffic": None},
-                     "lds_bytes": info["lds_bytes"], "grid": info["grid_fwd"]}
-        del plan, x, g, out, tan
+        return {"workload": f"batch {B} x {L} @ {sr} Hz, n_fft {info['n_fft']} (lambd {round(lam, 1)}), hop {hop}, n_mels {M}",
+                "frames_per_step": B * T, "step_us": round(step_us, 2), "frames_per_s": round(B * T / (step_us * 1e-6), 1),
+                "kernels_us": {"prep_partial_sums": round(prep_us, 2), "fused_forward": round(fwd_us, 2), "backward_dot": round(bwd_us, 2)},
+                "roofline": {"bound": "hbm", "kernel": f"dmel_fwd_kernel<{info['n_fft']},train>",
+                             "achieved": round(alg / (fwd_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(alg / (fwd_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": alg,
+                             "avg_launch_us": round(fwd_us, 2), "traffic": None},
+                "lds_bytes": info["lds_bytes"], "grid": info["grid_fwd"]}
+
+    for name in ("c3", "c5"):
+        res[name] = one(name, *CONFIGS[name])
+    # the shapes of the reference's own experiments (search_spaces.py:4-33 ESC-50, :36-66 Audio-MNIST: 8 kHz, hop 80, 64 mels,
+    # init_lambd = 8000 x / 6 for x = 0.01, 0.035, 0.3 -> n_fft 128, 512, 4096) and one lambd the run may drift to (n_fft 8192)
+    ref = {}
+    for name, (B, L, lam) in {"esc50_x0.01": (32, 40000, 8000 * 0.01 / 6), "esc50_x0.035": (32, 40000, 8000 * 0.035 / 6),
+                              "esc50_x0.3": (32, 40000, 8000 * 0.3 / 6), "esc50_lambd700": (32, 40000, 700.0),
+                              "audio_mnist_x0.3": (64, 8000, 8000 * 0.3 / 6)}.items():
+        try:
+            ref[name] = one(name, B, L, 8000, lam, 80, 64)
+        except Exception as e:                                          # noqa: BLE001
+            ref[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    res["reference_experiment_shapes"] = ref
     try:
         res["c5"]["train_step"] = c5_train_step(torch, synth, dev)
     except Exception as e:                                              # noqa: BLE001
