@@ -515,13 +515,13 @@ dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dm
         return DMEL_OK;
     }
 
-    // The fused kernel builds its own window table (n_fft <= 2048) and, for clips up to 32768 samples, its
+    // The fused kernel builds its own window table (n_fft <= 4096) and, for clips up to 32768 samples, its
     // own clip mean; the prep kernel only runs for what is left: partial sums of long clips, the window
-    // table of n_fft 4096, and everything the direct-DFT kernel (n_fft < 32) needs.
+    // table of n_fft 8192 / 16384, and everything the direct-DFT kernel (n_fft < 32) needs.
     const bool fast = N >= dmel::kMinFastNfft && N <= dmel::kMaxFastNfft;
     const bool kernel_mean = fast && pl->cfg.n_points <= 32768;
     const bool need_sums = remove_dc && !kernel_mean && !*sums_done;                  // the launches of one group share the sums
-    const bool need_window = !fast || N > 2048;
+    const bool need_window = !fast || !dmel::forward_window_in_lds(N);
     const size_t m0 = prof_mark(pl, s);
     if (need_sums || need_window) {
         dmel::PrepParams pp{};

@@ -1111,6 +1111,8 @@ hipError_t launch_forward(int n_fft, int mode, int tpw, const FwdParams& p, int 
     return hipErrorInvalidValue;
 }
 
+bool forward_window_in_lds(int n_fft) { return n_fft >= kMinFastNfft && n_fft <= kWinLdsMaxNfft; }
+
 // (R, C) of the plan for n_fft: the host builds the twiddle tables from these
 bool forward_plan_rc(int n_fft, int* R, int* C)
 {

@@ -137,6 +137,7 @@ template <> struct FftPlan<4096> { static constexpr int R = 64, C = 1, PASSES = 
 template <> struct FftPlan<8192> { static constexpr int R = 64, C = 2, PASSES = 1, WAVES = 8, NBPRE = 40, MINW = 2, PAIRING = 2, SPLIT = 1; };
 template <> struct FftPlan<16384> { static constexpr int R = 64, C = 4, PASSES = 1, WAVES = 8, NBPRE = 40, MINW = 2, PAIRING = 2, SPLIT = 1; };
 
+constexpr int kWinLdsMaxNfft = 4096;   // (the table in global memory at 4096: 184 us against 171 at the reference's ESC-50 shape)
 constexpr int kRedBytes = 80;          // 8 + 8 partial sums, then the tangent scale (word 16) computed once per workgroup
 struct FftGeom {
     int N, R, C, G, FPW, PASSES, WAVES, NLOC, THREADS, SLOTS, MT, EX_STRIDE, SLOT_STRIDE_F2, NBPRE, MINW, LDS_BYTES, AUX_OFF, RED_OFF, WIN_LDS;
@@ -174,7 +175,9 @@ template <int N> constexpr FftGeom geom()
     g.PAIRING = P::PAIRING; g.SPLIT = P::SPLIT;
     g.SLOT_STRIDE_F2 = slot_stride_f2(N, P::R, P::C, P::PAIRING, P::SPLIT);
     // LDS map: [FFT slots][aux: window table (phase 1) aliased with the half-tile exchange (phase 2)][8 sums]
-    g.WIN_LDS = (N <= 2048) ? 1 : 0;                      // n_fft 4096 has no room: its window stays in global memory
+    // the window table lives in LDS up to n_fft 4096 (half table there: 16 KB next to 8 x 16.6 KB of frames); beyond, in global
+    // memory, written by dmel_prep_kernel
+    g.WIN_LDS = (N <= kWinLdsMaxNfft) ? 1 : 0;
     const int xch = (g.WAVES == 8) ? 8 * 64 * 16 * g.MT : 0;
     // the Gaussian window is symmetric about N/2: the compact layout keeps entries 0..N/2 only
     g.WIN_SYM = (g.WIN_LDS && P::SPLIT) ? 1 : 0;
@@ -226,7 +229,8 @@ int forward_lds_bytes(int n_fft);
 int forward_frames_per_tile(int n_fft, int mode);
 int forward_waves(int n_fft);              // waves per workgroup of the fused kernel for this n_fft
 int forward_nbpre(int n_fft);              // k-steps per run kept in registers (layout of FwdParams::ent_pre)
-bool forward_plan_rc(int n_fft, int* R, int* C);   // radix per lane and cross-lane radix of the plan (layout of tw1 / tw2)
+bool forward_plan_rc(int n_fft, int* R, int* C);
+bool forward_window_in_lds(int n_fft);     // the kernel builds its own window table (otherwise dmel_prep_kernel writes FwdParams::win2)   // radix per lane and cross-lane radix of the plan (layout of tw1 / tw2)
 hipError_t forward_prepare_attributes();   // raises the dynamic-LDS limit of every instantiation once
 
 // direct-DFT kernel for n_fft < 32 (and as an on-device cross-check of the fast path)
