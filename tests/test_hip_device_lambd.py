@@ -68,13 +68,15 @@ def test_c_abi_forward_dev_and_scratch():
 
 
 def test_boundary_crossing_is_covered_by_guard_launches():
-    """lambd moves across 6*lambd = 512 (n_fft 512 -> 1024) and back between forwards without the host being told: the
-    guard launch of the right n_fft does the work, and the host's picture follows from the kernels' report."""
+    """lambd moves across 6*lambd = 512 (n_fft 512 -> 1024), on up to n_fft 16384 (several waves per frame) and back down to the
+    direct-DFT kernel between forwards without the host being told: the guard launch of the right n_fft does the work, and the
+    host's picture follows from the kernels' report."""
     case = C.BY_NAME["g1_c1"]
     x = torch.from_numpy(C.make_input(case)).to(DEV)
     layer = _mk(case, lam=85.0)
     layer.set_tracking(8, 1)                                  # always guard both neighbours
-    for lam, n in ((85.0, 512), (85.6, 1024), (170.0, 1024), (171.0, 2048), (85.6, 1024), (60.0, 512), (42.0, 256), (21.0, 128), (10.6, 64), (5.3, 32), (2.6, 16), (5.3, 32)):
+    for lam, n in ((85.0, 512), (85.6, 1024), (170.0, 1024), (171.0, 2048), (342.0, 4096), (683.0, 8192), (1366.0, 16384), (683.0, 8192),
+                   (342.0, 4096), (171.0, 2048), (85.6, 1024), (60.0, 512), (42.0, 256), (21.0, 128), (10.6, 64), (5.3, 32), (2.6, 16), (5.3, 32)):
         layer.lambd.data.fill_(lam)
         y = layer(x)
         ref = _mk(case, lam=lam, sync=True)(x)
