@@ -17,4 +17,6 @@ rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA SQ_
 # the n_fft 2048 kernel (configs 3 and 5): kernel trace of plain launch trains (registers, LDS, duration per dispatch)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_c3 -- python3 tools/ktime.py c3 train 60 > $OUT/kt_c3.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_c5 -- python3 tools/ktime.py c5 train 60 > $OUT/kt_c5.log 2>&1
+# the shapes of the reference's own experiments (search_spaces.py): forward + dot per training step through the C ABI
+python3 tools/time_reference_shapes.py > $OUT/reference_shapes.json 2> $OUT/reference_shapes.err
 ls -R $OUT | head -60

@@ -61,6 +61,15 @@ for cfg in ("c3", "c5"):
 if other:
     json.dump(other, open(os.path.join(out, f"{tag}_kernel_trace_summary_c3_c5.json"), "w"), indent=1)
 
+rs_path = os.path.join(src, "reference_shapes.json")
+if os.path.exists(rs_path):
+    lines = [ln for ln in open(rs_path) if ln.startswith("{")]
+    if lines:
+        json.dump({"_how": "tools/time_reference_shapes.py: forward + dot per training step through the C ABI (lambd by value), trains of 50 steps "
+                           "between two HIP events, best of 3; shapes of search_spaces.py:4-33 (ESC-50: 32 x 40000 @ 8 kHz, hop 80, 64 mels) and "
+                           ":36-66 (Audio-MNIST: 64 x 8000); lambd 13.3 / 46.7 / 400 are its init_lambd grid, 200 and 700 values a run may drift to",
+                   "shapes": json.loads(lines[-1])}, open(os.path.join(out, f"{tag}_reference_shapes.json"), "w"), indent=1)
+
 # one steady-state step of the timed region (graph replay): kernels in issue order with gaps
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 def tight(i):      # forward, dot and the optimizer's kernels back to back: a graph replay, not the eagerly issued trial
