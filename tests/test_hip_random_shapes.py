@@ -1,0 +1,67 @@
+"""GPU parity sweep over seeded random configurations: clip length, hop, lambd (every kernel path: direct DFT, the fused kernel
+with part of a wave / one wave / several waves per frame), n_mels, sample rate, band limits, window normalisation, batch.
+Each configuration: training forward (+ tangent through d lambd), inference forward, log and linear outputs, against the CPU
+oracle (oracle/, pinned to the reference's goldens by tests/test_oracle_golden.py).  Tolerances as in test_hip_parity.py."""
+import numpy as np
+import pytest
+import torch
+
+import cases as C
+from oracle import dmel_oracle as O
+from test_hip_parity import TOL, _dlam_tol, _layer, _log_err, _rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    # log-uniform lambd so that every n_fft from 4 to 16384 is drawn; clip lengths from shorter than a frame to a few frames
+    while len(out) < n:
+        n_fft_target = int(2 ** rng.integers(2, 15))                       # 4 ... 16384
+        lam = float(rng.uniform(0.55, 0.99) * n_fft_target / 6.0) * (1.0 if rng.random() < 0.8 else -1.0)
+        nf = O.n_fft(lam)
+        L = int(rng.integers(max(8, nf // 4), max(64, min(6 * nf, 30000))))
+        hop = int(rng.integers(1, max(2, L // 3))) if rng.random() < 0.3 else int(rng.integers(max(1, nf // 8), max(2, nf)))
+        T = L // hop + 1
+        if T > 400:
+            hop = max(1, L // 300)
+            T = L // hop + 1
+        sr = int(rng.choice([8000, 16000, 22050, 44100]))
+        n_mels = int(rng.choice([1, 7, 16, 40, 64, 80, 128, 130]))
+        f_min = float(rng.choice([0.0, 0.0, 50.0, 300.0]))
+        f_max = None if rng.random() < 0.6 else float(rng.uniform(0.3, 0.5) * sr)
+        if f_max is not None and f_max <= f_min + 100.0:
+            f_max = None
+        B = int(rng.integers(1, 5))
+        if B * T * nf > 6_000_000:                                         # keep the oracle in seconds
+            continue
+        out.append(dict(C.BY_NAME["g1_c1"], name=f"r{len(out)}_n{nf}_L{L}_h{hop}_m{n_mels}", B=B, L=L, lambd=lam, hop=hop, n_mels=n_mels,
+                        sr=sr, f_min=f_min, f_max=f_max, normalize_window=bool(rng.random() < 0.4), seed=1000 + len(out)))
+    return out
+
+
+RANDOM_CASES = _random_cases(36, seed=20240607) + [dict(c, name="s2_" + c["name"]) for c in _random_cases(36, seed=977)]
+
+
+@pytest.mark.parametrize("case", RANDOM_CASES, ids=[c["name"] for c in RANDOM_CASES])
+def test_random_configuration_matches_oracle(case):
+    x_np = C.make_input(case).astype(np.float32)
+    g_np = C.make_cotangent(case)
+    x = torch.from_numpy(x_np).to("cuda:0")
+    g = torch.from_numpy(g_np).to("cuda:0")
+    for log in (False, True):
+        layer = _layer(case, log=log)
+        y = layer(x)
+        assert y.shape == C.out_shape(case)
+        (y * g).sum().backward()
+        o_ref, t_ref = O.forward(x_np, case["lambd"], case["hop"], case["n_mels"], case["sr"], case["f_min"], case["f_max"],
+                                 case["normalize_window"], apply_log=log)
+        o = y.detach().cpu().numpy()
+        assert (_log_err(o, o_ref) if log else _rel_err(o, o_ref)) <= TOL
+        exp_d = O.backward(g_np, t_ref)
+        assert abs(float(layer.lambd.grad) - exp_d) <= _dlam_tol(exp_d, g_np, t_ref)
+        with torch.no_grad():
+            yi = _layer(case, log=log, trainable=False)(x)
+        oi = yi.cpu().numpy()
+        assert (_log_err(oi, o_ref) if log else _rel_err(oi, o_ref)) <= TOL
