@@ -32,7 +32,7 @@ SYMBOLS = (
     "dmel_forward", "dmel_backward", "dmel_backward_ex", "dmel_backward_fb", "dmel_backward_x", "dmel_spectrogram", "dmel_plan_get_info",
     "dmel_plan_set_profiling", "dmel_plan_get_profile", "dmel_spectrogram_ex",
     "dmel_comm_unique_id", "dmel_comm_create", "dmel_comm_destroy", "dmel_comm_allreduce_async", "dmel_comm_wait",
-    "dmel_comm_allreduce", "dmel_scratch_bytes", "dmel_plan_set_filterbank_dev", "dmel_forward_scratch", "dmel_forward_dev", "dmel_backward_scratch", "dmel_plan_get_config",
+    "dmel_comm_allreduce", "dmel_scratch_bytes", "dmel_plan_set_filterbank_dev", "dmel_forward_scratch", "dmel_forward_dev", "dmel_forward_dev_fixed", "dmel_backward_fb_dev", "dmel_backward_scratch", "dmel_plan_get_config",
     "dmel_plan_lambd_status", "dmel_plan_set_tracking", "dmel_plan_lambd_reset",
 )
 TORCH_LIB_PATH = os.path.join(_PKG_DIR, "libdmel_torch.so")
@@ -140,6 +140,10 @@ def load():
     L.dmel_forward_scratch.restype = C.c_int
     L.dmel_forward_dev.argtypes = [vp, vp, C.c_int32, vp, C.c_uint32, C.c_double, vp, vp, vp, vp]
     L.dmel_forward_dev.restype = C.c_int
+    L.dmel_forward_dev_fixed.argtypes = [vp, vp, C.c_int32, vp, C.c_int32, C.c_uint32, C.c_double, vp, vp, vp, vp]
+    L.dmel_forward_dev_fixed.restype = C.c_int
+    L.dmel_backward_fb_dev.argtypes = [vp, vp, C.c_int32, vp, C.c_int32, C.c_uint32, vp, vp, vp, vp]
+    L.dmel_backward_fb_dev.restype = C.c_int
     L.dmel_backward_scratch.argtypes = [vp, vp, C.c_int32, vp, C.c_int64, C.c_int32, vp, vp, vp]
     L.dmel_backward_scratch.restype = C.c_int
     L.dmel_plan_get_config.argtypes = [vp, C.POINTER(DmelConfig)]
@@ -251,6 +255,18 @@ class Plan:
         """dmel_forward_dev: lambd stays on the device (no host read)."""
         _check(load().dmel_forward_dev(self._h, x_ptr, batch, lambd_ptr, (DMEL_FLAG_LOG if log else 0) | int(extra_flags), float(eps),
                                        out_ptr, tangent_ptr, scratch_ptr, stream))
+
+    def forward_dev_fixed(self, x_ptr: int, batch: int, lambd_ptr: int, n_fft_: int, out_ptr: int, tangent_ptr: int | None, log: bool,
+                          eps: float, stream: int, scratch_ptr: int | None = None, extra_flags: int = 0):
+        """dmel_forward_dev_fixed: one launch for ``n_fft_``, lambd read and checked on the device (trainable filterbank)."""
+        _check(load().dmel_forward_dev_fixed(self._h, x_ptr, batch, lambd_ptr, int(n_fft_), (DMEL_FLAG_LOG if log else 0) | int(extra_flags),
+                                             float(eps), out_ptr, tangent_ptr, scratch_ptr, stream))
+
+    def backward_fb_dev(self, x_ptr: int, batch: int, lambd_ptr: int, n_fft_: int, grad_ptr: int, out_ptr: int | None, grad_fb_ptr: int,
+                        log: bool, stream: int):
+        """dmel_backward_fb_dev: dmel_backward_fb with lambd read on the device."""
+        _check(load().dmel_backward_fb_dev(self._h, x_ptr, batch, lambd_ptr, int(n_fft_), DMEL_FLAG_LOG if log else 0, grad_ptr,
+                                           out_ptr if log else None, grad_fb_ptr, stream))
 
     def backward_scratch(self, grad_ptr: int, tangent_ptr: int, count: int, dlambd_ptr: int, stream: int, scratch_ptr: int | None,
                          accumulate: bool = False, grad_bf16: bool = False):

@@ -978,6 +978,47 @@ dmel_status dmel_forward_dev(dmel_plan* plan, const float* x, int32_t batch, con
     return DMEL_OK;
 }
 
+dmel_status dmel_forward_dev_fixed(dmel_plan* plan, const float* x, int32_t batch, const float* lambd_dev, int32_t n_fft,
+                                   uint32_t flags, double eps, void* out, float* tangent, void* scratch, void* stream)
+{
+    dmel_status st = check_forward_args(plan, x, batch, out);
+    if (st != DMEL_OK) return st;
+    if (!lambd_dev) return fail(DMEL_ERR_INVALID_ARGUMENT, "lambd_dev is NULL");
+    if (flags & DMEL_FLAG_FULL_WINDOW)
+        return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_forward_dev_fixed: DMEL_FLAG_FULL_WINDOW needs lambd by value, use dmel_forward");
+    if (n_fft < 1 || n_fft > dmel::kMaxNfft || (n_fft & (n_fft - 1)))
+        return fail(DMEL_ERR_INVALID_ARGUMENT, "n_fft must be a power of two in [1, 16384]");
+    std::lock_guard<std::mutex> lock(plan->mu);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const unsigned long long err = __atomic_load_n(&plan->host_words[1], __ATOMIC_RELAXED);
+    if (err != 0) {
+        float lam; const unsigned bits = (unsigned)err; std::memcpy(&lam, &bits, 4);
+        __atomic_store_n(&plan->host_words[1], 0ull, __ATOMIC_RELAXED);
+        lam_reset(plan);
+        return fail(DMEL_ERR_LAMBD_TRACKING,
+                    "lambd = " + std::to_string(lam) + " asks for n_fft " + std::to_string(dmel_n_fft(lam)) + " but the forward was issued for the "
+                    "fixed n_fft " + std::to_string(n_fft) + " (a learnable filterbank is tied to one n_fft): call " +
+                    std::to_string((unsigned)(err >> 32)) + " produced NaN");
+    }
+    if (batch == 0) return DMEL_OK;
+    Scratch sc;
+    if (scratch) sc = carve(scratch);
+    else {
+        if ((st = order_after_last_stream(plan, s)) != DMEL_OK) return st;
+        if ((st = ensure_own_scratch(plan, batch, s, &sc)) != DMEL_OK) return st;
+    }
+    dmel::LamArgs lam{};
+    lam.dev = lambd_dev; lam.val = 0.f; lam.n_expected = n_fft;
+    lam.role = dmel::kLamFirst | dmel::kLamLast;
+    lam.seq = ++plan->issued; lam.handled = sc.handled;
+    lam.host_seen = &plan->host_words[0]; lam.host_error = &plan->host_words[1];
+    lam.dot_counter = scratch ? sc.counter : nullptr;
+    plan->last_guards = 0;
+    bool sums_done = false;
+    return launch_forward_n(plan, x, batch, n_fft, lam, flags, eps, static_cast<float*>(out), tangent,
+                            tangent ? dmel::kTrain : dmel::kInfer, /*remove_dc=*/1, sc, s, 0, &sums_done);
+}
+
 dmel_status dmel_plan_lambd_status(dmel_plan* plan, dmel_lambd_status* status)
 {
     if (!plan || !status) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan / status is NULL");
@@ -1070,15 +1111,23 @@ dmel_status dmel_backward(dmel_plan* plan, const float* grad_out, const float* t
     return dmel_backward_ex(plan, grad_out, DMEL_DTYPE_F32, tangent, count, accumulate, dlambd, stream);
 }
 
-dmel_status dmel_backward_fb(dmel_plan* plan, const float* x, int32_t batch, float lambd, uint32_t flags,
-                             const float* grad_out, const float* out, float* grad_fb, void* stream)
+}  // extern "C"
+
+namespace {
+// lambd by value (lambd_dev == nullptr; n_fft derived from it) or on the device with the n_fft the caller's forward was issued for
+dmel_status backward_fb_impl(dmel_plan* plan, const float* x, int32_t batch, float lambd, const float* lambd_dev, int32_t n_fft_dev,
+                             uint32_t flags, const float* grad_out, const float* out, float* grad_fb, void* stream)
 {
     if (!plan) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
     if (batch < 0) return fail(DMEL_ERR_INVALID_ARGUMENT, "batch < 0");
     if (!grad_fb || (batch > 0 && (!x || !grad_out))) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_backward_fb: x / grad_out / grad_fb is NULL");
     if ((flags & DMEL_FLAG_LOG) && batch > 0 && !out)
         return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_backward_fb: DMEL_FLAG_LOG needs the saved log output");
-    if (!std::isfinite(lambd)) return fail(DMEL_ERR_INVALID_ARGUMENT, "lambd is not finite");
+    if (!lambd_dev && !std::isfinite(lambd)) return fail(DMEL_ERR_INVALID_ARGUMENT, "lambd is not finite");
+    if (lambd_dev && (flags & DMEL_FLAG_FULL_WINDOW))
+        return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_backward_fb_dev: DMEL_FLAG_FULL_WINDOW needs lambd by value, use dmel_backward_fb");
+    if (lambd_dev && (n_fft_dev < 1 || n_fft_dev > dmel::kMaxNfft || (n_fft_dev & (n_fft_dev - 1))))
+        return fail(DMEL_ERR_INVALID_ARGUMENT, "n_fft must be a power of two in [1, 16384]");
     int n_over = 0, win_half = 0;
     if (flags & DMEL_FLAG_FULL_WINDOW) {
         const int L = plan->cfg.n_points;
@@ -1086,7 +1135,7 @@ dmel_status dmel_backward_fb(dmel_plan* plan, const float* x, int32_t batch, flo
             return fail(DMEL_ERR_UNSUPPORTED, "DMEL_FLAG_FULL_WINDOW needs n_points to be a power of two <= 8192");
         n_over = 2 * L; win_half = 1;
     }
-    const int N = n_over ? n_over : dmel_n_fft(lambd);
+    const int N = lambd_dev ? n_fft_dev : (n_over ? n_over : dmel_n_fft(lambd));
     if (N > dmel::kMaxNfft)
         return fail(DMEL_ERR_UNSUPPORTED, "n_fft = " + std::to_string(N) + " > " + std::to_string(dmel::kMaxNfft) + " is not supported by the HIP kernels");
     const int F = N / 2 + 1, M = plan->cfg.n_mels, T = plan->T;
@@ -1105,13 +1154,25 @@ dmel_status dmel_backward_fb(dmel_plan* plan, const float* x, int32_t batch, flo
     const size_t gm_floats = (flags & DMEL_FLAG_LOG) ? (size_t)batch * M * T + 16 : 0;
     const size_t need = spec_floats + part_floats + gm_floats;
     if (need > plan->fbw_floats) {
+        if (is_capturing(s)) return fail(DMEL_ERR_INVALID_ARGUMENT, "workspace must grow but the stream is capturing: run one call eagerly first");
         DMEL_HIP(hipStreamSynchronize(s));
         (void)hipFree(plan->fbw); plan->fbw = nullptr; plan->fbw_floats = 0;
         DMEL_HIP(hipMalloc(&plan->fbw, need * sizeof(float)));
         plan->fbw_floats = need;
     }
     // the spectrogram the layer contracted at models.py:53 (DC removed, models.py:38): P is recomputed, not saved
-    dmel_status st = run_forward_nolock(plan, x, batch, lambd, 0u, 0.0, plan->fbw, nullptr, dmel::kSpec, 1, stream, n_over, win_half);
+    dmel_status st;
+    if (lambd_dev) {
+        // lambd read on the device and checked against N: a mismatch (the forward of this step reported it) leaves NaN here too
+        Scratch sc;
+        if ((st = ensure_own_scratch(plan, batch, s, &sc)) != DMEL_OK) return st;
+        dmel::LamArgs lam{};
+        lam.dev = lambd_dev; lam.n_expected = N; lam.role = dmel::kLamFirst | dmel::kLamLast;
+        bool sums_done = false;
+        st = launch_forward_n(plan, x, batch, N, lam, 0u, 0.0, plan->fbw, nullptr, dmel::kSpec, 1, sc, s, 0, &sums_done);
+    } else {
+        st = run_forward_nolock(plan, x, batch, lambd, 0u, 0.0, plan->fbw, nullptr, dmel::kSpec, 1, stream, n_over, win_half);
+    }
     if (st != DMEL_OK) return st;
     dmel::FbGradParams fp{};
     fp.spec = plan->fbw; fp.grad_out = grad_out; fp.out = (flags & DMEL_FLAG_LOG) ? out : nullptr;
@@ -1122,6 +1183,22 @@ dmel_status dmel_backward_fb(dmel_plan* plan, const float* x, int32_t batch, flo
     DMEL_HIP(dmel::launch_fbgrad(fp, s));
     prof_span(plan, m0, prof_mark(plan, s), 2);
     return DMEL_OK;
+}
+}  // namespace
+
+extern "C" {
+
+dmel_status dmel_backward_fb(dmel_plan* plan, const float* x, int32_t batch, float lambd, uint32_t flags,
+                             const float* grad_out, const float* out, float* grad_fb, void* stream)
+{
+    return backward_fb_impl(plan, x, batch, lambd, nullptr, 0, flags, grad_out, out, grad_fb, stream);
+}
+
+dmel_status dmel_backward_fb_dev(dmel_plan* plan, const float* x, int32_t batch, const float* lambd_dev, int32_t n_fft, uint32_t flags,
+                                 const float* grad_out, const float* out, float* grad_fb, void* stream)
+{
+    if (!lambd_dev) return fail(DMEL_ERR_INVALID_ARGUMENT, "lambd_dev is NULL");
+    return backward_fb_impl(plan, x, batch, 0.f, lambd_dev, n_fft, flags, grad_out, out, grad_fb, stream);
 }
 
 dmel_status dmel_backward_x(dmel_plan* plan, const float* x, int32_t batch, float lambd, uint32_t flags,

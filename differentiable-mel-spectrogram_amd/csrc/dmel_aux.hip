@@ -3,6 +3,7 @@
 //                    forward has carried d out / d lambd; train.py:47 reaches exactly this scalar)
 //   * dmel_naive_* : direct-DFT forward for n_fft < 32 (lambd < 5.5 samples) and as an on-device
 //                    cross-check of the wave-FFT kernel; same semantics (models.py:33-56, :73).
+#include <algorithm>
 #include "dmel_kernels.h"
 #include "dmel_ldsfft.h"
 
@@ -114,13 +115,15 @@ hipError_t launch_dot(const void* g, int g_bf16, const float* t, long long count
 }
 
 // ---- filterbank tables from a device matrix -----------------------------------------------------------------
-// grid.x = runs (one (group, wave, run) entry of tile_ranges each) + 1: the last workgroup copies / transposes the matrix
+// grid.x = runs (one (group, wave, run) entry of tile_ranges each) + the workgroups that copy / transpose the matrix (one
+// workgroup doing all of it took 64 us for 513 x 128 entries: the longest kernel of a trainable-filterbank step)
 __global__ void __launch_bounds__(256) dmel_repack_kernel(RepackParams p)
 {
     const int tid = threadIdx.x;
-    if ((int)blockIdx.x == p.runs) {
+    if ((int)blockIdx.x >= p.runs) {
         const long long n = (long long)p.F * p.M;
-        for (long long i = tid; i < n; i += 256) {
+        const long long stride = 256LL * (gridDim.x - p.runs);
+        for (long long i = (long long)(blockIdx.x - p.runs) * 256 + tid; i < n; i += stride) {
             const float v = p.fb[i];
             p.fb_dense[i] = v;
             if (p.fbT) { const int f = (int)(i / p.M), m = (int)(i % p.M); p.fbT[(size_t)m * p.F + f] = v; }
@@ -141,7 +144,9 @@ __global__ void __launch_bounds__(256) dmel_repack_kernel(RepackParams p)
 
 hipError_t launch_repack(const RepackParams& p, hipStream_t s)
 {
-    hipLaunchKernelGGL(dmel_repack_kernel, dim3((unsigned)(p.runs + 1)), dim3(256), 0, s, p);
+    const long long n = (long long)p.F * p.M;
+    const int copiers = (int)std::max<long long>(1, std::min<long long>(256, (n + 1023) / 1024));
+    hipLaunchKernelGGL(dmel_repack_kernel, dim3((unsigned)(p.runs + copiers)), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 

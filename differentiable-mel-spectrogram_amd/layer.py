@@ -121,6 +121,73 @@ class _DmelFunction(torch.autograd.Function):
         return gx, dl, None, None, None, None, None, gfb, None
 
 
+class _DmelFbDevFunction(torch.autograd.Function):
+    """Trainable filterbank with lambd left on the device: dmel_forward_dev_fixed (one launch for the n_fft the matrix was
+    built for; lambd read and checked by the kernel), dmel_backward_scratch (d lambd) and dmel_backward_fb_dev (adjoint of
+    models.py:53).  No host read anywhere: the step queues without waiting and can be captured into a HIP graph."""
+
+    @staticmethod
+    def forward(ctx, x, lambd, plan, n_fft, log, eps, fb, out_dtype):
+        B = x.shape[0]
+        want_tangent = ctx.needs_input_grad[1]
+        want_fb = ctx.needs_input_grad[6]
+        round_later = out_dtype == torch.bfloat16 and log and want_fb       # see _DmelFunction.forward
+        kdtype = torch.float32 if round_later else out_dtype
+        out = torch.empty((B, 1, plan.n_mels, plan.n_time), dtype=kdtype, device=x.device)
+        tangent = torch.empty(out.shape, dtype=torch.float32, device=x.device) if want_tangent else None
+        scratch = torch.empty((plan.scratch_bytes(B),), dtype=torch.uint8, device=x.device)
+        lam = lambd.detach()
+        if lam.dtype != torch.float32:
+            lam = lam.to(torch.float32)
+        with _on_device(x.device):
+            plan.forward_dev_fixed(x.data_ptr(), B, lam.data_ptr(), n_fft, out.data_ptr(), tangent.data_ptr() if want_tangent else None,
+                                   log, eps, _stream_ptr(x.device), scratch.data_ptr(),
+                                   extra_flags=capi.DMEL_FLAG_OUT_BF16 if kdtype == torch.bfloat16 else 0)
+        ctx.plan, ctx.n_fft, ctx.log = plan, n_fft, bool(log)
+        ctx.lambd_shape, ctx.lambd_dtype = lambd.shape, lambd.dtype
+        ctx.want_tangent, ctx.want_fb = want_tangent, want_fb
+        ctx.fb_meta = (tuple(fb.shape), fb.dtype)
+        saved = [scratch]
+        if want_tangent:
+            saved.append(tangent)
+        if want_fb:
+            saved += [x, lam]
+            if log:
+                saved.append(out)
+        ctx.save_for_backward(*saved)
+        return out.to(torch.bfloat16) if round_later else out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        saved = list(ctx.saved_tensors)
+        scratch = saved.pop(0)
+        bf16 = grad_out.dtype == torch.bfloat16
+        g = grad_out
+        if not bf16 and g.dtype != torch.float32:
+            g = g.to(torch.float32)
+        if not g.is_contiguous():
+            g = g.contiguous()
+        dl = gfb = None
+        with _on_device(g.device):
+            if ctx.want_tangent:
+                tangent = saved.pop(0)
+                dl = torch.empty(tuple(ctx.lambd_shape), dtype=torch.float32, device=g.device)
+                ctx.plan.backward_scratch(g.data_ptr(), tangent.data_ptr(), g.numel(), dl.data_ptr(), _stream_ptr(g.device),
+                                          scratch.data_ptr(), grad_bf16=bf16)
+                if ctx.lambd_dtype != torch.float32:
+                    dl = dl.to(ctx.lambd_dtype)
+            if ctx.want_fb:
+                x, lam = saved.pop(0), saved.pop(0)
+                out = saved.pop(0).to(torch.float32) if ctx.log else None
+                g32 = g.to(torch.float32)
+                fb_shape, fb_dtype = ctx.fb_meta
+                gfb = torch.empty(fb_shape, dtype=torch.float32, device=g.device)
+                ctx.plan.backward_fb_dev(x.data_ptr(), x.shape[0], lam.data_ptr(), ctx.n_fft, g32.data_ptr(),
+                                         out.data_ptr() if ctx.log else None, gfb.data_ptr(), ctx.log, _stream_ptr(g.device))
+                gfb = gfb.to(fb_dtype)
+        return None, dl, None, None, None, None, gfb, None
+
+
 _MEL_OP = None
 
 
@@ -276,6 +343,19 @@ class MelSpectrogramLayer(nn.Module):
             if lam.dtype != torch.float32:
                 lam = lam.to(torch.float32)
             return _mel_op()(xf, lam, plan.handle, flags, self.eps, self.lambd_sync, self.out_dtype == torch.bfloat16)
+        if fb is not None and self.optimized and not x.requires_grad and not self.lambd_sync:
+            # trainable filterbank, sync-free: the matrix fixes n_fft (its row count), lambd is read and checked on the device;
+            # a lambd that has left that n_fft gives NaN now and a RuntimeError at the next forward (models.py:53 fails on the
+            # shape in the same situation)
+            n = 2 * (fb.shape[0] - 1)
+            if fb.device != x.device:
+                raise RuntimeError(f"mel_fb is on {fb.device} but x is on {x.device}; call layer.to(x.device)")
+            fbd = fb.detach()
+            if fbd.dtype != torch.float32 or not fbd.is_contiguous():
+                fbd = fbd.to(torch.float32).contiguous()
+            with _on_device(x.device):
+                plan.set_filterbank_dev(n, fbd.data_ptr(), _stream_ptr(x.device))
+            return _DmelFbDevFunction.apply(xf, self.lambd, plan, n, self.log, self.eps, fb, self.out_dtype)
         lam_host = self._lambd_host()
         if fb is not None:
             n = capi.n_fft(lam_host) if self.optimized else 2 * self.n_points

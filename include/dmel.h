@@ -145,6 +145,13 @@ dmel_status dmel_forward_scratch(dmel_plan* plan, const float* x, int32_t batch,
                                  double eps, void* out, float* tangent, void* scratch, void* stream);
 dmel_status dmel_forward_dev(dmel_plan* plan, const float* x, int32_t batch, const float* lambd_dev, uint32_t flags,
                              double eps, void* out, float* tangent, void* scratch, void* stream);
+/* The same forward for callers whose n_fft is fixed by something else than lambd -- a trainable filterbank matrix
+ * (dmel_plan_set_filterbank_dev) has n_fft/2+1 rows: exactly one launch for `n_fft`, lambd read and checked on the device, no
+ * guard launches, no host picture of lambd (never blocks, capturable from the first call).  If the device value asks for
+ * another n_fft the outputs are NaN and the NEXT call returns DMEL_ERR_LAMBD_TRACKING (models.py:42-48 ties the reference's
+ * matrix to the n_fft of the forward in the same way: torch.matmul fails on the shape). */
+dmel_status dmel_forward_dev_fixed(dmel_plan* plan, const float* x, int32_t batch, const float* lambd_dev, int32_t n_fft,
+                                   uint32_t flags, double eps, void* out, float* tangent, void* scratch, void* stream);
 
 typedef struct dmel_lambd_status {
     int32_t known;            /* 0 until a value has been seen                                             */
@@ -206,6 +213,10 @@ dmel_status dmel_backward_scratch(dmel_plan* plan, const void* grad_out, int32_t
  */
 dmel_status dmel_backward_fb(dmel_plan* plan, const float* x, int32_t batch, float lambd, uint32_t flags,
                              const float* grad_out, const float* out, float* grad_fb, void* stream);
+/* dmel_backward_fb with lambd read on the device (the spectrogram recompute checks it against `n_fft`, the one the forward
+ * of this step was issued for: dmel_forward_dev_fixed); no host read, capturable.  DMEL_FLAG_FULL_WINDOW is not accepted. */
+dmel_status dmel_backward_fb_dev(dmel_plan* plan, const float* x, int32_t batch, const float* lambd_dev, int32_t n_fft, uint32_t flags,
+                                 const float* grad_out, const float* out, float* grad_fb, void* stream);
 
 /*
  * Backward to the waveform: what torch autograd returns for x.requires_grad through models.py:38 (DC removal),

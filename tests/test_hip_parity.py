@@ -535,11 +535,75 @@ def test_learnable_filterbank_layer():
     y3 = lay(x).detach()
     ref3 = torch.log(torch.einsum("bft,fm->bmt", spec.double(), lay.mel_fb.detach().double()) + 1e-10).unsqueeze(1)
     assert float((y3.double() - ref3).abs().max()) <= TOL and not torch.equal(y3, y2)
-    # the bank is tied to its n_fft
+    # the bank is tied to its n_fft.  Sync-free layer: the kernel finds the mismatch (NaN, never a result from the wrong
+    # matrix) and the next forward raises; lambd_sync=True raises at once, like the shape error of models.py:53
     with torch.no_grad():
         lay.lambd.fill_(3.0 * float(case["lambd"]))
+    y4 = lay(x)
+    torch.cuda.synchronize()
+    assert torch.isnan(y4).all()
     with pytest.raises(RuntimeError, match="tied to one n_fft"):
         lay(x)
+    with torch.no_grad():
+        lay.lambd.fill_(float(case["lambd"]))
+    assert torch.equal(lay(x).detach(), y3)                                      # back inside its n_fft: works again
+    strict = MelSpectrogramLayer(torch.tensor(float(case["lambd"])), n_mels=case["n_mels"], n_points=case["L"], sample_rate=case["sr"],
+                                 hop_length=case["hop"], device="cuda:0", optimized=True, log=True, learnable_fb=True,
+                                 lambd_sync=True).to("cuda:0")
+    y5 = strict(x)
+    assert float((y5 - y0).detach().abs().max()) <= 1e-5
+    with torch.no_grad():
+        strict.lambd.fill_(3.0 * float(case["lambd"]))
+    with pytest.raises(RuntimeError, match="tied to one n_fft"):
+        strict(x)
+
+
+def test_trainable_filterbank_step_is_sync_free_and_graph_capturable():
+    """lambd AND the filterbank trained together: the step (forward with the dense bank refreshed on the device, d lambd,
+    d filterbank, Adam on both) queues without a host read and replays from a HIP graph; the replayed parameters equal the
+    eagerly stepped ones of a layer that reads lambd on the host at every forward."""
+    from dmel_amd import MelSpectrogramLayer
+    case = C.BY_NAME["g1_c1"]
+    x = torch.from_numpy(C.make_input(case).astype(np.float32)).to("cuda:0")
+    g = torch.from_numpy(C.make_cotangent(case)).to("cuda:0")
+
+    def mk(sync):
+        return MelSpectrogramLayer(torch.tensor(float(case["lambd"])), n_mels=case["n_mels"], n_points=case["L"], sample_rate=case["sr"],
+                                   hop_length=case["hop"], device="cuda:0", optimized=True, log=False, learnable_fb=True,
+                                   lambd_sync=sync).to("cuda:0")
+
+    def run(layer, steps, graphed):
+        opt = torch.optim.Adam([{"params": [layer.lambd], "lr": 0.05}, {"params": [layer.mel_fb], "lr": 1e-4}], capturable=True)
+
+        def step():
+            opt.zero_grad(set_to_none=False)
+            layer(x).backward(g)
+            opt.step()
+        if not graphed:
+            for _ in range(steps):
+                step()
+        else:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+            for _ in range(steps - 2):                      # (capturing does not execute)
+                graph.replay()
+        torch.cuda.synchronize()
+        return layer.lambd.detach().cpu().numpy().copy(), layer.mel_fb.detach().cpu().numpy().copy()
+
+    lam_e, fb_e = run(mk(True), 8, False)
+    lay = mk(False)
+    lam_g, fb_g = run(lay, 8, True)
+    assert lay.lambd_status()["error"] == 0
+    assert abs(float(lam_e) - float(case["lambd"])) > 0.1                        # the parameters did move
+    np.testing.assert_allclose(lam_g, lam_e, rtol=1e-5)
+    np.testing.assert_allclose(fb_g, fb_e, rtol=1e-4, atol=1e-6)
 
 
 @pytest.mark.parametrize("name", ["g1_c1", "g2_c2", "g5_n128", "g6_n32", "g5_n4096"])
