@@ -962,12 +962,25 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                     // the rest (long runs: dense custom filterbanks, further mel groups) streams with a 4-step prefetch
                     const int istart = (grp == 0) ? NBPRE : 0;
                     if (istart < nks) {
-                        float bc[4], bn[4];
-                        static_for<0, 4>([&](auto u) { bc[decltype(u)::value] = buf_f32(rb, bbase + (istart + decltype(u)::value) * 256); });
-                        for (int i = istart; i < nks; i += 4) {
-                            static_for<0, 4>([&](auto u) { bn[decltype(u)::value] = buf_f32(rb, bbase + (i + 4 + decltype(u)::value) * 256); });
-                            group4(ks0 + i, bc[0], bc[1], bc[2], bc[3]);
-                            static_for<0, 4>([&](auto u) { bc[decltype(u)::value] = bn[decltype(u)::value]; });
+                        // a ring of DEPTH groups of 4 fragments in flight: one group ahead left the loop waiting for an L2 round trip per
+                        // 4 MFMAs (dense banks -- a trainable filterbank -- and the long runs of n_fft >= 4096 live in this loop);
+                        // offsets past the run are range-checked by the buffer descriptor or read the next run: never used
+                        // (4 deep: n_fft 4096 at the reference's ESC-50 shape 171 -> 163 us, 8192 530 -> 512; at 2048 the 8 extra
+                        // registers spill and config 3 went 49.8 -> 51.9 us, so the sizes with 128 VGPRs keep two groups)
+                        constexpr int DEPTH = (N >= 4096) ? 4 : 2;
+                        float br[DEPTH][4];
+                        static_for<0, DEPTH>([&](auto dd) {
+                            constexpr int d = decltype(dd)::value;
+                            static_for<0, 4>([&](auto u) { br[d][decltype(u)::value] = buf_f32(rb, bbase + (istart + 4 * d + decltype(u)::value) * 256); });
+                        });
+                        for (int i = istart; i < nks; i += 4 * DEPTH) {
+                            static_for<0, DEPTH>([&](auto dd) {
+                                constexpr int d = decltype(dd)::value;
+                                if (i + 4 * d < nks) {
+                                    group4(ks0 + i + 4 * d, br[d][0], br[d][1], br[d][2], br[d][3]);
+                                    static_for<0, 4>([&](auto u) { br[d][decltype(u)::value] = buf_f32(rb, bbase + (i + 4 * (d + DEPTH) + decltype(u)::value) * 256); });
+                                }
+                            });
                         }
                     }
                 });
