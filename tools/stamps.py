@@ -37,7 +37,10 @@ from dmel_amd import capi, synth
 from bench import CONFIGS
 
 name = sys.argv[2] if len(sys.argv) > 2 else "c2"
-B, L, sr, lam, hop, M = CONFIGS[name]
+# besides bench.py's configs: the reference's ESC-50 shape (search_spaces.py:4-33) at its three starting lambd and one drift case
+EXTRA = {"esc_n128": (32, 40000, 8000, 8000 * 0.01 / 6, 80, 64), "esc_n512": (32, 40000, 8000, 8000 * 0.035 / 6, 80, 64),
+         "esc_n4096": (32, 40000, 8000, 400.0, 80, 64), "esc_n8192": (32, 40000, 8000, 700.0, 80, 64)}
+B, L, sr, lam, hop, M = CONFIGS[name] if name in CONFIGS else EXTRA[name]
 T = L // hop + 1
 x = torch.from_numpy(synth.waveforms(B, L, seed=0)).cuda()
 out = torch.empty((B, 1, M, T), device="cuda"); tan = torch.empty_like(out)
@@ -48,7 +51,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 info = plan.info()
 nwg = min(info["grid_fwd"], 4096)
-waves = 8 if info["n_fft"] in (1024, 2048) else 4
+waves = 8 if info["n_fft"] >= 1024 else 4
 SL = 32
 buf = np.zeros(4096 * 8 * SL, dtype=np.uint64)
 L_ = capi.load()
