@@ -606,12 +606,16 @@ def test_trainable_filterbank_step_is_sync_free_and_graph_capturable():
     np.testing.assert_allclose(fb_g, fb_e, rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("name", ["g1_c1", "g2_c2", "g5_n128", "g6_n32", "g5_n4096"])
+_FB_EXTRA = {"n8192": dict(C.BY_NAME["g1_c1"], name="n8192", B=2, L=20000, lambd=900.0, hop=1000, n_mels=40),
+             "n2048": dict(C.BY_NAME["g1_c1"], name="n2048", B=2, L=9000, lambd=-250.0, hop=300, n_mels=96)}
+
+
+@pytest.mark.parametrize("name", ["g1_c1", "g2_c2", "g5_n128", "g6_n32", "g5_n4096", "n2048", "n8192"])
 def test_filterbank_from_device_equals_filterbank_from_host(name):
     """dmel_plan_set_filterbank_dev (one small kernel on the stream, no host copy, no synchronisation) fills the same tables as
     dmel_plan_set_filterbank builds on the host: identical outputs, bit for bit, for a dense random matrix."""
     from dmel_amd import capi
-    case = C.BY_NAME[name]
+    case = C.BY_NAME[name] if name in C.BY_NAME else _FB_EXTRA[name]
     x = torch.from_numpy(C.make_input(case).astype(np.float32)).to("cuda:0")
     n = capi.n_fft(case["lambd"])
     fb = torch.rand((n // 2 + 1, case["n_mels"]), device="cuda:0") + 0.01
