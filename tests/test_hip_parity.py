@@ -739,10 +739,10 @@ def test_full_window_branch_on_the_compact_layout():
 
 
 # ---- bf16 activations (BASELINE config 2: "bf16 activations / fp32 grad") ----------------------------------------
-@pytest.mark.parametrize("name", ["g1_c1", "g2_c2", "g6_n256_ragged", "g6_n32"])
+@pytest.mark.parametrize("name", ["g1_c1", "g2_c2", "g6_n256_ragged", "g6_n32", "g6_n2048_short", "g5_n4096", "n8192"])
 def test_bf16_output_is_the_rounded_fp32_output(name):
     from dmel_amd import MelSpectrogramLayer
-    case = C.BY_NAME[name]
+    case = C.BY_NAME[name] if name in C.BY_NAME else _FB_EXTRA[name]
     x = torch.from_numpy(C.make_input(case).astype(np.float32)).to("cuda:0")
     g32 = torch.from_numpy(C.make_cotangent(case)).to("cuda:0")
     for log in (False, True):
