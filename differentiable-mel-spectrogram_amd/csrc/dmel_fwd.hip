@@ -954,8 +954,8 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                     // One group = 4 consecutive k-steps = 16 consecutive bins starting at a multiple of 16 (the host
                     // aligns every run to 4 k-steps), so the 4 reads of Z[k] share one base address and, except at one
                     // bin per 256, so do the 4 reads of the mirrored Z[N-k].
-                    auto group4 = [&](int ksg, float b0, float b1, float b2, float b3) {
-                        const float bq[4] = {b0, b1, b2, b3};
+                    // A operands of one group: 4 LDS reads per 16-row tile
+                    auto load_a = [&](int ksg, float (&av)[MT][4]) {
                         const int k0 = 4 * ksg + kofs;                               // bin of k-step 0 for this lane
                         const int zk0 = z_index<R, C>(k0 & (N - 1));
                         static_for<0, MT>([&](auto m) {
@@ -964,15 +964,40 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                             const bool valid = slot < SLOTS;
                             // rows of type 0 read PD.x (|S|^2), rows of type 1 PD.y: the A operand is a plain 4-byte LDS read
                             const float* slf = reinterpret_cast<const float*>(lds + (valid ? slot : 0) * SS) + type;
-                            float av[4];
-                            static_for<0, 4>([&](auto uu) { constexpr int u = decltype(uu)::value; av[u] = slf[2 * (zk0 + 4 * u)]; });
+                            static_for<0, 4>([&](auto uu) { constexpr int u = decltype(uu)::value; av[mt][u] = slf[2 * (zk0 + 4 * u)]; });
+                        });
+                    };
+                    auto mfma4 = [&](const float (&av)[MT][4], float b0, float b1, float b2, float b3) {
+                        const float bq[4] = {b0, b1, b2, b3};
+                        static_for<0, MT>([&](auto m) {
+                            constexpr int mt = decltype(m)::value;
+                            const bool valid = mt * 8 + slot8 < SLOTS;
                             static_for<0, 4>([&](auto uu) {
                                 constexpr int u = decltype(uu)::value;
-                                float val = av[u];
+                                float val = av[mt][u];
                                 if constexpr (SLOTS < 8) val = valid ? val : 0.f;
                                 acc[loc][mt][u & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(val, bq[u], acc[loc][mt][u & 1], 0, 0, 0);
                             });
                         });
+                    };
+                    // With two waves per SIMD (n_fft >= 4096) nobody covers the LDS round trip between the reads of a group and its
+                    // MFMAs: a wave with a long run spent ~85 cycles per MFMA instead of 32.  There the A operands of the NEXT group are
+                    // requested before the MFMAs of this one (reads past the run land on valid bins and are not used).  With four
+                    // waves per SIMD the same prefetch measured slower (23.5 against 23.4 us at config 2) and is not compiled in.
+                    constexpr bool APRE = (N >= 4096);       // ESC-50 shape: 157.5 -> 154.5 us at n_fft 4096, 486 -> 476 at 8192
+                    float a_cur[MT][4];
+                    if constexpr (APRE) load_a(ks0, a_cur);
+                    auto group4 = [&](int ksg, float b0, float b1, float b2, float b3) {
+                        if constexpr (APRE) {
+                            float a_nxt[MT][4];
+                            load_a(ksg + 4, a_nxt);
+                            mfma4(a_cur, b0, b1, b2, b3);
+                            static_for<0, MT>([&](auto m) { static_for<0, 4>([&](auto uu) { a_cur[decltype(m)::value][decltype(uu)::value] = a_nxt[decltype(m)::value][decltype(uu)::value]; }); });
+                        } else {
+                            float av[MT][4];
+                            load_a(ksg, av);
+                            mfma4(av, b0, b1, b2, b3);
+                        }
                     };
                     if (grp == 0) {
                         // k-steps whose B fragments are already in registers
