@@ -92,6 +92,7 @@ struct dmel_plan {
     // transforms beyond the LDS kernels (dmel_big.hip): chirp / filter tables per DFT length, twiddles per FFT length, the
     // window table and the per-workgroup sequences in global memory
     struct BigTab { int M = 0, logM = 0; float2* chirp = nullptr; float2* hbr = nullptr; };
+    std::map<int, float2*> big_wodd;   // per even N: exp(-2 pi i n / N), n < N/2 (split mode of the big kernel)
     std::map<int, BigTab> big_tabs;
     std::map<int, float2*> big_tw;
     float2* big_win = nullptr; size_t big_win_n = 0;
@@ -469,6 +470,31 @@ dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dm
         dmel_plan::BigTab bt;
         const float2* tw = nullptr;
         if ((st = big_tables_for(pl, N, &bt, &tw)) != DMEL_OK) return st;
+        // split mode (dmel_big.hip): the transform itself would live in global memory, its two halves fit LDS
+        const float2* wodd = nullptr;
+        bool split = false;
+        if (dmel::big_uses_global(bt.M)) {
+            const int H = N / 2;
+            int Mh = H;
+            if (H & (H - 1)) { Mh = 1; while (Mh < 2 * H - 1) Mh <<= 1; }
+            if (H >= 2 && dmel::big_can_split(Mh, pl->cfg.n_mels)) {
+                if ((st = big_tables_for(pl, H, &bt, &tw)) != DMEL_OK) return st;
+                auto wit = pl->big_wodd.find(N);
+                if (wit == pl->big_wodd.end()) {
+                    std::vector<float2> w((size_t)H);
+                    for (int n = 0; n < H; ++n) {
+                        const double th = -2.0 * M_PI * (double)n / (double)N;
+                        w[n] = make_float2((float)std::cos(th), (float)std::sin(th));
+                    }
+                    float2* d = nullptr;
+                    DMEL_HIP(hipMalloc(&d, w.size() * sizeof(float2)));
+                    DMEL_HIP(hipMemcpy(d, w.data(), w.size() * sizeof(float2), hipMemcpyHostToDevice));
+                    wit = pl->big_wodd.emplace(N, d).first;
+                }
+                wodd = wit->second;
+                split = true;
+            }
+        }
         if ((st = order_after_last_stream(pl, s)) != DMEL_OK) return st;          // window table and sequences are plan-owned
         const bool pair = (mode == dmel::kInfer || mode == dmel::kSpec);
         const long long units = (long long)batch * (pair ? (pl->T + 1) / 2 : pl->T);
@@ -507,6 +533,7 @@ dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dm
         bp.B = batch; bp.L = pl->cfg.n_points; bp.T = pl->T; bp.hop = pl->cfg.hop_length; bp.M = pl->cfg.n_mels;
         bp.nchunks = pl->nchunks; bp.N = N; bp.F = tb->F; bp.mode = mode; bp.Mfft = bt.M; bp.logM = bt.logM;
         bp.inv_L = 1.0f / (float)pl->cfg.n_points; bp.eps = (float)eps; bp.flags = flags; bp.remove_dc = remove_dc; bp.lam = lam;
+        bp.split = split ? 1 : 0; bp.wodd = wodd;
         DMEL_HIP(dmel::launch_big(bp, s));
         prof_span(pl, m1, prof_mark(pl, s), 1);
         pl->info.n_fft = N; pl->info.n_freqs = tb->F; pl->info.n_time = pl->T;
@@ -806,6 +833,7 @@ dmel_status dmel_plan_destroy(dmel_plan* plan)
     (void)hipFree(plan->own_scratch); (void)hipFree(plan->fbw);
     for (auto& kv : plan->big_tabs) { (void)hipFree(kv.second.chirp); (void)hipFree(kv.second.hbr); }
     for (auto& kv : plan->big_tw) (void)hipFree(kv.second);
+    for (auto& kv : plan->big_wodd) (void)hipFree(kv.second);
     (void)hipFree(plan->big_win); (void)hipFree(plan->big_z);
     if (plan->host_words) (void)hipHostFree(plan->host_words);
     if (plan->xev) (void)hipEventDestroy(plan->xev);

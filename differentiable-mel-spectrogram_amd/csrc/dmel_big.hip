@@ -10,7 +10,15 @@
 //     X[k] = c[k] * sum_n (x[n] c[n]) conj(c)[k - n],   c[n] = exp(-i pi n^2 / N)
 // i.e. one forward FFT of length M >= 2N - 1, a pointwise product with the precomputed transform of the chirp filter, and
 // one inverse FFT (run as a forward FFT on the conjugate).  The pairing pass and the band-limited mel stage are those of the
-// long-transform kernel (dmel_aux.hip).  A correctness path for sizes training rarely reaches, not a tuned one.
+// long-transform kernel (dmel_aux.hip).
+// Split mode (BigParams::split): an even length N whose own FFT would have to live in global memory but whose HALF fits LDS is
+// taken as one radix-2 decimation-in-frequency step done while loading,
+//     X[2m]   = DFT_{N/2}( z[n] + z[n + N/2] )[m],      X[2m+1] = DFT_{N/2}( (z[n] - z[n + N/2]) exp(-2 pi i n / N) )[m],
+// i.e. two half-length transforms (each a Bluestein round trip when N/2 is not a power of two) one after the other in the same
+// LDS.  The mirror of an even bin is even and of an odd bin odd (N - (2m+1) = 2 (N/2 - 1 - m) + 1), so the pairing pass stays
+// inside each half; the mel stage adds the two halves' contributions through a small accumulator behind the sequence.  This
+// is what the reference's default branch gives on Audio-MNIST's 8000-sample clips (n_fft 16000 = two 8000-point DFTs through
+// 16384-point FFTs in LDS instead of one through 32768-point FFTs in global memory).
 #include "dmel_kernels.h"
 #include "dmel_ldsfft.h"
 
@@ -31,6 +39,8 @@ __global__ void __launch_bounds__(kBigThreads) dmel_big_kernel(BigParams p)
     float2* Z = GLOBAL_Z ? p.zws + (size_t)blockIdx.x * p.Mfft : reinterpret_cast<float2*>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = p.N, M = p.Mfft, F = p.F, sh = 32 - p.logM;
+    const int NT = p.split ? N / 2 : N;                    // length of the transform(s) actually run
+    float2* macc = reinterpret_cast<float2*>(smem_raw + (size_t)M * sizeof(float2));     // split mode: mel sums of the even half
     const bool blue = p.chirp != nullptr;
     const bool pair = (p.mode == kInfer || p.mode == kSpec);
     const bool spec_mode = (p.mode == kSpec || p.mode == kSpecTrain);
@@ -63,19 +73,28 @@ __global__ void __launch_bounds__(kBigThreads) dmel_big_kernel(BigParams p)
             for (int c = 0; c < p.nchunks; ++c) s += (double)p.psum[(size_t)b * p.nchunks + c];
             mean = (float)(s * (double)p.inv_L);
         }
-        __syncthreads();                                   // the previous unit's readers are done with Z
+        // element n of the windowed complex frame (frame + tangent, or two frames), before any transform
+        auto elem = [&](int n) -> float2 {
+            const long long ia = (long long)tA * p.hop - N / 2 + n;
+            const float va = (ia >= 0 && ia < p.L) ? (xb[ia] - mean) : 0.f;      // zero padding after the DC removal
+            const float2 wd = p.win2[n];
+            if (pair) {
+                const long long ib = ia + p.hop;
+                const float vb = (tB < p.T && ib >= 0 && ib < p.L) ? (xb[ib] - mean) : 0.f;
+                return make_float2(va * wd.x, vb * wd.x);
+            }
+            return make_float2(va * wd.x, va * wd.y);
+        };
+        const int npar = p.split ? 2 : 1;
+        for (int par = 0; par < npar; ++par) {
+        __syncthreads();                                   // the previous unit's / half's readers are done with Z
         for (int n = tid; n < M; n += kBigThreads) {
             float2 z = make_float2(0.f, 0.f);
-            if (n < N) {
-                const long long ia = (long long)tA * p.hop - N / 2 + n;
-                const float va = (ia >= 0 && ia < p.L) ? (xb[ia] - mean) : 0.f;      // zero padding after the DC removal
-                const float2 wd = p.win2[n];
-                if (pair) {
-                    const long long ib = ia + p.hop;
-                    const float vb = (tB < p.T && ib >= 0 && ib < p.L) ? (xb[ib] - mean) : 0.f;
-                    z = make_float2(va * wd.x, vb * wd.x);
-                } else {
-                    z = make_float2(va * wd.x, va * wd.y);
+            if (n < NT) {
+                if (!p.split) z = elem(n);
+                else {
+                    const float2 za = elem(n), zb = elem(n + NT);
+                    z = par == 0 ? make_float2(za.x + zb.x, za.y + zb.y) : c_mul(make_float2(za.x - zb.x, za.y - zb.y), p.wodd[n]);
                 }
                 if (blue) z = c_mul(z, p.chirp[n]);
             }
@@ -92,25 +111,29 @@ __global__ void __launch_bounds__(kBigThreads) dmel_big_kernel(BigParams p)
             }
             __syncthreads();
             lds_fft_dit<kBigThreads>(Z, M, p.logM, tid, [&](int k) { return p.tw[k]; });
-            for (int k = tid; k < N; k += kBigThreads) {
+            for (int k = tid; k < NT; k += kBigThreads) {
                 const float2 v = Z[k];
                 Z[k] = c_mul(make_float2(v.x, -v.y), p.chirp[k]);
             }
             __syncthreads();
         }
-        // pairing pass (see dmel_fwd.hip): PD[k] = (|S|^2, Im(conj S * D)) or (|S|^2, |D|^2), in place at pos(k);
-        // the two addresses a thread touches belong to no other thread
-        for (int k = tid; k <= (N >> 1); k += kBigThreads) {
-            const unsigned ak = pos(k), an = pos((N - k) % N);
+        // pairing pass (see dmel_fwd.hip): PD = (|S|^2, Im(conj S * D)) or (|S|^2, |D|^2), in place at pos(m) for the output bin
+        // k = m (whole transform) or k = 2 m + par (split); the two addresses a thread touches belong to no other thread
+        const int mlim = !p.split ? (N >> 1) : (par == 0 ? NT / 2 : (NT - 1) / 2);
+        for (int m = tid; m <= mlim; m += kBigThreads) {
+            const int mm = !p.split ? (N - m) % N : (par == 0 ? (NT - m) % NT : NT - 1 - m);
+            const unsigned ak = pos(m), an = pos(mm);
             const float2 zk = Z[ak], zn = Z[an];
             const float sx = zk.x + zn.x, sy = zk.y - zn.y, dx = zk.x - zn.x, dy = zk.y + zn.y;
             Z[ak] = pair ? make_float2(fmaf(sx, sx, sy * sy), fmaf(dx, dx, dy * dy))
                          : make_float2(fmaf(sx, sx, sy * sy), fmaf(sx, dy, -(sy * dx)));
         }
         __syncthreads();
+        const int kstep = p.split ? 2 : 1;                  // this pass holds the bins k = par, par + kstep, ...
+        auto pd_of = [&](int k) -> float2 { return Z[pos(p.split ? (k >> 1) : k)]; };
         if (spec_mode) {
-            for (int k = tid; k < F; k += kBigThreads) {
-                const float2 pd = Z[pos(k)];
+            for (int k = par + kstep * tid; k < F; k += kstep * kBigThreads) {
+                const float2 pd = pd_of(k);
                 const size_t o = ((size_t)b * F + k) * p.T;
                 if (p.mode == kSpec) {
                     p.out[o + tA] = 0.25f * pd.x;
@@ -127,15 +150,22 @@ __global__ void __launch_bounds__(kBigThreads) dmel_big_kernel(BigParams p)
             const int2 bd = p.band[m];
             const float* fr = p.fbT + (size_t)m * F;
             float s0 = 0.f, s1 = 0.f;
-            for (int k = bd.x + lane; k < bd.y; k += 64) {
+            const int k0 = p.split ? bd.x + ((bd.x ^ par) & 1) : bd.x;        // first bin of the band this pass holds
+            for (int k = k0 + kstep * lane; k < bd.y; k += kstep * 64) {
                 const float c = fr[k];
-                const float2 pd = Z[pos(k)];
+                const float2 pd = pd_of(k);
                 s0 = fmaf(c, pd.x, s0);
                 s1 = fmaf(c, pd.y, s1);
             }
             s0 = big_wave_sum(s0);
             s1 = big_wave_sum(s1);
             if (lane != 0) continue;
+            if (p.split) {
+                // the same wave owns band m in both halves: even bins first, then odd bins on top of them
+                if (par == 0) { macc[m] = make_float2(s0, s1); continue; }
+                const float2 e = macc[m];
+                s0 += e.x; s1 += e.y;
+            }
             const size_t o = ((size_t)b * p.M + m) * p.T;
             const bool out_bf16 = (p.flags & 4u) != 0;
             auto put = [&](int t, float v) { if (out_bf16) reinterpret_cast<unsigned short*>(p.out)[o + t] = bf16_bits(v); else p.out[o + t] = v; };
@@ -155,15 +185,20 @@ __global__ void __launch_bounds__(kBigThreads) dmel_big_kernel(BigParams p)
                 }
             }
         }
+        }   // par
     }
 }
 
 constexpr int kBigLdsMax = 16384;          // complex entries: 128 KB
+constexpr int kBigSplitAccBytes = 16384;   // split mode: (n_mels) float2 sums of the even half behind the sequence
+
+// split mode is possible when the half-length transform (its own FFT of m_half points) fits LDS together with the mel sums
+bool big_can_split(int m_half, int n_mels) { return m_half <= kBigLdsMax && (long long)n_mels * 8 <= kBigSplitAccBytes; }
 
 hipError_t big_prepare_attributes()
 {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(dmel_big_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               kBigLdsMax * (int)sizeof(float2));
+                               kBigLdsMax * (int)sizeof(float2) + kBigSplitAccBytes);
 }
 
 bool big_uses_global(int m_fft) { return m_fft > kBigLdsMax; }
@@ -182,7 +217,8 @@ hipError_t launch_big(const BigParams& p, hipStream_t s)
     const long long units = (long long)p.B * (pair ? (p.T + 1) / 2 : p.T);
     const int grid = big_grid(units, p.Mfft);
     if (big_uses_global(p.Mfft)) hipLaunchKernelGGL(dmel_big_kernel<true>, dim3((unsigned)grid), dim3(kBigThreads), 0, s, p);
-    else hipLaunchKernelGGL(dmel_big_kernel<false>, dim3((unsigned)grid), dim3(kBigThreads), (size_t)p.Mfft * sizeof(float2), s, p);
+    else hipLaunchKernelGGL(dmel_big_kernel<false>, dim3((unsigned)grid), dim3(kBigThreads),
+                            (size_t)p.Mfft * sizeof(float2) + (p.split ? (size_t)p.M * sizeof(float2) : 0), s, p);
     return hipGetLastError();
 }
 

@@ -256,8 +256,11 @@ struct BigParams {
     int B, L, T, hop, M, nchunks, N, F, mode, Mfft, logM;
     float inv_L, eps; unsigned flags; int remove_dc;
     LamArgs lam;
+    int split;               // 1: N is taken as two transforms of length N/2 (tw, chirp, hbr, Mfft, logM then describe THAT length)
+    const float2* wodd;      // split: (N/2) exp(-2 pi i n / N), the twiddle of the odd half
 };
 hipError_t launch_big(const BigParams& p, hipStream_t s);
+bool big_can_split(int m_half, int n_mels);
 hipError_t big_prepare_attributes();
 bool big_uses_global(int m_fft);
 int big_grid(long long units, int m_fft);
