@@ -41,6 +41,18 @@ __global__ void __launch_bounds__(kBigThreads) dmel_big_kernel(BigParams p)
     const int N = p.N, M = p.Mfft, F = p.F, sh = 32 - p.logM;
     const int NT = p.split ? N / 2 : N;                    // length of the transform(s) actually run
     float2* macc = reinterpret_cast<float2*>(smem_raw + (size_t)M * sizeof(float2));     // split mode: mel sums of the even half
+    // LDS-resident sequences take their twiddles exp(-2 pi i k / M) as a product of two small LDS tables, k = 128 hi + lo (a
+    // global-memory table cost an L2 round trip per butterfly group and pass; the full table does not fit next to the sequence)
+    float2* twa = reinterpret_cast<float2*>(smem_raw + (size_t)M * sizeof(float2) + (p.split ? (size_t)p.M * sizeof(float2) : 0));
+    float2* twb = twa + 64;
+    if (!GLOBAL_Z) {
+        if (tid < 64) twa[tid] = (128 * tid < (M >> 1)) ? p.tw[128 * tid] : make_float2(1.f, 0.f);
+        if (tid >= 64 && tid < 192) twb[tid - 64] = (tid - 64 < (M >> 1)) ? p.tw[tid - 64] : make_float2(1.f, 0.f);
+    }
+    auto twid = [&](int k) -> float2 {
+        if (GLOBAL_Z) return p.tw[k];
+        return c_mul(twa[k >> 7], twb[k & 127]);
+    };
     const bool blue = p.chirp != nullptr;
     const bool pair = (p.mode == kInfer || p.mode == kSpec);
     const bool spec_mode = (p.mode == kSpec || p.mode == kSpecTrain);
@@ -101,7 +113,7 @@ __global__ void __launch_bounds__(kBigThreads) dmel_big_kernel(BigParams p)
             Z[n] = z;
         }
         __syncthreads();
-        lds_fft_dif<kBigThreads>(Z, M, p.logM, tid, [&](int k) { return p.tw[k]; });
+        lds_fft_dif<kBigThreads>(Z, M, p.logM, tid, twid);
         if (blue) {
             // Y H / M at the bit-reversed positions the DIF left, conjugated: a forward DIT of that is the conjugate of the
             // inverse transform, in natural order
@@ -110,7 +122,7 @@ __global__ void __launch_bounds__(kBigThreads) dmel_big_kernel(BigParams p)
                 Z[i] = make_float2(v.x, -v.y);
             }
             __syncthreads();
-            lds_fft_dit<kBigThreads>(Z, M, p.logM, tid, [&](int k) { return p.tw[k]; });
+            lds_fft_dit<kBigThreads>(Z, M, p.logM, tid, twid);
             for (int k = tid; k < NT; k += kBigThreads) {
                 const float2 v = Z[k];
                 Z[k] = c_mul(make_float2(v.x, -v.y), p.chirp[k]);
@@ -191,6 +203,7 @@ __global__ void __launch_bounds__(kBigThreads) dmel_big_kernel(BigParams p)
 
 constexpr int kBigLdsMax = 16384;          // complex entries: 128 KB
 constexpr int kBigSplitAccBytes = 16384;   // split mode: (n_mels) float2 sums of the even half behind the sequence
+constexpr int kBigTwBytes = (64 + 128) * 8; // the two twiddle factor tables behind that
 
 // split mode is possible when the half-length transform (its own FFT of m_half points) fits LDS together with the mel sums
 bool big_can_split(int m_half, int n_mels) { return m_half <= kBigLdsMax && (long long)n_mels * 8 <= kBigSplitAccBytes; }
@@ -198,7 +211,7 @@ bool big_can_split(int m_half, int n_mels) { return m_half <= kBigLdsMax && (lon
 hipError_t big_prepare_attributes()
 {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(dmel_big_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               kBigLdsMax * (int)sizeof(float2) + kBigSplitAccBytes);
+                               kBigLdsMax * (int)sizeof(float2) + kBigSplitAccBytes + kBigTwBytes);
 }
 
 bool big_uses_global(int m_fft) { return m_fft > kBigLdsMax; }
@@ -218,7 +231,7 @@ hipError_t launch_big(const BigParams& p, hipStream_t s)
     const int grid = big_grid(units, p.Mfft);
     if (big_uses_global(p.Mfft)) hipLaunchKernelGGL(dmel_big_kernel<true>, dim3((unsigned)grid), dim3(kBigThreads), 0, s, p);
     else hipLaunchKernelGGL(dmel_big_kernel<false>, dim3((unsigned)grid), dim3(kBigThreads),
-                            (size_t)p.Mfft * sizeof(float2) + (p.split ? (size_t)p.M * sizeof(float2) : 0), s, p);
+                            (size_t)p.Mfft * sizeof(float2) + (p.split ? (size_t)p.M * sizeof(float2) : 0) + kBigTwBytes, s, p);
     return hipGetLastError();
 }
 
