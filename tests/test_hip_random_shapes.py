@@ -65,3 +65,55 @@ def test_random_configuration_matches_oracle(case):
             yi = _layer(case, log=log, trainable=False)(x)
         oi = yi.cpu().numpy()
         assert (_log_err(oi, o_ref) if log else _rel_err(oi, o_ref)) <= TOL
+
+
+def _random_full_window_cases(n, seed):
+    """optimized=False (time_frequency.py:41,51): window = whole clip, n_fft = 2 L.  Power-of-two L take the fused kernel (n_fft up
+    to 16384), every other L the chirp-z kernel: sequence in LDS, split into two half transforms (16384 < M <= 32768), or in
+    global memory."""
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            L = int(2 ** rng.integers(4, 14))                                  # 16 ... 8192: fused kernel
+        elif kind == 1:
+            L = int(rng.integers(20, 4000))                                    # chirp-z in LDS
+        elif kind == 2:
+            L = int(rng.integers(4097, 8190))                                  # chirp-z, split mode (M = 32768 -> 2 x 16384)
+        else:
+            L = int(rng.choice([8000, 8193, 12000, 16384]))                     # split boundary, global-memory FFT, n_fft 32768
+        hop = int(rng.integers(max(1, L // 12), max(2, L // 2)))
+        lam = float(rng.uniform(0.05, 0.4) * L) * (1.0 if rng.random() < 0.8 else -1.0)
+        n_mels = int(rng.choice([8, 40, 64, 128]))
+        sr = int(rng.choice([8000, 16000]))
+        B = int(rng.integers(1, 4))
+        out.append(dict(C.BY_NAME["g7_mel_nonopt_1024n"], name=f"fw{len(out)}_L{L}_h{hop}_m{n_mels}", B=B, L=L, lambd=lam, hop=hop, n_mels=n_mels,
+                        sr=sr, f_min=0.0, f_max=None, normalize_window=bool(rng.random() < 0.5), seed=3000 + len(out)))
+    return out
+
+
+FULL_WINDOW_CASES = _random_full_window_cases(20, seed=4242)
+
+
+@pytest.mark.parametrize("case", FULL_WINDOW_CASES, ids=[c["name"] for c in FULL_WINDOW_CASES])
+def test_random_full_window_configuration_matches_oracle(case):
+    x_np = C.make_input(case).astype(np.float32)
+    g_np = C.make_cotangent(case)
+    x = torch.from_numpy(x_np).to("cuda:0")
+    g = torch.from_numpy(g_np).to("cuda:0")
+    for log in (False, True):
+        layer = _layer(case, log=log)
+        y = layer(x)
+        assert y.shape == C.out_shape(case)
+        (y * g).sum().backward()
+        o_ref, t_ref = O.forward(x_np, case["lambd"], case["hop"], case["n_mels"], case["sr"], case["f_min"], case["f_max"],
+                                 case["normalize_window"], apply_log=log, optimized=False)
+        o = y.detach().cpu().numpy()
+        assert (_log_err(o, o_ref) if log else _rel_err(o, o_ref)) <= TOL
+        exp_d = O.backward(g_np, t_ref)
+        assert abs(float(layer.lambd.grad) - exp_d) <= _dlam_tol(exp_d, g_np, t_ref)
+        with torch.no_grad():
+            yi = _layer(case, log=log, trainable=False)(x)
+        oi = yi.cpu().numpy()
+        assert (_log_err(oi, o_ref) if log else _rel_err(oi, o_ref)) <= TOL
