@@ -336,7 +336,7 @@ def test_dspec_layer_matches_reference_and_oracle():
     # normalised window, other hop, power-of-two lengths from 16 to 1024
     # (n_fft = 2L: 2048 and 4096 run the compact layout of the fused kernel with the half-length window)
     for L, hop, lam, norm in ((16, 1, 2.5, False), (64, 3, 5.0, True), (256, 8, 20.0, False), (1024, 64, 90.0, True),
-                              (1024, 100, -70.0, False), (2048, 128, 200.0, True)):
+                              (1024, 100, -70.0, False), (2048, 128, 200.0, True), (4096, 300, 500.0, False), (8192, 900, -900.0, True)):
         xn = synth.waveforms(3, L, seed=L, scale=1.0)
         lay = SpectrogramLayer(torch.tensor(lam), optimized=False, hop_length=hop, normalize_window=norm).to("cuda:0")
         out = lay(torch.from_numpy(xn).to("cuda:0"))
