@@ -34,6 +34,7 @@ SYMBOLS = (
     "dmel_comm_unique_id", "dmel_comm_create", "dmel_comm_destroy", "dmel_comm_allreduce_async", "dmel_comm_wait",
     "dmel_comm_allreduce", "dmel_scratch_bytes", "dmel_plan_set_filterbank_dev", "dmel_forward_scratch", "dmel_forward_dev", "dmel_forward_dev_fixed", "dmel_backward_fb_dev", "dmel_backward_scratch", "dmel_plan_get_config",
     "dmel_plan_lambd_status", "dmel_plan_set_tracking", "dmel_plan_lambd_reset",
+    "dmel_plan_retain", "dmel_plan_release", "dmel_plan_lambd_report", "dmel_decide_launch", "dmel_plan_force_launch",
 )
 TORCH_LIB_PATH = os.path.join(_PKG_DIR, "libdmel_torch.so")
 
@@ -56,7 +57,8 @@ class DmelPlanInfo(C.Structure):
 class DmelLambdStatus(C.Structure):
     _fields_ = [("known", C.c_int32), ("lambd_seen", C.c_float), ("n_fft_seen", C.c_int32), ("seq_issued", C.c_uint32),
                 ("seq_seen", C.c_uint32), ("rate", C.c_float), ("guards", C.c_int32), ("error", C.c_int32),
-                ("error_seq", C.c_uint32), ("error_lambd", C.c_float), ("next_n_fft", C.c_int32), ("next_guards", C.c_int32)]
+                ("error_seq", C.c_uint32), ("error_lambd", C.c_float), ("next_n_fft", C.c_int32), ("next_guards", C.c_int32),
+                ("calls", C.c_uint32)]
 
 
 class DmelProfile(C.Structure):
@@ -154,6 +156,16 @@ def load():
     L.dmel_plan_set_tracking.restype = C.c_int
     L.dmel_plan_lambd_reset.argtypes = [vp]
     L.dmel_plan_lambd_reset.restype = C.c_int
+    L.dmel_plan_retain.argtypes = [vp]
+    L.dmel_plan_retain.restype = C.c_int
+    L.dmel_plan_release.argtypes = [vp]
+    L.dmel_plan_release.restype = C.c_int
+    L.dmel_plan_lambd_report.argtypes = [vp, C.c_uint32, fp, C.POINTER(C.c_int32)]
+    L.dmel_plan_lambd_report.restype = C.c_int
+    L.dmel_decide_launch.argtypes = [C.c_float, C.c_float, C.c_float, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.dmel_decide_launch.restype = C.c_int
+    L.dmel_plan_force_launch.argtypes = [vp, C.c_int32, C.c_int32]
+    L.dmel_plan_force_launch.restype = C.c_int
     _lib = L
     return L
 
@@ -183,6 +195,14 @@ def _check(status: int):
 
 def n_fft(lambd: float) -> int:
     return int(load().dmel_n_fft(C.c_float(float(lambd))))
+
+
+def decide_launch(lambd: float, rate: float, stale_forwards: float) -> tuple[int, int]:
+    """(n_fft, guards) a forward must be launched for when lambd may move by ``rate`` per forward for ``stale_forwards`` forwards
+    unobserved (dmel_decide_launch: a pure function, no device)."""
+    n, g = C.c_int32(0), C.c_int32(0)
+    _check(load().dmel_decide_launch(C.c_float(float(lambd)), C.c_float(float(rate)), C.c_float(float(stale_forwards)), C.byref(n), C.byref(g)))
+    return int(n.value), int(g.value)
 
 
 def device_count() -> int:
@@ -283,6 +303,16 @@ class Plan:
 
     def lambd_reset(self):
         _check(load().dmel_plan_lambd_reset(self._h))
+
+    def lambd_report(self, number: int):
+        """lambd as read by execution ``number`` (None if its report has left the ring): timing-independent, see include/dmel.h."""
+        lam, found = C.c_float(0.0), C.c_int32(0)
+        _check(load().dmel_plan_lambd_report(self._h, C.c_uint32(int(number) & 0xFFFFFFFF), C.cast(C.byref(lam), C.POINTER(C.c_float)), C.byref(found)))
+        return float(lam.value) if found.value else None
+
+    def force_launch(self, n_fft_: int = 0, guards: int = 0):
+        """dmel_plan_force_launch: the caller chooses the launches of dmel_forward_dev (n_fft_ = 0: automatic again)."""
+        _check(load().dmel_plan_force_launch(self._h, int(n_fft_), int(guards)))
 
     def backward(self, grad_ptr: int, tangent_ptr: int, count: int, dlambd_ptr: int, stream: int, accumulate: bool = False,
                  grad_bf16: bool = False):

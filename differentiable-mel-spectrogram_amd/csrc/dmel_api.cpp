@@ -102,18 +102,24 @@ struct dmel_plan {
     hipStream_t last_stream = nullptr;
     bool last_stream_valid = false;
     hipEvent_t xev = nullptr;
-    // device-resident lambd (dmel_forward_dev): what the kernels report back and what the host has concluded from it
-    unsigned long long* host_words = nullptr;   // pinned, device-visible: [0] seen = (seq << 32) | bits(lambd), [1] sticky error
-    unsigned issued = 0;           // call number of the most recent dmel_forward_dev
+    // device-resident lambd (dmel_forward_dev): what the kernels report back and what the host has concluded from it.
+    // Every forward that executes draws an execution number from `exec_counter` (device) and reports under it (dmel_kernels.h).
+    unsigned long long* host_words = nullptr;   // pinned, device-visible: [0..kLamRing) reports (number << 32) | bits(lambd), [kLamRing] sticky error
+    unsigned* exec_counter = nullptr;           // device: executions so far
+    unsigned issued = 0;           // the host's estimate of the execution number of its most recent eagerly issued forward (caught up
+                                   // with the reports: replays of captured forwards execute without the host counting them)
+    unsigned calls = 0;            // dmel_forward_dev / _fixed calls, captured ones included; never adjusted
     bool lam_known = false;        // lam_seen / seq_seen hold an observation
     float lam_seen = 0.f;
-    unsigned seq_seen = 0;
-    unsigned seq_floor = 0;        // reports with a smaller call number predate the last reset
+    unsigned seq_seen = 0;         // execution number the observation belongs to
+    unsigned seq_floor = 0;        // reports with a smaller number predate the last reset
     int n_obs = 0;                 // observations since the last reset
-    float lam_rate = 0.f;          // decayed maximum of |d lambd| per call
-    int max_ahead = 8;             // calls the host may run ahead of the last observation (0: unbounded)
-    int guard_mode = 0;            // 0 auto, 1 always both neighbours, 2 never
+    float lam_rate = 0.f;          // decayed maximum of |d lambd| per execution
+    int max_ahead = 8;             // forwards the host may run ahead of the last observation (0: unbounded)
+    int guard_mode = 0;            // 0 auto, 1 always both neighbours, 2 never, 3 auto also under capture
+    int forced_n_fft = 0, forced_guards = 0;    // dmel_plan_force_launch: the caller chooses the launches (0: the library does)
     int last_guards = 0;           // bit 0: n_fft/2 launched, bit 1: 2 n_fft launched (most recent call)
+    int refs = 1;                  // dmel_plan_retain / dmel_plan_release (guarded by g_plans_mu)
     std::mutex mu;
     dmel_plan_info info{};
     // optional event timing
@@ -588,7 +594,7 @@ dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dm
     fp.remove_dc = remove_dc; fp.normalize = pl->cfg.normalize_window; fp.win_half = win_half;
     static const int force_tpw = std::getenv("DMEL_TILES_PER_WG") ? std::atoi(std::getenv("DMEL_TILES_PER_WG")) : 0;   // diagnostics
     int tpw = dmel::forward_tiles_per_wg(N, batch, fp.tiles_per_clip);
-    if (force_tpw == 1 || (force_tpw == 2 && N >= 256 && N <= 1024)) tpw = force_tpw;
+    if (force_tpw == 1 || (force_tpw == 2 && dmel::forward_two_tiles(N))) tpw = force_tpw;
     fp.wgs_per_clip = (fp.tiles_per_clip + tpw - 1) / tpw;
     const long long grid = (long long)batch * fp.wgs_per_clip;
     if (grid > 0x7fffffffLL) return fail(DMEL_ERR_INVALID_ARGUMENT, "too many tiles for one launch");
@@ -662,12 +668,27 @@ void lam_reset(dmel_plan* pl)
     pl->lam_known = false; pl->n_obs = 0; pl->lam_rate = 0.f; pl->seq_seen = pl->issued; pl->seq_floor = pl->issued + 1;
 }
 
+// The launch choice as a pure function (also exported: dmel_decide_launch): n_fft from lambd, and the neighbours within reach
+// of a boundary when lambd may move by `rate` per forward for `stale` forwards before anybody looks again (factor 2 of margin)
+void decide_launch(float lambd, float rate, float stale, int* n_fft, int* guards)
+{
+    const float a = std::fabs(lambd);
+    const int N = dmel_n_fft(lambd);
+    int g = 0;
+    const float reach = 2.0f * rate * stale + 1e-5f * a;
+    if ((a - reach) * 6.0f < (float)(N / 2 + 1)) g |= 1;
+    if ((a + reach) * 6.0f >= (float)N + 1.0f) g |= 2;
+    if (2 * N > dmel::kMaxBigFft) g &= ~2;
+    if (N < 2) g &= ~1;
+    *n_fft = N; *guards = g;
+}
+
 // which n_fft the next dmel_forward_dev launches for and which neighbours it guards (bit 0: n_fft / 2, bit 1: 2 n_fft), from
 // the host's current picture: both neighbours while the drift per call is unknown, on request, and under a graph capture
 // nobody manages; otherwise only the ones within reach of a boundary before the host would notice
 void lam_decide(const dmel_plan* pl, bool capturing, int* n_fft, int* guards)
 {
-    const float a = std::fabs(pl->lam_seen);
+    if (pl->forced_n_fft > 0) { *n_fft = pl->forced_n_fft; *guards = pl->forced_guards; return; }
     const int N = dmel_n_fft(pl->lam_seen);
     int g = 0;
     if (pl->guard_mode == 1 || (capturing && pl->guard_mode != 3 && pl->guard_mode != 2)) g = 3;
@@ -675,9 +696,8 @@ void lam_decide(const dmel_plan* pl, bool capturing, int* n_fft, int* guards)
         if (pl->n_obs < 2) g = 3;
         else {
             const float stale = (float)(pl->issued - pl->seq_seen) + 2.0f + (capturing ? (float)pl->max_ahead : 0.f);
-            const float reach = 2.0f * pl->lam_rate * stale + 1e-5f * a;
-            if ((a - reach) * 6.0f < (float)(N / 2 + 1)) g |= 1;
-            if ((a + reach) * 6.0f >= (float)N + 1.0f) g |= 2;
+            int n2 = 0;
+            decide_launch(pl->lam_seen, pl->lam_rate, stale, &n2, &g);
         }
     }
     if (2 * N > dmel::kMaxBigFft) g &= ~2;
@@ -685,23 +705,33 @@ void lam_decide(const dmel_plan* pl, bool capturing, int* n_fft, int* guards)
     *n_fft = N; *guards = g;
 }
 
-// fold the kernels' latest report into the host's picture; returns false if nothing new
+// fold the kernels' latest report into the host's picture; returns false if nothing new.  The ring is scanned for the
+// highest execution number past the last one seen (and past the last reset): whichever forward executed last -- an eager
+// call or a replay of a captured one -- is what the picture follows.
 bool lam_observe(dmel_plan* pl)
 {
-    const unsigned long long w = __atomic_load_n(&pl->host_words[0], __ATOMIC_RELAXED);
-    const unsigned seq = (unsigned)(w >> 32);
-    if (seq == 0 || (int)(seq - pl->seq_floor) < 0 || (int)(seq - pl->seq_seen) < 0) return false;    // older than the last reset
-    float lam; const unsigned bits = (unsigned)w; std::memcpy(&lam, &bits, 4);
-    // a replayed graph reports under the call number it was captured with: the same seq with another value is news too
-    if (pl->lam_known && seq == pl->seq_seen && lam == pl->lam_seen) return false;
+    bool any = false;
+    unsigned best_seq = 0; unsigned best_bits = 0;
+    for (unsigned i = 0; i < dmel::kLamRing; ++i) {
+        const unsigned long long w = __atomic_load_n(&pl->host_words[i], __ATOMIC_RELAXED);
+        const unsigned seq = (unsigned)(w >> 32);
+        if (seq == 0 || (int)(seq - pl->seq_floor) < 0) continue;                       // empty, or older than the last reset
+        if (pl->lam_known ? (int)(seq - pl->seq_seen) <= 0 : false) continue;           // not newer than what is known
+        if (!any || (int)(seq - best_seq) > 0) { best_seq = seq; best_bits = (unsigned)w; any = true; }
+    }
+    if (!any) return false;
+    float lam; std::memcpy(&lam, &best_bits, 4);
     if (pl->lam_known && pl->n_obs >= 1) {
-        const unsigned dseq = seq - pl->seq_seen;
+        const unsigned dseq = best_seq - pl->seq_seen;
         const float r = std::fabs(lam - pl->lam_seen) / (float)(dseq ? dseq : 1);
         pl->lam_rate = std::max(0.98f * pl->lam_rate, r);
     }
-    pl->lam_seen = lam; pl->seq_seen = seq; pl->lam_known = true; ++pl->n_obs;
+    pl->lam_seen = lam; pl->seq_seen = best_seq; pl->lam_known = true; ++pl->n_obs;
+    if ((int)(best_seq - pl->issued) > 0) pl->issued = best_seq;                      // replays executed forwards the host never counted
     return true;
 }
+
+std::mutex g_plans_mu;             // guards dmel_plan::refs
 
 }  // namespace
 
@@ -813,9 +843,12 @@ dmel_status dmel_plan_create(const dmel_config* cfg, dmel_plan** plan)
     pl->chunk = ((cfg->n_points + nch - 1) / nch + 3) / 4 * 4;   // multiple of 4 samples: chunks keep 16-byte alignment
     hipError_t e = hipEventCreateWithFlags(&pl->xev, hipEventDisableTiming);
     // two words the kernels write and the host reads without synchronising (device-resident lambd, dmel_forward_dev)
-    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&pl->host_words), 64, hipHostMallocMapped | hipHostMallocCoherent);
+    constexpr size_t kHostWordBytes = (dmel::kLamRing + 8) * sizeof(unsigned long long);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&pl->host_words), kHostWordBytes, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&pl->exec_counter), 64);
+    if (e == hipSuccess) e = hipMemset(pl->exec_counter, 0, 64);
     if (e != hipSuccess) { dmel_plan_destroy(pl); return fail(DMEL_ERR_HIP, std::string("plan resources: ") + hipGetErrorString(e)); }
-    std::memset(pl->host_words, 0, 64);
+    std::memset(pl->host_words, 0, kHostWordBytes);
     {
         Scratch sc;
         dmel_status st = ensure_own_scratch(pl, std::max(1, cfg->max_batch), nullptr, &sc);
@@ -825,9 +858,27 @@ dmel_status dmel_plan_create(const dmel_config* cfg, dmel_plan** plan)
     return DMEL_OK;
 }
 
-dmel_status dmel_plan_destroy(dmel_plan* plan)
+dmel_status dmel_plan_retain(dmel_plan* plan)
+{
+    if (!plan) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
+    std::lock_guard<std::mutex> lock(g_plans_mu);
+    if (plan->refs < 1) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_plan_retain: the plan has been destroyed");
+    ++plan->refs;
+    return DMEL_OK;
+}
+
+dmel_status dmel_plan_release(dmel_plan* plan)
 {
     if (!plan) return DMEL_OK;
+    {
+        std::lock_guard<std::mutex> lock(g_plans_mu);
+        if (--plan->refs > 0) return DMEL_OK;
+    }
+    // the last holder is gone.  Work that still reads the tables or writes the report words may be queued (a backward of a
+    // graph that outlived its layer, the last launches of a loop): let the device finish before the memory goes away
+    int cur = -1;
+    const bool switched = hipGetDevice(&cur) == hipSuccess && cur != plan->device && hipSetDevice(plan->device) == hipSuccess;
+    (void)hipDeviceSynchronize();
     for (auto& kv : plan->tables) kv.second.release();
     for (hipEvent_t e : plan->ev_pool) (void)hipEventDestroy(e);
     (void)hipFree(plan->own_scratch); (void)hipFree(plan->fbw);
@@ -835,17 +886,23 @@ dmel_status dmel_plan_destroy(dmel_plan* plan)
     for (auto& kv : plan->big_tw) (void)hipFree(kv.second);
     for (auto& kv : plan->big_wodd) (void)hipFree(kv.second);
     (void)hipFree(plan->big_win); (void)hipFree(plan->big_z);
+    (void)hipFree(plan->exec_counter);
     if (plan->host_words) (void)hipHostFree(plan->host_words);
     if (plan->xev) (void)hipEventDestroy(plan->xev);
+    if (switched) (void)hipSetDevice(cur);
+    (void)hipGetLastError();
     delete plan;
     return DMEL_OK;
 }
+
+dmel_status dmel_plan_destroy(dmel_plan* plan) { return dmel_plan_release(plan); }
 
 dmel_status dmel_plan_set_filterbank(dmel_plan* plan, int32_t n_fft, const float* fb)
 {
     if (!plan) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
     if (n_fft < 1 || n_fft > dmel::kMaxNfft || (n_fft & (n_fft - 1)))
         return fail(DMEL_ERR_INVALID_ARGUMENT, "n_fft must be a power of two in [1, 16384]");
+    { dmel_status sd = check_device(plan); if (sd != DMEL_OK) return sd; }      // the synchronisation below must be the plan's device's
     std::lock_guard<std::mutex> lock(plan->mu);
     DMEL_HIP(hipDeviceSynchronize());     // tables of this n_fft may be in use by queued kernels
     auto it = plan->tables.find(n_fft);
@@ -865,6 +922,7 @@ dmel_status dmel_plan_set_filterbank_dev(dmel_plan* plan, int32_t n_fft, const f
     if (!plan || !fb_dev) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan / fb_dev is NULL");
     if (n_fft < 1 || n_fft > dmel::kMaxNfft || (n_fft & (n_fft - 1)))
         return fail(DMEL_ERR_INVALID_ARGUMENT, "n_fft must be a power of two in [1, 16384]");
+    { dmel_status sd = check_device(plan); if (sd != DMEL_OK) return sd; }
     std::lock_guard<std::mutex> lock(plan->mu);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (!plan->dense_dev.count(n_fft)) {
@@ -937,10 +995,10 @@ dmel_status dmel_forward_dev(dmel_plan* plan, const float* x, int32_t batch, con
     const bool capturing = is_capturing(s);
 
     // a forward that no launch covered: its outputs are NaN on the device; tell the caller once and start over
-    const unsigned long long err = __atomic_load_n(&plan->host_words[1], __ATOMIC_RELAXED);
+    const unsigned long long err = __atomic_load_n(&plan->host_words[dmel::kLamRing], __ATOMIC_RELAXED);
     if (err != 0) {
         float lam; const unsigned bits = (unsigned)err; std::memcpy(&lam, &bits, 4);
-        __atomic_store_n(&plan->host_words[1], 0ull, __ATOMIC_RELAXED);
+        __atomic_store_n(&plan->host_words[dmel::kLamRing], 0ull, __ATOMIC_RELAXED);
         const float seen = plan->lam_seen;
         lam_reset(plan);
         return fail(DMEL_ERR_LAMBD_TRACKING,
@@ -958,6 +1016,12 @@ dmel_status dmel_forward_dev(dmel_plan* plan, const float* x, int32_t batch, con
         DMEL_HIP(hipMemcpyAsync(&lam, lambd_dev, sizeof(float), hipMemcpyDeviceToHost, s));
         DMEL_HIP(hipStreamSynchronize(s));
         if (!std::isfinite(lam)) return fail(DMEL_ERR_INVALID_ARGUMENT, "lambd is not finite");
+        // the stream is idle: every report of earlier forwards on it is in the ring; whatever executed without the host
+        // counting it (replays of captured forwards) is caught up with here
+        for (unsigned i = 0; i < dmel::kLamRing; ++i) {
+            const unsigned q = (unsigned)(__atomic_load_n(&plan->host_words[i], __ATOMIC_RELAXED) >> 32);
+            if (q != 0 && (int)(q - plan->issued) > 0) plan->issued = q;
+        }
         plan->lam_seen = lam; plan->seq_seen = plan->issued; plan->lam_known = true; plan->n_obs = 0; plan->lam_rate = 0.f;
     } else if (!capturing && plan->max_ahead > 0) {
         // bounded run-ahead: the picture of lambd the launches are chosen from is at most max_ahead calls old
@@ -987,15 +1051,16 @@ dmel_status dmel_forward_dev(dmel_plan* plan, const float* x, int32_t batch, con
         if ((st = order_after_last_stream(plan, s)) != DMEL_OK) return st;
         if ((st = ensure_own_scratch(plan, batch, s, &sc)) != DMEL_OK) return st;
     }
-    const unsigned seq = ++plan->issued;
+    ++plan->calls;
+    if (!capturing) ++plan->issued;          // a captured forward executes when (and as often as) its graph is replayed
     bool sums_done = false;
     dmel_plan_info primary_info = plan->info;
     for (int i = 0; i < nc; ++i) {
         dmel::LamArgs lam{};
         lam.dev = lambd_dev; lam.val = 0.f; lam.n_expected = cand[i];
         lam.role = (i == 0 ? dmel::kLamFirst : 0u) | (i == nc - 1 ? dmel::kLamLast : 0u);
-        lam.seq = seq; lam.handled = sc.handled;
-        lam.host_seen = &plan->host_words[0]; lam.host_error = &plan->host_words[1];
+        lam.exec_counter = plan->exec_counter; lam.handled = sc.handled;
+        lam.host_seen = &plan->host_words[0]; lam.host_error = &plan->host_words[dmel::kLamRing];
         lam.dot_counter = scratch ? sc.counter : nullptr;
         st = launch_forward_n(plan, x, batch, cand[i], lam, flags, eps, static_cast<float*>(out), tangent,
                               tangent ? dmel::kTrain : dmel::kInfer, /*remove_dc=*/1, sc, s, 0, &sums_done);
@@ -1018,10 +1083,10 @@ dmel_status dmel_forward_dev_fixed(dmel_plan* plan, const float* x, int32_t batc
         return fail(DMEL_ERR_INVALID_ARGUMENT, "n_fft must be a power of two in [1, 16384]");
     std::lock_guard<std::mutex> lock(plan->mu);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const unsigned long long err = __atomic_load_n(&plan->host_words[1], __ATOMIC_RELAXED);
+    const unsigned long long err = __atomic_load_n(&plan->host_words[dmel::kLamRing], __ATOMIC_RELAXED);
     if (err != 0) {
         float lam; const unsigned bits = (unsigned)err; std::memcpy(&lam, &bits, 4);
-        __atomic_store_n(&plan->host_words[1], 0ull, __ATOMIC_RELAXED);
+        __atomic_store_n(&plan->host_words[dmel::kLamRing], 0ull, __ATOMIC_RELAXED);
         lam_reset(plan);
         return fail(DMEL_ERR_LAMBD_TRACKING,
                     "lambd = " + std::to_string(lam) + " asks for n_fft " + std::to_string(dmel_n_fft(lam)) + " but the forward was issued for the "
@@ -1038,8 +1103,10 @@ dmel_status dmel_forward_dev_fixed(dmel_plan* plan, const float* x, int32_t batc
     dmel::LamArgs lam{};
     lam.dev = lambd_dev; lam.val = 0.f; lam.n_expected = n_fft;
     lam.role = dmel::kLamFirst | dmel::kLamLast;
-    lam.seq = ++plan->issued; lam.handled = sc.handled;
-    lam.host_seen = &plan->host_words[0]; lam.host_error = &plan->host_words[1];
+    ++plan->calls;
+    if (!is_capturing(s)) ++plan->issued;
+    lam.exec_counter = plan->exec_counter; lam.handled = sc.handled;
+    lam.host_seen = &plan->host_words[0]; lam.host_error = &plan->host_words[dmel::kLamRing];
     lam.dot_counter = scratch ? sc.counter : nullptr;
     plan->last_guards = 0;
     bool sums_done = false;
@@ -1056,10 +1123,10 @@ dmel_status dmel_plan_lambd_status(dmel_plan* plan, dmel_lambd_status* status)
     r.known = plan->lam_known ? 1 : 0;
     r.lambd_seen = plan->lam_seen;
     r.n_fft_seen = plan->lam_known ? dmel_n_fft(plan->lam_seen) : 0;
-    r.seq_issued = plan->issued; r.seq_seen = plan->seq_seen;
+    r.seq_issued = plan->issued; r.seq_seen = plan->seq_seen; r.calls = plan->calls;
     r.rate = plan->lam_rate; r.guards = plan->last_guards;
     if (plan->lam_known) lam_decide(plan, false, &r.next_n_fft, &r.next_guards);
-    const unsigned long long err = __atomic_load_n(&plan->host_words[1], __ATOMIC_RELAXED);
+    const unsigned long long err = __atomic_load_n(&plan->host_words[dmel::kLamRing], __ATOMIC_RELAXED);
     r.error = err != 0 ? 1 : 0;
     r.error_seq = (uint32_t)(err >> 32);
     { const unsigned bits = (unsigned)err; std::memcpy(&r.error_lambd, &bits, 4); }
@@ -1080,6 +1147,35 @@ dmel_status dmel_plan_lambd_reset(dmel_plan* plan)
     if (!plan) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
     std::lock_guard<std::mutex> lock(plan->mu);
     lam_reset(plan);
+    return DMEL_OK;
+}
+
+dmel_status dmel_plan_lambd_report(dmel_plan* plan, uint32_t number, float* lambd, int32_t* found)
+{
+    if (!plan || !lambd || !found) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_plan_lambd_report: NULL argument");
+    const unsigned long long w = __atomic_load_n(&plan->host_words[number % dmel::kLamRing], __ATOMIC_RELAXED);
+    *found = (number != 0 && (unsigned)(w >> 32) == number) ? 1 : 0;
+    if (*found) { const unsigned bits = (unsigned)w; std::memcpy(lambd, &bits, 4); }
+    return DMEL_OK;
+}
+
+dmel_status dmel_plan_force_launch(dmel_plan* plan, int32_t n_fft, int32_t guards)
+{
+    if (!plan || n_fft < 0 || guards < 0 || guards > 3) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_plan_force_launch: bad arguments");
+    if (n_fft > dmel::kMaxBigFft) return fail(DMEL_ERR_UNSUPPORTED, "n_fft beyond the HIP path");
+    std::lock_guard<std::mutex> lock(plan->mu);
+    plan->forced_n_fft = n_fft; plan->forced_guards = n_fft > 0 ? guards : 0;
+    if (n_fft > 0 && 2 * n_fft > dmel::kMaxBigFft) plan->forced_guards &= ~2;
+    if (n_fft > 0 && n_fft < 2) plan->forced_guards &= ~1;
+    return DMEL_OK;
+}
+
+dmel_status dmel_decide_launch(float lambd, float rate, float stale_forwards, int32_t* n_fft, int32_t* guards)
+{
+    if (!n_fft || !guards || !(rate >= 0.f) || !(stale_forwards >= 0.f)) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_decide_launch: bad arguments");
+    int n = 0, g = 0;
+    decide_launch(lambd, rate, stale_forwards, &n, &g);
+    *n_fft = n; *guards = g;
     return DMEL_OK;
 }
 

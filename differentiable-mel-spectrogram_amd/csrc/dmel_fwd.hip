@@ -298,9 +298,9 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
     constexpr bool BPERM = g.PAIRING == kPairBperm, PLANE = g.PAIRING == kPairPlane, SPLIT = g.SPLIT != 0, WIN_SYM = g.WIN_SYM != 0;
     constexpr bool KEEPZ = BPERM || PLANE;                      // the spectrum stays in registers until the pairing pass
     constexpr int WPF = g.WPF;                                  // waves per frame (n_fft 8192: 2, 16384: 4)
-    static_assert(!BPERM || (G == 64 && PASSES == 1), "the bpermute pairing pass assumes one frame per wave");
+    static_assert(!BPERM || (G <= 64 && PASSES == 1 && (G == 64 || C == 1)), "the bpermute pairing pass: whole frames inside one wave");
     static_assert(!SPLIT || KEEPZ, "a one-plane slot cannot hold the whole spectrum");
-    static_assert(!WIN_SYM || G == 64, "half window table: one frame per wave");
+    static_assert(!WIN_SYM || G <= 64, "half window table: frames inside one wave");
     static_assert(WPF == 1 || (PLANE && SPLIT && PASSES == 1 && !WIN_LDS), "frames spread over several waves exchange through planes");
     static_assert(!PLANE || G >= 64, "plane pairing: whole waves per frame");
     constexpr int WPT = (N / 2 + THREADS - 1) / THREADS;       // window entries a thread computes (and keeps when TPW > 1)
@@ -321,6 +321,13 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
     const int tile0 = (wg % p.wgs_per_clip) * TPW;              // first tile of this workgroup inside its clip
     STAMP(0);
     STAMP_PLACE();
+#if defined(DMEL_WGPRIO)
+    // timing experiment: the two workgroups that share a CU on a one-round launch (blockIdx b and b + 256) at different static priorities
+    if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(DMEL_WGPRIO);
+#endif
+#if defined(DMEL_WAVEPRIO)
+    if (wave >= 4) __builtin_amdgcn_s_setprio(DMEL_WAVEPRIO);
+#endif
 #ifdef DMEL_ABLATE
     // timing ablations (tools/ablate.py builds its own library with -DDMEL_ABLATE; never in libdmel_hip.so)
     const bool dbg_skip_fft = (p.flags & 0x200u) != 0;
@@ -418,6 +425,18 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
     };
 
     // ================= prologue, once per workgroup ============================================
+    // first-stage twiddles w_N^(lg q): rows q = 1 and q = 8a of the table are per-lane constants of the whole workgroup (lg is fixed):
+    // requested here, before anything waits, instead of in the middle of every transform
+    constexpr bool TW1_POW = (R >= 16);
+#ifndef DMEL_TW1_EARLY
+#define DMEL_TW1_EARLY 0
+#endif
+    constexpr bool TW1_EARLY = TW1_POW && WPF == 1 && (DMEL_TW1_EARLY != 0) && N == 1024;
+    float2 tw1_w1 = make_float2(1.f, 0.f), tw1_anchor[TW1_POW ? R / 8 : 1];
+    if constexpr (TW1_EARLY) {
+        tw1_w1 = p.tw1[G + lg];
+        static_for<1, R / 8>([&](auto aa) { constexpr int a8 = decltype(aa)::value; tw1_anchor[a8] = p.tw1[(8 * a8) * G + lg]; });
+    }
     float mean = 0.f;
     float2 wkeep[WPT];                                          // this thread's window entries (TPW > 1: written back per tile)
     float2 wmid = make_float2(1.f, 0.f);                        // ... and the centre entry
@@ -444,7 +463,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
         // d out / d lambd = htan * (contraction of the scaled tangent spectrum): an fp64 division, done by ONE wave of the
         // workgroup and handed to the epilogue through LDS (every barrier below lies between this store and that load)
         if constexpr (MODE == kTrain || MODE == kSpecTrain) {
-            if (wave == 0) { const float h = 0.5f * lam_tangent_scale(ls); if (lane == 0) red[16] = h; }
+            if (wave == 0) { const float h = 0.5f * lam_tangent_scale(ls); if (lane == 0) red[kRedTan] = h; }
         }
         if constexpr (TW2_LDS) { if (tid < R * C) tw2l[tid] = p.tw2[tid]; }          // visible after the barrier below
         // ---- window table into LDS (time_frequency.py:21-30): every workgroup evaluates the same fp32
@@ -481,10 +500,10 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                 s_ww = wave_sum(s_ww);
                 s_wd = wave_sum(s_wd);
                 __syncthreads();
-                if (lane == 0) { red[wave] = s_ww; red[8 + wave] = s_wd; }
+                if (lane == 0) { red[wave] = s_ww; red[16 + wave] = s_wd; }
                 __syncthreads();
                 float ww = 0.f, wd = 0.f;
-                for (int q = 0; q < WAVES; ++q) { ww += red[q]; wd += red[8 + q]; }
+                for (int q = 0; q < WAVES; ++q) { ww += red[q]; wd += red[16 + q]; }
                 __syncthreads();
                 const float inv = 1.0f / sqrtf(ww);
                 for (int n = tid; n < (WIN_SYM ? N / 2 + 1 : N); n += THREADS) {
@@ -503,7 +522,39 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
             }
         }
         // ---- clip mean (models.py:38) --------------------------------------------------------------
-        if (p.remove_dc && p.psum == nullptr) {
+#ifdef DMEL_ABLATE
+        const bool dbg_no_mean = (p.flags & 0x1000u) != 0;      // timing ablation: no clip sum (mean = 0)
+#else
+        constexpr bool dbg_no_mean = false;
+#endif
+        if (dbg_no_mean) {
+            if constexpr (WIN_LDS) __syncthreads();
+        } else if (WPF == 1 && p.remove_dc && p.psum == nullptr && p.tiles_per_clip == 1 && p.hop <= N / 2) {
+            // The whole clip is this workgroup's: its frames already hold every sample -- frame t owns the hop segment
+            // [t hop, (t + 1) hop) of the clip, which lies in its second half (hop <= N/2) -- so the clip is added up from the
+            // registers the transform is about to use and never read a second time.  Fixed order: registers ascending inside a lane,
+            // the 64 lanes by wave_sum, the waves ascending.
+            float ps = 0.f;
+            static_for<0, PASSES>([&](auto pp) {
+                constexpr int pass = decltype(pp)::value;
+                const int slot = pass * (WAVES * FPW) + wave * FPW + j;
+                const int tA = PAIR ? 2 * slot : slot;                       // tile 0 of a one-tile clip: t0 = 0
+                static_for<R / 2, R>([&](auto aa) {
+                    constexpr int a = decltype(aa)::value;
+                    const int n = lg + G * a;                                // >= N/2: inside the frame's second half
+                    const bool seg = n < N / 2 + p.hop;
+                    const int ia = tA * p.hop - N / 2 + n;
+                    ps += (seg && tA < p.T && ia < p.L) ? xa[0][pass][a] : 0.f;
+                    if constexpr (PAIR) ps += (seg && tA + 1 < p.T && ia + p.hop < p.L) ? xb2[0][pass][a] : 0.f;
+                });
+            });
+            ps = wave_sum(ps);
+            if (lane == 0) red[wave] = ps;
+            __syncthreads();
+            float tot = 0.f;
+            for (int q = 0; q < WAVES; ++q) tot += red[q];
+            mean = tot * p.inv_L;
+        } else if (p.remove_dc && p.psum == nullptr) {
             // short clips: every workgroup adds up its clip itself (L2 hits after the first toucher), in a
             // fixed order, instead of a separate pass over x
             // Loads go out in batches of 8 per thread before anything is added: one memory round trip per batch
@@ -646,10 +697,9 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                 // roundings: ~5e-7 relative, the transform's own noise): R/8 loads and about R complex products instead of R - 1 loads.
                 // Measured: config 2 21.87 -> 21.52 us, config 3 49.7 -> 47.4, config 5 74.3 -> 71.9, ESC-50 shape 164 -> 157 (n_fft 4096)
                 // and 514 -> 485 (8192); errors against the fp64 oracle unchanged (3e-7 of the loudest bin)
-                constexpr bool TW1_POW = (R >= 16);
                 v2f wb[TW1_POW ? 8 : 1];
                 if constexpr (TW1_POW) {
-                    const float2 w1 = p.tw1[G + lg];
+                    const float2 w1 = TW1_EARLY ? tw1_w1 : p.tw1[G + lg];
                     wb[1] = v2f{w1.x, w1.y};
                     static_for<2, 8>([&](auto bb) { constexpr int b = decltype(bb)::value; wb[b] = cmul(wb[b - 1], w1); });
                 }
@@ -661,7 +711,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                         constexpr int a8 = q / 8, b8 = q % 8;
                         if constexpr (a8 == 0) return cmul(v, float2{wb[b8].x, wb[b8].y});
                         else {
-                            const float2 anchor = p.tw1[(8 * a8) * G + lg];
+                            const float2 anchor = TW1_EARLY ? tw1_anchor[a8] : p.tw1[(8 * a8) * G + lg];
                             if constexpr (b8 == 0) return cmul(v, anchor);
                             else { const v2f t = cmul(wb[b8], anchor); return cmul(v, float2{t.x, t.y}); }
                         }
@@ -779,8 +829,9 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                     const bool q0 = (qp == 0);
                     const bool dir_a = (2 * p2 < C);                             // this lane's bins are <= N/2: it writes PD[k], else PD[N-k]
                     const int p2m = C - 1 - p2;
-                    const int pull1 = (((R - qp) & (R - 1)) * C + lane_of_p2(p2m)) * 4;
-                    const int pull0 = q0 ? lane_of_p2((C - p2) % C) * 4 : pull1;
+                    const int fl0 = j * G;                                      // first lane of this frame inside the wave (G < 64: FPW frames)
+                    const int pull1 = (fl0 + ((R - qp) & (R - 1)) * C + lane_of_p2(p2m)) * 4;
+                    const int pull0 = q0 ? (fl0 + lane_of_p2((C - p2) % C)) * 4 : pull1;
                     // PLANE (frames of several waves): the partner lane may sit in another wave, so Z[N-k] goes through one plane
                     // of floats in the frame's slot, indexed k + PLANE_PAD (k / R^2): real parts written, read mirrored, then the
                     // imaginary parts through the same plane.  Mirror index of (qp, p1, p2): the partner's own index, linear in p1.
@@ -902,7 +953,7 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
         if (dbg_skip_gemm) { if (tid == 0 && lds[0].x == 12345.678f) p.out[0] = 0.f; return; }
 #endif
         float htan = 0.f;
-        if constexpr (MODE == kTrain || MODE == kSpecTrain) htan = red[16];       // see the prologue
+        if constexpr (MODE == kTrain || MODE == kSpecTrain) htan = red[kRedTan];       // see the prologue
         if constexpr (IS_SPEC) {
             // power spectrogram (time_frequency.py:53), layout (B, F, T); kSpecTrain also writes d P / d lambd
             for (int idx = tid; idx < SLOTS * F; idx += THREADS) {
@@ -1042,10 +1093,16 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
                     tot[decltype(l)::value][decltype(m)::value] = acc[decltype(l)::value][decltype(m)::value][0] + acc[decltype(l)::value][decltype(m)::value][1]; }); });
                 if constexpr (WAVES == 8) {
                     // run 1 of this wave is the second half of tile 7-wave: hand it to its owner through LDS
+                    // (one 16-row tile at a time through the same 8 KB: two tiles at once would put the 16-frame workgroup of
+                    // n_fft 1024 past half of the CU's LDS)
                     floatx4* xch = reinterpret_cast<floatx4*>(smem_raw + SLOTS * SS * 8);
-                    static_for<0, MT>([&](auto mm) { constexpr int mt = decltype(mm)::value; xch[((7 - wave) * MT + mt) * 64 + lane] = tot[1][mt]; });
-                    __syncthreads();
-                    static_for<0, MT>([&](auto mm) { constexpr int mt = decltype(mm)::value; tot[0][mt] += xch[(wave * MT + mt) * 64 + lane]; });
+                    static_for<0, MT>([&](auto mm) {
+                        constexpr int mt = decltype(mm)::value;
+                        if constexpr (mt > 0) __syncthreads();
+                        xch[(7 - wave) * 64 + lane] = tot[1][mt];
+                        __syncthreads();
+                        tot[0][mt] += xch[wave * 64 + lane];
+                    });
                     if (p.groups > 1) __syncthreads();
                     tile_of[1] = -1;
                 }
@@ -1131,7 +1188,7 @@ template <int N, int MODE, int TPW> static hipError_t launch_one(const FwdParams
 }
 
 // two tiles per workgroup are built for the sizes whose launches are large enough to use them (forward_tiles_per_wg)
-template <int N> constexpr bool has_tpw2() { return N >= 256 && N <= 1024; }
+template <int N> constexpr bool has_tpw2() { return N >= 256 && (N <= 512 || (N == 1024 && geom<N>().G == 64)); }   // (32 x 32 plan at 1024: 16-frame tiles, two of them spill)
 
 template <int N> static hipError_t launch_n(int mode, int tpw, const FwdParams& p, int grid, hipStream_t s)
 {
@@ -1156,19 +1213,32 @@ template <int N> static hipError_t launch_n(int mode, int tpw, const FwdParams& 
     return hipErrorInvalidValue;
 }
 
+// -DDMEL_ONLY_NFFT=<n>: development builds that instantiate one transform size only (tools/build_variant.sh; the whole family
+// takes minutes to compile).  Never defined for libdmel_hip.so.
+#ifdef DMEL_ONLY_NFFT
+#define DMEL_FWD_SIZE(n) ((n) == DMEL_ONLY_NFFT)
+#else
+#define DMEL_FWD_SIZE(n) true
+#endif
+template <int N> static hipError_t launch_size(int mode, int tpw, const FwdParams& p, int grid, hipStream_t s)
+{
+    if constexpr (DMEL_FWD_SIZE(N)) return launch_n<N>(mode, tpw, p, grid, s);
+    else return hipErrorInvalidValue;
+}
+
 hipError_t launch_forward(int n_fft, int mode, int tpw, const FwdParams& p, int grid, hipStream_t s)
 {
     switch (n_fft) {
-        case 32: return launch_n<32>(mode, tpw, p, grid, s);
-        case 64: return launch_n<64>(mode, tpw, p, grid, s);
-        case 128: return launch_n<128>(mode, tpw, p, grid, s);
-        case 256: return launch_n<256>(mode, tpw, p, grid, s);
-        case 512: return launch_n<512>(mode, tpw, p, grid, s);
-        case 1024: return launch_n<1024>(mode, tpw, p, grid, s);
-        case 2048: return launch_n<2048>(mode, tpw, p, grid, s);
-        case 4096: return launch_n<4096>(mode, tpw, p, grid, s);
-        case 8192: return launch_n<8192>(mode, tpw, p, grid, s);
-        case 16384: return launch_n<16384>(mode, tpw, p, grid, s);
+        case 32: return launch_size<32>(mode, tpw, p, grid, s);
+        case 64: return launch_size<64>(mode, tpw, p, grid, s);
+        case 128: return launch_size<128>(mode, tpw, p, grid, s);
+        case 256: return launch_size<256>(mode, tpw, p, grid, s);
+        case 512: return launch_size<512>(mode, tpw, p, grid, s);
+        case 1024: return launch_size<1024>(mode, tpw, p, grid, s);
+        case 2048: return launch_size<2048>(mode, tpw, p, grid, s);
+        case 4096: return launch_size<4096>(mode, tpw, p, grid, s);
+        case 8192: return launch_size<8192>(mode, tpw, p, grid, s);
+        case 16384: return launch_size<16384>(mode, tpw, p, grid, s);
     }
     return hipErrorInvalidValue;
 }
@@ -1219,9 +1289,15 @@ int forward_frames_per_tile(int n_fft, int mode)
 // the chip holds at once (160 KB of LDS per CU, 256 CUs); a two-tile workgroup lives about 1.9 times as long as a one-tile
 // one (it pays the prologue once: measured 21.97 against 23.1 us at BASELINE config 2, one round instead of two).  Two tiles
 // are used when that model says the launch gets shorter -- e.g. not for 5 rounds becoming 3 double ones (config 3).
+bool forward_two_tiles(int n_fft)
+{
+    switch (n_fft) { case 256: return has_tpw2<256>(); case 512: return has_tpw2<512>(); case 1024: return has_tpw2<1024>(); }
+    return false;
+}
+
 int forward_tiles_per_wg(int n_fft, int batch, int tiles_per_clip)
 {
-    if (n_fft < 256 || n_fft > 1024 || tiles_per_clip < 2 || batch < 1) return 1;
+    if (!forward_two_tiles(n_fft) || tiles_per_clip < 2 || batch < 1) return 1;
     const int lds = forward_lds_bytes(n_fft);
     const long long resident = 256LL * (lds > 0 && 163840 / lds > 0 ? 163840 / lds : 1);
     const long long wg1 = (long long)batch * tiles_per_clip, wg2 = (long long)batch * ((tiles_per_clip + 1) / 2);
@@ -1259,6 +1335,8 @@ template <int N, int MODE, int TPW> static hipError_t set_attr()
 template <int N> static hipError_t set_attr_n()
 {
     hipError_t e;
+    if constexpr (!DMEL_FWD_SIZE(N)) return hipSuccess;
+    else {
     if ((e = set_attr<N, kTrain, 1>()) != hipSuccess) return e;
     if ((e = set_attr<N, kInfer, 1>()) != hipSuccess) return e;
     if ((e = set_attr<N, kSpec, 1>()) != hipSuccess) return e;
@@ -1270,6 +1348,7 @@ template <int N> static hipError_t set_attr_n()
         if ((e = set_attr<N, kSpecTrain, 2>()) != hipSuccess) return e;
     }
     return hipSuccess;
+    }
 }
 
 hipError_t forward_prepare_attributes()

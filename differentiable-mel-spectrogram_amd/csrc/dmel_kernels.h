@@ -25,15 +25,22 @@ enum Mode : int { kTrain = 0, kInfer = 1, kSpec = 2, kSpecTrain = 3 };   // kSpe
 // launches for the neighbouring n_fft that return at once unless the device value says the work is theirs.  If no launch
 // of the group matches, the last one fills the outputs with NaN and raises a sticky error word in pinned host memory.
 constexpr unsigned kLamFirst = 1u, kLamLast = 2u, kLamQuiet = 4u;   // quiet: read and check only (the window-table kernel)
+// Every forward that EXECUTES on a plan draws the next execution number from a device counter (first launch of its group, one
+// atomic add by one lane) and reports (number << 32) | bits(lambd) into slot (number % kLamRing) of a pinned ring.  The number
+// counts executions, not host calls: a forward replayed from a HIP graph draws a fresh one at every replay, so the host can
+// tell a replay's report from an older eager call's, and can look up the report of one particular execution (what a
+// multi-rank caller needs to take the same decision on every rank).
+constexpr unsigned kLamRing = 64;
 struct LamArgs {
     const float* dev;                 // device scalar (nullptr: use val)
     float val;                        // lambd by value (dmel_forward: the host read it, as the reference does)
     int n_expected;                   // 0: no check (explicit n_fft: optimized=False branches, dmel_spectrogram_ex)
     unsigned role;                    // kLamFirst | kLamLast inside the group
-    unsigned seq;                     // call number, echoed into host_seen
-    unsigned* handled;                // device word of the group (caller scratch): set by the launch that does the work
-    unsigned long long* host_seen;    // pinned: (seq << 32) | bits(lambd), written by the first launch of every group
-    unsigned long long* host_error;   // pinned, sticky: (seq << 32) | bits(lambd) of a forward no launch covered
+    unsigned* exec_counter;           // device, plan-owned: execution numbers (nullptr: nothing is reported)
+    unsigned* handled;                // 2 device words of the group (caller scratch): [0] set by the launch that does the work,
+                                      // [1] the execution number drawn by the first launch (the last one reports errors under it)
+    unsigned long long* host_seen;    // pinned ring of kLamRing words, written by the first launch of every group
+    unsigned long long* host_error;   // pinned, sticky: (number << 32) | bits(lambd) of a forward no launch covered
     unsigned* dot_counter;            // ticket word of the caller's dot scratch, zeroed by the first launch (or nullptr)
 };
 
@@ -75,23 +82,29 @@ __device__ __forceinline__ LamState lam_prologue(const LamArgs& la, int n_launch
     if (la.role & kLamQuiet) return st;
     if (la.role & kLamFirst) {
         if (leader) {
-            if (la.host_seen)
-                __hip_atomic_store(la.host_seen, ((unsigned long long)la.seq << 32) | __builtin_bit_cast(unsigned, st.lam),
+            if (la.exec_counter && la.host_seen) {
+                const unsigned num = __hip_atomic_fetch_add(la.exec_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+                __hip_atomic_store(la.host_seen + (num % kLamRing), ((unsigned long long)num << 32) | __builtin_bit_cast(unsigned, st.lam),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (la.handled) la.handled[1] = num;
+            }
             if (la.dot_counter) *la.dot_counter = 0u;
-            if (la.handled) *la.handled = match ? 1u : 0u;
+            if (la.handled) la.handled[0] = match ? 1u : 0u;
         }
     } else if (match && leader && la.handled) {
-        *la.handled = 1u;
+        la.handled[0] = 1u;
     }
     if (!match && (la.role & kLamLast)) {
-        // earlier launches of the group are complete (stream order): their word is visible to a plain load
-        const unsigned prior = ((la.role & kLamFirst) || !la.handled) ? 0u : *la.handled;
+        // earlier launches of the group are complete (stream order): their words are visible to a plain load
+        const unsigned prior = ((la.role & kLamFirst) || !la.handled) ? 0u : la.handled[0];
         if (!prior) {
             st.action = kLamPoison;
-            if (leader && la.host_error)
-                __hip_atomic_store(la.host_error, ((unsigned long long)la.seq << 32) | __builtin_bit_cast(unsigned, st.lam),
+            if (leader && la.host_error) {
+                // the leader of a single-launch group wrote handled[1] itself (program order); otherwise an earlier launch did
+                const unsigned num = la.handled ? la.handled[1] : 0u;
+                __hip_atomic_store(la.host_error, ((unsigned long long)num << 32) | __builtin_bit_cast(unsigned, st.lam),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
     return st;
@@ -129,7 +142,17 @@ template <> struct FftPlan<64>   { static constexpr int R = 8,  C = 1, PASSES = 
 template <> struct FftPlan<128>  { static constexpr int R = 8,  C = 2, PASSES = 1, WAVES = 4, NBPRE = 8, MINW = 4, PAIRING = 0, SPLIT = 0; };
 template <> struct FftPlan<256>  { static constexpr int R = 16, C = 1, PASSES = 1, WAVES = 4, NBPRE = 12, MINW = 4, PAIRING = 0, SPLIT = 0; };
 template <> struct FftPlan<512>  { static constexpr int R = 16, C = 2, PASSES = 1, WAVES = 4, NBPRE = 20, MINW = 4, PAIRING = 0, SPLIT = 0; };
+// 1024 = 32 x 32: two frames per wave (G = 32 lanes each), no cross-lane stage, compact layout.  16 frames per workgroup of 8 waves at
+// 76.6 KB of LDS: two workgroups = 32 frames per CU, which is BASELINE config 2's whole share of a CU in ONE round.
+// (R = 16, C = 4, one frame per wave, spectrum in LDS -- rounds 1 and 2 -- is kept selectable for A/B timing: -DDMEL_PLAN1024_R16)
+#ifdef DMEL_PLAN1024_R16
 template <> struct FftPlan<1024> { static constexpr int R = 16, C = 4, PASSES = 1, WAVES = 8, NBPRE = 20, MINW = 4, PAIRING = 0, SPLIT = 0; };
+#else
+// (one workgroup of 16 waves per CU -- 32 frames, a whole 16000-sample clip at hop 512, whose mean then comes from the samples the
+// frames load anyway, one window table per CU -- measured 20.3-20.6 us against 19.9 at BASELINE config 2, inference 23.1 against
+// 16.3: the barriers of 16 waves cost more than the second pass over the clip)
+template <> struct FftPlan<1024> { static constexpr int R = 32, C = 1, PASSES = 1, WAVES = 8, NBPRE = 20, MINW = 4, PAIRING = 1, SPLIT = 1; };
+#endif
 template <> struct FftPlan<2048> { static constexpr int R = 32, C = 2, PASSES = 1, WAVES = 8, NBPRE = 40, MINW = 4, PAIRING = 1, SPLIT = 1; };
 // (4096 as two waves per frame, R = 32, C = 4, two workgroups per CU: 291 us against 184 at the reference's ESC-50 shape --
 // the workgroup barriers of a shared frame cost more than the occupancy gives)
@@ -138,7 +161,8 @@ template <> struct FftPlan<8192> { static constexpr int R = 64, C = 2, PASSES = 
 template <> struct FftPlan<16384> { static constexpr int R = 64, C = 4, PASSES = 1, WAVES = 8, NBPRE = 40, MINW = 2, PAIRING = 2, SPLIT = 1; };
 
 constexpr int kWinLdsMaxNfft = 4096;   // (the table in global memory at 4096: 184 us against 171 at the reference's ESC-50 shape)
-constexpr int kRedBytes = 80;          // 8 + 8 partial sums, then the tangent scale (word 16) computed once per workgroup
+constexpr int kRedBytes = 160;         // 16 + 16 partial sums (one per wave), then the tangent scale (word 32) computed once per workgroup
+constexpr int kRedTan = 32;
 struct FftGeom {
     int N, R, C, G, FPW, PASSES, WAVES, NLOC, THREADS, SLOTS, MT, EX_STRIDE, SLOT_STRIDE_F2, NBPRE, MINW, LDS_BYTES, AUX_OFF, RED_OFF, WIN_LDS;
     int PAIRING, SPLIT, WIN_SYM, WPF, PLANE_PAD;
@@ -178,7 +202,7 @@ template <int N> constexpr FftGeom geom()
     // the window table lives in LDS up to n_fft 4096 (half table there: 16 KB next to 8 x 16.6 KB of frames); beyond, in global
     // memory, written by dmel_prep_kernel
     g.WIN_LDS = (N <= kWinLdsMaxNfft) ? 1 : 0;
-    const int xch = (g.WAVES == 8) ? 8 * 64 * 16 * g.MT : 0;
+    const int xch = (g.WAVES == 8) ? 8 * 64 * 16 : 0;     // the half-tile exchange passes one 16-row tile at a time
     // the Gaussian window is symmetric about N/2: the compact layout keeps entries 0..N/2 only
     g.WIN_SYM = (g.WIN_LDS && P::SPLIT) ? 1 : 0;
     const int win = g.WIN_LDS ? (g.WIN_SYM ? (N / 2 + 1) * 8 : N * 8) : 0;
@@ -225,6 +249,7 @@ struct PrepParams {
 hipError_t launch_prep(const PrepParams& p, hipStream_t s);
 hipError_t launch_forward(int n_fft, int mode, int tiles_per_wg, const FwdParams& p, int grid, hipStream_t s);
 int forward_tiles_per_wg(int n_fft, int batch, int tiles_per_clip);          // 1 or 2: what launch_forward should be given
+bool forward_two_tiles(int n_fft);          // the two-tiles-per-workgroup instantiation exists for this size
 int forward_lds_bytes(int n_fft);
 int forward_frames_per_tile(int n_fft, int mode);
 int forward_waves(int n_fft);              // waves per workgroup of the fused kernel for this n_fft

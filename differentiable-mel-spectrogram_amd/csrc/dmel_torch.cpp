@@ -119,6 +119,18 @@ at::Tensor dmel_mel_fbanks_op(int64_t n_freqs, double f_min, double f_max, int64
     return fb;
 }
 
+// A reference on the plan that lives as long as the autograd graph does: the op takes the plan as an integer, and the Python
+// object that created it (capi.Plan, held by the layer) may be collected before backward runs -- `y = make_layer()(x);
+// y.backward(g)` or `del net; loss.backward()`.  The reference travels in ctx->saved_data as a one-byte CPU tensor whose
+// deleter releases it (dmel_plan_retain / dmel_plan_release, include/dmel.h); a plain torch module (models.py:33-56) has no
+// such hazard and neither has this one.
+at::Tensor plan_reference(dmel_plan* plan)
+{
+    check(dmel_plan_retain(plan));
+    static char anchor = 0;
+    return at::from_blob(&anchor, {1}, [plan](void*) { (void)dmel_plan_release(plan); }, at::TensorOptions().dtype(at::kByte));
+}
+
 // forward carries d out / d lambd (one trainable scalar: forward mode), backward is one dot product (train.py:47)
 struct DmelFn : public torch::autograd::Function<DmelFn> {
     static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& x, const at::Tensor& lambd, int64_t plan_h,
@@ -126,6 +138,7 @@ struct DmelFn : public torch::autograd::Function<DmelFn> {
     {
         auto r = dmel_forward_op(x, lambd, plan_h, flags, eps, want_tangent, lambd_sync, out_bf16);
         ctx->saved_data["plan"] = plan_h;
+        if (want_tangent) ctx->saved_data["plan_ref"] = plan_reference(as_plan(plan_h));      // backward dereferences the plan
         ctx->saved_data["want"] = want_tangent;
         ctx->saved_data["lam_dim"] = (int64_t)lambd.dim();
         ctx->saved_data["lam_dtype"] = (int64_t)lambd.scalar_type();

@@ -1,78 +1,217 @@
-"""A training step replayed from a HIP graph, kept valid while ``lambd`` moves.
+"""A training step replayed from a HIP graph, kept valid while ``lambd`` moves -- with the same decisions on every rank.
 
 HIP streams and graphs are this package's answer to per-launch host overhead: at BASELINE config 2 the kernels of one
-step (fused forward, dot, optimizer update) take ~40 us while issuing them from Python takes ~100 us.  A step captured
+step (fused forward, dot, optimizer update) take ~35 us while issuing them from Python takes ~100 us.  A step captured
 once replays with one launch.  What a captured DMEL forward cannot do by itself is change its n_fft: the graph holds the
-launch for the n_fft the host saw at capture time (plus guard launches for the neighbours that were within reach then, see
-include/dmel.h).  ``GraphedStep`` closes that gap the way the reference's per-forward host read does, without the read: the
-kernels report ``lambd`` into pinned memory at every replay, ``__call__`` looks at that word (no synchronisation) and
-re-captures when the launch the library would choose now differs from what the graph holds.  Replays are allowed to queue
-``max_ahead`` deep (an event ring, not a device synchronisation), so the picture is never older than that.
+launch for one n_fft (plus guard launches for the neighbours within reach, include/dmel.h).  ``GraphedStep`` closes that
+gap the way the reference's per-forward host read does (time_frequency.py:39), without the read: every forward that
+executes reports ``(execution number, lambd)`` into a pinned ring, and ``__call__`` re-captures when the launches that
+value asks for differ from what the graph holds.
+
+*Which* report it looks at is what makes this safe with several ranks.  A re-capture runs the step eagerly, and the step
+of a data-parallel job contains the all-reduce of ``lambd.grad``: ranks that re-captured at different calls would issue
+different numbers of collectives and hang.  The pinned "latest report" depends on when a host happens to look; the report
+of ONE PARTICULAR execution does not.  Call ``i`` therefore waits (an event, not a device synchronisation) for the replay
+issued ``max_ahead`` calls earlier and reads exactly that replay's report (``dmel_plan_lambd_report``): every rank issues
+the same forwards in the same order, ``lambd`` is identical on all of them after each all-reduced update, so every rank
+reads the same number and -- the decision being a pure function of the numbers read so far (``dmel_decide_launch``) --
+re-captures at the same call.  The launches are chosen for everything ``lambd`` can reach until that delayed look comes
+round: ``2 * rate * ((max_ahead + 1) * forwards per replay + 2)``.
 """
 from __future__ import annotations
 
-import torch
+
+class LaunchTracker:
+    """What one plan's captured launches must cover, from the reports of particular executions only (no timing enters).
+
+    ``decide(lambd, rate, stale_forwards) -> (n_fft, guards)`` is ``capi.decide_launch``; tests pass their own."""
+
+    BOTH = 1.0e30        # a rate that puts both neighbours within reach: the drift is unknown until two reports have been seen
+
+    def __init__(self, decide):
+        self.decide = decide
+        self.lam, self.seq, self.rate, self.n_obs = None, None, 0.0, 0
+        self.seq0, self.per_replay, self.held = 0, 1, None
+
+    def observe(self, seq: int, lam: float) -> None:
+        if self.lam is not None and seq == self.seq:
+            return                                       # the same execution again
+        if self.lam is not None:
+            self.rate = max(0.98 * self.rate, abs(lam - self.lam) / max(1, (seq - self.seq) & 0xFFFFFFFF))
+        self.lam, self.seq = float(lam), int(seq)
+        self.n_obs += 1
+
+    def want(self, horizon: float):
+        return tuple(self.decide(self.lam, self.rate if self.n_obs >= 2 else self.BOTH, horizon))
+
+    def rebase(self, seq: int, lam: float, per_replay: int) -> None:
+        """an exact picture (the device was idle): execution numbers of the replays that follow count from here"""
+        self.observe(seq, lam)
+        self.seq0, self.per_replay = int(seq), max(1, int(per_replay))
+
+
+class _CudaBackend:
+    """torch / HIP plumbing of GraphedStep (tests substitute a CPU stand-in to drive the decision logic)."""
+
+    def __init__(self):
+        import torch
+        self.torch = torch
+        self.dev = torch.cuda.current_device()
+
+    def synchronize(self):
+        self.torch.cuda.synchronize(self.dev)
+
+    def run_eager(self, fn, n):
+        t = self.torch
+        side = t.cuda.Stream(self.dev)               # allocator pools, optimizer state, table builds: off the capturing stream
+        side.wait_stream(t.cuda.current_stream(self.dev))
+        with t.cuda.stream(side):
+            for _ in range(n):
+                fn()
+        t.cuda.current_stream(self.dev).wait_stream(side)
+
+    def capture(self, fn, k):
+        g = self.torch.cuda.CUDAGraph()
+        with self.torch.cuda.graph(g):
+            for _ in range(k):
+                fn()
+        return g
+
+    def event(self):
+        return self.torch.cuda.Event()
 
 
 class GraphedStep:
-    """``gs = GraphedStep(step_fn, layers=[net.spectrogram_layer]); for _ in range(n): gs()``
+    """``gs = GraphedStep(step_fn, layers=[net.spectrogram_layer]); for batch in loader: x_static.copy_(batch); gs()``
 
-    ``step_fn()`` is one whole training step written as usual (zero_grad, forward, backward, optimizer.step) on static
-    tensors; optimizers must be capturable.  ``layers``: the MelSpectrogramLayers used inside (with ``lambd_sync=False``).
+    ``step_fn()`` is one whole training step written as usual (zero_grad, forward, backward, [all-reduce], optimizer.step)
+    on static tensors; optimizers must be capturable.  ``layers``: the MelSpectrogramLayers used inside (``lambd_sync=False``).
     ``steps_per_replay`` unrolls that many steps into one graph (the ~8 us between two graph launches are paid once per
-    replay).  The first call runs eagerly (warm-up) and captures."""
+    replay).  Every call performs exactly ``steps_per_replay`` steps: replayed from the graph, or -- on the first call and
+    whenever the graph has to be captured again -- run eagerly, after which the graph is captured for the calls that follow
+    (capturing executes nothing).  ``warmup`` extra eager steps before the first capture are real steps too (default 0).
+    With several ranks every rank must make the same calls in the same order (as any SPMD loop does); eager forwards through
+    the same layers between calls (a validation pass) are fine as long as every rank makes them."""
 
-    def __init__(self, step_fn, layers, max_ahead: int = 8, steps_per_replay: int = 1, warmup: int = 3):
+    def __init__(self, step_fn, layers, max_ahead: int = 8, steps_per_replay: int = 1, warmup: int = 0, backend=None, decide=None):
         self.step_fn, self.layers = step_fn, list(layers)
-        self.max_ahead, self.k, self.warmup = int(max_ahead), int(steps_per_replay), int(warmup)
-        self.graph, self.held = None, None
-        self.captures = 0
-        self._ring, self._i = [], 0
+        self.max_ahead, self.k, self.warmup = max(1, int(max_ahead)), int(steps_per_replay), int(warmup)
+        self.backend = backend
+        if decide is None:
+            from . import capi
+            decide = capi.decide_launch
+        self._decide = decide
+        self.graph = None
+        self.captures, self.capture_calls, self.calls = 0, [], 0
+        self._trackers = {}                              # id(plan) -> LaunchTracker
+        self._ring, self._replays, self._expected_calls = [], 0, {}
         for lay in self.layers:
             if getattr(lay, "lambd_sync", False):
                 raise ValueError("GraphedStep needs lambd_sync=False layers (a host read cannot be captured)")
-            lay.set_tracking(self.max_ahead, 3)          # guard near boundaries only, also under capture: this object watches
+            lay.set_tracking(self.max_ahead, 3)          # eager steps: guard near boundaries only; this object watches the rest
 
-    def _decision(self):
-        out = []
-        for lay in self.layers:
-            for plan in lay._plans.values():
-                st = plan.lambd_status()
-                if st["error"]:
-                    raise RuntimeError(f"DMEL layer: a replay was not covered by the graph's launches (lambd {st['error_lambd']} at call "
-                                       f"{st['error_seq']}): outputs were NaN.  lambd moved faster than max_ahead={self.max_ahead} replays allow")
-                out.append((st["next_n_fft"], st["next_guards"]))
-        return tuple(out)
+    # -- helpers ------------------------------------------------------------------------------------------------------------
+    def _plans(self):
+        return [p for lay in self.layers for p in lay._plans.values()]
 
-    def _capture(self):
-        dev = torch.cuda.current_device()
-        torch.cuda.synchronize(dev)
-        side = torch.cuda.Stream(dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):                    # eager steps: allocator, optimizer state, lambd tracking, table builds
-            for _ in range(self.warmup if self.graph is None else 1):
-                self.step_fn()
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)
-        self.held = self._decision()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            for _ in range(self.k):
-                self.step_fn()
-        self.graph = g
+    def _tracker(self, plan) -> LaunchTracker:
+        tr = self._trackers.get(id(plan))
+        if tr is None:
+            tr = self._trackers[id(plan)] = LaunchTracker(self._decide)
+        return tr
+
+    def _horizon(self, tr: LaunchTracker) -> float:
+        return float((self.max_ahead + 1) * tr.per_replay + 2)
+
+    @staticmethod
+    def _status(plan) -> dict:
+        st = plan.lambd_status()
+        if st["error"]:
+            raise RuntimeError(f"DMEL layer: a forward was not covered by the launches issued for it (lambd {st['error_lambd']} at execution "
+                               f"{st['error_seq']}): its outputs were NaN.  lambd moved faster than the graph's guards allow")
+        return st
+
+    def _rebase(self, per_replay=None) -> None:
+        """the device is idle: take the exact picture of every plan"""
+        for plan in self._plans():
+            st = self._status(plan)
+            tr = self._tracker(plan)
+            tr.rebase(st["seq_seen"], st["lambd_seen"], tr.per_replay if per_replay is None else per_replay[id(plan)])
+            self._expected_calls[id(plan)] = st["calls"]
+        self._replays = 0
+
+    def _capture(self) -> None:
+        b = self.backend
+        if b is None:
+            b = self.backend = _CudaBackend()
+        b.synchronize()
+        first = self.graph is None
+        before = {id(p): p.lambd_status() for p in self._plans()}
+        n_eager = self.k + (self.warmup if first else 0)
+        b.run_eager(self.step_fn, n_eager)               # this call's steps (and what capture needs warm)
+        b.synchronize()
+        plans = self._plans()                            # plans are created by the first forward
+        per = {}
+        for p in plans:
+            st0, st1 = before.get(id(p)), self._status(p)
+            per[id(p)] = max(1, (st1["calls"] - (st0["calls"] if st0 else 0)) * self.k // n_eager)
+            # the eager forwards just run reported too: exact values, the same on every rank (the drift per forward is known
+            # from the first capture on when this call ran two or more)
+            lo = st0["seq_seen"] if (st0 and st0["known"]) else st1["seq_seen"] - min(st1["seq_seen"], 32)
+            for seq in range(lo + 1, st1["seq_seen"]):
+                lam = p.lambd_report(seq & 0xFFFFFFFF)
+                if lam is not None:
+                    self._tracker(p).observe(seq & 0xFFFFFFFF, lam)
+        self._rebase(per)
+        for plan in plans:
+            tr = self._tracker(plan)
+            tr.held = tr.want(self._horizon(tr))
+            plan.force_launch(*tr.held)                  # the graph holds exactly these launches, on every rank
+        try:
+            self.graph = b.capture(self.step_fn, self.k)
+        finally:
+            for plan in plans:
+                plan.force_launch(0, 0)
+        for plan in plans:
+            self._expected_calls[id(plan)] = plan.lambd_status()["calls"]
         self.captures += 1
-        self._ring = [torch.cuda.Event() for _ in range(max(1, self.max_ahead))]
-        self._i = 0
+        self.capture_calls.append(self.calls)
+        self._ring = [b.event() for _ in range(self.max_ahead + 1)]
+        self._replays = 0
 
+    # -- one call = steps_per_replay steps ----------------------------------------------------------------------------------
     def __call__(self):
-        if self.graph is None or self._decision() != self.held:
-            self._capture()
+        self.calls += 1
+        if self.graph is None:
+            return self._capture()
+        plans = self._plans()
+        # forwards through these layers that this object did not issue (an eager validation pass) shift the execution numbers:
+        # take an exact picture again.  Host-side call counts: the same on every rank.
+        if any(self._status(p)["calls"] != self._expected_calls.get(id(p)) for p in plans):
+            self.backend.synchronize()
+            self._rebase()
+            if any(self._tracker(p).want(self._horizon(self._tracker(p))) != self._tracker(p).held for p in plans):
+                return self._capture()
+        j = self._replays - self.max_ahead               # the replay (1-based, since the last exact picture) whose report is due
+        if j >= 1:
+            self._ring[(j - 1) % len(self._ring)].synchronize()     # bounds the queue; not a device synchronisation
+            stale = False
+            for plan in plans:
+                tr = self._tracker(plan)
+                seq = (tr.seq0 + j * tr.per_replay) & 0xFFFFFFFF
+                lam = plan.lambd_report(seq)
+                if lam is None:                          # overwritten (more than 64 executions ahead): fall back to an exact picture
+                    stale = True
+                    break
+                tr.observe(seq, lam)
+            if stale:
+                self.backend.synchronize()
+                self._rebase()
+            if any(self._tracker(p).want(self._horizon(self._tracker(p))) != self._tracker(p).held for p in plans):
+                return self._capture()
         self.graph.replay()
-        ev = self._ring[self._i % len(self._ring)]
-        if self._i >= len(self._ring):
-            ev.synchronize()                             # the replay issued max_ahead calls ago: bounds the queue, not a device sync
-        ev.record()
-        self._i += 1
+        self._ring[self._replays % len(self._ring)].record()
+        self._replays += 1
 
     def steps_done_per_call(self) -> int:
         return self.k

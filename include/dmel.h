@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DMEL_ABI_VERSION 2
+#define DMEL_ABI_VERSION 3
 
 typedef enum dmel_status {
     DMEL_OK = 0,
@@ -92,7 +92,14 @@ int32_t dmel_device_count(void);
 
 /* MelSpectrogramLayer.__init__ (models.py:15-30).  Binds to the current HIP device. */
 dmel_status dmel_plan_create(const dmel_config* cfg, dmel_plan** plan);
+/* A plan is reference counted: dmel_plan_create returns it with one reference, dmel_plan_destroy (= dmel_plan_release) drops one,
+ * and the plan is freed -- after the device has finished what was queued on it -- when the last one goes.  Whoever keeps a
+ * dmel_plan* beyond the owner's lifetime takes a reference: the autograd node of torch.ops.dmel.mel_spectrogram does, so
+ * `y = layer(x); del layer; y.backward(g)` is safe (a plain torch module, models.py:33-56, has no such hazard either).
+ * A HIP graph that captured launches of a plan does NOT hold one: keep the layer (or a reference) while the graph lives. */
 dmel_status dmel_plan_destroy(dmel_plan* plan);
+dmel_status dmel_plan_retain(dmel_plan* plan);
+dmel_status dmel_plan_release(dmel_plan* plan);
 dmel_status dmel_plan_get_config(const dmel_plan* plan, dmel_config* cfg);
 
 /* Replace the mel filterbank of the plan by a caller-supplied (n_freqs, n_mels) fp32 HOST matrix for
@@ -153,12 +160,15 @@ dmel_status dmel_forward_dev(dmel_plan* plan, const float* x, int32_t batch, con
 dmel_status dmel_forward_dev_fixed(dmel_plan* plan, const float* x, int32_t batch, const float* lambd_dev, int32_t n_fft,
                                    uint32_t flags, double eps, void* out, float* tangent, void* scratch, void* stream);
 
+/* Every forward that EXECUTES on a plan (an eager dmel_forward_dev, or one replay of a captured one) draws the next
+ * EXECUTION NUMBER from a device counter and reports (number, lambd as it read it) into a pinned ring of 64 entries. */
 typedef struct dmel_lambd_status {
     int32_t known;            /* 0 until a value has been seen                                             */
     float lambd_seen;         /* lambd as read by the most recent forward that has EXECUTED                */
     int32_t n_fft_seen;
-    uint32_t seq_issued;      /* dmel_forward_dev calls issued / the call the observation belongs to       */
-    uint32_t seq_seen;
+    uint32_t seq_issued;      /* execution number the host expects its most recent eager call to draw (caught up with the
+                                 reports: replays of captured forwards execute without the host counting them)            */
+    uint32_t seq_seen;        /* execution number lambd_seen belongs to                                    */
     float rate;               /* decayed maximum of |change of lambd| per call                             */
     int32_t guards;           /* most recent call: bit 0 = n_fft/2 guard launched, bit 1 = 2 n_fft guard   */
     int32_t error;            /* 1: a forward was not covered (reported by the next dmel_forward_dev)      */
@@ -166,8 +176,22 @@ typedef struct dmel_lambd_status {
     float error_lambd;
     int32_t next_n_fft;       /* what a dmel_forward_dev issued now would launch for, and guard (bits as `guards`)        */
     int32_t next_guards;
+    uint32_t calls;           /* dmel_forward_dev / _fixed calls on this plan so far, captured ones included               */
 } dmel_lambd_status;
 dmel_status dmel_plan_lambd_status(dmel_plan* plan, dmel_lambd_status* status);
+/* lambd as read by execution `number`, if its report is still in the ring (found = 1).  Unlike dmel_plan_lambd_status, whose
+ * picture is "whatever executed last when the host looked", this answer does not depend on timing: ranks of a data-parallel
+ * job that issue the same forwards in the same order read the same value for the same number, and can therefore take the
+ * same re-capture decision without a collective (dmel_amd.graph.GraphedStep). */
+dmel_status dmel_plan_lambd_report(dmel_plan* plan, uint32_t number, float* lambd, int32_t* found);
+/* The launch choice as a pure function: n_fft of `lambd` (time_frequency.py:39,60-65) and the neighbouring n_fft a forward
+ * must guard (bit 0: n_fft / 2, bit 1: 2 n_fft) when lambd may move by up to `rate` per forward for `stale_forwards` forwards
+ * before anybody looks again. */
+dmel_status dmel_decide_launch(float lambd, float rate, float stale_forwards, int32_t* n_fft, int32_t* guards);
+/* While n_fft > 0, dmel_forward_dev launches exactly for `n_fft` plus the guards given (bits as above) instead of choosing
+ * from its own picture; the kernels still check the device value and poison + report a forward nothing covered.  For callers
+ * that decide themselves (a captured step that must hold the same launches on every rank).  n_fft = 0: back to automatic. */
+dmel_status dmel_plan_force_launch(dmel_plan* plan, int32_t n_fft, int32_t guards);
 /* max_ahead: calls the host may be ahead of the last observation before dmel_forward_dev waits (0 = unbounded, default 8);
  * guard_mode: 0 = near boundaries only, and both neighbours whenever the stream is capturing (default: a captured forward
  * is replayed without the host looking); 1 = always both neighbours; 2 = never; 3 = near boundaries only, also under

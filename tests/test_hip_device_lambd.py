@@ -275,18 +275,19 @@ def test_torch_ops_are_registered():
 
 @pytest.mark.parametrize("k", [1, 2])
 def test_graphed_step_recaptures_when_n_fft_changes(k):
-    """dmel_amd.GraphedStep: the step replays from a HIP graph; the object reads what the kernels report about lambd between
-    replays (pinned word, no synchronisation) and re-captures when the launch the library would choose has changed.  The
-    trajectory equals the eagerly issued one across the 512 -> 1024 boundary, with guards only while the boundary is near."""
+    """dmel_amd.GraphedStep: the step replays from a HIP graph; the object reads the report of the replay issued max_ahead calls
+    earlier (an exact, timing-independent value: every rank of a data-parallel job reads the same) and re-captures when the
+    launches that value asks for differ from what the graph holds.  Every call takes exactly k steps -- capture calls run them
+    eagerly -- so the trajectory equals the eagerly issued one step for step across the 512 -> 1024 boundary."""
     from dmel_amd import GraphedStep, capi
     case = C.BY_NAME["g1_c1"]
     x = torch.from_numpy(C.make_input(case)).to(DEV)
     g = torch.from_numpy(C.make_cotangent(case)).to(DEV)
-    lam0, steps = 84.0, 32
+    lam0, steps = 84.0, 48
     ref_layer = _mk(case, lam=lam0, sync=True)
     ref_opt = torch.optim.Adam([ref_layer.lambd], lr=0.25, capturable=True)
     ref = []
-    for _ in range(steps + 40):                               # GraphedStep adds eager steps: 3 before the first capture, 1 per re-capture
+    for _ in range(steps):
         ref_opt.zero_grad(set_to_none=True)
         ref_layer(x).backward(g)
         ref_opt.step()
@@ -299,20 +300,137 @@ def test_graphed_step_recaptures_when_n_fft_changes(k):
         layer(x).backward(g)
         opt.step()
 
-    gs = GraphedStep(step, [layer], max_ahead=4, steps_per_replay=k, warmup=3)
-    got, guards_seen = [], set()
-    n_eager = 3
-    for _ in range(steps // k):
-        before = gs.captures
+    gs = GraphedStep(step, [layer], max_ahead=4, steps_per_replay=k)
+    got = []
+    for i in range(steps // k):
         gs()
-        if gs.captures != before and before > 0:
-            n_eager += 1                                      # every re-capture runs one eager step first
         torch.cuda.synchronize()
         got.append(float(layer.lambd.detach()))
-        guards_seen.add(layer.lambd_status()["guards"])
-    total = n_eager + (steps // k) * k
-    # capture itself does not execute the step; replays do: the layer has taken n_eager + steps steps in all
-    np.testing.assert_allclose(got[-1], ref[total - 1], rtol=1e-5)
-    assert gs.captures >= 2, "lambd crossed 85.5 (n_fft 512 -> 1024): the graph must have been re-captured"
-    assert {capi.n_fft(v) for v in got} == {512, 1024} or capi.n_fft(got[0]) == 1024
+        np.testing.assert_allclose(got[-1], ref[(i + 1) * k - 1], rtol=1e-5)      # call i has taken exactly (i + 1) k steps
+    assert gs.captures >= 3, "both-guards graph, guard-free graph, and lambd crossed 85.5 (n_fft 512 -> 1024)"
+    assert {capi.n_fft(v) for v in got} == {512, 1024}
     assert layer.lambd_status()["error"] == 0
+
+
+def test_graphed_step_with_an_eager_forward_between_replays():
+    """a validation forward through the same layer between replays used to freeze the host's picture of lambd
+    (its call number ran past the one the graph reports under), so the graph was never re-captured and a boundary crossing
+    produced NaN.  Execution numbers are drawn on the device now: replays and eager calls share one sequence."""
+    from dmel_amd import GraphedStep, capi
+    case = C.BY_NAME["g1_c1"]
+    x = torch.from_numpy(C.make_input(case)).to(DEV)
+    g = torch.from_numpy(C.make_cotangent(case)).to(DEV)
+    layer = _mk(case, lam=84.0, sync=False)
+    opt = torch.optim.Adam([layer.lambd], lr=0.25, capturable=True)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        layer(x).backward(g)
+        opt.step()
+
+    gs = GraphedStep(step, [layer], max_ahead=4)
+    for i in range(60):
+        gs()
+        if i in (3, 4, 11, 30):
+            with torch.no_grad():
+                y = layer(x)                                 # eager, same plan, same stream
+            assert torch.isfinite(y).all()
+    torch.cuda.synchronize()
+    st = layer.lambd_status()
+    assert st["error"] == 0 and capi.n_fft(float(layer.lambd.detach())) == 1024 and gs.captures >= 3
+    with torch.no_grad():
+        assert torch.isfinite(layer(x)).all()
+
+
+def test_execution_numbers_and_reports():
+    """every forward that executes draws the next execution number; dmel_plan_lambd_report returns the value that execution read"""
+    from dmel_amd import capi
+    case = C.BY_NAME["g1_c1"]
+    B, M, T = case["B"], case["n_mels"], case["L"] // case["hop"] + 1
+    x = torch.from_numpy(C.make_input(case).astype(np.float32)).to(DEV)
+    lam = torch.tensor([64.0], dtype=torch.float32, device=DEV)
+    plan = capi.Plan(case["L"], case["hop"], M, case["sr"])
+    out = torch.empty((B, 1, M, T), device=DEV)
+    s = torch.cuda.current_stream().cuda_stream
+    for i in range(70):
+        plan.forward_dev(x.data_ptr(), B, lam.data_ptr(), out.data_ptr(), None, True, 1e-10, s)
+        lam += 0.01
+    torch.cuda.synchronize()
+    st = plan.lambd_status()
+    assert st["seq_seen"] == 70 and st["seq_issued"] == 70 and st["calls"] == 70 and st["error"] == 0
+    assert plan.lambd_report(70) == pytest.approx(64.0 + 0.69, abs=1e-4)
+    assert plan.lambd_report(7) == pytest.approx(64.0 + 0.06, abs=1e-4)       # still in the 64-deep ring
+    assert plan.lambd_report(6) is None and plan.lambd_report(71) is None and plan.lambd_report(0) is None
+    # a captured forward draws a fresh number at every replay
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        plan.forward_dev(x.data_ptr(), B, lam.data_ptr(), out.data_ptr(), None, True, 1e-10, torch.cuda.current_stream().cuda_stream)
+    for _ in range(5):
+        g.replay()
+    torch.cuda.synchronize()
+    st = plan.lambd_status()
+    assert st["seq_seen"] == 75 and st["calls"] == 71 and st["seq_issued"] == 75
+    plan.forward_dev(x.data_ptr(), B, lam.data_ptr(), out.data_ptr(), None, True, 1e-10, s)      # eager again: number 76, not 72
+    torch.cuda.synchronize()
+    assert plan.lambd_status()["seq_seen"] == 76
+
+
+def test_forced_launches_are_checked_on_the_device():
+    """dmel_plan_force_launch: the caller's choice is launched as given; a value it does not cover still poisons and reports"""
+    from dmel_amd import capi
+    case = C.BY_NAME["g1_c1"]
+    x = torch.from_numpy(C.make_input(case)).to(DEV)
+    layer = _mk(case, lam=64.0, sync=False)
+    with torch.no_grad():
+        y0 = layer(x)
+        plan = next(iter(layer._plans.values()))
+        plan.force_launch(512, 0)
+        assert torch.equal(layer(x), y0) and layer.lambd_status()["guards"] == 0
+        plan.force_launch(256, 2)                            # 256 does not match, its guard 512 does
+        assert torch.equal(layer(x), y0) and layer.lambd_status()["guards"] == 2
+        plan.force_launch(256, 1)                            # nothing covers 512
+        y = layer(x)
+        torch.cuda.synchronize()
+        assert torch.isnan(y).all() and layer.lambd_status()["error"] == 1
+        plan.force_launch(0, 0)
+        with pytest.raises(RuntimeError):
+            layer(x)
+        assert torch.equal(layer(x), y0)
+
+
+def test_backward_after_the_layer_is_gone():
+    """the autograd node of torch.ops.dmel.mel_spectrogram keeps a reference on the plan, so a layer that
+    is collected before backward runs (a temporary, or `del net; loss.backward()`) is no use-after-free."""
+    import gc
+    case = C.BY_NAME["g1_c1"]
+    x = torch.from_numpy(C.make_input(case)).to(DEV)
+    g = torch.from_numpy(C.make_cotangent(case)).to(DEV)
+    keep = _mk(case)
+    keep(x).backward(g)
+    want = keep.lambd.grad.clone()
+    lam = torch.nn.Parameter(torch.tensor(float(case["lambd"]), device=DEV))
+
+    def temp_layer_output():
+        lay = _mk(case)
+        lay.lambd = lam                                     # the parameter outlives the module
+        return lay(x)
+
+    y = temp_layer_output()
+    gc.collect()
+    torch.cuda.synchronize()
+    junk = [torch.empty(1 << 20, device=DEV) for _ in range(8)]          # churn the allocators
+    y.backward(g)
+    torch.cuda.synchronize()
+    assert torch.equal(lam.grad, want)
+    from dmel_amd import nets
+    net = nets.MelLinearNet(10, torch.tensor(float(case["lambd"])), DEV, case["n_mels"], case["sr"], case["L"], hop_length=case["hop"],
+                            optimized=True).to(DEV)
+    params = list(net.parameters())
+    logits, _ = net(x)
+    loss = logits.square().mean()
+    del net, logits
+    gc.collect()
+    loss.backward()
+    torch.cuda.synchronize()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in params)
+    del junk

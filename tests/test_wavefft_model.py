@@ -21,3 +21,10 @@ def test_wave_fft_model(N):
     assert max(conf.values()) <= 2
     assert W.slot_stride_bytes(N) % 128 == 48
     assert W.a_operand_conflicts(N) == 1 and W.a_operand_conflicts(N, W.slot_stride_bytes(N) // 256 * 256 + 32) == 2
+
+
+@pytest.mark.parametrize("N,R,C", [(1024, 32, 1), (2048, 32, 2), (4096, 64, 1), (1024, 16, 4), (256, 16, 1), (512, 16, 2)])
+def test_bpermute_pairing_model(N, R, C):
+    """every PD[k], k <= N/2, of every frame of the wave is produced exactly once, from a true pair (Z[k], Z[N-k])"""
+    cover = W.bperm_pairing(N, R, C)
+    assert cover.shape[1] == N // 2 + 1 and (cover == 1).all(), np.argwhere(cover != 1)[:8]

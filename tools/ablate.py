@@ -21,7 +21,8 @@ for name in names:
     s = torch.cuda.current_stream().cuda_stream
     for label, fl, tg in (("full train", 0, True), ("fft only (train)", 0x100, True), ("gemm+epilogue only", 0x200, True),
                           ("gemm only, no epilogue", 0x600, True), ("epilogue only, no mfma", 0xA00, True),
-                          ("neither", 0x300, True), ("full infer", 0, False), ("fft only (infer)", 0x100, False)):
+                          ("neither", 0x300, True), ("no clip sum (mean = 0)", 0x1000, True), ("fft only, no clip sum", 0x1100, True),
+                          ("full infer", 0, False), ("fft only (infer)", 0x100, False)):
         for _ in range(5):
             plan.forward(x.data_ptr(), B, lam, out.data_ptr(), tan.data_ptr() if tg else None, True, 1e-10, s, extra_flags=fl)
         torch.cuda.synchronize()

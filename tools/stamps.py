@@ -18,7 +18,7 @@ NAMES = ["start->loads issued", "window table + clip mean", "samples arrive, win
 
 if sys.argv[1] == "build":
     srcs = [os.path.join(PKG, "csrc", f) for f in ("dmel_fwd.hip", "dmel_aux.hip", "dmel_big.hip", "dmel_xgrad.hip", "dmel_api.cpp", "dmel_comm.cpp")]
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-DDMEL_STAMPS", "-shared", "-o", LIB]
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-DDMEL_STAMPS", "-shared", "-o", LIB] + sys.argv[2:]   # e.g. -DDMEL_ONLY_NFFT=1024
     for s in srcs:
         cmd += ["-x", "hip", s]
     cmd += ["-ldl"]

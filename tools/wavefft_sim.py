@@ -17,7 +17,7 @@ from __future__ import annotations
 import numpy as np
 
 # N -> (R, C)
-PLAN = {32: (4, 2), 64: (8, 1), 128: (8, 2), 256: (16, 1), 512: (16, 2), 1024: (16, 4), 2048: (32, 2), 4096: (64, 1)}
+PLAN = {32: (4, 2), 64: (8, 1), 128: (8, 2), 256: (16, 1), 512: (16, 2), 1024: (32, 1), 2048: (32, 2), 4096: (64, 1)}
 WAVE = 64
 
 
@@ -164,6 +164,56 @@ def a_operand_conflicts(N: int, stride_bytes: int | None = None) -> int:
                     banks.setdefault((a // 4) % 32, set()).add(a // 4)
                 worst = max(worst, max(len(v) for v in banks.values()))
     return worst
+
+
+def bperm_pairing(N: int, R: int, C: int) -> np.ndarray:
+    """Index model of the pairing pass that takes Z[N-k] from the lane holding it (ds_bpermute_b32; kPairBperm in
+    csrc/dmel_fwd.hip) for frames of G = R*C <= 64 lanes, 64/G frames per wave.  Lane fl0 + C*qp + rho(p2) holds
+    Z[qp + R*p1 + R*R*p2] in register p1.  Returns cover[frame, k] = how many times PD[k] (k <= N/2) is written with the right
+    pair (Z[k], Z[N-k]); every entry must be 1."""
+    G = N // R
+    assert G == R * C and G <= WAVE
+    FPW = WAVE // G
+    rho = (lambda v: ((v & 1) << 1) | (v >> 1)) if C == 4 else (lambda v: v)      # lane <-> p2 digit reversal (its own inverse)
+    lane = np.arange(WAVE)
+    j, lg = lane // G, lane % G
+    qp, r = lg // C, lg % C
+    p2 = np.array([rho(int(v)) for v in r])
+    held = qp[:, None] + R * np.arange(R)[None, :] + R * R * p2[:, None]            # bin in (lane, register)
+    q0 = qp == 0
+    dir_a = 2 * p2 < C
+    p2m = C - 1 - p2
+    fl0 = j * G
+    pull1 = fl0 + ((R - qp) & (R - 1)) * C + np.array([rho(int(v)) for v in p2m])
+    pull0 = np.where(q0, fl0 + np.array([rho(int(v)) for v in (C - p2) % C]), pull1)
+    nyq = q0 & (2 * p2 == C)
+    cover = np.zeros((FPW, N // 2 + 1), int)
+    for p1 in range(R // 2 + 1):
+        s_a = R // 2 if p1 == R // 2 else R - 1 - p1
+        s_b = R // 2 if p1 == R // 2 else (R - p1) % R
+        send = np.where(q0, held[lane, s_b], held[lane, s_a])                      # what every lane offers this round
+        pull = pull0 if p1 == 0 else pull1
+        got = send[pull]                                                           # bin received from the partner
+        mine = held[lane, p1]
+        for l in range(WAVE):
+            ok = (mine[l] + got[l]) % N == 0                                       # a true pair {k, N-k}
+            if p1 == 0:
+                if nyq[l]:
+                    kk = N // 2
+                elif dir_a[l] or not q0[l]:
+                    kk = mine[l] if dir_a[l] else N - mine[l]
+                else:
+                    continue
+            elif p1 < R // 2:
+                kk = mine[l] if dir_a[l] else N - mine[l]
+            else:
+                if not (q0[l] and dir_a[l]):
+                    continue
+                kk = mine[l]
+            assert 0 <= kk <= N // 2 and ok and (kk == mine[l] or kk == got[l] or kk == N - mine[l]), (l, p1, mine[l], got[l], kk)
+            assert min(mine[l], got[l] % N) % N == kk % N or max(mine[l], got[l]) == N - kk or kk in (mine[l], got[l]), (l, p1)
+            cover[j[l], kk] += 1
+    return cover
 
 
 if __name__ == "__main__":
