@@ -358,8 +358,8 @@ def test_execution_numbers_and_reports():
     torch.cuda.synchronize()
     st = plan.lambd_status()
     assert st["seq_seen"] == 70 and st["seq_issued"] == 70 and st["calls"] == 70 and st["error"] == 0
-    assert plan.lambd_report(70) == pytest.approx(64.0 + 0.69, abs=1e-4)
-    assert plan.lambd_report(7) == pytest.approx(64.0 + 0.06, abs=1e-4)       # still in the 64-deep ring
+    assert plan.lambd_report(70) == pytest.approx(64.0 + 0.69, abs=2e-3)
+    assert plan.lambd_report(7) == pytest.approx(64.0 + 0.06, abs=2e-3)       # still in the 64-deep ring
     assert plan.lambd_report(6) is None and plan.lambd_report(71) is None and plan.lambd_report(0) is None
     # a captured forward draws a fresh number at every replay
     g = torch.cuda.CUDAGraph()
