@@ -24,9 +24,16 @@ template <int CTRL> __device__ __forceinline__ double dpp_f64(double v)
     const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xF, 0xF, true);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
 }
+#ifndef DMEL_DOT_THREADS
+#define DMEL_DOT_THREADS 256
+#endif
+// 8192 elements per workgroup and tensor whatever the workgroup size (the number of tickets on the one counter stays).  Measured at
+// BASELINE config 2, trains of launches: 256 threads (two rounds of four 16-byte loads per tensor) 4.8 us, 512 threads (every load in
+// flight at once) 4.9-5.1, 1024 threads 5.3 -- the kernel is bounded by its launch and its hand-off tail, not by the loads.
+constexpr int kDotThreads = DMEL_DOT_THREADS;
 __device__ __forceinline__ double block_sum(double v, double* red4)
 {
-    // inside each row of 16 lanes with DPP (no LDS round trips), then the 4 rows x 4 waves through LDS
+    // inside each row of 16 lanes with DPP (no LDS round trips), then the rows of all waves through LDS
     v += dpp_f64<0xB1>(v);      // quad_perm [1,0,3,2]
     v += dpp_f64<0x4E>(v);      // quad_perm [2,3,0,1]
     v += dpp_f64<0x141>(v);     // row_half_mirror
@@ -35,7 +42,7 @@ __device__ __forceinline__ double block_sum(double v, double* red4)
     if ((tid & 15) == 0) red4[tid >> 4] = v;
     __syncthreads();
     double s = 0.0;
-    for (int q = 0; q < 16; ++q) s += red4[q];
+    for (int q = 0; q < kDotThreads / 16; ++q) s += red4[q];
     return s;
 }
 
@@ -56,19 +63,19 @@ template <bool GBF16> __device__ __forceinline__ float load_g1(const void* g, lo
 }
 
 template <bool GBF16>
-__global__ void __launch_bounds__(kThreads) dmel_dot_kernel(const void* __restrict__ g, const float* __restrict__ t,
+__global__ void __launch_bounds__(kDotThreads) dmel_dot_kernel(const void* __restrict__ g, const float* __restrict__ t,
                                                             long long count, double* partials, unsigned* counter,
                                                             int accumulate, float* result)
 {
-    __shared__ double red4[16], red4b[16];
+    __shared__ double red4[kDotThreads / 16], red4b[kDotThreads / 16];
     __shared__ int is_last;
     const int tid = threadIdx.x;
-    const long long stride = (long long)gridDim.x * kThreads;
+    const long long stride = (long long)gridDim.x * kDotThreads;
     double acc = 0.0;
     const uintptr_t galign = GBF16 ? 7 : 15;
     const long long n4 = ((reinterpret_cast<uintptr_t>(g) & galign) | (reinterpret_cast<uintptr_t>(t) & 15)) == 0 ? count / 4 : 0;
     const float4* t4 = reinterpret_cast<const float4*>(t);
-    long long i = (long long)blockIdx.x * kThreads + tid;
+    long long i = (long long)blockIdx.x * kDotThreads + tid;
     for (; i + 3 * stride < n4; i += 4 * stride) {        // four independent 16-byte loads per tensor in flight
         const float4 a0 = load_g4<GBF16>(g, i), a1 = load_g4<GBF16>(g, i + stride), a2 = load_g4<GBF16>(g, i + 2 * stride), a3 = load_g4<GBF16>(g, i + 3 * stride);
         const float4 b0 = t4[i], b1 = t4[i + stride], b2 = t4[i + 2 * stride], b3 = t4[i + 3 * stride];
@@ -81,7 +88,7 @@ __global__ void __launch_bounds__(kThreads) dmel_dot_kernel(const void* __restri
         const float4 a = load_g4<GBF16>(g, i), b = t4[i];
         acc += ((double)a.x * (double)b.x + (double)a.y * (double)b.y) + ((double)a.z * (double)b.z + (double)a.w * (double)b.w);
     }
-    for (long long k = n4 * 4 + (long long)blockIdx.x * kThreads + tid; k < count; k += stride)
+    for (long long k = n4 * 4 + (long long)blockIdx.x * kDotThreads + tid; k < count; k += stride)
         acc += (double)load_g1<GBF16>(g, k) * (double)t[k];
     const double bsum = block_sum(acc, red4);
     if (tid == 0) {
@@ -93,7 +100,7 @@ __global__ void __launch_bounds__(kThreads) dmel_dot_kernel(const void* __restri
     __syncthreads();
     if (!is_last) return;
     double sum = 0.0;
-    for (int q = tid; q < (int)gridDim.x; q += kThreads)
+    for (int q = tid; q < (int)gridDim.x; q += kDotThreads)
         sum += __hip_atomic_load(&partials[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const double total = block_sum(sum, red4b);
     if (tid == 0) {
@@ -105,12 +112,12 @@ __global__ void __launch_bounds__(kThreads) dmel_dot_kernel(const void* __restri
 hipError_t launch_dot(const void* g, int g_bf16, const float* t, long long count, int accumulate, double* partials,
                       unsigned* counter, int max_partials, float* result, hipStream_t s)
 {
-    // 32 floats per thread and tensor: few workgroups on purpose -- every workgroup ends with one ticket on a single
+    // 8192 floats per workgroup and tensor: few workgroups on purpose -- every workgroup ends with one ticket on a single
     // counter (~11 ns each, serialised), which cost more than the loads at 256+ workgroups
-    long long want = (count + (long long)kThreads * 32 - 1) / ((long long)kThreads * 32);
+    long long want = (count + 8191) / 8192;
     int blocks = (int)(want < 1 ? 1 : (want > max_partials ? max_partials : want));
-    if (g_bf16) hipLaunchKernelGGL(dmel_dot_kernel<true>, dim3(blocks), dim3(kThreads), 0, s, g, t, count, partials, counter, accumulate, result);
-    else hipLaunchKernelGGL(dmel_dot_kernel<false>, dim3(blocks), dim3(kThreads), 0, s, g, t, count, partials, counter, accumulate, result);
+    if (g_bf16) hipLaunchKernelGGL(dmel_dot_kernel<true>, dim3(blocks), dim3(kDotThreads), 0, s, g, t, count, partials, counter, accumulate, result);
+    else hipLaunchKernelGGL(dmel_dot_kernel<false>, dim3(blocks), dim3(kDotThreads), 0, s, g, t, count, partials, counter, accumulate, result);
     return hipGetLastError();
 }
 
