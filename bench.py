@@ -61,6 +61,10 @@ def parse(argv=None):
                     "(DMEL_FLAG_OUT_BF16); the arithmetic, the tangent and d lambd stay fp32.  Default: fp32, the reference's output type")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the config 3 / config 5 side measurements")
+    ap.add_argument("--reducer", default="rccl", choices=["rccl", "mailbox"],
+                    help="N > 1: how lambd.grad is summed over the ranks.  rccl: ncclAllReduce issued in the step's stream between the dot "
+                         "kernel and the update (the default).  mailbox: peer-to-peer granules written by the dot kernel's last workgroup "
+                         "(dmel_mailbox_*, include/dmel.h): no launch of its own")
     ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the launcher and the reporting path (gloo, no kernels): "
                     "what tests/test_bench_launcher_cpu.py runs")
     return ap.parse_args(argv)
@@ -202,13 +206,37 @@ def dry_run(args, rank, world):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         assert float(grad) == world * (world + 1) / 2
+    # the agreed-decision path: the real GraphedStep against a CPU stand-in of the device whose "latest lambd" picture is seen
+    # late by a rank-dependent amount, every step containing a real collective (tools/graph_rehearsal.py).  A rank that re-captured
+    # at another call than the others would strand them in that collective.
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import graph_rehearsal as GR
+    from dmel_amd import GraphedStep, capi
+
+    def allreduce(v):
+        tt = torch.tensor([v], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tt)
+        return float(tt)
+
+    caps, gsteps, colls, uncovered = GR.rehearse(GraphedStep, capi.n_fft, capi.decide_launch, allreduce, rank, world, calls=120, k=2,
+                                                 max_ahead=4, eval_at=(60,))
+    agreed = True
+    if world > 1:
+        mine = torch.tensor(caps + [-1] * (64 - len(caps)))
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        agreed = all(torch.equal(e, every[0]) for e in every)
+    assert agreed and not uncovered and gsteps == 240, (caps, uncovered, gsteps)
     if rank == 0:
         print(json.dumps({"metric": "spectrogram frames/sec (fwd+bwd)", "value": round(world * B * T * args.steps / max(elapsed, 1e-9), 1),
                           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(1e3 * elapsed / max(1, args.steps), 5), "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f32", "data": "none (dry run: launcher and collective only, no kernels)",
                           "config": {"workload": "dry run", "parallelism": f"batch-sharded x{world}",
-                                     "collective": "none" if sar is None else ("native dmel_comm" if sar.native else "torch.distributed: " + sar.why)}}),
+                                     "collective": "none" if sar is None else ("native dmel_comm" if sar.native else "torch.distributed: " + sar.why),
+                                     "graphed_step_rehearsal": {"calls": 120, "steps_per_replay": 2, "capture_calls": caps, "collectives": colls,
+                                                                "same_on_every_rank": agreed}}}),
               flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -230,14 +258,24 @@ def main():
     import numpy as np
     import torch
     assert torch.cuda.is_available(), "bench.py needs a GPU (use --dry-run for the CPU rehearsal of the launcher)"
+    # DMEL_BENCH_SHARE_GPU=1: every rank on device 0 (a rehearsal of the N-rank code path on a one-GPU box: RCCL refuses two ranks
+    # on one device, so the group is gloo and the reducer must be the mailbox, whose IPC-mapped inboxes work within one GPU too)
+    share = os.environ.get("DMEL_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
+        assert args.reducer == "mailbox" or world == 1, "DMEL_BENCH_SHARE_GPU needs --reducer mailbox"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1 or os.environ.get("DMEL_BENCH_FORCE_DIST") == "1":     # the env knob exercises the RCCL path on one GPU
+    if world > 1 or os.environ.get("DMEL_BENCH_FORCE_DIST") == "1":     # the env knob exercises the reducer path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    cdev = "cpu" if share else dev                                     # where the tensors of the bench's own collectives live
 
     from dmel_amd import MelSpectrogramLayer, capi, synth
     from dmel_amd import dist as ddist
@@ -261,7 +299,15 @@ def main():
     except Exception:                                                   # noqa: BLE001
         opt = torch.optim.Adam([layer.lambd], lr=ADAM_LR, capturable=True)
         opt_kind = "Adam(capturable=True)"
-    sar = ddist.ScalarAllReduce() if dist is not None else None
+    sar, mar, reducer = None, None, "none (one rank)"
+    if dist is not None:
+        if args.reducer == "mailbox":
+            mar = ddist.MailboxAllReduce()                              # raises on every rank if any rank cannot set it up
+            mar.attach(layer, dev)
+            reducer = "peer-to-peer mailbox folded into dmel_dot_kernel (dmel_mailbox_*): no launch of its own"
+        else:
+            sar = ddist.ScalarAllReduce()
+            reducer = "RCCL ncclAllReduce in the step's stream (" + ("native dmel_comm" if sar.native else "torch.distributed: " + sar.why) + ")"
     lam_param = layer.lambd
 
     def module_step():
@@ -290,7 +336,7 @@ def main():
         barrier()
         el = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            t = torch.tensor([el], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el
@@ -317,7 +363,7 @@ def main():
             if dist is not None:
                 # every rank must time the same set of modes: a capture that failed on one rank only would leave the others
                 # replaying a graph with an all-reduce in it that this rank never joins
-                flag = torch.tensor([1 if ok else 0], device=dev)
+                flag = torch.tensor([1 if ok else 0], device=cdev)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 if ok and int(flag.item()) == 0:
                     graph_why = graph_why or "graph capture failed on another rank"
@@ -342,7 +388,7 @@ def main():
         chosen = min(trial, key=trial.get)
         if dist is not None:                                            # every rank must take the same path
             order = list(modes)
-            pick = torch.tensor([order.index(chosen)], device=dev)
+            pick = torch.tensor([order.index(chosen)], device=cdev)
             dist.all_reduce(pick, op=dist.ReduceOp.MIN)
             chosen = order[int(pick.item())]
     elif chosen == "auto":
@@ -463,9 +509,10 @@ def main():
                      "other_kernels_us": {"prep": round(prep_us, 2), "backward_dot": round(bwd_us, 2)}, "mfma_stage": mfma})
 
     par = f"batch-sharded x{world}"
-    if sar is not None:
-        par += ", one all-reduce (SUM) of lambd.grad per step before the update (RCCL, " + \
-               ("native dmel_comm in the step's stream" if sar.native else "torch.distributed: " + sar.why) + ")"
+    if dist is not None:
+        par += ", one all-reduce (SUM) of lambd.grad per step before the update: " + reducer
+        if mar is not None:
+            mar.check()
     result = {
         "metric": "spectrogram frames/sec (fwd+bwd)", "value": round(value, 1), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
@@ -474,7 +521,7 @@ def main():
         "config": {"workload": f"BASELINE config 2 per GPU: batch {B} x {L} samples @ {sr} Hz, n_fft {info['n_fft']} "
                                f"(lambd {lam}), hop {hop}, n_mels {M}, log fused; step = nn.Module forward + backward to lambd.grad + Adam update of lambd"
                    if args.config == "c2" else f"{args.config}: batch {B} x {L} @ {sr}, lambd {lam}, hop {hop}, n_mels {M}",
-                   "global_batch": B * world, "frames_per_step": frames_per_rank * world, "parallelism": par,
+                   "global_batch": B * world, "frames_per_step": frames_per_rank * world, "parallelism": par, "reducer": reducer,
                    "launch": ("eager from Python: torch.ops.dmel.mel_spectrogram + autograd + optimizer.step()" if chosen == "eager" else
                               f"HIP graph captured from the nn.Module step (dmel_amd.GraphedStep), {modes[chosen][1]} step(s) per replay") +
                              "; lambd stays on the device, no host synchronisation inside the timed region"},

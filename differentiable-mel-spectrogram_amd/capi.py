@@ -35,6 +35,8 @@ SYMBOLS = (
     "dmel_comm_allreduce", "dmel_scratch_bytes", "dmel_plan_set_filterbank_dev", "dmel_forward_scratch", "dmel_forward_dev", "dmel_forward_dev_fixed", "dmel_backward_fb_dev", "dmel_backward_scratch", "dmel_plan_get_config",
     "dmel_plan_lambd_status", "dmel_plan_set_tracking", "dmel_plan_lambd_reset",
     "dmel_plan_retain", "dmel_plan_release", "dmel_plan_lambd_report", "dmel_decide_launch", "dmel_plan_force_launch",
+    "dmel_mailbox_create", "dmel_mailbox_connect", "dmel_mailbox_destroy", "dmel_mailbox_allreduce", "dmel_mailbox_error",
+    "dmel_mailbox_set_spin_limit", "dmel_plan_attach_mailbox",
 )
 TORCH_LIB_PATH = os.path.join(_PKG_DIR, "libdmel_torch.so")
 
@@ -166,6 +168,20 @@ def load():
     L.dmel_decide_launch.restype = C.c_int
     L.dmel_plan_force_launch.argtypes = [vp, C.c_int32, C.c_int32]
     L.dmel_plan_force_launch.restype = C.c_int
+    L.dmel_mailbox_create.argtypes = [C.c_int32, C.c_int32, C.POINTER(vp), C.c_char_p]
+    L.dmel_mailbox_create.restype = C.c_int
+    L.dmel_mailbox_connect.argtypes = [vp, C.c_char_p]
+    L.dmel_mailbox_connect.restype = C.c_int
+    L.dmel_mailbox_destroy.argtypes = [vp]
+    L.dmel_mailbox_destroy.restype = C.c_int
+    L.dmel_mailbox_allreduce.argtypes = [vp, vp, vp]
+    L.dmel_mailbox_allreduce.restype = C.c_int
+    L.dmel_mailbox_error.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]
+    L.dmel_mailbox_error.restype = C.c_int
+    L.dmel_mailbox_set_spin_limit.argtypes = [vp, C.c_uint32]
+    L.dmel_mailbox_set_spin_limit.restype = C.c_int
+    L.dmel_plan_attach_mailbox.argtypes = [vp, vp]
+    L.dmel_plan_attach_mailbox.restype = C.c_int
     _lib = L
     return L
 
@@ -310,6 +326,11 @@ class Plan:
         _check(load().dmel_plan_lambd_report(self._h, C.c_uint32(int(number) & 0xFFFFFFFF), C.cast(C.byref(lam), C.POINTER(C.c_float)), C.byref(found)))
         return float(lam.value) if found.value else None
 
+    def attach_mailbox(self, mailbox):
+        """dmel_plan_attach_mailbox: backward() on this plan returns the sum over the mailbox's ranks (None detaches)."""
+        _check(load().dmel_plan_attach_mailbox(self._h, mailbox._h if mailbox is not None else None))
+        self._mailbox = mailbox                       # keep it alive as long as the plan points at it
+
     def force_launch(self, n_fft_: int = 0, guards: int = 0):
         """dmel_plan_force_launch: the caller chooses the launches of dmel_forward_dev (n_fft_ = 0: automatic again)."""
         _check(load().dmel_plan_force_launch(self._h, int(n_fft_), int(guards)))
@@ -402,6 +423,48 @@ class Comm:
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             load().dmel_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Mailbox:
+    """Owner of a dmel_mailbox handle: the peer-to-peer all-reduce of lambd.grad folded into the backward's kernel (include/dmel.h)."""
+
+    HANDLE_BYTES = 64
+
+    def __init__(self, rank: int, world: int):
+        self._h = C.c_void_p()
+        buf = C.create_string_buffer(Mailbox.HANDLE_BYTES)
+        _check(load().dmel_mailbox_create(int(rank), int(world), C.byref(self._h), buf))
+        self.rank, self.world, self.handle = int(rank), int(world), buf.raw
+
+    def connect(self, handles):
+        """``handles``: the 64-byte handles of all ranks in rank order (this rank's own entry is not opened)."""
+        blob = b"".join(handles)
+        assert len(blob) == self.world * Mailbox.HANDLE_BYTES
+        _check(load().dmel_mailbox_connect(self._h, C.create_string_buffer(blob, len(blob))))
+
+    def allreduce(self, buf_ptr: int, stream: int) -> None:
+        """buf[0] = sum over ranks of buf[0], one tiny launch on ``stream``."""
+        _check(load().dmel_mailbox_allreduce(self._h, buf_ptr, stream))
+
+    def error(self):
+        """None, or (step, missing_rank) of the first exchange that timed out since the last call."""
+        failed, step, miss = C.c_int32(0), C.c_uint32(0), C.c_int32(0)
+        _check(load().dmel_mailbox_error(self._h, C.byref(failed), C.byref(step), C.byref(miss)))
+        return (int(step.value), int(miss.value)) if failed.value else None
+
+    def set_spin_limit(self, polls: int) -> None:
+        _check(load().dmel_mailbox_set_spin_limit(self._h, int(polls)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            load().dmel_mailbox_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -29,6 +29,8 @@ dmel_status fail(dmel_status st, const std::string& msg)
 
 namespace dmel {
 dmel_status set_error(dmel_status st, const std::string& msg) { return fail(st, msg); }   // for dmel_comm.cpp
+bool mailbox_args(const dmel_mailbox* mb, MailboxArgs* out);                              // dmel_comm.cpp
+int mailbox_device(const dmel_mailbox* mb);
 }
 
 namespace {
@@ -120,6 +122,7 @@ struct dmel_plan {
     int forced_n_fft = 0, forced_guards = 0;    // dmel_plan_force_launch: the caller chooses the launches (0: the library does)
     int last_guards = 0;           // bit 0: n_fft/2 launched, bit 1: 2 n_fft launched (most recent call)
     int refs = 1;                  // dmel_plan_retain / dmel_plan_release (guarded by g_plans_mu)
+    dmel_mailbox* mailbox = nullptr;    // dmel_plan_attach_mailbox: the backward's result is the sum over the mailbox's ranks
     std::mutex mu;
     dmel_plan_info info{};
     // optional event timing
@@ -1222,10 +1225,22 @@ dmel_status dmel_backward_scratch(dmel_plan* plan, const void* grad_out, int32_t
         if (st != DMEL_OK) return st;
         if ((st = ensure_own_scratch(plan, 1, s, &sc)) != DMEL_OK) return st;
     }
+    dmel::MailboxArgs mba;
+    const bool use_mb = plan->mailbox != nullptr;
+    if (use_mb && !dmel::mailbox_args(plan->mailbox, &mba)) return fail(DMEL_ERR_INVALID_ARGUMENT, "the plan's mailbox is not connected");
     const size_t m0 = prof_mark(plan, s);
     DMEL_HIP(dmel::launch_dot(grad_out, grad_dtype == DMEL_DTYPE_BF16, tangent, (long long)count, accumulate, sc.partials,
-                              sc.counter, kMaxPartials, dlambd, s));
+                              sc.counter, kMaxPartials, dlambd, s, use_mb ? &mba : nullptr));
     prof_span(plan, m0, prof_mark(plan, s), 2);
+    return DMEL_OK;
+}
+
+dmel_status dmel_plan_attach_mailbox(dmel_plan* plan, dmel_mailbox* mb)
+{
+    if (!plan) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
+    if (mb && dmel::mailbox_device(mb) != plan->device) return fail(DMEL_ERR_INVALID_ARGUMENT, "the mailbox and the plan live on different devices");
+    std::lock_guard<std::mutex> lock(plan->mu);
+    plan->mailbox = mb;
     return DMEL_OK;
 }
 

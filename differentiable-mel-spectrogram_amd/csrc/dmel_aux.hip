@@ -62,10 +62,51 @@ template <bool GBF16> __device__ __forceinline__ float load_g1(const void* g, lo
     else return __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(g)[k] << 16);
 }
 
-template <bool GBF16>
+// The exchange step of the mailbox reducer (MailboxArgs in dmel_kernels.h), executed by ONE lane: returns the sum over ranks.
+__device__ __forceinline__ float mailbox_exchange(const MailboxArgs& mb, float local)
+{
+    const unsigned step = *mb.step + 1u;
+    *mb.step = step;
+    const unsigned long long mine = ((unsigned long long)step << 32) | __builtin_bit_cast(unsigned, local);
+    const int par = (int)(step & 1u) * mb.world;
+    for (int r = 0; r < mb.world; ++r)                               // own inbox included: one code path, and the sum is in rank order
+        __hip_atomic_store(mb.peer_inbox[r] + par + mb.rank, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    float sum = 0.f;
+    bool ok = true;
+    for (int r = 0; r < mb.world; ++r) {
+        unsigned long long w = 0;
+        unsigned spins = 0;
+        for (;;) {
+            w = __hip_atomic_load(mb.my_inbox + par + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((unsigned)(w >> 32) == step) break;
+            if (++spins >= mb.spin_limit) { ok = false; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (!ok) {
+            if (mb.host_error)
+                __hip_atomic_store(mb.host_error, ((unsigned long long)step << 32) | (unsigned)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return __builtin_nanf("");
+        }
+        sum += __builtin_bit_cast(float, (unsigned)w);
+    }
+    return sum;
+}
+
+__global__ void __launch_bounds__(64) dmel_mailbox_kernel(float* buf, MailboxArgs mb)
+{
+    if (threadIdx.x == 0) buf[0] = mailbox_exchange(mb, buf[0]);
+}
+
+hipError_t launch_mailbox_allreduce(float* buf, const MailboxArgs& mb, hipStream_t s)
+{
+    hipLaunchKernelGGL(dmel_mailbox_kernel, dim3(1), dim3(64), 0, s, buf, mb);
+    return hipGetLastError();
+}
+
+template <bool GBF16, bool MBOX>
 __global__ void __launch_bounds__(kDotThreads) dmel_dot_kernel(const void* __restrict__ g, const float* __restrict__ t,
                                                             long long count, double* partials, unsigned* counter,
-                                                            int accumulate, float* result)
+                                                            int accumulate, float* result, MailboxArgs mb)
 {
     __shared__ double red4[kDotThreads / 16], red4b[kDotThreads / 16];
     __shared__ int is_last;
@@ -104,20 +145,33 @@ __global__ void __launch_bounds__(kDotThreads) dmel_dot_kernel(const void* __res
         sum += __hip_atomic_load(&partials[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const double total = block_sum(sum, red4b);
     if (tid == 0) {
-        result[0] = accumulate ? (float)((double)result[0] + total) : (float)total;
         __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (MBOX) {
+            // data-parallel ranks: what is accumulated is the sum over ranks of this step's local sums
+            const float all = mailbox_exchange(mb, (float)total);
+            result[0] = accumulate ? result[0] + all : all;
+        } else {
+            result[0] = accumulate ? (float)((double)result[0] + total) : (float)total;
+        }
     }
 }
 
 hipError_t launch_dot(const void* g, int g_bf16, const float* t, long long count, int accumulate, double* partials,
-                      unsigned* counter, int max_partials, float* result, hipStream_t s)
+                      unsigned* counter, int max_partials, float* result, hipStream_t s, const MailboxArgs* mb)
 {
     // 8192 floats per workgroup and tensor: few workgroups on purpose -- every workgroup ends with one ticket on a single
     // counter (~11 ns each, serialised), which cost more than the loads at 256+ workgroups
     long long want = (count + 8191) / 8192;
     int blocks = (int)(want < 1 ? 1 : (want > max_partials ? max_partials : want));
-    if (g_bf16) hipLaunchKernelGGL(dmel_dot_kernel<true>, dim3(blocks), dim3(kDotThreads), 0, s, g, t, count, partials, counter, accumulate, result);
-    else hipLaunchKernelGGL(dmel_dot_kernel<false>, dim3(blocks), dim3(kDotThreads), 0, s, g, t, count, partials, counter, accumulate, result);
+    const MailboxArgs none{};
+    const dim3 gr(blocks), bl(kDotThreads);
+    if (mb) {
+        if (g_bf16) hipLaunchKernelGGL((dmel_dot_kernel<true, true>), gr, bl, 0, s, g, t, count, partials, counter, accumulate, result, *mb);
+        else hipLaunchKernelGGL((dmel_dot_kernel<false, true>), gr, bl, 0, s, g, t, count, partials, counter, accumulate, result, *mb);
+    } else {
+        if (g_bf16) hipLaunchKernelGGL((dmel_dot_kernel<true, false>), gr, bl, 0, s, g, t, count, partials, counter, accumulate, result, none);
+        else hipLaunchKernelGGL((dmel_dot_kernel<false, false>), gr, bl, 0, s, g, t, count, partials, counter, accumulate, result, none);
+    }
     return hipGetLastError();
 }
 

@@ -8,6 +8,7 @@
 // RCCL is resolved with dlopen at first use (the library must stay loadable on machines without it), and the
 // copy torch already loaded is preferred so that the process holds ONE RCCL.
 #include "../../include/dmel.h"
+#include "dmel_kernels.h"
 
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
@@ -163,6 +164,142 @@ dmel_status dmel_comm_wait(dmel_comm* c, int32_t ticket, void* stream)
 {
     if (!c || ticket < 0 || ticket >= kRing) return dmel::set_error(DMEL_ERR_INVALID_ARGUMENT, "dmel_comm_wait: bad ticket");
     COMM_HIP(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), c->done[ticket], 0));
+    return DMEL_OK;
+}
+
+}  // extern "C"
+
+
+// ---- peer-to-peer mailbox (include/dmel.h; the kernel side is mailbox_exchange in dmel_aux.hip) ---------------------------------
+struct dmel_mailbox {
+    int rank = 0, world = 1, device = 0;
+    unsigned long long* inbox = nullptr;        // [2][world] granules on this device
+    unsigned* step = nullptr;                   // device word
+    unsigned long long* host_error = nullptr;   // pinned
+    void* peer[DMEL_MAILBOX_MAX_WORLD] = {};    // mapped inboxes (peer[rank] == inbox)
+    bool opened[DMEL_MAILBOX_MAX_WORLD] = {};
+    bool connected = false;
+    unsigned spin_limit = 1u << 21;
+};
+
+namespace dmel {
+// what dmel_api.cpp needs to launch the dot kernel with the exchange in its tail
+bool mailbox_args(const dmel_mailbox* mb, MailboxArgs* out)
+{
+    if (!mb || !mb->connected) return false;
+    MailboxArgs a{};
+    for (int r = 0; r < mb->world; ++r) a.peer_inbox[r] = static_cast<unsigned long long*>(mb->peer[r]);
+    a.my_inbox = mb->inbox; a.step = mb->step; a.host_error = mb->host_error;
+    a.rank = mb->rank; a.world = mb->world; a.spin_limit = mb->spin_limit;
+    *out = a;
+    return true;
+}
+int mailbox_device(const dmel_mailbox* mb) { return mb ? mb->device : -1; }
+}  // namespace dmel
+
+extern "C" {
+
+dmel_status dmel_mailbox_create(int32_t rank, int32_t world, dmel_mailbox** out, uint8_t handle[DMEL_MAILBOX_HANDLE_BYTES])
+{
+    if (!out || !handle || world < 1 || world > DMEL_MAILBOX_MAX_WORLD || rank < 0 || rank >= world)
+        return dmel::set_error(DMEL_ERR_INVALID_ARGUMENT, "dmel_mailbox_create: bad arguments (world <= 16)");
+    *out = nullptr;
+    static_assert(sizeof(hipIpcMemHandle_t) == DMEL_MAILBOX_HANDLE_BYTES, "hipIpcMemHandle_t is 64 bytes");
+    static_assert(DMEL_MAILBOX_MAX_WORLD == dmel::kMailboxMaxWorld, "header and kernel agree on the largest world");
+    dmel_mailbox* mb = new (std::nothrow) dmel_mailbox();
+    if (!mb) return dmel::set_error(DMEL_ERR_OUT_OF_MEMORY, "host allocation failed");
+    mb->rank = rank; mb->world = world;
+    hipError_t e = hipGetDevice(&mb->device);
+    const size_t bytes = 4096;                                           // 2 x 16 granules; a page of its own
+    // uncached (fine-grained) device memory: remote stores and local polls both go to memory, not to a cache of either device
+    if (e == hipSuccess) {
+        e = hipExtMallocWithFlags(reinterpret_cast<void**>(&mb->inbox), bytes, hipDeviceMallocUncached);
+        if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(reinterpret_cast<void**>(&mb->inbox), bytes); }
+    }
+    if (e == hipSuccess) e = hipMemset(mb->inbox, 0, bytes);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&mb->step), 64);
+    if (e == hipSuccess) e = hipMemset(mb->step, 0, 64);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&mb->host_error), 64, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) { std::memset(mb->host_error, 0, 64); e = hipDeviceSynchronize(); }
+    hipIpcMemHandle_t h;
+    std::memset(&h, 0, sizeof(h));
+    if (e == hipSuccess && world > 1) {
+        e = hipIpcGetMemHandle(&h, mb->inbox);
+        if (e != hipSuccess) {
+            // not every allocation kind can be exported: fall back to ordinary device memory (the exchange uses system-scope
+            // stores and loads either way)
+            (void)hipGetLastError();
+            (void)hipFree(mb->inbox); mb->inbox = nullptr;
+            e = hipMalloc(reinterpret_cast<void**>(&mb->inbox), bytes);
+            if (e == hipSuccess) e = hipMemset(mb->inbox, 0, bytes);
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+            if (e == hipSuccess) e = hipIpcGetMemHandle(&h, mb->inbox);
+        }
+    }
+    if (e != hipSuccess) {
+        const std::string msg = std::string("dmel_mailbox_create: ") + hipGetErrorString(e);
+        dmel_mailbox_destroy(mb);
+        return dmel::set_error(DMEL_ERR_HIP, msg);
+    }
+    std::memcpy(handle, &h, sizeof(h));
+    *out = mb;
+    return DMEL_OK;
+}
+
+dmel_status dmel_mailbox_connect(dmel_mailbox* mb, const uint8_t* handles)
+{
+    if (!mb || (!handles && mb->world > 1)) return dmel::set_error(DMEL_ERR_INVALID_ARGUMENT, "dmel_mailbox_connect: NULL argument");
+    if (mb->connected) return dmel::set_error(DMEL_ERR_INVALID_ARGUMENT, "dmel_mailbox_connect: already connected");
+    for (int r = 0; r < mb->world; ++r) {
+        if (r == mb->rank) { mb->peer[r] = mb->inbox; continue; }
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, handles + (size_t)r * DMEL_MAILBOX_HANDLE_BYTES, sizeof(h));
+        void* p = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return dmel::set_error(DMEL_ERR_HIP, "dmel_mailbox_connect: hipIpcOpenMemHandle(rank " + std::to_string(r) + "): " + hipGetErrorString(e));
+        }
+        mb->peer[r] = p; mb->opened[r] = true;
+    }
+    mb->connected = true;
+    return DMEL_OK;
+}
+
+dmel_status dmel_mailbox_destroy(dmel_mailbox* mb)
+{
+    if (!mb) return DMEL_OK;
+    (void)hipDeviceSynchronize();
+    for (int r = 0; r < mb->world; ++r) if (mb->opened[r]) (void)hipIpcCloseMemHandle(mb->peer[r]);
+    (void)hipFree(mb->inbox); (void)hipFree(mb->step);
+    if (mb->host_error) (void)hipHostFree(mb->host_error);
+    (void)hipGetLastError();
+    delete mb;
+    return DMEL_OK;
+}
+
+dmel_status dmel_mailbox_allreduce(dmel_mailbox* mb, float* buf, void* stream)
+{
+    dmel::MailboxArgs a;
+    if (!buf || !dmel::mailbox_args(mb, &a)) return dmel::set_error(DMEL_ERR_INVALID_ARGUMENT, "dmel_mailbox_allreduce: NULL buffer or a mailbox that is not connected");
+    COMM_HIP(dmel::launch_mailbox_allreduce(buf, a, reinterpret_cast<hipStream_t>(stream)));
+    return DMEL_OK;
+}
+
+dmel_status dmel_mailbox_error(dmel_mailbox* mb, int32_t* failed, uint32_t* step, int32_t* missing_rank)
+{
+    if (!mb || !failed) return dmel::set_error(DMEL_ERR_INVALID_ARGUMENT, "dmel_mailbox_error: NULL argument");
+    const unsigned long long w = __atomic_exchange_n(mb->host_error, 0ull, __ATOMIC_RELAXED);
+    *failed = w != 0 ? 1 : 0;
+    if (step) *step = (uint32_t)(w >> 32);
+    if (missing_rank) *missing_rank = (int32_t)(uint32_t)w;
+    return DMEL_OK;
+}
+
+dmel_status dmel_mailbox_set_spin_limit(dmel_mailbox* mb, uint32_t polls)
+{
+    if (!mb || polls == 0) return dmel::set_error(DMEL_ERR_INVALID_ARGUMENT, "dmel_mailbox_set_spin_limit: bad arguments");
+    mb->spin_limit = polls;
     return DMEL_OK;
 }
 

@@ -334,8 +334,27 @@ struct RepackParams {
 };
 hipError_t launch_repack(const RepackParams& p, hipStream_t s);
 
+// Peer-to-peer all-reduce of the one scalar this path exchanges (d lambd), folded into the tail of the dot kernel: the workgroup
+// that draws the last ticket stores (step, local sum) as ONE 8-byte granule into slot `rank` of every rank's inbox -- peer memory
+// mapped over xGMI, system-scope stores -- then polls its own inbox until every rank's granule of this step has arrived and adds
+// them in rank order (the same fp32 sum on every rank).  Two slots per source, by step parity: a rank cannot be two steps ahead
+// of another (it needs the other's granule of step k + 1, written only after that rank has read step k).  Every spin is bounded:
+// a peer that never arrives yields NaN and raises a pinned error word instead of hanging the device.
+constexpr int kMailboxMaxWorld = 16;
+struct MailboxArgs {
+    unsigned long long* peer_inbox[kMailboxMaxWorld];   // inbox of every rank as seen from this device ([2][world] granules each)
+    unsigned long long* my_inbox;
+    unsigned* step;                   // device word: reduce steps done so far on this rank (identical on all ranks)
+    unsigned long long* host_error;   // pinned: (step << 32) | rank that was missing, or nullptr
+    int rank, world;
+    unsigned spin_limit;              // polls per source before giving up
+};
+
 // g: fp32, or bf16 when g_bf16 != 0 (the gradient of a bf16 output); t (the tangent) is always fp32
+// mb != nullptr: the result is the SUM over all ranks of the mailbox (dmel_comm.cpp)
 hipError_t launch_dot(const void* g, int g_bf16, const float* t, long long count, int accumulate, double* partials,
-                      unsigned* counter, int max_partials, float* result, hipStream_t s);
+                      unsigned* counter, int max_partials, float* result, hipStream_t s, const MailboxArgs* mb = nullptr);
+// the same exchange for a value that is already in memory (one wave): buf[0] = sum over ranks of buf[0]
+hipError_t launch_mailbox_allreduce(float* buf, const MailboxArgs& mb, hipStream_t s);
 
 }  // namespace dmel

@@ -112,3 +112,65 @@ class ScalarAllReduce:
         if self._comm is not None:
             self._comm.close()
             self._comm = None
+
+
+class MailboxAllReduce:
+    """The scalar all-reduce without RCCL and without a launch of its own: a peer-to-peer mailbox folded into the tail of the
+    backward's dot kernel (include/dmel.h, dmel_mailbox_*).  Opt-in; ``ScalarAllReduce`` (RCCL) stays the default.
+
+        mar = MailboxAllReduce()                  # collective: every rank creates an inbox, the IPC handles are all-gathered
+        mar.attach(layer, x.device)               # from now on layer's backward leaves the SUM over ranks in lambd.grad
+        ... loss.backward(); optimizer.step()     # no reduce call in the step
+
+    Every rank must run the same number of backwards through the attached layer (as with any collective).  Ranks are other
+    processes on GPUs of one node reachable through hipIpcOpenMemHandle (xGMI peers, or the same GPU).  If any rank fails to set
+    the mailbox up, every rank raises (the set-up collectives are symmetric)."""
+
+    def __init__(self, group=None):
+        if not dist.is_available() or not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        from . import capi
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        err, self.mailbox = "", None
+        try:
+            self.mailbox = capi.Mailbox(self.rank, self.world)
+        except Exception as e:      # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"
+        info = [None] * self.world
+        dist.all_gather_object(info, (self.mailbox.handle if self.mailbox else None, err), group=group)
+        bad = [f"rank {r}: {e}" for r, (h, e) in enumerate(info) if h is None]
+        if not bad:
+            try:
+                self.mailbox.connect([h for h, _ in info])
+            except Exception as e:      # noqa: BLE001
+                err = f"{type(e).__name__}: {e}"
+        oks = [None] * self.world
+        dist.all_gather_object(oks, err if not bad else "create failed elsewhere", group=group)
+        bad += [f"rank {r}: {e}" for r, e in enumerate(oks) if e and not bad]
+        if bad:
+            self.close()
+            raise RuntimeError("mailbox all-reduce could not be set up (" + "; ".join(bad) + "): use ScalarAllReduce")
+
+    def attach(self, layer, device) -> None:
+        """``layer``: a MelSpectrogramLayer (its plan for ``device`` is created if needed)."""
+        import torch as _t
+        layer._plan_for(_t.device(device)).attach_mailbox(self.mailbox)
+
+    def detach(self, layer, device) -> None:
+        import torch as _t
+        layer._plan_for(_t.device(device)).attach_mailbox(None)
+
+    def reduce(self, grad: torch.Tensor, stream: int) -> None:
+        """For gradients that did not come out of an attached layer: grad[0] = sum over ranks (one tiny launch in ``stream``)."""
+        self.mailbox.allreduce(grad.data_ptr(), stream)
+
+    def check(self) -> None:
+        e = self.mailbox.error() if self.mailbox is not None else None
+        if e is not None:
+            raise RuntimeError(f"mailbox all-reduce: rank {e[1]} never arrived at exchange {e[0]} (the result was NaN)")
+
+    def close(self):
+        if self.mailbox is not None:
+            self.mailbox.close()
+            self.mailbox = None

@@ -293,6 +293,33 @@ dmel_status dmel_comm_allreduce(dmel_comm* comm, float* buf, int32_t count, void
 /* make `stream` wait for the all-reduce `ticket`; the host does not block */
 dmel_status dmel_comm_wait(dmel_comm* comm, int32_t ticket, void* stream);
 
+/* ---- the same exchange without RCCL: a peer-to-peer mailbox folded into the backward's own kernel ---------------------------
+ * ncclAllReduce of 4 bytes costs a kernel of its own and the small-message latency of its ring on the critical path of a
+ * ~35 us step (the optimizer update needs the reduced gradient).  With a mailbox the workgroup of dmel_backward's dot kernel
+ * that finishes last stores (step, local sum) as one 8-byte granule straight into every rank's inbox (peer memory over xGMI,
+ * system-scope stores), polls its own inbox for the other ranks' granules of the same step and adds them in rank order: no
+ * extra launch, no ring, the same fp32 result on every rank.  Opt-in; RCCL (dmel_comm_*) stays the default.  Every spin is
+ * bounded: a rank that never arrives makes the result NaN and raises the error word instead of hanging the device.
+ *   1. every rank: dmel_mailbox_create (allocates its inbox on the current device, returns a 64-byte IPC handle)
+ *   2. the handles of all ranks, in rank order, travel by any means (dmel_amd.dist uses torch.distributed) to
+ *      dmel_mailbox_connect, which maps the peers' inboxes (hipIpcOpenMemHandle; ranks of one process: pass the handle, the
+ *      pointer is used directly)
+ *   3. dmel_plan_attach_mailbox(plan, mb): from then on dmel_backward / dmel_backward_scratch on that plan return the SUM over
+ *      ranks (every rank must call them the same number of times, as with any collective); mb = NULL detaches.
+ *      dmel_mailbox_allreduce does the same exchange for a value already in memory (one tiny launch on `stream`). */
+#define DMEL_MAILBOX_HANDLE_BYTES 64
+#define DMEL_MAILBOX_MAX_WORLD 16
+typedef struct dmel_mailbox dmel_mailbox;
+dmel_status dmel_mailbox_create(int32_t rank, int32_t world, dmel_mailbox** mb, uint8_t handle[DMEL_MAILBOX_HANDLE_BYTES]);
+dmel_status dmel_mailbox_connect(dmel_mailbox* mb, const uint8_t* handles /* world x DMEL_MAILBOX_HANDLE_BYTES, rank order */);
+dmel_status dmel_mailbox_destroy(dmel_mailbox* mb);
+dmel_status dmel_mailbox_allreduce(dmel_mailbox* mb, float* buf, void* stream);
+/* 0 = no exchange has timed out; otherwise *step / *missing_rank name the first one that did (sticky until read) */
+dmel_status dmel_mailbox_error(dmel_mailbox* mb, int32_t* failed, uint32_t* step, int32_t* missing_rank);
+/* polls per source rank before an exchange gives up (default 1 << 21, a few seconds) */
+dmel_status dmel_mailbox_set_spin_limit(dmel_mailbox* mb, uint32_t polls);
+dmel_status dmel_plan_attach_mailbox(dmel_plan* plan, dmel_mailbox* mb);
+
 /* Introspection for tests / benchmarks */
 typedef struct dmel_plan_info {
     int32_t n_fft;             /* of the most recent forward                                */
