@@ -56,8 +56,10 @@ void linspace_f32(float start, float end, int steps, std::vector<float>& out)
 struct NfftTables {
     int n_fft = 0, F = 0, KS = 0, NT = 0, groups = 0;
     int n_entries = 0, n_dense = 0;
-    float2* tw1 = nullptr;
+    float2* tw1 = nullptr;       // twiddles of the plan of the training modes ...
     float2* tw2 = nullptr;
+    float2* tw1p = nullptr;      // ... and of the modes that pack two frames per FFT, where that plan differs (else the same pointers)
+    float2* tw2p = nullptr;
     float* ent_b = nullptr;
     float* ent_pre = nullptr;
     int pre_groups[16] = {};     // per (wave, run) of group 0: real groups of 4 k-steps inside ent_pre
@@ -70,7 +72,9 @@ struct NfftTables {
     int2* rowband = nullptr;     // (F): non-zero column range of every filterbank row (dL/dx)
     void release()
     {
-        void* ptrs[] = {tw1, tw2, ent_b, ent_pre, tile_ranges, fb_dense, tw_long, fbT, band, rowband};
+        if (tw1p == tw1) tw1p = nullptr;
+        if (tw2p == tw2) tw2p = nullptr;
+        void* ptrs[] = {tw1, tw2, tw1p, tw2p, ent_b, ent_pre, tile_ranges, fb_dense, tw_long, fbT, band, rowband};
         for (void* q : ptrs) (void)hipFree(q);
         *this = NfftTables();
     }
@@ -217,24 +221,36 @@ dmel_status build_tables(dmel_plan* pl, int N, NfftTables** out)
         DMEL_HIP(hipMalloc(&tb.band, band.size() * sizeof(int2)));
         DMEL_HIP(hipMemcpy(tb.band, band.data(), band.size() * sizeof(int2), hipMemcpyHostToDevice));
     } else if (N >= dmel::kMinFastNfft) {
-        int R = 0, C = 0;
-        if (!dmel::forward_plan_rc(N, &R, &C)) return fail(DMEL_ERR_UNSUPPORTED, "n_fft has no FFT plan");
-        const int G = N / R;
-        std::vector<float2> tw1((size_t)R * G), tw2((size_t)R * C);
-        for (int q = 0; q < R; ++q)
-            for (int lg = 0; lg < G; ++lg) {
-                const double th = -2.0 * M_PI * (double)((long long)lg * q % N) / (double)N;
-                tw1[(size_t)q * G + lg] = make_float2((float)std::cos(th), (float)std::sin(th));
-            }
-        for (int p1 = 0; p1 < R; ++p1)
-            for (int r = 0; r < C; ++r) {
-                const double th = -2.0 * M_PI * (double)(r * p1 % G) / (double)G;
-                tw2[(size_t)p1 * C + r] = make_float2((float)std::cos(th), (float)std::sin(th));
-            }
-        DMEL_HIP(hipMalloc(&tb.tw1, tw1.size() * sizeof(float2)));
-        DMEL_HIP(hipMemcpy(tb.tw1, tw1.data(), tw1.size() * sizeof(float2), hipMemcpyHostToDevice));
-        DMEL_HIP(hipMalloc(&tb.tw2, tw2.size() * sizeof(float2)));
-        DMEL_HIP(hipMemcpy(tb.tw2, tw2.data(), tw2.size() * sizeof(float2), hipMemcpyHostToDevice));
+        // twiddle tables of a plan (R, C): tw1 (R, G) = w_N^(lg q), tw2 (R, C) = w_G^(r p1)
+        auto make_tw = [&](bool pair, float2** d1, float2** d2) -> dmel_status {
+            int R = 0, C = 0;
+            if (!dmel::forward_plan_rc(N, pair, &R, &C)) return fail(DMEL_ERR_UNSUPPORTED, "n_fft has no FFT plan");
+            const int G = N / R;
+            std::vector<float2> tw1((size_t)R * G), tw2((size_t)R * C);
+            for (int q = 0; q < R; ++q)
+                for (int lg = 0; lg < G; ++lg) {
+                    const double th = -2.0 * M_PI * (double)((long long)lg * q % N) / (double)N;
+                    tw1[(size_t)q * G + lg] = make_float2((float)std::cos(th), (float)std::sin(th));
+                }
+            for (int p1 = 0; p1 < R; ++p1)
+                for (int r = 0; r < C; ++r) {
+                    const double th = -2.0 * M_PI * (double)(r * p1 % G) / (double)G;
+                    tw2[(size_t)p1 * C + r] = make_float2((float)std::cos(th), (float)std::sin(th));
+                }
+            DMEL_HIP(hipMalloc(d1, tw1.size() * sizeof(float2)));
+            DMEL_HIP(hipMemcpy(*d1, tw1.data(), tw1.size() * sizeof(float2), hipMemcpyHostToDevice));
+            DMEL_HIP(hipMalloc(d2, tw2.size() * sizeof(float2)));
+            DMEL_HIP(hipMemcpy(*d2, tw2.data(), tw2.size() * sizeof(float2), hipMemcpyHostToDevice));
+            return DMEL_OK;
+        };
+        {
+            dmel_status stw = make_tw(false, &tb.tw1, &tb.tw2);
+            if (stw != DMEL_OK) return stw;
+            int r0 = 0, c0 = 0, r1 = 0, c1 = 0;
+            dmel::forward_plan_rc(N, false, &r0, &c0); dmel::forward_plan_rc(N, true, &r1, &c1);
+            if (r0 == r1 && c0 == c1) { tb.tw1p = tb.tw1; tb.tw2p = tb.tw2; }
+            else if ((stw = make_tw(true, &tb.tw1p, &tb.tw2p)) != DMEL_OK) return stw;
+        }
 
         // Non-zero 4 x 16 blocks of the filterbank as MFMA B-fragments.  Mel tiles are handled in
         // groups of 8 (128 mel bands); inside a group wave w owns tiles w and 7-w (the HTK bands
@@ -587,7 +603,7 @@ dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dm
     }
     dmel::FwdParams fp{};
     fp.x = x; fp.out = out; fp.tangent = tangent; fp.psum = (remove_dc && !kernel_mean) ? sc.psum : nullptr; fp.win2 = sc.win;
-    fp.tw1 = tb->tw1; fp.tw2 = tb->tw2; fp.ent_b = tb->ent_b; fp.tile_ranges = tb->tile_ranges; fp.ent_b_floats = tb->ent_b_floats; fp.ent_pre = tb->ent_pre;
+    fp.tw1 = dmel::mode_pairs(mode) ? tb->tw1p : tb->tw1; fp.tw2 = dmel::mode_pairs(mode) ? tb->tw2p : tb->tw2; fp.ent_b = tb->ent_b; fp.tile_ranges = tb->tile_ranges; fp.ent_b_floats = tb->ent_b_floats; fp.ent_pre = tb->ent_pre;
     for (int i = 0; i < 16; ++i) fp.pre_groups[i] = tb->pre_groups[i];
     fp.B = batch; fp.L = pl->cfg.n_points; fp.T = pl->T; fp.hop = pl->cfg.hop_length; fp.M = pl->cfg.n_mels;
     fp.nchunks = pl->nchunks; fp.groups = tb->groups;
@@ -596,8 +612,8 @@ dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dm
     fp.inv_L = inv_L; fp.eps = (float)eps; fp.flags = flags; fp.lam = lam;
     fp.remove_dc = remove_dc; fp.normalize = pl->cfg.normalize_window; fp.win_half = win_half;
     static const int force_tpw = std::getenv("DMEL_TILES_PER_WG") ? std::atoi(std::getenv("DMEL_TILES_PER_WG")) : 0;   // diagnostics
-    int tpw = dmel::forward_tiles_per_wg(N, batch, fp.tiles_per_clip);
-    if (force_tpw == 1 || (force_tpw == 2 && dmel::forward_two_tiles(N))) tpw = force_tpw;
+    int tpw = dmel::forward_tiles_per_wg(N, mode, batch, fp.tiles_per_clip);
+    if (force_tpw == 1 || (force_tpw == 2 && dmel::forward_two_tiles(N, mode))) tpw = force_tpw;
     fp.wgs_per_clip = (fp.tiles_per_clip + tpw - 1) / tpw;
     const long long grid = (long long)batch * fp.wgs_per_clip;
     if (grid > 0x7fffffffLL) return fail(DMEL_ERR_INVALID_ARGUMENT, "too many tiles for one launch");
@@ -605,7 +621,7 @@ dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dm
     prof_span(pl, m1, prof_mark(pl, s), 1);
     pl->info.kernel_path = 0; pl->info.frames_per_tile = fpt; pl->info.grid_fwd = (int)grid;
     pl->info.fb_blocks = tb->n_entries; pl->info.fb_blocks_dense = tb->n_dense;
-    pl->info.lds_bytes = dmel::forward_lds_bytes(N);
+    pl->info.lds_bytes = dmel::forward_lds_bytes(N, mode);
     return DMEL_OK;
 }
 

@@ -272,9 +272,9 @@ __device__ __forceinline__ void stamp_place(int wgid, int wave, int lane)
 // are requested while the first is transformed, and a launch needs half the workgroups (one round of resident workgroups
 // instead of two at BASELINE config 2).
 template <int N, int MODE, int TPW>
-__global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_kernel(FwdParams p)
+__global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N, mode_pairs(MODE)>().MINW)) dmel_fwd_kernel(FwdParams p)
 {
-    constexpr FftGeom g = geom<N>();
+    constexpr FftGeom g = geom<N, mode_pairs(MODE)>();
     constexpr int R = g.R, C = g.C, G = g.G, FPW = g.FPW, PASSES = g.PASSES, SLOTS = g.SLOTS, MT = g.MT;
     constexpr int WAVES = g.WAVES, NLOC = g.NLOC, THREADS = g.THREADS;
     constexpr int LB = ilog2(R);
@@ -1181,34 +1181,29 @@ __global__ void __launch_bounds__(geom<N>().THREADS, geom<N>().MINW) dmel_fwd_ke
 
 template <int N, int MODE, int TPW> static hipError_t launch_one(const FwdParams& p, int grid, hipStream_t s)
 {
-    constexpr FftGeom g = geom<N>();
+    constexpr FftGeom g = geom<N, mode_pairs(MODE)>();
     constexpr int lds = g.LDS_BYTES;
     hipLaunchKernelGGL((dmel_fwd_kernel<N, MODE, TPW>), dim3(grid), dim3(g.THREADS), lds, s, p);
     return hipGetLastError();
 }
 
 // two tiles per workgroup are built for the sizes whose launches are large enough to use them (forward_tiles_per_wg)
-template <int N> constexpr bool has_tpw2() { return N >= 256 && (N <= 512 || (N == 1024 && geom<N>().G == 64)); }   // (32 x 32 plan at 1024: 16-frame tiles, two of them spill)
+template <int N, bool PAIR> constexpr bool has_tpw2() { return N >= 256 && (N <= 512 || (N == 1024 && geom<N, PAIR>().G == 64)); }   // (32 x 32 plan at 1024: 16-frame tiles, two of them spill)
+
+template <int N, int MODE> static hipError_t launch_mode(int tpw, const FwdParams& p, int grid, hipStream_t s)
+{
+    if constexpr (has_tpw2<N, mode_pairs(MODE)>()) { if (tpw == 2) return launch_one<N, MODE, 2>(p, grid, s); }
+    if (tpw != 1) return hipErrorInvalidValue;
+    return launch_one<N, MODE, 1>(p, grid, s);
+}
 
 template <int N> static hipError_t launch_n(int mode, int tpw, const FwdParams& p, int grid, hipStream_t s)
 {
-    if constexpr (has_tpw2<N>()) {
-        if (tpw == 2) {
-            switch (mode) {
-                case kTrain: return launch_one<N, kTrain, 2>(p, grid, s);
-                case kInfer: return launch_one<N, kInfer, 2>(p, grid, s);
-                case kSpec: return launch_one<N, kSpec, 2>(p, grid, s);
-                case kSpecTrain: return launch_one<N, kSpecTrain, 2>(p, grid, s);
-            }
-            return hipErrorInvalidValue;
-        }
-    }
-    if (tpw != 1) return hipErrorInvalidValue;
     switch (mode) {
-        case kTrain: return launch_one<N, kTrain, 1>(p, grid, s);
-        case kInfer: return launch_one<N, kInfer, 1>(p, grid, s);
-        case kSpec: return launch_one<N, kSpec, 1>(p, grid, s);
-        case kSpecTrain: return launch_one<N, kSpecTrain, 1>(p, grid, s);
+        case kTrain: return launch_mode<N, kTrain>(tpw, p, grid, s);
+        case kInfer: return launch_mode<N, kInfer>(tpw, p, grid, s);
+        case kSpec: return launch_mode<N, kSpec>(tpw, p, grid, s);
+        case kSpecTrain: return launch_mode<N, kSpecTrain>(tpw, p, grid, s);
     }
     return hipErrorInvalidValue;
 }
@@ -1245,109 +1240,108 @@ hipError_t launch_forward(int n_fft, int mode, int tpw, const FwdParams& p, int 
 
 bool forward_window_in_lds(int n_fft) { return n_fft >= kMinFastNfft && n_fft <= kWinLdsMaxNfft; }
 
-// (R, C) of the plan for n_fft: the host builds the twiddle tables from these
-bool forward_plan_rc(int n_fft, int* R, int* C)
+// One place that maps a run-time (n_fft, pair) to the compile-time geometry
+template <class F> static bool with_geom(int n_fft, bool pair, F&& f)
 {
     switch (n_fft) {
-        case 32: *R = geom<32>().R; *C = geom<32>().C; return true;       case 64: *R = geom<64>().R; *C = geom<64>().C; return true;
-        case 128: *R = geom<128>().R; *C = geom<128>().C; return true;    case 256: *R = geom<256>().R; *C = geom<256>().C; return true;
-        case 512: *R = geom<512>().R; *C = geom<512>().C; return true;    case 1024: *R = geom<1024>().R; *C = geom<1024>().C; return true;
-        case 2048: *R = geom<2048>().R; *C = geom<2048>().C; return true; case 4096: *R = geom<4096>().R; *C = geom<4096>().C; return true;
-        case 8192: *R = geom<8192>().R; *C = geom<8192>().C; return true; case 16384: *R = geom<16384>().R; *C = geom<16384>().C; return true;
+        case 32: f(pair ? geom<32, true>() : geom<32, false>()); return true;
+        case 64: f(pair ? geom<64, true>() : geom<64, false>()); return true;
+        case 128: f(pair ? geom<128, true>() : geom<128, false>()); return true;
+        case 256: f(pair ? geom<256, true>() : geom<256, false>()); return true;
+        case 512: f(pair ? geom<512, true>() : geom<512, false>()); return true;
+        case 1024: f(pair ? geom<1024, true>() : geom<1024, false>()); return true;
+        case 2048: f(pair ? geom<2048, true>() : geom<2048, false>()); return true;
+        case 4096: f(pair ? geom<4096, true>() : geom<4096, false>()); return true;
+        case 8192: f(pair ? geom<8192, true>() : geom<8192, false>()); return true;
+        case 16384: f(pair ? geom<16384, true>() : geom<16384, false>()); return true;
     }
     return false;
 }
 
-template <int N> static constexpr int lds_of() { return geom<N>().LDS_BYTES; }
-
-int forward_lds_bytes(int n_fft)
+// (R, C) of the plan for n_fft: the host builds the twiddle tables from these
+bool forward_plan_rc(int n_fft, bool pair, int* R, int* C)
 {
-    switch (n_fft) {
-        case 32: return lds_of<32>(); case 64: return lds_of<64>(); case 128: return lds_of<128>();
-        case 256: return lds_of<256>(); case 512: return lds_of<512>(); case 1024: return lds_of<1024>();
-        case 2048: return lds_of<2048>(); case 4096: return lds_of<4096>();
-        case 8192: return lds_of<8192>(); case 16384: return lds_of<16384>();
-    }
-    return -1;
+    return with_geom(n_fft, pair, [&](const FftGeom& g) { *R = g.R; *C = g.C; });
+}
+
+int forward_lds_bytes(int n_fft, int mode)
+{
+    int v = -1;
+    with_geom(n_fft, mode_pairs(mode), [&](const FftGeom& g) { v = g.LDS_BYTES; });
+    return v;
 }
 
 int forward_frames_per_tile(int n_fft, int mode)
 {
     int slots = -1;
-    switch (n_fft) {
-        case 32: slots = geom<32>().SLOTS; break; case 64: slots = geom<64>().SLOTS; break;
-        case 128: slots = geom<128>().SLOTS; break; case 256: slots = geom<256>().SLOTS; break;
-        case 512: slots = geom<512>().SLOTS; break; case 1024: slots = geom<1024>().SLOTS; break;
-        case 2048: slots = geom<2048>().SLOTS; break; case 4096: slots = geom<4096>().SLOTS; break;
-        case 8192: slots = geom<8192>().SLOTS; break; case 16384: slots = geom<16384>().SLOTS; break;
-    }
+    with_geom(n_fft, mode_pairs(mode), [&](const FftGeom& g) { slots = g.SLOTS; });
     if (slots < 0) return -1;
-    return (mode == kTrain || mode == kSpecTrain) ? slots : 2 * slots;
+    return mode_pairs(mode) ? 2 * slots : slots;
+}
+
+bool forward_two_tiles(int n_fft, int mode)
+{
+    const bool pr = mode_pairs(mode);
+    switch (n_fft) {
+        case 256: return pr ? has_tpw2<256, true>() : has_tpw2<256, false>();
+        case 512: return pr ? has_tpw2<512, true>() : has_tpw2<512, false>();
+        case 1024: return pr ? has_tpw2<1024, true>() : has_tpw2<1024, false>();
+    }
+    return false;
 }
 
 // Tiles per workgroup for a launch over `batch` clips of `tiles_per_clip` tiles.  A launch runs in rounds of the workgroups
 // the chip holds at once (160 KB of LDS per CU, 256 CUs); a two-tile workgroup lives about 1.9 times as long as a one-tile
-// one (it pays the prologue once: measured 21.97 against 23.1 us at BASELINE config 2, one round instead of two).  Two tiles
-// are used when that model says the launch gets shorter -- e.g. not for 5 rounds becoming 3 double ones (config 3).
-bool forward_two_tiles(int n_fft)
+// one (it pays the prologue once: measured 21.97 against 23.1 us at BASELINE config 2 with the 16 x 16 x 4 plan, one round instead of
+// two).  Two tiles are used when that model says the launch gets shorter -- e.g. not for 5 rounds becoming 3 double ones.
+int forward_tiles_per_wg(int n_fft, int mode, int batch, int tiles_per_clip)
 {
-    switch (n_fft) { case 256: return has_tpw2<256>(); case 512: return has_tpw2<512>(); case 1024: return has_tpw2<1024>(); }
-    return false;
-}
-
-int forward_tiles_per_wg(int n_fft, int batch, int tiles_per_clip)
-{
-    if (!forward_two_tiles(n_fft) || tiles_per_clip < 2 || batch < 1) return 1;
-    const int lds = forward_lds_bytes(n_fft);
+    if (!forward_two_tiles(n_fft, mode) || tiles_per_clip < 2 || batch < 1) return 1;
+    const int lds = forward_lds_bytes(n_fft, mode);
     const long long resident = 256LL * (lds > 0 && 163840 / lds > 0 ? 163840 / lds : 1);
     const long long wg1 = (long long)batch * tiles_per_clip, wg2 = (long long)batch * ((tiles_per_clip + 1) / 2);
     const long long r1 = (wg1 + resident - 1) / resident, r2 = (wg2 + resident - 1) / resident;
     return 19 * r2 < 10 * r1 ? 2 : 1;
 }
 
+// the layout of tile_ranges / ent_pre depends on these two; they are the same for both plans of a size
 int forward_waves(int n_fft)
 {
-    switch (n_fft) {
-        case 32: return geom<32>().WAVES; case 64: return geom<64>().WAVES; case 128: return geom<128>().WAVES;
-        case 256: return geom<256>().WAVES; case 512: return geom<512>().WAVES; case 1024: return geom<1024>().WAVES;
-        case 2048: return geom<2048>().WAVES; case 4096: return geom<4096>().WAVES;
-        case 8192: return geom<8192>().WAVES; case 16384: return geom<16384>().WAVES;
-    }
-    return -1;
+    int v = -1;
+    with_geom(n_fft, false, [&](const FftGeom& g) { v = g.WAVES; });
+    return v;
 }
 
 int forward_nbpre(int n_fft)
 {
-    switch (n_fft) {
-        case 32: return geom<32>().NBPRE; case 64: return geom<64>().NBPRE; case 128: return geom<128>().NBPRE;
-        case 256: return geom<256>().NBPRE; case 512: return geom<512>().NBPRE; case 1024: return geom<1024>().NBPRE;
-        case 2048: return geom<2048>().NBPRE; case 4096: return geom<4096>().NBPRE;
-        case 8192: return geom<8192>().NBPRE; case 16384: return geom<16384>().NBPRE;
-    }
-    return -1;
+    int v = -1;
+    with_geom(n_fft, false, [&](const FftGeom& g) { v = g.NBPRE; });
+    return v;
 }
 
 template <int N, int MODE, int TPW> static hipError_t set_attr()
 {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&dmel_fwd_kernel<N, MODE, TPW>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_of<N>());
+                               hipFuncAttributeMaxDynamicSharedMemorySize, geom<N, mode_pairs(MODE)>().LDS_BYTES);
+}
+template <int N, int MODE> static hipError_t set_attr_mode()
+{
+    hipError_t e = set_attr<N, MODE, 1>();
+    if (e != hipSuccess) return e;
+    if constexpr (has_tpw2<N, mode_pairs(MODE)>()) return set_attr<N, MODE, 2>();
+    else return hipSuccess;
 }
 template <int N> static hipError_t set_attr_n()
 {
-    hipError_t e;
     if constexpr (!DMEL_FWD_SIZE(N)) return hipSuccess;
     else {
-    if ((e = set_attr<N, kTrain, 1>()) != hipSuccess) return e;
-    if ((e = set_attr<N, kInfer, 1>()) != hipSuccess) return e;
-    if ((e = set_attr<N, kSpec, 1>()) != hipSuccess) return e;
-    if ((e = set_attr<N, kSpecTrain, 1>()) != hipSuccess) return e;
-    if constexpr (has_tpw2<N>()) {
-        if ((e = set_attr<N, kTrain, 2>()) != hipSuccess) return e;
-        if ((e = set_attr<N, kInfer, 2>()) != hipSuccess) return e;
-        if ((e = set_attr<N, kSpec, 2>()) != hipSuccess) return e;
-        if ((e = set_attr<N, kSpecTrain, 2>()) != hipSuccess) return e;
-    }
-    return hipSuccess;
+        static_assert(geom<N, true>().WAVES == geom<N, false>().WAVES && geom<N, true>().NBPRE == geom<N, false>().NBPRE,
+                      "both plans of a size share the filterbank fragment layout");
+        hipError_t e;
+        if ((e = set_attr_mode<N, kTrain>()) != hipSuccess) return e;
+        if ((e = set_attr_mode<N, kInfer>()) != hipSuccess) return e;
+        if ((e = set_attr_mode<N, kSpec>()) != hipSuccess) return e;
+        return set_attr_mode<N, kSpecTrain>();
     }
 }
 

@@ -143,22 +143,24 @@ template <> struct FftPlan<128>  { static constexpr int R = 8,  C = 2, PASSES = 
 template <> struct FftPlan<256>  { static constexpr int R = 16, C = 1, PASSES = 1, WAVES = 4, NBPRE = 12, MINW = 4, PAIRING = 0, SPLIT = 0; };
 template <> struct FftPlan<512>  { static constexpr int R = 16, C = 2, PASSES = 1, WAVES = 4, NBPRE = 20, MINW = 4, PAIRING = 0, SPLIT = 0; };
 // 1024 = 32 x 32: two frames per wave (G = 32 lanes each), no cross-lane stage, compact layout.  16 frames per workgroup of 8 waves at
-// 76.6 KB of LDS: two workgroups = 32 frames per CU, which is BASELINE config 2's whole share of a CU in ONE round.
-// (R = 16, C = 4, one frame per wave, spectrum in LDS -- rounds 1 and 2 -- is kept selectable for A/B timing: -DDMEL_PLAN1024_R16)
-#ifdef DMEL_PLAN1024_R16
-template <> struct FftPlan<1024> { static constexpr int R = 16, C = 4, PASSES = 1, WAVES = 8, NBPRE = 20, MINW = 4, PAIRING = 0, SPLIT = 0; };
-#else
+// 76.6 KB of LDS: two workgroups = 32 frames per CU, which is BASELINE config 2's whole share of a CU in ONE round (21.6 -> 19.9 us).
 // (one workgroup of 16 waves per CU -- 32 frames, a whole 16000-sample clip at hop 512, whose mean then comes from the samples the
-// frames load anyway, one window table per CU -- measured 20.3-20.6 us against 19.9 at BASELINE config 2, inference 23.1 against
-// 16.3: the barriers of 16 waves cost more than the second pass over the clip)
+// frames load anyway, one window table per CU -- measured 20.3-20.6 us against 19.9 at BASELINE config 2: the barriers of 16 waves
+// cost more than the second pass over the clip)
 template <> struct FftPlan<1024> { static constexpr int R = 32, C = 1, PASSES = 1, WAVES = 8, NBPRE = 20, MINW = 4, PAIRING = 1, SPLIT = 1; };
-#endif
 template <> struct FftPlan<2048> { static constexpr int R = 32, C = 2, PASSES = 1, WAVES = 8, NBPRE = 40, MINW = 4, PAIRING = 1, SPLIT = 1; };
 // (4096 as two waves per frame, R = 32, C = 4, two workgroups per CU: 291 us against 184 at the reference's ESC-50 shape --
 // the workgroup barriers of a shared frame cost more than the occupancy gives)
 template <> struct FftPlan<4096> { static constexpr int R = 64, C = 1, PASSES = 1, WAVES = 8, NBPRE = 40, MINW = 2, PAIRING = 1, SPLIT = 1; };
 template <> struct FftPlan<8192> { static constexpr int R = 64, C = 2, PASSES = 1, WAVES = 8, NBPRE = 40, MINW = 2, PAIRING = 2, SPLIT = 1; };
 template <> struct FftPlan<16384> { static constexpr int R = 64, C = 4, PASSES = 1, WAVES = 8, NBPRE = 40, MINW = 2, PAIRING = 2, SPLIT = 1; };
+
+// The plan also depends on the MODE: when two neighbouring frames share one complex FFT (inference, spectrogram pass) a wave of
+// the 32 x 32 plan would carry four frames and a workgroup 32 -- one workgroup per CU at config 2, half the waves (measured 16.3 us
+// against 14.0).  Those modes keep 1024 = 16 x 16 x 4, one frame pair per wave, spectrum in LDS.
+template <int N, bool PAIR> struct FftPlanSel : FftPlan<N> {};
+template <> struct FftPlanSel<1024, true> { static constexpr int R = 16, C = 4, PASSES = 1, WAVES = 8, NBPRE = 20, MINW = 4, PAIRING = 0, SPLIT = 0; };
+constexpr bool mode_pairs(int mode) { return mode == kInfer || mode == kSpec; }
 
 constexpr int kWinLdsMaxNfft = 4096;   // (the table in global memory at 4096: 184 us against 171 at the reference's ESC-50 shape)
 constexpr int kRedBytes = 160;         // 16 + 16 partial sums (one per wave), then the tangent scale (word 32) computed once per workgroup
@@ -183,9 +185,9 @@ constexpr int slot_stride_f2(int N, int R, int C, int pairing = 0, int split = 0
     return ((need + 127) / 128 * 128 + 48) / 8;
 }
 
-template <int N> constexpr FftGeom geom()
+template <int N, bool PAIR = false> constexpr FftGeom geom()
 {
-    using P = FftPlan<N>;
+    using P = FftPlanSel<N, PAIR>;
     FftGeom g{};
     g.N = N; g.R = P::R; g.C = P::C; g.G = N / P::R; g.PASSES = P::PASSES;
     g.WPF = g.G > kWave ? g.G / kWave : 1;                // waves per frame
@@ -221,7 +223,7 @@ struct FwdParams {
     float* tangent;            // same shape as out or nullptr
     const float* psum;         // (B, nchunks) partial sums of x, or nullptr: the kernel sums the clip itself (short clips)
     const float2* win2;        // [n] = (w[n], w[n] d^2 2^(-2e)) from the prep kernel (n_fft 4096 only)
-    const float2* tw1;         // (R, G): w_N^(lg*q)
+    const float2* tw1;         // (R, G): w_N^(lg*q)      (of the plan of this launch's mode)
     const float2* tw2;         // (R, C): w_G^(r*p1)
     const float* ent_b;        // 64 floats per 4x16 block, blocks of one mel tile contiguous in k
     const int4* tile_ranges;   // (groups, WAVES, 2): {first k-step, #k-steps (multiple of 4), offset into ent_b, mel tile or -1}
@@ -248,13 +250,13 @@ struct PrepParams {
 
 hipError_t launch_prep(const PrepParams& p, hipStream_t s);
 hipError_t launch_forward(int n_fft, int mode, int tiles_per_wg, const FwdParams& p, int grid, hipStream_t s);
-int forward_tiles_per_wg(int n_fft, int batch, int tiles_per_clip);          // 1 or 2: what launch_forward should be given
-bool forward_two_tiles(int n_fft);          // the two-tiles-per-workgroup instantiation exists for this size
-int forward_lds_bytes(int n_fft);
+int forward_tiles_per_wg(int n_fft, int mode, int batch, int tiles_per_clip);          // 1 or 2: what launch_forward should be given
+bool forward_two_tiles(int n_fft, int mode);          // the two-tiles-per-workgroup instantiation exists for this size and mode
+int forward_lds_bytes(int n_fft, int mode);
 int forward_frames_per_tile(int n_fft, int mode);
 int forward_waves(int n_fft);              // waves per workgroup of the fused kernel for this n_fft
 int forward_nbpre(int n_fft);              // k-steps per run kept in registers (layout of FwdParams::ent_pre)
-bool forward_plan_rc(int n_fft, int* R, int* C);
+bool forward_plan_rc(int n_fft, bool pair, int* R, int* C);   // pair: the plan of the modes that pack two frames per FFT
 bool forward_window_in_lds(int n_fft);     // the kernel builds its own window table (otherwise dmel_prep_kernel writes FwdParams::win2)   // radix per lane and cross-lane radix of the plan (layout of tw1 / tw2)
 hipError_t forward_prepare_attributes();   // raises the dynamic-LDS limit of every instantiation once
 
