@@ -1301,12 +1301,10 @@ dmel_status backward_fb_impl(dmel_plan* plan, const float* x, int32_t batch, flo
         dmel_status so = order_after_last_stream(plan, s);       // fbw is shared by every call on the plan
         if (so != DMEL_OK) return so;
     }
-    // enough batch slices to fill the chip a few times over, never more than clips
-    const int tiles = ((F + 31) / 32) * ((M + 127) / 128);
-    const int splits = std::max(1, std::min(batch, (1024 + tiles - 1) / tiles));
+    const int splits = dmel::fbgrad_splits(batch, F, M);
     const size_t spec_floats = ((size_t)batch * F * T + 63) / 64 * 64;
     const size_t part_floats = ((size_t)splits * F * M + 63) / 64 * 64;
-    const size_t gm_floats = (flags & DMEL_FLAG_LOG) ? (size_t)batch * M * T + 16 : 0;
+    const size_t gm_floats = 0;      // (gm = grad_out * exp(-out) is formed inside the GEMM kernel)
     const size_t need = spec_floats + part_floats + gm_floats;
     if (need > plan->fbw_floats) {
         if (is_capturing(s)) return fail(DMEL_ERR_INVALID_ARGUMENT, "workspace must grow but the stream is capturing: run one call eagerly first");

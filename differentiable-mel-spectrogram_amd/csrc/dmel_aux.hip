@@ -4,6 +4,7 @@
 //   * dmel_naive_* : direct-DFT forward for n_fft < 32 (lambd < 5.5 samples) and as an on-device
 //                    cross-check of the wave-FFT kernel; same semantics (models.py:33-56, :73).
 #include <algorithm>
+#include <cstdlib>
 #include "dmel_kernels.h"
 #include "dmel_ldsfft.h"
 
@@ -304,11 +305,8 @@ hipError_t launch_naive(const NaiveParams& p, hipStream_t s)
 
 // ---- filterbank gradient ----------------------------------------------------------------------
 // grad_fb = sum over clips of  spec_b (F x T) * gm_b^T (T x M): per clip a small GEMM whose K dimension (time) is
-// contiguous in both operands.  One workgroup owns a 32 (freq) x 128 (mel) tile of grad_fb for one slice of the
-// batch; exact-fp32 MFMA 16x16x4, A = spec rows, B = gm rows, both read straight from global memory as 16-byte
-// pieces along t (lane (row, kq) holds t = 16 j + 4 kq + i for k-step i -- any bijection of t onto (step, k) is
-// a valid K order as long as A and B use the same one).  Slices are summed in index order by a second kernel:
-// deterministic, no atomics.  For the log output gm = grad_out * exp(-out) is formed once by a small pre-pass.
+// contiguous in both operands; exact-fp32 MFMA 16x16x4.  (Rounds 1-2: a 32 x 128 tile per 4-wave workgroup with both operands
+// read straight from global memory, a pre-pass for gm, 61 batch slices at config 2: 32 us for GEMM + reduction.)
 typedef float floatx4_t __attribute__((ext_vector_type(4)));
 template <int I> struct IdxC { static constexpr int value = I; };
 template <int B, int E, class Fn> __device__ __forceinline__ void unrolled(Fn&& f)
@@ -317,91 +315,108 @@ template <int B, int E, class Fn> __device__ __forceinline__ void unrolled(Fn&& 
 }
 struct __attribute__((packed, aligned(4))) f4u { float v[4]; };       // 16-byte load that only needs 4-byte alignment
 
-// gm = grad_out * exp(-out): once per element instead of once per frequency tile
-__global__ void __launch_bounds__(256) dmel_fbgrad_gm_kernel(const float* __restrict__ g, const float* __restrict__ y, float* __restrict__ gm, long long n)
-{
-    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i + 3 < n && ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gm)) & 15) == 0) {
-        const float4 a = *reinterpret_cast<const float4*>(g + i), b = *reinterpret_cast<const float4*>(y + i);
-        *reinterpret_cast<float4*>(gm + i) = make_float4(a.x * expf(-b.x), a.y * expf(-b.y), a.z * expf(-b.z), a.w * expf(-b.w));
-    } else {
-        for (long long k = i; k < n && k < i + 4; ++k) gm[k] = g[k] * expf(-y[k]);
-    }
-}
+// One workgroup of 8 waves owns a 64 (freq) x 128 (mel) tile of grad_fb for one slice of the batch: wave (wf, wm) the 32 x 32
+// sub-tile (2 x 2 MFMA tiles).  A K-block is 16 time steps of one clip: spec[b][f0 .. f0+63][t .. t+15] and gm[b][0 .. 127][t .. t+15]
+// (12 KB) are fetched ONCE per workgroup as 16-byte pieces along t -- the 32 x 128 kernel above fetched the spectrogram rows
+// four times, once per wave -- parked in registers while the previous block is multiplied, and written to one of two LDS images
+// whose rows are padded to 24 floats (the 16 lanes of a ds_read_b128 group then touch 16 different 16-byte slots).  For the log
+// output gm = grad_out * exp(-out) is formed while staging (no pre-pass, no gm workspace).  Same K order in A and B (lane
+// (row, kq) holds t = 16 j + 4 kq + u for k-step u), slices summed in index order by dmel_fbgrad_reduce_kernel: deterministic.
+constexpr int kFbgBF = 64, kFbgBM = 128, kFbgRow = 24, kFbgThreads = 512;     // rows of 24 floats: ds_read_b128 of 16 rows x 4 pieces is conflict-free (20: 2-way)
 
-__global__ void __launch_bounds__(256) dmel_fbgrad_kernel(FbGradParams p)
+__global__ void __launch_bounds__(kFbgThreads) dmel_fbgrad_lds_kernel(FbGradParams p)
 {
+    __shared__ __attribute__((aligned(16))) float lds_a[2][kFbgBF * kFbgRow];
+    __shared__ __attribute__((aligned(16))) float lds_b[2][kFbgBM * kFbgRow];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row = lane & 15, kq = lane >> 4;
-    const int f0 = blockIdx.x * 32, m0 = blockIdx.z * 128;
+    const int wf = wave >> 2, wm = wave & 3;
+    const int f0 = blockIdx.x * kFbgBF, m0 = blockIdx.z * kFbgBM;
     const int split = blockIdx.y;
     const int b_lo = (int)((long long)p.B * split / p.splits), b_hi = (int)((long long)p.B * (split + 1) / p.splits);
     const int F = p.F, M = p.M, T = p.T;
-    // rows of the two freq sub-tiles and of this wave's two mel sub-tiles (clamped: rows past the edge are computed on
-    // valid memory and never stored)
-    int fr[2], mr[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        fr[i] = min(f0 + 16 * i + row, F - 1);
-        mr[i] = min(m0 + 16 * (wave + 4 * i) + row, M - 1);
-    }
-    floatx4_t acc[2][2];
-    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) acc[i][j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
-    // full blocks of 16 time steps, flattened over (clip, block): a ring of DEPTH register buffers keeps DEPTH blocks of
-    // loads in flight (the loop is otherwise one memory round trip per 16 MFMAs)
-    constexpr int DEPTH = 4;
-    const int ntc = T / 16, total = (b_hi - b_lo) * ntc;
-    f4u a[DEPTH][2], g[DEPTH][2];
-    auto issue = [&](int c, int slot) {          // always inlined with a constant slot
+    const int ntc = (T + 15) / 16, total = (b_hi - b_lo) * ntc;
+    // staging roles: every thread one 16-byte piece of the B tile (row tid / 4, piece tid % 4), threads 0 .. 255 one of the A tile
+    const int srow = tid >> 2, sc = tid & 3;
+    const int mrow = min(m0 + srow, M - 1);                       // rows past the edge: valid memory, results never stored
+    const int frow = min(f0 + (srow & (kFbgBF - 1)), F - 1);
+    const bool has_a = tid < 4 * kFbgBF;
+    // DEPTH blocks of loads in flight per thread (one block ahead left every iteration waiting for a memory round trip: 24 us)
+    constexpr int DEPTH = 3;
+    float4 ring_a[DEPTH], ring_b[DEPTH];
+    auto fetch = [&](int c, float4& ra, float4& rb) {
         if (c >= total) return;
-        const int b = b_lo + c / ntc, t = (c % ntc) * 16 + 4 * kq;
-        a[slot][0] = *reinterpret_cast<const f4u*>(p.spec + ((size_t)b * F + fr[0]) * T + t);
-        a[slot][1] = *reinterpret_cast<const f4u*>(p.spec + ((size_t)b * F + fr[1]) * T + t);
-        g[slot][0] = *reinterpret_cast<const f4u*>(p.gm + ((size_t)b * M + mr[0]) * T + t);
-        g[slot][1] = *reinterpret_cast<const f4u*>(p.gm + ((size_t)b * M + mr[1]) * T + t);
-    };
-    unrolled<0, DEPTH>([&](auto dd) { issue(decltype(dd)::value, decltype(dd)::value); });
-    for (int c0 = 0; c0 < total; c0 += DEPTH) {
-        unrolled<0, DEPTH>([&](auto dd) {
-            constexpr int d = decltype(dd)::value;          // compile-time ring slot: the buffers stay in registers
-            if (c0 + d < total) {
-                unrolled<0, 4>([&](auto uu) {
-                    constexpr int u = decltype(uu)::value;
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[d][0].v[u], g[d][0].v[u], acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[d][0].v[u], g[d][1].v[u], acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[d][1].v[u], g[d][0].v[u], acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[d][1].v[u], g[d][1].v[u], acc[1][1], 0, 0, 0);
-                });
+        const int b = b_lo + c / ntc, t = (c % ntc) * 16 + 4 * sc;
+        const size_t ob = ((size_t)b * M + mrow) * T + t;
+        const size_t oa = ((size_t)b * F + frow) * T + t;
+        if (t + 3 < T) {
+            const f4u g = *reinterpret_cast<const f4u*>(p.grad_out + ob);
+            rb = make_float4(g.v[0], g.v[1], g.v[2], g.v[3]);
+            if (p.out) {
+                const f4u y = *reinterpret_cast<const f4u*>(p.out + ob);
+                rb = make_float4(rb.x * expf(-y.v[0]), rb.y * expf(-y.v[1]), rb.z * expf(-y.v[2]), rb.w * expf(-y.v[3]));
             }
-            issue(c0 + DEPTH + d, d);
-        });
-    }
-    const int tfull = ntc * 16;
-    if (tfull < T) {
-        for (int b = b_lo; b < b_hi; ++b) {
-            // last partial block of 16: element-wise, zero past the end of the row
-            float at[2][4], gt[2][4];
+            if (has_a) { const f4u a = *reinterpret_cast<const f4u*>(p.spec + oa); ra = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]); }
+        } else {
+            // the last block of a row whose length is not a multiple of 16 (or of 4): element-wise, zero past the end of the row
+            float gb[4], ga[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int tt = tfull + 4 * kq + u;
-                const bool ok = tt < T;
-                const int tc = ok ? tt : T - 1;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const float av = p.spec[((size_t)b * F + fr[i]) * T + tc];
-                    const float gv = p.gm[((size_t)b * M + mr[i]) * T + tc];
-                    at[i][u] = ok ? av : 0.f;
-                    gt[i][u] = ok ? gv : 0.f;
-                }
+                const bool ok = t + u < T;
+                const size_t ib = ok ? ob + u : ((size_t)b * M + mrow) * T, ia = ok ? oa + u : ((size_t)b * F + frow) * T;
+                float g = p.grad_out[ib];
+                if (p.out) g *= expf(-p.out[ib]);
+                gb[u] = ok ? g : 0.f;
+                ga[u] = (ok && has_a) ? p.spec[ia] : 0.f;
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(at[i][u], gt[j][u], acc[i][j], 0, 0, 0);
+            rb = make_float4(gb[0], gb[1], gb[2], gb[3]);
+            ra = make_float4(ga[0], ga[1], ga[2], ga[3]);
         }
+    };
+    auto park = [&](int buf, const float4& ra, const float4& rb) {
+        *reinterpret_cast<float4*>(&lds_b[buf][srow * kFbgRow + 4 * sc]) = rb;
+        if (has_a) *reinterpret_cast<float4*>(&lds_a[buf][srow * kFbgRow + 4 * sc]) = ra;
+    };
+    floatx4_t acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) acc[i][j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+    {
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), b0 = a0;
+        fetch(0, a0, b0);
+        unrolled<0, DEPTH>([&](auto dd) {                     // block k >= 1 lives in ring slot (k - 1) % DEPTH
+            constexpr int d = decltype(dd)::value;
+            ring_a[d] = make_float4(0.f, 0.f, 0.f, 0.f); ring_b[d] = ring_a[d];
+            fetch(1 + d, ring_a[d], ring_b[d]);
+        });
+        park(0, a0, b0);
+    }
+    __syncthreads();
+    for (int c0 = 0; c0 < total; c0 += DEPTH) {
+        unrolled<0, DEPTH>([&](auto dd) {
+            constexpr int d = decltype(dd)::value;            // compile-time ring slot: the buffers stay in registers
+            const int c = c0 + d;
+            if (c >= total) return;
+            const int buf = c & 1;
+            float4 a[2], g[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *reinterpret_cast<const float4*>(&lds_a[buf][(wf * 32 + 16 * i + row) * kFbgRow + 4 * kq]);
+                g[i] = *reinterpret_cast<const float4*>(&lds_b[buf][(wm * 32 + 16 * i + row) * kFbgRow + 4 * kq]);
+            }
+            // block c + 1 (requested DEPTH iterations ago) into the other image: nobody reads that image before the barrier below;
+            // then block c + 1 + DEPTH is requested into the slot just emptied
+            if (c + 1 < total) park(buf ^ 1, ring_a[d], ring_b[d]);
+            fetch(c + 1 + DEPTH, ring_a[d], ring_b[d]);
+            const float av[2][4] = {{a[0].x, a[0].y, a[0].z, a[0].w}, {a[1].x, a[1].y, a[1].z, a[1].w}};
+            const float gv[2][4] = {{g[0].x, g[0].y, g[0].z, g[0].w}, {g[1].x, g[1].y, g[1].z, g[1].w}};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][u], gv[0][u], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][u], gv[1][u], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][u], gv[0][u], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][u], gv[1][u], acc[1][1], 0, 0, 0);
+            }
+            __syncthreads();
+        });
     }
     // D[4 * (lane >> 4) + r][lane & 15]: rows = freq, columns = mel
     float* part = p.partials + (size_t)split * F * M;
@@ -409,10 +424,10 @@ __global__ void __launch_bounds__(256) dmel_fbgrad_kernel(FbGradParams p)
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int m = m0 + 16 * (wave + 4 * j) + row;
+            const int m = m0 + wm * 32 + 16 * j + row;
             if (m >= M) continue;
             for (int r = 0; r < 4; ++r) {
-                const int f = f0 + 16 * i + 4 * kq + r;
+                const int f = f0 + wf * 32 + 16 * i + 4 * kq + r;
                 if (f < F) part[(size_t)f * M + m] = acc[i][j][r];
             }
         }
@@ -436,20 +451,21 @@ __global__ void __launch_bounds__(256) dmel_fbgrad_reduce_kernel(FbGradParams p)
     p.grad_fb[i] = s;
 }
 
+int fbgrad_splits(int batch, int F, int M)
+{
+    // enough batch slices for about two workgroups of 8 waves per CU, never more than clips (every slice writes an F x M partial)
+    const int tiles = ((F + kFbgBF - 1) / kFbgBF) * ((M + kFbgBM - 1) / kFbgBM);
+    static const int target = std::getenv("DMEL_FBG_TARGET") ? std::atoi(std::getenv("DMEL_FBG_TARGET")) : 512;     // (diagnostics)
+    const int s = (target + tiles - 1) / tiles;
+    return s < 1 ? 1 : (s > batch ? (batch < 1 ? 1 : batch) : s);
+}
+
 hipError_t launch_fbgrad(const FbGradParams& p_in, hipStream_t s)
 {
     FbGradParams p = p_in;
-    if (p.out) {
-        const long long n = (long long)p.B * p.M * p.T;
-        hipLaunchKernelGGL(dmel_fbgrad_gm_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, p.grad_out, p.out, p.gm_ws, n);
-        hipError_t e0 = hipGetLastError();
-        if (e0 != hipSuccess) return e0;
-        p.gm = p.gm_ws;
-    } else {
-        p.gm = p.grad_out;
-    }
-    const dim3 grid((p.F + 31) / 32, p.splits, (p.M + 127) / 128);
-    hipLaunchKernelGGL(dmel_fbgrad_kernel, grid, dim3(256), 0, s, p);
+    p.gm = p.grad_out;                 // gm = grad_out * exp(-out) is formed by the kernel while it stages the operand (p.out != nullptr)
+    const dim3 grid((p.F + kFbgBF - 1) / kFbgBF, p.splits, (p.M + kFbgBM - 1) / kFbgBM);
+    hipLaunchKernelGGL(dmel_fbgrad_lds_kernel, grid, dim3(kFbgThreads), 0, s, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const size_t n = (size_t)p.F * p.M;

@@ -41,6 +41,17 @@ def _random_cases(n, seed):
     return out
 
 
+def _assert_dlam(got_d, exp_d, g_np, t_ref, name):
+    """rel 1e-4 with the fp32 floor of an ill-conditioned sum (_dlam_tol) always; and north_star's plain relative 1e-4, without
+    any floor, wherever the sum is not dominated by cancellation (|d lambd| more than 1e-3 of sum |g t|) -- as
+    test_matches_reference_golden does for the fixtures"""
+    assert abs(got_d - exp_d) <= _dlam_tol(exp_d, g_np, t_ref), (name, got_d, exp_d)
+    cancel = float(np.abs(g_np.astype(np.float64) * t_ref.astype(np.float64)).sum())
+    if abs(exp_d) > 1e-3 * cancel:
+        assert abs(got_d - exp_d) <= TOL * abs(exp_d), (name, got_d, exp_d, abs(got_d - exp_d) / abs(exp_d))
+
+
+
 RANDOM_CASES = _random_cases(36, seed=20240607) + [dict(c, name="s2_" + c["name"]) for c in _random_cases(36, seed=977)]
 
 
@@ -60,7 +71,7 @@ def test_random_configuration_matches_oracle(case):
         o = y.detach().cpu().numpy()
         assert (_log_err(o, o_ref) if log else _rel_err(o, o_ref)) <= TOL
         exp_d = O.backward(g_np, t_ref)
-        assert abs(float(layer.lambd.grad) - exp_d) <= _dlam_tol(exp_d, g_np, t_ref)
+        _assert_dlam(float(layer.lambd.grad), exp_d, g_np, t_ref, case["name"])
         with torch.no_grad():
             yi = _layer(case, log=log, trainable=False)(x)
         oi = yi.cpu().numpy()
@@ -112,7 +123,7 @@ def test_random_full_window_configuration_matches_oracle(case):
         o = y.detach().cpu().numpy()
         assert (_log_err(o, o_ref) if log else _rel_err(o, o_ref)) <= TOL
         exp_d = O.backward(g_np, t_ref)
-        assert abs(float(layer.lambd.grad) - exp_d) <= _dlam_tol(exp_d, g_np, t_ref)
+        _assert_dlam(float(layer.lambd.grad), exp_d, g_np, t_ref, case["name"])
         with torch.no_grad():
             yi = _layer(case, log=log, trainable=False)(x)
         oi = yi.cpu().numpy()
