@@ -36,7 +36,7 @@ SYMBOLS = (
     "dmel_plan_lambd_status", "dmel_plan_set_tracking", "dmel_plan_lambd_reset",
     "dmel_plan_retain", "dmel_plan_release", "dmel_plan_lambd_report", "dmel_decide_launch", "dmel_plan_force_launch",
     "dmel_mailbox_create", "dmel_mailbox_connect", "dmel_mailbox_destroy", "dmel_mailbox_allreduce", "dmel_mailbox_error",
-    "dmel_mailbox_set_spin_limit", "dmel_plan_attach_mailbox",
+    "dmel_mailbox_set_spin_limit", "dmel_plan_attach_mailbox", "dmel_backward_x_spec",
 )
 TORCH_LIB_PATH = os.path.join(_PKG_DIR, "libdmel_torch.so")
 
@@ -114,6 +114,8 @@ def load():
     L.dmel_backward_fb.restype = C.c_int
     L.dmel_backward_x.argtypes = [vp, vp, C.c_int32, C.c_float, C.c_uint32, vp, vp, vp, vp]
     L.dmel_backward_x.restype = C.c_int
+    L.dmel_backward_x_spec.argtypes = [vp, vp, C.c_int32, C.c_float, C.c_int32, C.c_uint32, vp, vp, vp]
+    L.dmel_backward_x_spec.restype = C.c_int
     L.dmel_spectrogram.argtypes = [vp, vp, C.c_int32, C.c_float, C.c_int32, vp, vp]
     L.dmel_spectrogram.restype = C.c_int
     L.dmel_spectrogram_ex.argtypes = [vp, vp, C.c_int32, C.c_float, C.c_int32, C.c_uint32, vp, vp, vp]
@@ -350,10 +352,16 @@ class Plan:
                                        grad_fb_ptr, stream))
 
     def backward_x(self, x_ptr: int, batch: int, lambd: float, grad_ptr: int, out_ptr: int | None, grad_x_ptr: int,
-                   log: bool, stream: int):
+                   log: bool, stream: int, extra_flags: int = 0):
         """grad of the loss w.r.t. the waveform (adjoint of models.py:38-53)."""
-        _check(load().dmel_backward_x(self._h, x_ptr, batch, C.c_float(float(lambd)), DMEL_FLAG_LOG if log else 0, grad_ptr,
+        _check(load().dmel_backward_x(self._h, x_ptr, batch, C.c_float(float(lambd)), (DMEL_FLAG_LOG if log else 0) | int(extra_flags), grad_ptr,
                                       out_ptr if log else None, grad_x_ptr, stream))
+
+    def backward_x_spec(self, x_ptr: int, batch: int, lambd: float, n_fft_: int, grad_spec_ptr: int, grad_x_ptr: int, stream: int,
+                        half_window: bool = False):
+        """grad of the loss w.r.t. the waveform through the spectrogram layer (models.py:171-200)."""
+        _check(load().dmel_backward_x_spec(self._h, x_ptr, batch, C.c_float(float(lambd)), int(n_fft_), 1 | (2 if half_window else 0),
+                                           grad_spec_ptr, grad_x_ptr, stream))
 
     def spectrogram(self, x_ptr: int, batch: int, lambd: float, spec_ptr: int, stream: int, remove_dc: bool = False):
         _check(load().dmel_spectrogram(self._h, x_ptr, batch, C.c_float(float(lambd)), int(remove_dc), spec_ptr, stream))

@@ -919,8 +919,8 @@ dmel_status dmel_plan_destroy(dmel_plan* plan) { return dmel_plan_release(plan);
 dmel_status dmel_plan_set_filterbank(dmel_plan* plan, int32_t n_fft, const float* fb)
 {
     if (!plan) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
-    if (n_fft < 1 || n_fft > dmel::kMaxNfft || (n_fft & (n_fft - 1)))
-        return fail(DMEL_ERR_INVALID_ARGUMENT, "n_fft must be a power of two in [1, 16384]");
+    if (n_fft < 1 || n_fft > dmel::kMaxBigFft || (n_fft > 1 && (n_fft & 1)))
+        return fail(DMEL_ERR_INVALID_ARGUMENT, "n_fft must be 1 or an even length up to 262144");
     { dmel_status sd = check_device(plan); if (sd != DMEL_OK) return sd; }      // the synchronisation below must be the plan's device's
     std::lock_guard<std::mutex> lock(plan->mu);
     DMEL_HIP(hipDeviceSynchronize());     // tables of this n_fft may be in use by queued kernels
@@ -939,8 +939,8 @@ dmel_status dmel_plan_set_filterbank(dmel_plan* plan, int32_t n_fft, const float
 dmel_status dmel_plan_set_filterbank_dev(dmel_plan* plan, int32_t n_fft, const float* fb_dev, void* stream)
 {
     if (!plan || !fb_dev) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan / fb_dev is NULL");
-    if (n_fft < 1 || n_fft > dmel::kMaxNfft || (n_fft & (n_fft - 1)))
-        return fail(DMEL_ERR_INVALID_ARGUMENT, "n_fft must be a power of two in [1, 16384]");
+    if (n_fft < 1 || n_fft > dmel::kMaxBigFft || (n_fft > 1 && (n_fft & 1)))
+        return fail(DMEL_ERR_INVALID_ARGUMENT, "n_fft must be 1 or an even length up to 262144");
     { dmel_status sd = check_device(plan); if (sd != DMEL_OK) return sd; }
     std::lock_guard<std::mutex> lock(plan->mu);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -1284,15 +1284,11 @@ dmel_status backward_fb_impl(dmel_plan* plan, const float* x, int32_t batch, flo
     if (lambd_dev && (n_fft_dev < 1 || n_fft_dev > dmel::kMaxNfft || (n_fft_dev & (n_fft_dev - 1))))
         return fail(DMEL_ERR_INVALID_ARGUMENT, "n_fft must be a power of two in [1, 16384]");
     int n_over = 0, win_half = 0;
-    if (flags & DMEL_FLAG_FULL_WINDOW) {
-        const int L = plan->cfg.n_points;
-        if ((L & (L - 1)) || 2 * L > dmel::kMaxNfft)
-            return fail(DMEL_ERR_UNSUPPORTED, "DMEL_FLAG_FULL_WINDOW needs n_points to be a power of two <= 8192");
-        n_over = 2 * L; win_half = 1;
-    }
+    if (flags & DMEL_FLAG_FULL_WINDOW) { n_over = 2 * plan->cfg.n_points; win_half = 1; }     // any clip length: the spectrogram pass takes
+                                                                                            // the chirp-z path where it has to
     const int N = lambd_dev ? n_fft_dev : (n_over ? n_over : dmel_n_fft(lambd));
-    if (N > dmel::kMaxNfft)
-        return fail(DMEL_ERR_UNSUPPORTED, "n_fft = " + std::to_string(N) + " > " + std::to_string(dmel::kMaxNfft) + " is not supported by the HIP kernels");
+    if (N > dmel::kMaxBigFft)
+        return fail(DMEL_ERR_UNSUPPORTED, "n_fft = " + std::to_string(N) + " > " + std::to_string(dmel::kMaxBigFft) + " is not supported by the HIP kernels");
     const int F = N / 2 + 1, M = plan->cfg.n_mels, T = plan->T;
     std::lock_guard<std::mutex> lock(plan->mu);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -1354,19 +1350,19 @@ dmel_status dmel_backward_fb_dev(dmel_plan* plan, const float* x, int32_t batch,
     return backward_fb_impl(plan, x, batch, 0.f, lambd_dev, n_fft, flags, grad_out, out, grad_fb, stream);
 }
 
-dmel_status dmel_backward_x(dmel_plan* plan, const float* x, int32_t batch, float lambd, uint32_t flags,
+}  // extern "C"
+
+namespace {
+// gradient w.r.t. the waveform on the power-of-two transforms: the mel layer (spec_mode 0; n_over / win_half describe the
+// optimized=False branch) and the spectrogram layer (spec_mode 1: grad_out is the gradient of the power spectrogram)
+dmel_status backward_x_impl(dmel_plan* plan, const float* x, int32_t batch, float lambd, int n_over, int win_half, int spec_mode, bool log,
                             const float* grad_out, const float* out, float* grad_x, void* stream)
 {
-    if (!plan) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
-    if (batch < 0) return fail(DMEL_ERR_INVALID_ARGUMENT, "batch < 0");
-    if (batch == 0) return DMEL_OK;
-    if (!x || !grad_out || !grad_x) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_backward_x: x / grad_out / grad_x is NULL");
-    if ((flags & DMEL_FLAG_LOG) && !out) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_backward_x: DMEL_FLAG_LOG needs the saved log output");
-    if (flags & DMEL_FLAG_FULL_WINDOW) return fail(DMEL_ERR_UNSUPPORTED, "dmel_backward_x: the optimized=False branch is not supported");
-    if (!std::isfinite(lambd)) return fail(DMEL_ERR_INVALID_ARGUMENT, "lambd is not finite");
-    const int N = dmel_n_fft(lambd);
-    if (N > dmel::kMaxNfft)
-        return fail(DMEL_ERR_UNSUPPORTED, "n_fft = " + std::to_string(N) + " > " + std::to_string(dmel::kMaxNfft) + " is not supported by the HIP kernels");
+    const int N = n_over > 0 ? n_over : dmel_n_fft(lambd);
+    if (N > dmel::kMaxNfft || (N & (N - 1)))
+        return fail(DMEL_ERR_UNSUPPORTED, "gradient w.r.t. the waveform: n_fft = " + std::to_string(N) + " is not a power of two <= " +
+                    std::to_string(dmel::kMaxNfft) + " (the chirp-z path has no adjoint yet)");
+    { dmel_status sd = check_device(plan); if (sd != DMEL_OK) return sd; }
     std::lock_guard<std::mutex> lock(plan->mu);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     NfftTables* tb = nullptr;
@@ -1378,6 +1374,7 @@ dmel_status dmel_backward_x(dmel_plan* plan, const float* x, int32_t batch, floa
     const size_t frame_floats = ((size_t)batch * plan->T * N + 63) / 64 * 64;
     const size_t need = frame_floats + 2 * (size_t)batch * dmel::xgrad_chunks(plan->cfg.n_points) + 16;    // + fp64 chunk sums
     if (need > plan->fbw_floats) {
+        if (is_capturing(s)) return fail(DMEL_ERR_INVALID_ARGUMENT, "workspace must grow but the stream is capturing: run one call eagerly first");
         DMEL_HIP(hipStreamSynchronize(s));
         (void)hipFree(plan->fbw); plan->fbw = nullptr; plan->fbw_floats = 0;
         DMEL_HIP(hipMalloc(&plan->fbw, need * sizeof(float)));
@@ -1387,22 +1384,52 @@ dmel_status dmel_backward_x(dmel_plan* plan, const float* x, int32_t batch, floa
     dmel::PrepParams pp{};
     pp.x = x; pp.psum = sc.psum; pp.win2 = sc.win;
     pp.B = batch; pp.L = plan->cfg.n_points; pp.nchunks = plan->nchunks; pp.chunk = plan->chunk;
-    pp.N = N; pp.normalize = plan->cfg.normalize_window; pp.win_half = 0; pp.center = (float)N / 2.0f;
+    pp.N = N; pp.normalize = plan->cfg.normalize_window; pp.win_half = win_half;
+    pp.center = win_half ? (float)((N / 2) / 2) + (float)(N / 2) / 2.0f : (float)N / 2.0f;      // as launch_forward_n
     pp.lam.val = lambd; pp.lam.role = dmel::kLamQuiet;
     DMEL_HIP(dmel::launch_prep(pp, s));
     dmel::XgradParams xp{};
     xp.x = x; xp.psum = sc.psum; xp.win2 = sc.win; xp.tw = tb->tw_long;
-    xp.fb = tb->fb_dense; xp.rowband = tb->rowband; xp.grad_out = grad_out; xp.out = (flags & DMEL_FLAG_LOG) ? out : nullptr;
+    xp.fb = tb->fb_dense; xp.rowband = tb->rowband; xp.grad_out = grad_out; xp.out = log ? out : nullptr;
     xp.frames = plan->fbw; xp.grad_x = grad_x;
     xp.csum = reinterpret_cast<double*>(plan->fbw + frame_floats);      // 256-byte aligned: frame_floats is a multiple of 64
     xp.B = batch; xp.L = plan->cfg.n_points; xp.T = plan->T; xp.hop = plan->cfg.hop_length; xp.M = plan->cfg.n_mels;
-    xp.nchunks = plan->nchunks; xp.N = N; xp.F = tb->F; xp.remove_dc = 1;
+    xp.nchunks = plan->nchunks; xp.N = N; xp.F = tb->F; xp.remove_dc = 1; xp.spec_mode = spec_mode;
     xp.logN = 0; while ((1 << xp.logN) < N) ++xp.logN;
     xp.inv_L = 1.0f / (float)plan->cfg.n_points;
     const size_t m0 = prof_mark(plan, s);
     DMEL_HIP(dmel::launch_xgrad(xp, s));
     prof_span(plan, m0, prof_mark(plan, s), 2);
     return DMEL_OK;
+}
+}  // namespace
+
+extern "C" {
+
+dmel_status dmel_backward_x(dmel_plan* plan, const float* x, int32_t batch, float lambd, uint32_t flags,
+                            const float* grad_out, const float* out, float* grad_x, void* stream)
+{
+    if (!plan) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
+    if (batch < 0) return fail(DMEL_ERR_INVALID_ARGUMENT, "batch < 0");
+    if (batch == 0) return DMEL_OK;
+    if (!x || !grad_out || !grad_x) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_backward_x: x / grad_out / grad_x is NULL");
+    if ((flags & DMEL_FLAG_LOG) && !out) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_backward_x: DMEL_FLAG_LOG needs the saved log output");
+    if (!std::isfinite(lambd)) return fail(DMEL_ERR_INVALID_ARGUMENT, "lambd is not finite");
+    const bool full = (flags & DMEL_FLAG_FULL_WINDOW) != 0;                      // optimized=False: n_fft = 2 L, window = the clip
+    return backward_x_impl(plan, x, batch, lambd, full ? 2 * plan->cfg.n_points : 0, full ? 1 : 0, 0, (flags & DMEL_FLAG_LOG) != 0,
+                           grad_out, out, grad_x, stream);
+}
+
+dmel_status dmel_backward_x_spec(dmel_plan* plan, const float* x, int32_t batch, float lambd, int32_t n_fft, uint32_t flags,
+                                 const float* grad_spec, float* grad_x, void* stream)
+{
+    if (!plan) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
+    if (batch < 0 || n_fft < 0) return fail(DMEL_ERR_INVALID_ARGUMENT, "batch / n_fft < 0");
+    if (batch == 0) return DMEL_OK;
+    if (!x || !grad_spec || !grad_x) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_backward_x_spec: x / grad_spec / grad_x is NULL");
+    if (!(flags & DMEL_SPEC_REMOVE_DC)) return fail(DMEL_ERR_UNSUPPORTED, "dmel_backward_x_spec: only the DC-removed spectrogram (models.py:187) is differentiated");
+    if (!std::isfinite(lambd)) return fail(DMEL_ERR_INVALID_ARGUMENT, "lambd is not finite");
+    return backward_x_impl(plan, x, batch, lambd, n_fft, (flags & DMEL_SPEC_HALF_WINDOW) ? 1 : 0, 1, false, grad_spec, nullptr, grad_x, stream);
 }
 
 dmel_status dmel_plan_set_profiling(dmel_plan* plan, int32_t enable)

@@ -304,6 +304,7 @@ struct XgradParams {
     double* csum;               // (B, chunks) fp64 sums of the gather chunks (mean of the clip's gradient)
     int B, L, T, hop, M, nchunks, N, F, logN, remove_dc;
     int tw_in_lds;              // set by launch_xgrad: the twiddle table is copied behind the sequence in LDS
+    int spec_mode;              // 1: grad_out is (B, F, T), the gradient of the power spectrogram itself (SpectrogramLayer): no filterbank
     float inv_L;
 };
 hipError_t launch_xgrad(const XgradParams& p, hipStream_t s);

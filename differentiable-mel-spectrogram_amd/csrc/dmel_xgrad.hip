@@ -66,7 +66,13 @@ __global__ void __launch_bounds__(kXgThreads) dmel_xgrad_frames_kernel(XgradPara
         const float xar = 0.5f * (zk.x + zn.x), xai = 0.5f * (zk.y - zn.y);
         const float xbr = 0.5f * (zk.y + zn.y), xbi = -0.5f * (zk.x - zn.x);
         float gpa = 0.f, gpb = 0.f;
-        const int2 band = p.rowband[k];
+        if (p.spec_mode) {
+            // DSPEC (models.py:171-200): the layer's output IS the power spectrogram, its gradient arrives per bin
+            const float* gs = p.grad_out + ((size_t)b * p.F + k) * T + tA;
+            gpa = gs[0];
+            gpb = hasB ? gs[1] : 0.f;
+        }
+        const int2 band = p.spec_mode ? make_int2(0, 0) : p.rowband[k];
         for (int m = band.x; m < band.y; ++m) {
             const float c = p.fb[(size_t)k * M + m];
             float g0 = ga[(size_t)m * T], g1 = hasB ? ga[(size_t)m * T + 1] : 0.f;

@@ -111,7 +111,7 @@ class _DmelFunction(torch.autograd.Function):
             if ctx.want_x:
                 gx = torch.empty_like(x)
                 ctx.plan.backward_x(x.data_ptr(), x.shape[0], lam_host, g.data_ptr(), out.data_ptr() if log else None,
-                                    gx.data_ptr(), log, _stream_ptr(g.device))
+                                    gx.data_ptr(), log, _stream_ptr(g.device), extra_flags=flags)
             if ctx.want_fb:
                 fb_shape, fb_dtype = fb_meta
                 gfb = torch.empty(fb_shape, dtype=torch.float32, device=g.device)
@@ -320,11 +320,9 @@ class MelSpectrogramLayer(nn.Module):
             raise RuntimeError(f"input has {n_points} points, the layer was built for n_points={self.n_points}")
         if not x.is_cuda:
             raise RuntimeError("dmel_amd runs on MI355X only: x must be a CUDA/HIP tensor (no CPU fallback)")
-        if x.requires_grad and not self.optimized:
-            raise NotImplementedError("gradient w.r.t. the waveform is implemented for optimized=True only")
-        if self.mel_fb is not None and not self.optimized and (n_points & (n_points - 1) or 2 * n_points > capi.MAX_NFFT):
-            raise NotImplementedError("a learnable filterbank with optimized=False needs a power-of-two n_points <= "
-                                      f"{capi.MAX_NFFT // 2} (its gradient kernel runs on the power-of-two transforms only)")
+        if x.requires_grad and not self.optimized and (n_points & (n_points - 1) or 2 * n_points > capi.MAX_NFFT):
+            raise NotImplementedError("gradient w.r.t. the waveform with optimized=False needs a power-of-two n_points <= "
+                                      f"{capi.MAX_NFFT // 2} (the chirp-z transform of other lengths has no adjoint kernel yet)")
         if self.lambd.device != x.device:
             raise RuntimeError(f"lambd is on {self.lambd.device} but x is on {x.device}; call layer.to(x.device)")
         # dtype / layout conversions only when needed (each no-op torch call still costs ~2 us of host time); when x requires
@@ -381,7 +379,8 @@ class MelSpectrogramLayer(nn.Module):
 
 
 class _DspecFunction(torch.autograd.Function):
-    """forward: dmel_spectrogram_ex (carries d spec / d lambd); backward: dmel_backward."""
+    """forward: dmel_spectrogram_ex (carries d spec / d lambd); backward: dmel_backward and, for a waveform that requires grad,
+    dmel_backward_x_spec."""
 
     @staticmethod
     def forward(ctx, x, lambd, plan, lam_host, n_fft, half_window):
@@ -393,20 +392,30 @@ class _DspecFunction(torch.autograd.Function):
             plan.spectrogram_ex(x.data_ptr(), B, lam_host, n_fft, out.data_ptr(), tangent.data_ptr() if want_tangent else None,
                                 _stream_ptr(x.device), remove_dc=True, half_window=half_window)
         ctx.plan, ctx.lambd_shape, ctx.lambd_dtype = plan, lambd.shape, lambd.dtype
-        if want_tangent:
-            ctx.save_for_backward(tangent)
+        ctx.want_tangent, ctx.want_x = want_tangent, ctx.needs_input_grad[0]
+        ctx.args = (lam_host, n_fft, half_window)
+        saved = ([tangent] if want_tangent else []) + ([x] if ctx.want_x else [])
+        ctx.save_for_backward(*saved)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        if not ctx.needs_input_grad[1]:
-            return None, None, None, None, None, None
-        (tangent,) = ctx.saved_tensors
+        saved = list(ctx.saved_tensors)
         g = grad_out.to(torch.float32).contiguous()
-        dl = torch.empty((1,), dtype=torch.float32, device=g.device)
+        dl = gx = None
         with torch.cuda.device(g.device):
-            ctx.plan.backward(g.data_ptr(), tangent.data_ptr(), g.numel(), dl.data_ptr(), _stream_ptr(g.device))
-        return None, dl.reshape(ctx.lambd_shape).to(ctx.lambd_dtype), None, None, None, None
+            if ctx.want_tangent:
+                tangent = saved.pop(0)
+                dl = torch.empty((1,), dtype=torch.float32, device=g.device)
+                ctx.plan.backward(g.data_ptr(), tangent.data_ptr(), g.numel(), dl.data_ptr(), _stream_ptr(g.device))
+                dl = dl.reshape(ctx.lambd_shape).to(ctx.lambd_dtype)
+            if ctx.want_x:
+                x = saved.pop(0)
+                lam_host, n_fft, half_window = ctx.args
+                gx = torch.empty_like(x)
+                ctx.plan.backward_x_spec(x.data_ptr(), x.shape[0], lam_host, n_fft, g.data_ptr(), gx.data_ptr(), _stream_ptr(g.device),
+                                         half_window=half_window)
+        return gx, dl, None, None, None, None
 
 
 class SpectrogramLayer(nn.Module):
@@ -442,8 +451,6 @@ class SpectrogramLayer(nn.Module):
             raise ValueError(f"expected x of shape (batch, n_points), got {tuple(x.shape)}")
         if not x.is_cuda:
             raise RuntimeError("dmel_amd runs on MI355X only: x must be a CUDA/HIP tensor (no CPU fallback)")
-        if x.requires_grad:
-            raise NotImplementedError("gradient w.r.t. the waveform is not implemented (the reference never uses it)")
         batch_size, n_points = x.shape
         lam_host = float(self.lambd.detach())
         if self.optimized:
@@ -459,7 +466,11 @@ class SpectrogramLayer(nn.Module):
             with torch.cuda.device(x.device):
                 plan = capi.Plan(n_points, self.hop_length, 1, 2, 0.0, 1.0, bool(self.normalize_window))
             self._plans[key] = plan
-        return _DspecFunction.apply(x.detach().to(torch.float32).contiguous(), self.lambd, plan, lam_host, n_fft, half)
+        if x.requires_grad and (n_fft & (n_fft - 1) or n_fft > capi.MAX_NFFT):
+            raise NotImplementedError(f"gradient w.r.t. the waveform needs a power-of-two n_fft <= {capi.MAX_NFFT} (this forward uses n_fft = {n_fft}: "
+                                      "the chirp-z transform has no adjoint kernel yet)")
+        xf = x if x.dtype == torch.float32 else x.to(torch.float32)
+        return _DspecFunction.apply(xf.contiguous(), self.lambd, plan, lam_host, n_fft, half)
 
 
 # BASELINE.json's north_star calls the layer by this name; the reference has no such symbol.

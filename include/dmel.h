@@ -103,8 +103,8 @@ dmel_status dmel_plan_release(dmel_plan* plan);
 dmel_status dmel_plan_get_config(const dmel_plan* plan, dmel_config* cfg);
 
 /* Replace the mel filterbank of the plan by a caller-supplied (n_freqs, n_mels) fp32 HOST matrix for
- * the given n_fft (n_freqs = n_fft/2+1): the contraction of models.py:53 then uses it instead of the
- * HTK table.  Pass fb = NULL to return to the built-in table. */
+ * the given n_fft (n_freqs = n_fft/2+1; 1 or any even length up to 262144): the contraction of models.py:53 then uses it instead
+ * of the HTK table.  Pass fb = NULL to return to the built-in table. */
 dmel_status dmel_plan_set_filterbank(dmel_plan* plan, int32_t n_fft, const float* fb);
 
 /* The same from a DEVICE matrix (a trainable filterbank after an optimizer step): the first call for an n_fft rebuilds that
@@ -231,7 +231,8 @@ dmel_status dmel_backward_scratch(dmel_plan* plan, const void* grad_out, int32_t
  *   x         device, (batch, n_points) fp32       grad_out  device, (batch, 1, n_mels, n_time) fp32
  *   out       device, same shape as grad_out, or NULL without DMEL_FLAG_LOG
  *   grad_fb   device, (n_fft/2+1, n_mels) fp32, overwritten
- * flags: DMEL_FLAG_LOG, DMEL_FLAG_FULL_WINDOW as in dmel_forward.  Deterministic (fixed-order sum over batch
+ * flags: DMEL_FLAG_LOG, DMEL_FLAG_FULL_WINDOW as in dmel_forward; any transform length the forward accepts (the spectrogram pass
+ * takes the chirp-z path for lengths that are not powers of two).  Deterministic (fixed-order sum over batch
  * slices, exact-fp32 MFMA).  Asynchronous on `stream`; uses a plan-owned workspace, so calls on one plan must be
  * issued on one stream at a time.
  */
@@ -247,11 +248,17 @@ dmel_status dmel_backward_fb_dev(dmel_plan* plan, const float* x, int32_t batch,
  * time_frequency.py:43-53 (zero padding, framing, window, rfft, |.|^2), models.py:53 (mel contraction) and, with
  * DMEL_FLAG_LOG, models.py:73.  The reference never differentiates the waveform; provided for completeness
  * (adversarial / saliency uses).  Arguments as dmel_backward_fb; grad_x: device, (batch, n_points) fp32, overwritten.
- * The optimized=False branch (DMEL_FLAG_FULL_WINDOW) is not supported.  Deterministic (overlap-add as an ordered
- * gather).  Asynchronous on `stream`; shares the plan-owned workspace with dmel_backward_fb.
+ * Power-of-two transforms up to 16384 points: every optimized=True case, and the optimized=False branch (DMEL_FLAG_FULL_WINDOW) on
+ * clips of a power-of-two length up to 8192 samples (the chirp-z path has no adjoint yet: DMEL_ERR_UNSUPPORTED).  Deterministic
+ * (overlap-add as an ordered gather).  Asynchronous on `stream`; shares the plan-owned workspace with dmel_backward_fb.
  */
 dmel_status dmel_backward_x(dmel_plan* plan, const float* x, int32_t batch, float lambd, uint32_t flags,
                             const float* grad_out, const float* out, float* grad_x, void* stream);
+/* The same through SpectrogramLayer.forward (models.py:171-200; dmel_spectrogram_ex with DMEL_SPEC_REMOVE_DC): grad_spec is the
+ * gradient of the power spectrogram, device (batch, n_fft/2+1, n_time) fp32; n_fft and flags as in dmel_spectrogram_ex (power-of-two
+ * n_fft up to 16384). */
+dmel_status dmel_backward_x_spec(dmel_plan* plan, const float* x, int32_t batch, float lambd, int32_t n_fft, uint32_t flags,
+                                 const float* grad_spec, float* grad_x, void* stream);
 
 /* Power spectrogram only, (batch, n_fft/2+1, n_time) fp32 = time_frequency.differentiable_spectrogram
  * (time_frequency.py:32-58, optimized branch) applied per clip; remove_dc != 0 adds models.py:38. */

@@ -128,7 +128,18 @@ def run_dspec(models, tf, L=128):
     return dict(spec=s.detach().numpy().astype(np.float32), dlam_lin=np.float32(dl.item()))
 
 
-FBGRAD_CASES = ("g1_c1", "g2_c2", "g5_n128", "g6_n256_ragged")
+def run_dspec_xgrad(models, tf, L=128):
+    """G7b: d loss / d x through the reference's SpectrogramLayer (models.py:171-200, optimized=False, hop 1) by torch autograd"""
+    from dmel_amd import synth
+    x = torch.from_numpy(synth.waveforms(2, L, seed=77, scale=1.0)).requires_grad_(True)
+    layer = models.SpectrogramLayer(torch.tensor(6.38), optimized=False, hop_length=1)
+    s = layer(x)
+    g = torch.from_numpy(synth.cotangent(tuple(s.shape), seed=78))
+    (gx,) = torch.autograd.grad((s * g).sum(), x)
+    return dict(gx=gx.numpy().astype(np.float32))
+
+
+FBGRAD_CASES = ("g1_c1", "g2_c2", "g5_n128", "g6_n256_ragged", "g7_mel_nonopt_256", "g7_mel_nonopt_601")   # the last two: optimized=False (n_fft = 2L; 601: not a power of two)
 
 
 def run_fbgrad(models, tf, case):
@@ -185,7 +196,7 @@ def run_panns(models):
     return out
 
 
-XGRAD_CASES = ("g1_c1", "g5_n128", "g6_n256_ragged", "g6_tone_dc", "g6_n32")
+XGRAD_CASES = ("g1_c1", "g5_n128", "g6_n256_ragged", "g6_tone_dc", "g6_n32", "g7_mel_nonopt_256", "g7_mel_nonopt_1024n")   # the last two: optimized=False
 
 
 def run_xgrad(models, tf, case):
@@ -260,12 +271,14 @@ def main(argv):
         argv = [a for a in argv if a != "net_keys"]
         if len(argv) == 1 and "net_keys" in sys.argv:
             return
-    names = argv[1:] or [c["name"] for c in C.CASES] + ["g7_dspec", "g7_dspec_100"] + ["g8_fbgrad_" + n for n in FBGRAD_CASES] + ["g9_panns"] + ["g10_xgrad_" + n for n in XGRAD_CASES] + ["g11_nets"]
+    names = argv[1:] or [c["name"] for c in C.CASES] + ["g7_dspec", "g7_dspec_100", "g7_dspec_xgrad"] + ["g8_fbgrad_" + n for n in FBGRAD_CASES] + ["g9_panns"] + ["g10_xgrad_" + n for n in XGRAD_CASES] + ["g11_nets"]
     for name in names:
         if name == "g7_dspec":
             out = run_dspec(models, tf)
         elif name == "g7_dspec_100":
             out = run_dspec(models, tf, L=100)
+        elif name == "g7_dspec_xgrad":
+            out = run_dspec_xgrad(models, tf)
         elif name.startswith("g10_xgrad_"):
             out = run_xgrad(models, tf, C.BY_NAME[name[len("g10_xgrad_"):]])
         elif name == "g9_panns":

@@ -654,7 +654,7 @@ def test_backward_fb_rejects_bad_arguments():
     with pytest.raises(capi.DmelError):
         plan.backward_fb(x.data_ptr(), 2, 9.0, g.data_ptr(), None, gfb.data_ptr(), True, st)        # log without the saved output
     with pytest.raises(capi.DmelError):
-        plan.backward_fb(x.data_ptr(), 2, 3000.0, g.data_ptr(), None, gfb.data_ptr(), False, st)    # n_fft 32768
+        plan.backward_fb(x.data_ptr(), 2, 50000.0, g.data_ptr(), None, gfb.data_ptr(), False, st)   # n_fft 524288: beyond the HIP path
     plan.backward_fb(x.data_ptr(), 0, 9.0, g.data_ptr(), None, gfb.fill_(1.0).data_ptr(), False, st)   # empty batch: zeros
     torch.cuda.synchronize()
     assert float(gfb.abs().max()) == 0.0
@@ -1029,3 +1029,80 @@ def test_config5_training_step_front_end_share():
     ls = [float(v) for v in losses]
     assert all(np.isfinite(ls)) and ls[-1] < ls[1]          # the first Adam step overshoots (3.95 -> 68), then the loss falls
     assert float(net.spectrogram_layer.lambd) != lam and net.spectrogram_layer.lambd_status()["error"] == 0
+
+
+# ---- the optional gradients outside optimized=True (missing #2 and #3) -------------------------------------------------
+@pytest.mark.parametrize("name", ["g7_mel_nonopt_256", "g7_mel_nonopt_1024n"])
+def test_xgrad_full_window_matches_reference_golden(name):
+    """x.requires_grad through the optimized=False branch (window = the clip, n_fft = 2 L; time_frequency.py:41,51) against torch
+    autograd through the reference (g10_xgrad_g7_*.npz)."""
+    import os
+    case = C.BY_NAME[name]
+    gold = np.load(os.path.join(os.path.dirname(C.__file__), f"g10_xgrad_{name}.npz"))
+    x_np = C.make_input(case).astype(np.float32)
+    g = torch.from_numpy(C.make_cotangent(case)).to("cuda:0")
+    for log, key in ((False, "gx_lin"), (True, "gx_log")):
+        x = torch.from_numpy(x_np).to("cuda:0").requires_grad_(True)
+        layer = _layer(case, log=log)
+        assert not layer.optimized
+        (layer(x) * g).sum().backward()
+        gx = x.grad.cpu().numpy()
+        k = gold[key].shape[0]
+        assert np.isfinite(gx).all() and _gx_err(gx[:k], gold[key].astype(np.float64)) <= TOL
+        assert layer.lambd.grad is not None
+
+
+def test_xgrad_full_window_other_lengths_raise():
+    from dmel_amd import MelSpectrogramLayer
+    lay = MelSpectrogramLayer(torch.tensor(50.0), n_mels=24, n_points=601, sample_rate=8000, hop_length=20, device="cuda:0",
+                              optimized=False).to("cuda:0")
+    x = torch.zeros(2, 601, device="cuda:0", requires_grad=True)
+    with pytest.raises(NotImplementedError):
+        lay(x)
+    assert lay(x.detach()).shape == (2, 1, 24, 31)
+
+
+@pytest.mark.parametrize("name", ["g7_mel_nonopt_256", "g7_mel_nonopt_601"])
+def test_learnable_filterbank_full_window_matches_reference_golden(name):
+    """learnable_fb with optimized=False -- n_fft = 2 L, a power of two (512) and not (1202: the spectrogram pass of the gradient
+    takes the chirp-z path) -- against torch autograd through the reference with mel_fb made a leaf (g8_fbgrad_g7_*.npz)"""
+    import os
+    from dmel_amd import MelSpectrogramLayer
+    case = C.BY_NAME[name]
+    gold = np.load(os.path.join(os.path.dirname(C.__file__), f"g8_fbgrad_{name}.npz"))
+    fwd = C.load(case)
+    x = torch.from_numpy(C.make_input(case).astype(np.float32)).to("cuda:0")
+    g = torch.from_numpy(C.make_cotangent(case)).to("cuda:0")
+    for log, key in ((False, "gfb_lin"), (True, "gfb_log")):
+        layer = MelSpectrogramLayer(torch.tensor(float(case["lambd"])), n_mels=case["n_mels"], n_points=case["L"], sample_rate=case["sr"],
+                                    f_min=case["f_min"], f_max=case["f_max"], hop_length=case["hop"], device="cuda:0", optimized=False,
+                                    normalize_window=case["normalize_window"], log=log, learnable_fb=True).to("cuda:0")
+        assert tuple(layer.mel_fb.shape) == gold[key].shape
+        y = layer(x)
+        (y * g).sum().backward()
+        got = layer.mel_fb.grad.cpu().numpy()
+        assert np.isfinite(got).all() and _gfb_err(got, gold[key].astype(np.float64)) <= TOL
+        assert layer.lambd.grad is not None and np.isfinite(float(layer.lambd.grad))
+        # the forward with the parameter as its filterbank equals the forward with the built-in table
+        plain = _layer(case, log=log)
+        with torch.no_grad():
+            assert (_log_err if log else _rel_err)(y.detach().cpu().numpy(), plain(x).cpu().numpy()) <= TOL
+    del fwd
+
+
+def test_dspec_xgrad_matches_reference_golden():
+    """x.requires_grad through SpectrogramLayer (models.py:171-200, optimized=False, L = 128 -> n_fft 256) against torch autograd
+    through the reference (g7_dspec_xgrad.npz)"""
+    import os
+    from dmel_amd import SpectrogramLayer, synth
+    gold = np.load(os.path.join(os.path.dirname(C.__file__), "g7_dspec_xgrad.npz"))
+    x = torch.from_numpy(synth.waveforms(2, 128, seed=77, scale=1.0)).to("cuda:0").requires_grad_(True)
+    lay = SpectrogramLayer(torch.tensor(6.38), optimized=False, hop_length=1).to("cuda:0")
+    s = lay(x)
+    g = torch.from_numpy(synth.cotangent(tuple(s.shape), seed=78)).to("cuda:0")
+    (s * g).sum().backward()
+    assert _gx_err(x.grad.cpu().numpy(), gold["gx"].astype(np.float64)) <= TOL
+    assert lay.lambd.grad is not None
+    x100 = torch.zeros(2, 100, device="cuda:0", requires_grad=True)
+    with pytest.raises(NotImplementedError):
+        lay(x100)
