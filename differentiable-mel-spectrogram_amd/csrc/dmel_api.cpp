@@ -1372,7 +1372,7 @@ dmel_status backward_x_impl(dmel_plan* plan, const float* x, int32_t batch, floa
     Scratch sc;
     if ((st = ensure_own_scratch(plan, batch, s, &sc)) != DMEL_OK) return st;
     const size_t frame_floats = ((size_t)batch * plan->T * N + 63) / 64 * 64;
-    const size_t need = frame_floats + 2 * (size_t)batch * dmel::xgrad_chunks(plan->cfg.n_points) + 16;    // + fp64 chunk sums
+    const size_t need = frame_floats + 2 * (size_t)batch * plan->T + 16;    // + one fp64 sum per frame
     if (need > plan->fbw_floats) {
         if (is_capturing(s)) return fail(DMEL_ERR_INVALID_ARGUMENT, "workspace must grow but the stream is capturing: run one call eagerly first");
         DMEL_HIP(hipStreamSynchronize(s));

@@ -301,7 +301,7 @@ struct XgradParams {
     const float* out;           // (B, M, T) saved log output or nullptr
     float* frames;              // (B, T, N) workspace: windowed gradient of every frame
     float* grad_x;              // (B, L)
-    double* csum;               // (B, chunks) fp64 sums of the gather chunks (mean of the clip's gradient)
+    double* csum;               // (B, T) fp64: what every frame contributes to the sum of the clip's gradient (its mean is removed)
     int B, L, T, hop, M, nchunks, N, F, logN, remove_dc;
     int tw_in_lds;              // set by launch_xgrad: the twiddle table is copied behind the sequence in LDS
     int spec_mode;              // 1: grad_out is (B, F, T), the gradient of the power spectrogram itself (SpectrogramLayer): no filterbank

@@ -13,8 +13,8 @@
 // the same bit-reversed addresses, which is exactly the input order of an in-place decimation-in-time FFT; its output
 // is conj(dv_a + i dv_b) in natural order.  No permutation pass, no second buffer.  The windowed frame gradients go to a
 // (B, T, N) workspace.
-// Kernels 2 and 3 (one workgroup per 4096 samples): overlap-add as a gather in increasing frame order (deterministic, no
-// atomics) with an fp64 sum per chunk, then the mean of the clip's gradient (chunk sums in index order) is subtracted.
+// Kernel 2 (one workgroup per 4096 samples): overlap-add as a gather in increasing frame order (deterministic, no atomics) minus
+// the mean of the clip's gradient, which comes from fp64 per-frame sums left by kernel 1 (a third kernel used to subtract it).
 // A correctness-first path: about 10x the time of the fused forward at config 2.
 #include "dmel_kernels.h"
 #include "dmel_ldsfft.h"
@@ -94,16 +94,33 @@ __global__ void __launch_bounds__(kXgThreads) dmel_xgrad_frames_kernel(XgradPara
     // decimation in time, bit-reversed order in, natural order out: R = FFT(conj W) = conj(dv_a + i dv_b)
     lds_fft_dit<kXgThreads>(Z, N, p.logN, tid, twiddle);
     float* fa = p.frames + ((size_t)b * T + tA) * N;
+    double sa = 0.0, sb = 0.0;                                 // what each frame contributes to the sum of the clip's gradient
     for (int n = tid; n < N; n += kXgThreads) {
         const float2 r = Z[n];
         const float w = p.win2[n].x;
-        fa[n] = r.x * w;
-        if (hasB) fa[N + n] = -r.y * w;
+        const float va = r.x * w, vb = -r.y * w;
+        fa[n] = va;
+        if (hasB) fa[N + n] = vb;
+        const long long ia = (long long)tA * p.hop - N / 2 + n, ib = ia + p.hop;
+        if (ia >= 0 && ia < p.L) sa += (double)va;
+        if (hasB && ib >= 0 && ib < p.L) sb += (double)vb;
     }
+    // fixed-order tree over the 256 threads (the sequence is dead: its first 4 KB hold the partials)
+    __syncthreads();
+    double* red = reinterpret_cast<double*>(smem_raw);
+    red[tid] = sa; red[kXgThreads + tid] = sb;
+    __syncthreads();
+    for (int o = kXgThreads / 2; o > 0; o >>= 1) {
+        if (tid < o) { red[tid] += red[tid + o]; red[kXgThreads + tid] += red[kXgThreads + tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) { p.csum[(size_t)b * T + tA] = red[0]; if (hasB) p.csum[(size_t)b * T + tB] = red[kXgThreads]; }
 }
 
-// grid (chunks, B): every workgroup overlap-adds one chunk of kXgChunk samples of one clip and leaves the chunk's sum
-// (fp64, fixed tree) in csum[b][chunk]
+// grid (chunks, B): every workgroup overlap-adds one chunk of kXgChunk samples of one clip as a gather in increasing frame
+// order (deterministic, no atomics) and subtracts the mean of the clip's gradient (models.py:38 removes the clip's DC, so the
+// gradient has none either).  The mean comes from the per-frame sums the first kernel left: every workgroup adds them up in the
+// same fixed order (strided partial sums, then a tree), so every chunk of a clip subtracts the same bits.
 constexpr int kXgChunk = 4096;
 
 __global__ void __launch_bounds__(256) dmel_xgrad_gather_kernel(XgradParams p)
@@ -111,10 +128,18 @@ __global__ void __launch_bounds__(256) dmel_xgrad_gather_kernel(XgradParams p)
     __shared__ double red[256];
     const int tid = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
     const int N = p.N, T = p.T, hop = p.hop, half = N / 2;
+    float mean = 0.f;
+    if (p.remove_dc) {
+        double acc = 0.0;
+        for (int t = tid; t < T; t += 256) acc += p.csum[(size_t)b * T + t];
+        red[tid] = acc;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+        mean = (float)(red[0] / (double)p.L);
+    }
     const float* fr = p.frames + (size_t)b * T * N;
     float* gx = p.grad_x + (size_t)b * p.L;
     const int lo = chunk * kXgChunk, hi = min(lo + kXgChunk, p.L);
-    double acc = 0.0;
     for (int i = lo + tid; i < hi; i += 256) {
         // frames with 0 <= i - t hop + N/2 < N, in increasing t
         int t_lo = i + half - N + 1;
@@ -123,25 +148,8 @@ __global__ void __launch_bounds__(256) dmel_xgrad_gather_kernel(XgradParams p)
         if (t_hi > T - 1) t_hi = T - 1;
         float s = 0.f;
         for (int t = t_lo; t <= t_hi; ++t) s += fr[(size_t)t * N + (i - t * hop + half)];
-        gx[i] = s;
-        acc += (double)s;
+        gx[i] = s - mean;
     }
-    red[tid] = acc;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
-    if (tid == 0) p.csum[(size_t)b * gridDim.x + chunk] = red[0];
-}
-
-// dx = dx~ - mean(dx~): the chunk sums are added in index order by every workgroup (same value everywhere)
-__global__ void __launch_bounds__(256) dmel_xgrad_mean_kernel(XgradParams p)
-{
-    const int tid = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
-    double tot = 0.0;
-    for (int c = 0; c < (int)gridDim.x; ++c) tot += p.csum[(size_t)b * gridDim.x + c];
-    const float mean = (float)(tot / (double)p.L);
-    float* gx = p.grad_x + (size_t)b * p.L;
-    const int lo = chunk * kXgChunk, hi = min(lo + kXgChunk, p.L);
-    for (int i = lo + tid; i < hi; i += 256) gx[i] -= mean;
 }
 
 hipError_t xgrad_prepare_attributes()
@@ -159,19 +167,17 @@ hipError_t launch_xgrad(const XgradParams& p, hipStream_t s)
     if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
     XgradParams q = p;
     q.tw_in_lds = p.N <= 8192 ? 1 : 0;
-    const size_t lds = (size_t)p.N * sizeof(float2) + (q.tw_in_lds ? (size_t)(p.N / 2) * sizeof(float2) : 0);
+    size_t lds = (size_t)p.N * sizeof(float2) + (q.tw_in_lds ? (size_t)(p.N / 2) * sizeof(float2) : 0);
+    if (lds < 2 * kXgThreads * sizeof(double)) lds = 2 * kXgThreads * sizeof(double);      // the per-frame sums are reduced where the sequence was
     if (q.tw_in_lds) hipLaunchKernelGGL(dmel_xgrad_frames_kernel<true>, dim3((unsigned)grid), dim3(kXgThreads), lds, s, q);
     else hipLaunchKernelGGL(dmel_xgrad_frames_kernel<false>, dim3((unsigned)grid), dim3(kXgThreads), lds, s, q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const dim3 g2((unsigned)((p.L + kXgChunk - 1) / kXgChunk), (unsigned)p.B);
     hipLaunchKernelGGL(dmel_xgrad_gather_kernel, g2, dim3(256), 0, s, p);
-    e = hipGetLastError();
-    if (e != hipSuccess || !p.remove_dc) return e;
-    hipLaunchKernelGGL(dmel_xgrad_mean_kernel, g2, dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
 }  // namespace dmel
 
-namespace dmel { int xgrad_chunks(int L) { return (L + kXgChunk - 1) / kXgChunk; } }
+namespace dmel { int xgrad_chunks(int L) { return (L + kXgChunk - 1) / kXgChunk; } }      // (kept for the workspace layout of dmel_api.cpp)
