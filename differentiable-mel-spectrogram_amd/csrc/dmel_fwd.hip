@@ -321,13 +321,6 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
     const int tile0 = (wg % p.wgs_per_clip) * TPW;              // first tile of this workgroup inside its clip
     STAMP(0);
     STAMP_PLACE();
-#if defined(DMEL_WGPRIO)
-    // timing experiment: the two workgroups that share a CU on a one-round launch (blockIdx b and b + 256) at different static priorities
-    if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(DMEL_WGPRIO);
-#endif
-#if defined(DMEL_WAVEPRIO)
-    if (wave >= 4) __builtin_amdgcn_s_setprio(DMEL_WAVEPRIO);
-#endif
 #ifdef DMEL_ABLATE
     // timing ablations (tools/ablate.py builds its own library with -DDMEL_ABLATE; never in libdmel_hip.so)
     const bool dbg_skip_fft = (p.flags & 0x200u) != 0;
@@ -425,18 +418,7 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
     };
 
     // ================= prologue, once per workgroup ============================================
-    // first-stage twiddles w_N^(lg q): rows q = 1 and q = 8a of the table are per-lane constants of the whole workgroup (lg is fixed):
-    // requested here, before anything waits, instead of in the middle of every transform
-    constexpr bool TW1_POW = (R >= 16);
-#ifndef DMEL_TW1_EARLY
-#define DMEL_TW1_EARLY 0
-#endif
-    constexpr bool TW1_EARLY = TW1_POW && WPF == 1 && (DMEL_TW1_EARLY != 0) && N == 1024;
-    float2 tw1_w1 = make_float2(1.f, 0.f), tw1_anchor[TW1_POW ? R / 8 : 1];
-    if constexpr (TW1_EARLY) {
-        tw1_w1 = p.tw1[G + lg];
-        static_for<1, R / 8>([&](auto aa) { constexpr int a8 = decltype(aa)::value; tw1_anchor[a8] = p.tw1[(8 * a8) * G + lg]; });
-    }
+    constexpr bool TW1_POW = (R >= 16);     // first-stage twiddles by powers: see phase 1
     float mean = 0.f;
     float2 wkeep[WPT];                                          // this thread's window entries (TPW > 1: written back per tile)
     float2 wmid = make_float2(1.f, 0.f);                        // ... and the centre entry
@@ -696,10 +678,12 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
                 // only rows q = 1 and q = 8a are loaded, w^(8a+b) = w^(8a) w^b with w^2..w^7 by repeated multiplication (<= 7
                 // roundings: ~5e-7 relative, the transform's own noise): R/8 loads and about R complex products instead of R - 1 loads.
                 // Measured: config 2 21.87 -> 21.52 us, config 3 49.7 -> 47.4, config 5 74.3 -> 71.9, ESC-50 shape 164 -> 157 (n_fft 4096)
-                // and 514 -> 485 (8192); errors against the fp64 oracle unchanged (3e-7 of the loudest bin)
+                // and 514 -> 485 (8192); errors against the fp64 oracle unchanged (3e-7 of the loudest bin).  The two or four rows are
+                // requested HERE: asked for at the top of the kernel (8 more live registers through the prologue) the 32 x 32 plan measured
+                // 22.0 us against 20.0 at config 2, copied to LDS once per workgroup 20.2 against 19.7
                 v2f wb[TW1_POW ? 8 : 1];
                 if constexpr (TW1_POW) {
-                    const float2 w1 = TW1_EARLY ? tw1_w1 : p.tw1[G + lg];
+                    const float2 w1 = p.tw1[G + lg];
                     wb[1] = v2f{w1.x, w1.y};
                     static_for<2, 8>([&](auto bb) { constexpr int b = decltype(bb)::value; wb[b] = cmul(wb[b - 1], w1); });
                 }
@@ -711,7 +695,7 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
                         constexpr int a8 = q / 8, b8 = q % 8;
                         if constexpr (a8 == 0) return cmul(v, float2{wb[b8].x, wb[b8].y});
                         else {
-                            const float2 anchor = TW1_EARLY ? tw1_anchor[a8] : p.tw1[(8 * a8) * G + lg];
+                            const float2 anchor = p.tw1[(8 * a8) * G + lg];
                             if constexpr (b8 == 0) return cmul(v, anchor);
                             else { const v2f t = cmul(wb[b8], anchor); return cmul(v, float2{t.x, t.y}); }
                         }
