@@ -3,7 +3,7 @@
 # FETCH_SIZE / WRITE_SIZE / SQ counter passes (each in its own run, --pmc never combined with other trace domains),
 # the un-profiled bench line of the same build.  Raw output under gpurun_out/prof_$TAG; tools/summarize_profile.py turns
 # it into the files committed under profiles/.
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -19,4 +19,15 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_c3 -- python3 to
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_c5 -- python3 tools/ktime.py c5 train 60 > $OUT/kt_c5.log 2>&1
 # the shapes of the reference's own experiments (search_spaces.py): forward + dot per training step through the C ABI
 python3 tools/time_reference_shapes.py > $OUT/reference_shapes.json 2> $OUT/reference_shapes.err
-ls -R $OUT | head -60
+# the optional backward outputs (dL/dfb, dL/dx) and the global-memory FFT / chirp-z kernel: per-kernel durations
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_f2 -- python3 tools/time_backward_extras.py > $OUT/kt_f2.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_big -- python3 tools/time_full_window.py > $OUT/kt_big.log 2>&1
+# the step with each reducer on one rank (the exchange's own cost: one-rank communicator / self-addressed mailbox), and two ranks
+# sharing this GPU through the mailbox (HIP IPC; RCCL refuses two ranks on one device)
+A="--steps 200 --warmup 20 --no-cpu-baseline --no-other-configs"
+DMEL_BENCH_FORCE_DIST=1 python3 bench.py $A --reducer rccl 2> /dev/null | grep "^{" > $OUT/bench_1rank_rccl.json
+DMEL_BENCH_FORCE_DIST=1 python3 bench.py $A --reducer mailbox 2> /dev/null | grep "^{" > $OUT/bench_1rank_mailbox.json
+DMEL_BENCH_SHARE_GPU=1 python3 bench.py $A --gpus 2 --reducer mailbox 2> /dev/null | grep "^{" > $OUT/bench_2ranks_one_gpu_mailbox.json
+# phase stamps of the n_fft 1024 training kernel (diagnostic build made by `python tools/stamps.py build -DDMEL_ONLY_NFFT=1024` before the call)
+python3 tools/stamps.py run c2 > $OUT/stamps_c2.txt 2>&1
+ls -R $OUT | head -80

@@ -11,8 +11,8 @@ import statistics
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "prof_r02")
-tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "prof_r03")
+tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
 out = os.path.join(ROOT, "profiles")
 FWD = "dmel_fwd_kernel<1024, 0"          # the training-mode forward at n_fft 1024 (any tiles-per-workgroup variant)
 
@@ -60,6 +60,46 @@ for cfg in ("c3", "c5"):
     other[cfg] = lst
 if other:
     json.dump(other, open(os.path.join(out, f"{tag}_kernel_trace_summary_c3_c5.json"), "w"), indent=1)
+
+# optional backward outputs and the big-transform kernel: per-kernel summaries
+for sub, name in (("kt_f2", "f2_backward_extras"), ("kt_big", "big_transforms")):
+    hits = glob.glob(os.path.join(src, f"{sub}/**/*_kernel_trace.csv"), recursive=True)
+    if len(hits) != 1:
+        continue
+    rws = list(csv.DictReader(open(hits[0])))
+    lst = []
+    for k in sorted({r["Kernel_Name"] for r in rws if "dmel" in r["Kernel_Name"]}):
+        rs = [r for r in rws if r["Kernel_Name"] == k]
+        # the scripts time several shapes with one kernel name: split by grid size
+        for grid in sorted({r.get("Grid_Size", r.get("Grid_Size_X")) for r in rs}, key=lambda v: int(v)):
+            rg = [r for r in rs if r.get("Grid_Size", r.get("Grid_Size_X")) == grid]
+            d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rg]
+            r0 = rg[0]
+            lst.append(dict(kernel=short(k)[:110], grid=grid, calls=len(d), avg_ns=round(statistics.mean(d), 1), median_ns=statistics.median(d), min_ns=min(d),
+                            vgpr=r0.get("VGPR_Count"), lds=r0.get("LDS_Block_Size"), scratch=r0.get("Scratch_Size"), wg=r0.get("Workgroup_Size", r0.get("Workgroup_Size_X"))))
+    json.dump(lst, open(os.path.join(out, f"{tag}_kernel_trace_summary_{name}.json"), "w"), indent=1)
+    log = os.path.join(src, sub + ".log")
+    if os.path.exists(log):
+        lines = [ln for ln in open(log) if ln.startswith("{")]
+        if lines:
+            json.dump(json.loads(lines[-1]), open(os.path.join(out, f"{tag}_{name}_timings.json"), "w"), indent=1)
+red = {}
+for nm in ("bench_1rank_rccl", "bench_1rank_mailbox", "bench_2ranks_one_gpu_mailbox"):
+    pth = os.path.join(src, nm + ".json")
+    if os.path.exists(pth):
+        lines = [ln for ln in open(pth) if ln.startswith("{")]
+        if lines:
+            d = json.loads(lines[-1])
+            red[nm] = {"value_frames_per_s": d["value"], "ms_per_step": d["ms_per_step"], "n_ranks": d["n_gpus"], "reducer": d["config"].get("reducer"),
+                       "issued": d["module_step"]["issued"], "trial_ms_per_step": d["module_step"]["trial_ms_per_step"]}
+if red:
+    json.dump({"_how": "bench.py --steps 200 --warmup 20 with DMEL_BENCH_FORCE_DIST=1 (one rank, the reducer still runs: one-rank RCCL communicator / "
+                       "mailbox addressed to itself) and DMEL_BENCH_SHARE_GPU=1 --gpus 2 --reducer mailbox (two processes on ONE GPU exchanging through "
+                       "IPC-mapped inboxes: the code path of two GPUs, not their speed -- the two ranks' kernels overlap on the one device)", **red},
+              open(os.path.join(out, f"{tag}_reducers.json"), "w"), indent=1)
+st = os.path.join(src, "stamps_c2.txt")
+if os.path.exists(st):
+    shutil.copy(st, os.path.join(out, f"{tag}_stamps_c2.txt"))
 
 rs_path = os.path.join(src, "reference_shapes.json")
 if os.path.exists(rs_path):
