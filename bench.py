@@ -343,12 +343,14 @@ def main():
 
     # ways of issuing the same step: eagerly from Python, or replayed from a HIP graph captured from that very code
     # (dmel_amd.GraphedStep: watches the lambd the kernels report and re-captures when the n_fft or its guards change);
-    # "graph xk" unrolls k steps into one graph, which pays the ~8 us between two graph launches once per k steps
+    # "graph xk" unrolls k steps into one graph, which pays the ~8-14 us between two graph launches once per k steps
     from dmel_amd import GraphedStep
     modes, graph_why = {"eager": (module_step, 1)}, ""
     MAX_AHEAD = 8
     if args.mode in ("auto", "graph"):
-        ks = [1] + [k for k in (4,) if args.steps % k == 0]
+        # (a graph launch costs ~8-14 us of idle time on the device between two replays -- profiles/r03_step_timeline_c2.json --
+        # whatever the graph holds: the more steps one replay carries, the less of it each step pays)
+        ks = [1] + [k for k in (4, 10) if args.steps % k == 0]
         for k in ks:
             ok = True
             try:
@@ -381,10 +383,12 @@ def main():
     if chosen == "graph":
         chosen = "graph" if "graph" in modes else "eager"
     if chosen in ("auto", "graph") and len(modes) > 1:
-        ntrial = 40
+        # the trial times what the timed region will: exactly --steps steps behind a synchronisation (a replay of many steps pays
+        # less launch gap per step, but the first launch after a synchronisation is exposed, which counts when --steps is small)
+        ntrial = args.steps
         names = [m for m in modes if (args.mode == "auto" or m != "eager")]
         for name in names:
-            trial[name] = run_mode(name, 4, ntrial) / ntrial
+            trial[name] = min(run_mode(name, 4, ntrial), run_mode(name, 0, ntrial)) / ntrial
         chosen = min(trial, key=trial.get)
         if dist is not None:                                            # every rank must take the same path
             order = list(modes)
