@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libdmel_hip.so")
 TORCH_LIB_PATH = os.path.join(PKG_DIR, "libdmel_torch.so")
 OBJ_DIR = os.path.join(PKG_DIR, "build")
 SOURCES = ["dmel_fwd.hip", "dmel_aux.hip", "dmel_big.hip", "dmel_xgrad.hip", "dmel_api.cpp", "dmel_comm.cpp"]
-HEADERS = [os.path.join(CSRC, "dmel_kernels.h"), os.path.join(CSRC, "dmel_ldsfft.h"), os.path.join(os.path.dirname(PKG_DIR), "include", "dmel.h")]
+HEADERS = [os.path.join(CSRC, "dmel_kernels.h"), os.path.join(CSRC, "dmel_ldsfft.h"), os.path.join(CSRC, "dmel_wavefft.h"), os.path.join(os.path.dirname(PKG_DIR), "include", "dmel.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 

@@ -70,11 +70,13 @@ struct NfftTables {
     float* fbT = nullptr;        // long transforms: (M, F) transposed bank, (M) bands
     int2* band = nullptr;
     int2* rowband = nullptr;     // (F): non-zero column range of every filterbank row (dL/dx)
+    float4* rowpk = nullptr;     // (F): (first two non-zero coefficients, first column, columns) of every row (dL/dx, wave-FFT kernel)
+    bool long_rows = false;      // some row has more than two columns
     void release()
     {
         if (tw1p == tw1) tw1p = nullptr;
         if (tw2p == tw2) tw2p = nullptr;
-        void* ptrs[] = {tw1, tw2, tw1p, tw2p, ent_b, ent_pre, tile_ranges, fb_dense, tw_long, fbT, band, rowband};
+        void* ptrs[] = {tw1, tw2, tw1p, tw2p, ent_b, ent_pre, tile_ranges, fb_dense, tw_long, fbT, band, rowband, rowpk};
         for (void* q : ptrs) (void)hipFree(q);
         *this = NfftTables();
     }
@@ -202,6 +204,16 @@ dmel_status build_tables(dmel_plan* pl, int N, NfftTables** out)
         }
         DMEL_HIP(hipMalloc(&tb.rowband, rowband.size() * sizeof(int2)));
         DMEL_HIP(hipMemcpy(tb.rowband, rowband.data(), rowband.size() * sizeof(int2), hipMemcpyHostToDevice));
+        std::vector<float4> rowpk(tb.F);
+        for (int f = 0; f < tb.F; ++f) {
+            const int b0 = rowband[f].x, nb = rowband[f].y - rowband[f].x;
+            float bits0, bitsn;
+            std::memcpy(&bits0, &b0, 4); std::memcpy(&bitsn, &nb, 4);
+            rowpk[f] = make_float4(nb > 0 ? fb[(size_t)f * M + b0] : 0.f, nb > 1 ? fb[(size_t)f * M + b0 + 1] : 0.f, bits0, bitsn);
+            if (nb > 2) tb.long_rows = true;
+        }
+        DMEL_HIP(hipMalloc(&tb.rowpk, rowpk.size() * sizeof(float4)));
+        DMEL_HIP(hipMemcpy(tb.rowpk, rowpk.data(), rowpk.size() * sizeof(float4), hipMemcpyHostToDevice));
     }
     const bool is_pow2 = (N & (N - 1)) == 0;
     if (N > dmel::kMaxFastNfft || !is_pow2) {
@@ -959,7 +971,7 @@ dmel_status dmel_plan_set_filterbank_dev(dmel_plan* plan, int32_t n_fft, const f
     if (st != DMEL_OK) return st;
     dmel::RepackParams rp{};
     rp.fb = fb_dev; rp.ent_b = tb->ent_b; rp.ent_pre = tb->ent_pre; rp.tile_ranges = tb->tile_ranges;
-    rp.fb_dense = tb->fb_dense; rp.fbT = tb->fbT; rp.F = tb->F; rp.M = plan->cfg.n_mels;
+    rp.fb_dense = tb->fb_dense; rp.fbT = tb->fbT; rp.rowpk = tb->rowpk; rp.F = tb->F; rp.M = plan->cfg.n_mels;
     const bool fast = n_fft >= dmel::kMinFastNfft && n_fft <= dmel::kMaxFastNfft;
     const int waves = fast ? dmel::forward_waves(n_fft) : 0;
     rp.runs = fast ? tb->groups * waves * 2 : 0;
@@ -1371,8 +1383,16 @@ dmel_status backward_x_impl(dmel_plan* plan, const float* x, int32_t batch, floa
     if ((st = order_after_last_stream(plan, s)) != DMEL_OK) return st;
     Scratch sc;
     if ((st = ensure_own_scratch(plan, batch, s, &sc)) != DMEL_OK) return st;
-    const size_t frame_floats = ((size_t)batch * plan->T * N + 63) / 64 * 64;
-    const size_t need = frame_floats + 2 * (size_t)batch * plan->T + 16;    // + one fp64 sum per frame
+    // n_fft 32 ... 2048: the wave-FFT kernel leaves one overlap-added segment per tile of frames; otherwise one row per frame
+    int fpt = 0;
+    const int win_n = win_half ? N : N / 2 + 1;             // the plain Gaussian is symmetric about N/2 (the whole-clip window need not be)
+    const bool wave_path = dmel::xgrad_wave_shape(N, spec_mode ? 0 : plan->cfg.n_mels, win_n, &fpt) && std::getenv("DMEL_XGRAD_LDS") == nullptr;
+    const int tiles = wave_path ? (plan->T + fpt - 1) / fpt : 0;
+    const long long span = wave_path ? (long long)(fpt - 1) * plan->cfg.hop_length + N : 0;
+    if (span > 0x3fffffffLL) return fail(DMEL_ERR_UNSUPPORTED, "gradient w.r.t. the waveform: hop_length too large");
+    const size_t rows = wave_path ? (size_t)tiles : (size_t)plan->T, row_len = wave_path ? (size_t)span : (size_t)N;
+    const size_t frame_floats = ((size_t)batch * rows * row_len + 63) / 64 * 64;
+    const size_t need = frame_floats + 2 * (size_t)batch * rows + 16;    // + one fp64 sum per frame / tile
     if (need > plan->fbw_floats) {
         if (is_capturing(s)) return fail(DMEL_ERR_INVALID_ARGUMENT, "workspace must grow but the stream is capturing: run one call eagerly first");
         DMEL_HIP(hipStreamSynchronize(s));
@@ -1387,16 +1407,21 @@ dmel_status backward_x_impl(dmel_plan* plan, const float* x, int32_t batch, floa
     pp.N = N; pp.normalize = plan->cfg.normalize_window; pp.win_half = win_half;
     pp.center = win_half ? (float)((N / 2) / 2) + (float)(N / 2) / 2.0f : (float)N / 2.0f;      // as launch_forward_n
     pp.lam.val = lambd; pp.lam.role = dmel::kLamQuiet;
-    DMEL_HIP(dmel::launch_prep(pp, s));
+    // short clips with the plain Gaussian window: the wave-FFT kernel evaluates the window and adds up its clip itself
+    const bool own_prep = wave_path && !win_half && !plan->cfg.normalize_window && plan->cfg.n_points <= 32768 && std::getenv("DMEL_XGRAD_PREP") == nullptr;
+    if (!own_prep) DMEL_HIP(dmel::launch_prep(pp, s));
     dmel::XgradParams xp{};
+    xp.own_prep = own_prep ? 1 : 0; xp.win_denom = std::fabs(lambd) + 1e-15f;
     xp.x = x; xp.psum = sc.psum; xp.win2 = sc.win; xp.tw = tb->tw_long;
-    xp.fb = tb->fb_dense; xp.rowband = tb->rowband; xp.grad_out = grad_out; xp.out = log ? out : nullptr;
+    xp.fb = tb->fb_dense; xp.rowband = tb->rowband; xp.rowpk = tb->rowpk; xp.long_rows = tb->long_rows ? 1 : 0; xp.grad_out = grad_out; xp.out = log ? out : nullptr;
     xp.frames = plan->fbw; xp.grad_x = grad_x;
     xp.csum = reinterpret_cast<double*>(plan->fbw + frame_floats);      // 256-byte aligned: frame_floats is a multiple of 64
     xp.B = batch; xp.L = plan->cfg.n_points; xp.T = plan->T; xp.hop = plan->cfg.hop_length; xp.M = plan->cfg.n_mels;
     xp.nchunks = plan->nchunks; xp.N = N; xp.F = tb->F; xp.remove_dc = 1; xp.spec_mode = spec_mode;
     xp.logN = 0; while ((1 << xp.logN) < N) ++xp.logN;
     xp.inv_L = 1.0f / (float)plan->cfg.n_points;
+    xp.tw1 = tb->tw1p; xp.tw2 = tb->tw2p;
+    xp.win_n = win_n; xp.tiles = tiles; xp.span = (int)span; xp.tile_step = wave_path ? fpt * plan->cfg.hop_length : 0;
     const size_t m0 = prof_mark(plan, s);
     DMEL_HIP(dmel::launch_xgrad(xp, s));
     prof_span(plan, m0, prof_mark(plan, s), 2);

@@ -190,6 +190,10 @@ __global__ void __launch_bounds__(256) dmel_repack_kernel(RepackParams p)
             p.fb_dense[i] = v;
             if (p.fbT) { const int f = (int)(i / p.M), m = (int)(i % p.M); p.fbT[(size_t)m * p.F + f] = v; }
         }
+        // packed rows of the waveform gradient (dense structure: every row starts at column 0 and has M columns)
+        if (p.rowpk)
+            for (long long f = (long long)(blockIdx.x - p.runs) * 256 + tid; f < p.F; f += stride)
+                p.rowpk[f] = make_float4(p.fb[f * p.M], p.M > 1 ? p.fb[f * p.M + 1] : 0.f, __builtin_bit_cast(float, 0), __builtin_bit_cast(float, p.M));
         return;
     }
     const int run = blockIdx.x;

@@ -25,129 +25,11 @@
 // Reference semantics restated here: models.py:33-56 (layer forward), time_frequency.py:21-30
 // (window), :32-58 (STFT, |.|^2), models.py:73 (log).
 #include "dmel_kernels.h"
+#include "dmel_wavefft.h"
 
 
 namespace dmel {
 
-typedef float floatx4 __attribute__((ext_vector_type(4)));
-
-// ---- compile-time helpers -------------------------------------------------------------------
-template <int I> struct IC { static constexpr int value = I; };
-template <int B, int E, class F> __device__ __forceinline__ void static_for(F&& f)
-{
-    if constexpr (B < E) { f(IC<B>{}); static_for<B + 1, E>(f); }
-}
-constexpr int ilog2(int v) { int r = 0; while (v > 1) { v >>= 1; ++r; } return r; }
-constexpr int bitrev(int i, int bits) { int r = 0; for (int b = 0; b < bits; ++b) { r = (r << 1) | (i & 1); i >>= 1; } return r; }
-
-// cos(2 pi j / 64), j = 0..16
-constexpr float kCos64[17] = {
-    1.0f, 0.99518472667219688624f, 0.98078528040323044913f, 0.95694033573220886494f,
-    0.92387953251128675613f, 0.88192126434835502971f, 0.83146961230254523708f, 0.77301045336273696081f,
-    0.70710678118654752440f, 0.63439328416364549822f, 0.55557023301960222474f, 0.47139673682599764856f,
-    0.38268343236508977173f, 0.29028467725446236764f, 0.19509032201612826785f, 0.09801714032956060199f,
-    0.0f};
-constexpr float cos64(int j)   // j in [0, 32]
-{
-    return j <= 16 ? kCos64[j] : -kCos64[32 - j];
-}
-constexpr float sin64(int j)   // j in [0, 32]
-{
-    return j <= 16 ? kCos64[16 - j] : kCos64[j - 16];
-}
-
-// Complex numbers live in one 64-bit register pair (re, im) through every stage, so that each complex
-// add / multiply is one or two packed VALU instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 with
-// op_sel / neg modifiers for the swaps and sign flips) and no register shuffling is needed between stages.
-typedef float v2f __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ v2f rot_mi(v2f a) { return v2f{a.y, -a.x}; }          // a * (-i)
-__device__ __forceinline__ v2f splat(float c) { return v2f{c, c}; }
-
-// a * exp(-2 pi i TW / 64), TW in [0, 32)
-template <int TW> __device__ __forceinline__ v2f cmul_tw(v2f a)
-{
-    if constexpr (TW == 0) return a;
-    else if constexpr (TW == 16) return rot_mi(a);
-    else {
-        // (a.x c + a.y s, a.y c - a.x s) = a * (c, c) + a.yx * (s, -s): two packed ops, signs in the constant
-        constexpr float c = (TW == 8) ? 0.70710678118654752440f : (TW == 24) ? -0.70710678118654752440f : cos64(TW);
-        constexpr float sn = (TW == 8 || TW == 24) ? 0.70710678118654752440f : sin64(TW);
-        return __builtin_elementwise_fma(a.yx, v2f{sn, -sn}, a * splat(c));
-    }
-}
-
-// Radix-2 decimation-in-frequency FFT of R points held in registers; logical output q ends up in
-// v[bitrev(q)].  Fully unrolled: every index and twiddle is a compile-time constant.
-// The twiddle -i (j == SPAN/2) is never applied where it arises: the element is left unrotated and the
-// rotation is folded into its only consumer, the j == 0 butterfly of the odd block one stage later,
-// as a +- (b.y, -b.x) packed FMA with a constant -- no swap / sign-flip instructions are issued.
-template <int R, int SPAN = R / 2> __device__ __forceinline__ void fft_reg(v2f (&v)[R])
-{
-    if constexpr (SPAN >= 1) {
-        static_for<0, R / (2 * SPAN)>([&](auto blk) {
-            constexpr int bi = decltype(blk)::value;
-            constexpr int base = bi * 2 * SPAN;
-            static_for<0, SPAN>([&](auto jj) {
-                constexpr int j = decltype(jj)::value;
-                const v2f a = v[base + j], b = v[base + j + SPAN];
-                if constexpr (j == 0 && (bi & 1) != 0 && 2 * SPAN < R) {
-                    // b carries a pending factor -i: a +- rot_mi(b)
-                    v[base + j] = __builtin_elementwise_fma(b.yx, v2f{1.f, -1.f}, a);
-                    v[base + j + SPAN] = __builtin_elementwise_fma(b.yx, v2f{-1.f, 1.f}, a);
-                } else {
-                    v[base + j] = a + b;
-                    if constexpr (2 * j == SPAN) v[base + j + SPAN] = a - b;          // -i applied by the consumer
-                    else v[base + j + SPAN] = cmul_tw<j * 32 / SPAN>(a - b);
-                }
-            });
-        });
-        fft_reg<R, SPAN / 2>(v);
-    }
-}
-
-// a * w for a table twiddle w = (re, im): a * (re, re) + a.yx * (-im, im)
-__device__ __forceinline__ v2f cmul(v2f a, float2 w)
-{
-    return __builtin_elementwise_fma(a.yx, v2f{-w.y, w.y}, a * splat(w.x));
-}
-
-// value of lane (l ^ 1) / (l ^ 2) inside each quad: DPP quad_perm, no LDS traffic
-__device__ __forceinline__ float quad_xor1(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float quad_xor2(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
-}
-
-// Sum over the 64 lanes in a fixed order, same value in every lane: four DPP steps inside each row of 16
-// (xor 1, xor 2, half-mirror, mirror: no LDS round trips, unlike __shfl_xor = ds_bpermute), then the four
-// row sums through scalar registers.
-template <int CTRL> __device__ __forceinline__ float dpp_f(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float wave_sum(float v)
-{
-    v += dpp_f<0xB1>(v);      // quad_perm [1,0,3,2]
-    v += dpp_f<0x4E>(v);      // quad_perm [2,3,0,1]
-    v += dpp_f<0x141>(v);     // row_half_mirror
-    v += dpp_f<0x140>(v);     // row_mirror
-    const int vi = __builtin_bit_cast(int, v);
-    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 0));
-    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16));
-    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32));
-    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
-    return (r0 + r1) + (r2 + r3);
-}
-
-template <int R, int C> __device__ __forceinline__ int z_index(int k)
-{
-    if constexpr (C == 1) return k;
-    else return k + (k / (R * R)) * 4;
-}
 
 // ---- prep kernel: per-clip partial sums (DC removal, models.py:38) + window tables -----------
 __global__ void __launch_bounds__(kThreads) dmel_prep_kernel(PrepParams p)
@@ -222,19 +104,6 @@ hipError_t launch_prep(const PrepParams& p, hipStream_t s)
 }
 
 // ---- fused forward --------------------------------------------------------------------------
-// Raw buffer loads: 32-bit offsets from an SGPR descriptor, and the hardware range check returns 0
-// for offsets outside [0, bytes) -- a negative sample index wraps to a huge unsigned offset.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ptr, unsigned bytes)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ float buf_f32(__amdgpu_buffer_rsrc_t r, int byte_off)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
-}
-__device__ __forceinline__ int clampi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }   // v_med3_i32
-// (the 64-bit form __builtin_amdgcn_raw_buffer_load_b64 is mis-lowered to a single dword load by hipcc 7.2:
-// twiddle tables are therefore read with ordinary float2 loads)
 
 #ifdef DMEL_STAMPS
 // Diagnostic build only (tools/stamps.py): s_memtime stamps of every wave at the phase boundaries of the

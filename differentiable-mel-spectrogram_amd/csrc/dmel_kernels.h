@@ -297,6 +297,8 @@ struct XgradParams {
     const float* x; const float* psum; const float2* win2; const float2* tw;
     const float* fb;            // (F, M) dense filterbank
     const int2* rowband;        // (F): [first, last+1) non-zero columns of every filterbank row
+    const float4* rowpk;        // (F): row k as (fb[k][b0], fb[k][b0 + 1], bits(b0), bits(columns)); zeros where the row has fewer columns
+    int long_rows;              // some row has more than two columns (their tails are read from fb)
     const float* grad_out;      // (B, M, T)
     const float* out;           // (B, M, T) saved log output or nullptr
     float* frames;              // (B, T, N) workspace: windowed gradient of every frame
@@ -306,9 +308,18 @@ struct XgradParams {
     int tw_in_lds;              // set by launch_xgrad: the twiddle table is copied behind the sequence in LDS
     int spec_mode;              // 1: grad_out is (B, F, T), the gradient of the power spectrogram itself (SpectrogramLayer): no filterbank
     float inv_L;
+    // wave-FFT path (n_fft 32 ... 2048; tiles == 0: the LDS radix-2 kernels): `frames` then holds (B, tiles, span) overlap-added
+    // tile segments and csum one fp64 sum per tile
+    const float2* tw1; const float2* tw2;     // tables of the plan that packs two frames per FFT (FftPlanSel<N, true>)
+    int tiles, span, tile_step;               // tiles per clip, (FPT - 1) hop + N, FPT hop
+    int own_prep;                             // the kernel evaluates the window and the clip mean itself (no dmel_prep_kernel launch)
+    float win_denom;                          // |lambd| + 1e-15 (time_frequency.py:24), own_prep only
+    int tw2_off;                              // set by launch_xgrad: byte offset of the radix-C twiddles in LDS
+    int win_n;                                // window entries kept in LDS: N/2 + 1 (symmetric about N/2) or N
 };
 hipError_t launch_xgrad(const XgradParams& p, hipStream_t s);
 hipError_t xgrad_prepare_attributes();
+bool xgrad_wave_shape(int n_fft, int n_mels, int win_n, int* frames_per_tile);   // the wave-FFT kernel takes this shape
 int xgrad_chunks(int L);      // gather chunks per clip (size of XgradParams::csum per clip)
 
 // gradient w.r.t. the filterbank matrix of models.py:53 (adjoint of  mel = spec^T @ fb):
@@ -334,6 +345,7 @@ struct RepackParams {
     float* ent_b; float* ent_pre; const int4* tile_ranges;
     float* fb_dense;            // (F, M) copy for the kernels that read the matrix as it is
     float* fbT;                 // (M, F) transposed copy (long / big transforms) or nullptr
+    float4* rowpk;              // (F) packed rows of XgradParams (dense structure: first column 0, M columns)
     int F, M, runs, nbpre, runs_group0;
 };
 hipError_t launch_repack(const RepackParams& p, hipStream_t s);
