@@ -183,7 +183,9 @@ __device__ __forceinline__ void xstamp(int wgid, int wave, int lane, int idx)
 template <int N> struct XgPlan {
     using P = FftPlanSel<N, true>;
     static constexpr int R = P::R, C = P::C, G = N / R, FPW = 64 / G;
+    // (2048 with 8 waves -- one workgroup per CU, 16-frame tiles: kernel 81 us against 77 at BASELINE config 3, combine pass 8.8 against 10.1)
     static constexpr int WAVES = (N == 1024) ? 8 : 4;
+    static constexpr int LDS_MAX = 80 * 1024;                          // two workgroups per CU
     static constexpr int SLOTS = WAVES * FPW, FPT = 2 * SLOTS, THREADS = 64 * WAVES;
     static constexpr int SS = slot_stride_f2(N, R, C, 0, 0);          // float2 entries per slot
     static constexpr int MINW = (N >= 2048) ? 2 : 4;                   // waves per SIMD the LDS footprint admits
@@ -621,7 +623,7 @@ bool xgrad_wave_shape(int n_fft, int n_mels, int win_n, int* frames_per_tile)
     bool ok = false;
     xgrad_with_plan(n_fft, [&](auto nn) {
         constexpr int N = decltype(nn)::value;
-        ok = xgrad_wave_lds<N>(n_mels, win_n) <= 80 * 1024;
+        ok = xgrad_wave_lds<N>(n_mels, win_n) <= (size_t)XgPlan<N>::LDS_MAX;
         if (frames_per_tile) *frames_per_tile = XgPlan<N>::FPT;
     });
     return ok;
@@ -636,7 +638,7 @@ hipError_t xgrad_prepare_attributes()
     for (int n = 32; n <= 2048 && e == hipSuccess; n *= 2)
         xgrad_with_plan(n, [&](auto nn) {
             constexpr int N = decltype(nn)::value;
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(dmel_xgrad_wave_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(dmel_xgrad_wave_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, XgPlan<N>::LDS_MAX);
         });
     return e;
 }
