@@ -1309,7 +1309,7 @@ dmel_status backward_fb_impl(dmel_plan* plan, const float* x, int32_t batch, flo
         dmel_status so = order_after_last_stream(plan, s);       // fbw is shared by every call on the plan
         if (so != DMEL_OK) return so;
     }
-    const int splits = dmel::fbgrad_splits(batch, F, M);
+    const int splits = dmel::fbgrad_splits(batch, F, M, T);
     const size_t spec_floats = ((size_t)batch * F * T + 63) / 64 * 64;
     const size_t part_floats = ((size_t)splits * F * M + 63) / 64 * 64;
     const size_t gm_floats = 0;      // (gm = grad_out * exp(-out) is formed inside the GEMM kernel)

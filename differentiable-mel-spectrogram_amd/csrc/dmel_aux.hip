@@ -337,9 +337,14 @@ __global__ void __launch_bounds__(kFbgThreads) dmel_fbgrad_lds_kernel(FbGradPara
     const int wf = wave >> 2, wm = wave & 3;
     const int f0 = blockIdx.x * kFbgBF, m0 = blockIdx.z * kFbgBM;
     const int split = blockIdx.y;
-    const int b_lo = (int)((long long)p.B * split / p.splits), b_hi = (int)((long long)p.B * (split + 1) / p.splits);
     const int F = p.F, M = p.M, T = p.T;
-    const int ntc = (T + 15) / 16, total = (b_hi - b_lo) * ntc;
+    // a slice = a run of consecutive K-blocks (16 time steps of one clip) of the batch, cut at block -- not clip -- boundaries:
+    // the slices differ by at most one block
+    const int ntc = (T + 15) / 16;
+    const long long all_blocks = (long long)p.B * ntc;
+    const int blk_lo = (int)(all_blocks * split / p.splits), blk_hi = (int)(all_blocks * (split + 1) / p.splits);
+    const int total = blk_hi - blk_lo;
+    const int b_lo = blk_lo / ntc;
     // staging roles: every thread one 16-byte piece of the B tile (row tid / 4, piece tid % 4), threads 0 .. 255 one of the A tile
     const int srow = tid >> 2, sc = tid & 3;
     const int mrow = min(m0 + srow, M - 1);                       // rows past the edge: valid memory, results never stored
@@ -351,13 +356,15 @@ __global__ void __launch_bounds__(kFbgThreads) dmel_fbgrad_lds_kernel(FbGradPara
     // for its own loads (config 3, log output: 143 -> 126 us for the whole gradient).
     constexpr int DEPTH = 3;
     float4 ring_a[DEPTH], ring_g[DEPTH], ring_y[DEPTH];
-    int nb = b_lo, nblk = 0;                                        // clip and 16-step block of the NEXT request
+    int nb = b_lo, nblk = blk_lo - b_lo * ntc;                      // clip and 16-step block of the NEXT request
+    int left = total;                                               // requests still to be made
     const float* pg = p.grad_out + ((size_t)b_lo * M + mrow) * T;
     const float* py = p.out ? p.out + ((size_t)b_lo * M + mrow) * T : nullptr;
     const float* pa = p.spec + ((size_t)b_lo * F + frow) * T;
     const size_t step_g = (size_t)M * T, step_a = (size_t)F * T;
     auto fetch = [&](float4& ra, float4& rg, float4& ry) {
-        if (nb >= b_hi) return;
+        if (left <= 0) return;
+        --left;
         const int t = nblk * 16 + 4 * sc;
         if (t + 3 < T) {
             const f4u g = *reinterpret_cast<const f4u*>(pg + t);
@@ -389,6 +396,10 @@ __global__ void __launch_bounds__(kFbgThreads) dmel_fbgrad_lds_kernel(FbGradPara
     };
     floatx4_t acc[2][2];
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) acc[i][j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+    // 16-row / 16-column pieces of this wave's sub-tile that exist (n_fft / 2 + 1 rows: the last tile of 64 holds ONE): a wave
+    // with none only stages
+    const bool act_f0 = f0 + wf * 32 < F, act_f1 = f0 + wf * 32 + 16 < F;
+    const bool act_m0 = m0 + wm * 32 < M, act_m1 = m0 + wm * 32 + 16 < M;
     {
         const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
         float4 a0 = zero, g0 = zero, y0 = zero;
@@ -419,12 +430,21 @@ __global__ void __launch_bounds__(kFbgThreads) dmel_fbgrad_lds_kernel(FbGradPara
             fetch(ring_a[d], ring_g[d], ring_y[d]);
             const float av[2][4] = {{a[0].x, a[0].y, a[0].z, a[0].w}, {a[1].x, a[1].y, a[1].z, a[1].w}};
             const float gv[2][4] = {{g[0].x, g[0].y, g[0].z, g[0].w}, {g[1].x, g[1].y, g[1].z, g[1].w}};
+            if (act_f1 && act_m1) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][u], gv[0][u], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][u], gv[1][u], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][u], gv[0][u], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][u], gv[1][u], acc[1][1], 0, 0, 0);
+                for (int u = 0; u < 4; ++u) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][u], gv[0][u], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][u], gv[1][u], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][u], gv[0][u], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][u], gv[1][u], acc[1][1], 0, 0, 0);
+                }
+            } else if (act_f0 && act_m0) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][u], gv[0][u], acc[0][0], 0, 0, 0);
+                    if (act_m1) acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][u], gv[1][u], acc[0][1], 0, 0, 0);
+                    if (act_f1) acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][u], gv[0][u], acc[1][0], 0, 0, 0);
+                }
             }
             __syncthreads();
         });
@@ -444,31 +464,55 @@ __global__ void __launch_bounds__(kFbgThreads) dmel_fbgrad_lds_kernel(FbGradPara
         }
 }
 
-__global__ void __launch_bounds__(256) dmel_fbgrad_reduce_kernel(FbGradParams p)
+// Eight waves per 64 elements of grad_fb: wave j adds its eighth of the slices in index order (all of its loads in flight at once
+// at the usual slice counts), the eighths meet in LDS and are added as ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7)): a fixed
+// order, full 256-byte rows per request
+constexpr int kFbgRedWaves = 8;
+__global__ void __launch_bounds__(64 * kFbgRedWaves) dmel_fbgrad_reduce_kernel(FbGradParams p)
 {
+    __shared__ float part[kFbgRedWaves][64];
     const size_t n = (size_t)p.F * p.M;
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    const int lane = threadIdx.x & 63, j = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + lane;
+    const size_t ii = i < n ? i : n - 1;
+    const int q_lo = (int)((long long)p.splits * j / kFbgRedWaves), q_hi = (int)((long long)p.splits * (j + 1) / kFbgRedWaves);
     float s = 0.f;
-    int q = 0;
-    for (; q + 8 <= p.splits; q += 8) {          // eight loads in flight, added in index order
+    int q = q_lo;
+    for (; q + 8 <= q_hi; q += 8) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = p.partials[(size_t)(q + u) * n + i];
+        for (int u = 0; u < 8; ++u) v[u] = p.partials[(size_t)(q + u) * n + ii];
 #pragma unroll
         for (int u = 0; u < 8; ++u) s += v[u];
     }
-    for (; q < p.splits; ++q) s += p.partials[(size_t)q * n + i];     // fixed order
-    p.grad_fb[i] = s;
+    {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (q + u < q_hi) ? p.partials[(size_t)(q + u) * n + ii] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];          // (adding 0.f past the end changes nothing)
+    }
+    part[j][lane] = s;
+    __syncthreads();
+    if (j == 0 && i < n)
+        p.grad_fb[i] = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) + ((part[4][lane] + part[5][lane]) + (part[6][lane] + part[7][lane]));
 }
 
-int fbgrad_splits(int batch, int F, int M)
+int fbgrad_splits(int batch, int F, int M, int T)
 {
-    // enough batch slices for about two workgroups of 8 waves per CU, never more than clips (every slice writes an F x M partial)
+    // as many slices as keep EVERY workgroup resident at once -- two workgroups of 8 waves per CU -- and never one more: a 513th
+    // workgroup on 256 CUs ran alone after the others (26 us instead of 15 at BASELINE config 2)
+    static const int slots = [] {
+        if (const char* e = std::getenv("DMEL_FBG_TARGET")) return std::atoi(e);                     // (diagnostics)
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        return 2 * cus;
+    }();
     const int tiles = ((F + kFbgBF - 1) / kFbgBF) * ((M + kFbgBM - 1) / kFbgBM);
-    static const int target = std::getenv("DMEL_FBG_TARGET") ? std::atoi(std::getenv("DMEL_FBG_TARGET")) : 512;     // (diagnostics)
-    const int s = (target + tiles - 1) / tiles;
-    return s < 1 ? 1 : (s > batch ? (batch < 1 ? 1 : batch) : s);
+    const long long blocks = (long long)batch * ((T + 15) / 16);
+    long long s = slots / tiles;
+    if (s > blocks) s = blocks;
+    return s < 1 ? 1 : (int)s;
 }
 
 hipError_t launch_fbgrad(const FbGradParams& p_in, hipStream_t s)
@@ -480,7 +524,7 @@ hipError_t launch_fbgrad(const FbGradParams& p_in, hipStream_t s)
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const size_t n = (size_t)p.F * p.M;
-    hipLaunchKernelGGL(dmel_fbgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(dmel_fbgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * kFbgRedWaves), 0, s, p);
     return hipGetLastError();
 }
 

@@ -336,7 +336,7 @@ struct FbGradParams {
     int B, F, M, T, splits;
 };
 hipError_t launch_fbgrad(const FbGradParams& p, hipStream_t s);
-int fbgrad_splits(int batch, int F, int M);      // batch slices (= F x M partials) of one launch
+int fbgrad_splits(int batch, int F, int M, int T);      // slices of the batch's K-blocks (= F x M partials) of one launch
 
 // device-side refresh of every table that holds filterbank VALUES from an (F, M) fp32 device matrix, for tables built with the
 // dense structure (all 4x16 blocks present): what a trainable filterbank needs after each optimizer step
