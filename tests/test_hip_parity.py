@@ -558,6 +558,37 @@ def test_learnable_filterbank_layer():
         strict(x)
 
 
+@pytest.mark.parametrize("name", ["g1_c1", "g5_n128", "g6_n2048_short"])
+def test_xgrad_through_a_trained_dense_filterbank(name):
+    """x.requires_grad with learnable_fb=True after the bank has moved: every row of the matrix is dense, so the waveform
+    gradient takes the first two columns from the packed rows (refreshed on the device with the other tables) and the rest
+    from the matrix itself; against the oracle with the same matrix."""
+    from dmel_amd import MelSpectrogramLayer
+    case = C.BY_NAME[name]
+    x_np = C.make_input(case).astype(np.float32)
+    g_np = C.make_cotangent(case)
+    g = torch.from_numpy(g_np).to("cuda:0")
+    for log in (False, True):
+        lay = MelSpectrogramLayer(torch.tensor(float(case["lambd"])), n_mels=case["n_mels"], n_points=case["L"], sample_rate=case["sr"],
+                                  f_min=case["f_min"], f_max=case["f_max"], hop_length=case["hop"], device="cuda:0", optimized=True,
+                                  normalize_window=case["normalize_window"], log=log, learnable_fb=True).to("cuda:0")
+        gen = torch.Generator(device="cpu").manual_seed(7)
+        with torch.no_grad():
+            lay.mel_fb.add_((0.02 * torch.rand(lay.mel_fb.shape, generator=gen)).to("cuda:0"))
+        fb_np = lay.mel_fb.detach().cpu().numpy()
+        for _ in range(2):                                                       # second pass: the bank moves again, same tables
+            x = torch.from_numpy(x_np).to("cuda:0").requires_grad_(True)
+            y = lay(x)
+            (y * g).sum().backward()
+            ref = O.backward_x(x_np, case["lambd"], case["hop"], case["sr"], g_np, y.detach().cpu().numpy() if log else None,
+                               case["f_min"], case["f_max"], case["normalize_window"], fb=fb_np)
+            assert _gx_err(x.grad.cpu().numpy(), ref) <= TOL
+            with torch.no_grad():
+                lay.mel_fb.mul_(1.1)
+            fb_np = lay.mel_fb.detach().cpu().numpy()
+            lay.mel_fb.grad = None
+
+
 def test_trainable_filterbank_step_is_sync_free_and_graph_capturable():
     """lambd AND the filterbank trained together: the step (forward with the dense bank refreshed on the device, d lambd,
     d filterbank, Adam on both) queues without a host read and replays from a HIP graph; the replayed parameters equal the
