@@ -420,6 +420,41 @@ def main():
                 module_step_info[m.replace(" ", "_") + "_ms_per_step"] = round(1e3 * run_mode(m, 8, 80) / 80, 4)
         module_step_info[chosen.replace(" ", "_") + "_ms_per_step"] = round(ms_per_step, 4)
 
+    # ---- side figure, never `value`: the same step with the opt-in dmel_amd.LambdAdam (torch.optim.Adam's update of lambd as
+    # one launch instead of torch's two), issued the way the headline was
+    if dist is None and not args.no_other_configs:
+        try:
+            from dmel_amd import LambdAdam
+            layer2 = MelSpectrogramLayer(torch.tensor(lam), n_mels=M, n_points=L, sample_rate=sr, hop_length=hop, device=str(dev),
+                                         optimized=True, log=True, out_dtype=act).to(dev)
+            opt2 = LambdAdam([layer2.lambd], lr=ADAM_LR)
+
+            def module_step2():
+                opt2.zero_grad(set_to_none=True)
+                layer2(x).backward(g)
+                opt2.step()
+
+            for _ in range(3):
+                module_step2()
+            torch.cuda.synchronize()
+            fn2 = module_step2
+            if chosen != "eager":
+                fn2 = GraphedStep(module_step2, [layer2], max_ahead=MAX_AHEAD, steps_per_replay=k_chosen)
+                for _ in range(MAX_AHEAD + 4):
+                    fn2()
+                torch.cuda.synchronize()
+            n2 = max(200, 50 * k_chosen)
+            el2 = min(time_loop(fn2, 8, n2 // k_chosen), time_loop(fn2, 0, n2 // k_chosen))
+            st2 = layer2.lambd_status()
+            assert st2["error"] == 0
+            module_step_info["with_lambd_adam"] = {"ms_per_step": round(1e3 * el2 / n2, 5), "frames_per_s": round(frames_per_rank * n2 / el2, 1),
+                                                   "steps": n2, "issued": chosen, "lambd_end": round(float(layer2.lambd.detach()), 4),
+                                                   "note": "opt-in dmel_amd.LambdAdam (dmel_adam_step: one launch) in place of torch.optim.Adam; "
+                                                           "a side figure, never `value`"}
+            del fn2, opt2, layer2
+        except Exception as e:                                          # noqa: BLE001
+            module_step_info["with_lambd_adam"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+
     # ---- the bare kernels through the C ABI (round 1's headline): fused forward + dot, lambd by value, no autograd, no update -
     plan = capi.Plan(L, hop, M, sr, max_batch=B)
     out = torch.empty((B, 1, M, T), dtype=act, device=dev)

@@ -11,8 +11,8 @@ from __future__ import annotations
 
 import importlib
 
-__all__ = ["MelSpectrogramLayer", "DifferentiableMelSpectrogram", "SpectrogramLayer", "dmel_log_mel", "GraphedStep", "capi", "synth", "dist",
-           "nets", "panns", "graph"]
+__all__ = ["MelSpectrogramLayer", "DifferentiableMelSpectrogram", "SpectrogramLayer", "dmel_log_mel", "GraphedStep", "LambdAdam", "capi", "synth", "dist",
+           "nets", "panns", "graph", "optim"]
 
 _LAZY = {
     "MelSpectrogramLayer": ("layer", "MelSpectrogramLayer"),
@@ -20,6 +20,7 @@ _LAZY = {
     "dmel_log_mel": ("layer", "dmel_log_mel"),
     "SpectrogramLayer": ("layer", "SpectrogramLayer"),
     "GraphedStep": ("graph", "GraphedStep"),
+    "LambdAdam": ("optim", "LambdAdam"),
 }
 
 
@@ -27,6 +28,6 @@ def __getattr__(name):
     if name in _LAZY:
         mod, attr = _LAZY[name]
         return getattr(importlib.import_module(f"dmel_amd.{mod}"), attr)
-    if name in ("capi", "synth", "layer", "dist", "nets", "panns", "graph"):
+    if name in ("capi", "synth", "layer", "dist", "nets", "panns", "graph", "optim"):
         return importlib.import_module(f"dmel_amd.{name}")
     raise AttributeError(name)

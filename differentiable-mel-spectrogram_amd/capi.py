@@ -35,7 +35,7 @@ SYMBOLS = (
     "dmel_comm_allreduce", "dmel_scratch_bytes", "dmel_plan_set_filterbank_dev", "dmel_forward_scratch", "dmel_forward_dev", "dmel_forward_dev_fixed", "dmel_backward_fb_dev", "dmel_backward_scratch", "dmel_plan_get_config",
     "dmel_plan_lambd_status", "dmel_plan_set_tracking", "dmel_plan_lambd_reset",
     "dmel_plan_retain", "dmel_plan_release", "dmel_plan_lambd_report", "dmel_decide_launch", "dmel_plan_force_launch",
-    "dmel_mailbox_create", "dmel_mailbox_connect", "dmel_mailbox_destroy", "dmel_mailbox_allreduce", "dmel_mailbox_error",
+    "dmel_adam_step", "dmel_mailbox_create", "dmel_mailbox_connect", "dmel_mailbox_destroy", "dmel_mailbox_allreduce", "dmel_mailbox_error",
     "dmel_mailbox_set_spin_limit", "dmel_plan_attach_mailbox", "dmel_backward_x_spec",
 )
 TORCH_LIB_PATH = os.path.join(_PKG_DIR, "libdmel_torch.so")
@@ -176,6 +176,8 @@ def load():
     L.dmel_mailbox_connect.restype = C.c_int
     L.dmel_mailbox_destroy.argtypes = [vp]
     L.dmel_mailbox_destroy.restype = C.c_int
+    L.dmel_adam_step.argtypes = [vp, vp, vp, vp, vp, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, vp]
+    L.dmel_adam_step.restype = C.c_int
     L.dmel_mailbox_allreduce.argtypes = [vp, vp, vp]
     L.dmel_mailbox_allreduce.restype = C.c_int
     L.dmel_mailbox_error.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]
@@ -221,6 +223,13 @@ def decide_launch(lambd: float, rate: float, stale_forwards: float) -> tuple[int
     n, g = C.c_int32(0), C.c_int32(0)
     _check(load().dmel_decide_launch(C.c_float(float(lambd)), C.c_float(float(rate)), C.c_float(float(stale_forwards)), C.byref(n), C.byref(g)))
     return int(n.value), int(g.value)
+
+
+def adam_step(param_ptr: int, grad_ptr: int, exp_avg_ptr: int, exp_avg_sq_ptr: int, step_ptr: int, n: int, lr: float, beta1: float,
+              beta2: float, eps: float, weight_decay: float, maximize: bool, stream: int) -> None:
+    """dmel_adam_step: torch.optim.Adam's update of a small fp32 parameter as one launch on ``stream`` (device pointers)."""
+    _check(load().dmel_adam_step(param_ptr, grad_ptr, exp_avg_ptr, exp_avg_sq_ptr, step_ptr, int(n), C.c_double(float(lr)), C.c_double(float(beta1)),
+                                 C.c_double(float(beta2)), C.c_double(float(eps)), C.c_double(float(weight_decay)), 1 if maximize else 0, stream))
 
 
 def device_count() -> int:

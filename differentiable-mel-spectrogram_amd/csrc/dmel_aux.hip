@@ -307,6 +307,39 @@ hipError_t launch_naive(const NaiveParams& p, hipStream_t s)
     return hipGetLastError();
 }
 
+// ---- Adam on a small parameter (lambd) ---------------------------------------------------------------
+// torch.optim.Adam's update (main.py:52-53; the fused / capturable variant's arithmetic: fp32, step count on the device) as ONE
+// launch instead of torch's two: an opt-in for callers whose step is a few tens of microseconds.  n is small (1 for
+// lambd): one workgroup.
+__global__ void __launch_bounds__(256) dmel_adam_kernel(AdamParams p)
+{
+    const float step = *p.step + 1.0f;                            // every thread reads the old count before thread 0 bumps it
+    __syncthreads();
+    if (threadIdx.x == 0) *p.step = step;
+    // the hyper-parameters are doubles, as torch passes them to its kernel: 1 - beta is formed in fp64 (in fp32 1 - 0.999f is off by
+    // 5e-5 of itself, which the second moment would carry), the state stays fp32
+    const float bc1 = (float)(1.0 - pow(p.beta1, (double)step)), bc2 = (float)(1.0 - pow(p.beta2, (double)step));
+    const float step_size = (float)(p.lr / (double)bc1), bc2_sqrt = sqrtf(bc2);
+    for (int i = threadIdx.x; i < p.n; i += 256) {
+        float g = p.grad[i];
+        const float w = p.param[i];
+        if (p.maximize) g = -g;
+        if (p.weight_decay != 0.0) g = (float)((double)g + (double)w * p.weight_decay);
+        float m = p.exp_avg[i], v = p.exp_avg_sq[i];
+        m = (float)((double)m + (1.0 - p.beta1) * ((double)g - (double)m));            // lerp(m, g, 1 - beta1)
+        v = (float)(p.beta2 * (double)v + (1.0 - p.beta2) * (double)g * (double)g);
+        const float denom = (float)((double)(sqrtf(v) / bc2_sqrt) + p.eps);
+        p.param[i] = w - step_size * m / denom;
+        p.exp_avg[i] = m; p.exp_avg_sq[i] = v;
+    }
+}
+
+hipError_t launch_adam(const AdamParams& p, hipStream_t s)
+{
+    hipLaunchKernelGGL(dmel_adam_kernel, dim3(1), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
 // ---- filterbank gradient ----------------------------------------------------------------------
 // grad_fb = sum over clips of  spec_b (F x T) * gm_b^T (T x M): per clip a small GEMM whose K dimension (time) is
 // contiguous in both operands; exact-fp32 MFMA 16x16x4.  (Rounds 1-2: a 32 x 128 tile per 4-wave workgroup with both operands

@@ -350,6 +350,14 @@ struct RepackParams {
 };
 hipError_t launch_repack(const RepackParams& p, hipStream_t s);
 
+// Adam on a small fp32 parameter (dmel_adam_step)
+struct AdamParams {
+    float* param; const float* grad; float* exp_avg; float* exp_avg_sq; float* step;
+    int n, maximize;
+    double lr, beta1, beta2, eps, weight_decay;
+};
+hipError_t launch_adam(const AdamParams& p, hipStream_t s);
+
 // Peer-to-peer all-reduce of the one scalar this path exchanges (d lambd), folded into the tail of the dot kernel: the workgroup
 // that draws the last ticket stores (step, local sum) as ONE 8-byte granule into slot `rank` of every rank's inbox -- peer memory
 // mapped over xGMI, system-scope stores -- then polls its own inbox until every rank's granule of this step has arrived and adds

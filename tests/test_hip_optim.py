@@ -1,0 +1,79 @@
+"""GPU tests of the opt-in optimizer for the layer's parameter (dmel_adam_step, dmel_amd.LambdAdam) against torch.optim.Adam."""
+import numpy as np
+import pytest
+import torch
+
+import cases as C
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("kw", [dict(lr=1e-3), dict(lr=1.0, betas=(0.8, 0.99), eps=1e-6), dict(lr=0.05, weight_decay=0.01),
+                                dict(lr=0.02, maximize=True)])
+def test_lambd_adam_follows_torch_adam(kw):
+    """the same gradients through both optimizers, 300 steps: parameters and moments stay within a few ulps"""
+    from dmel_amd import LambdAdam
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    for shape in ((), (5,), (3, 7)):
+        p0 = torch.randn(shape, generator=gen) * 10.0 + 100.0
+        a = torch.nn.Parameter(p0.clone().to(DEV))
+        b = torch.nn.Parameter(p0.clone().to(DEV))
+        ours, ref = LambdAdam([a], **kw), torch.optim.Adam([b], **kw)
+        for step in range(300):
+            g = (torch.randn(shape, generator=gen) * (1.0 + 0.01 * step)).to(DEV)
+            a.grad = g.clone(); b.grad = g.clone()
+            ours.step(); ref.step()
+        torch.cuda.synchronize()
+        assert torch.allclose(a.detach(), b.detach(), rtol=2e-6, atol=1e-6), (shape, float((a - b).abs().max()))
+        assert torch.allclose(ours.state[a]["exp_avg"], ref.state[b]["exp_avg"], rtol=1e-5, atol=1e-7)
+        assert torch.allclose(ours.state[a]["exp_avg_sq"], ref.state[b]["exp_avg_sq"], rtol=1e-5, atol=1e-9)
+        assert float(ours.state[a]["step"]) == 300.0
+
+
+def test_lambd_adam_trains_the_layer_inside_a_hip_graph():
+    """the whole step -- forward, backward to lambd.grad, the one-launch update -- captured once and replayed: lambd ends where
+    torch's capturable Adam puts it"""
+    from dmel_amd import LambdAdam, MelSpectrogramLayer
+    case = C.BY_NAME["g1_c1"]
+    x = torch.from_numpy(C.make_input(case)).to(DEV)
+    g = torch.from_numpy(C.make_cotangent(case)).to(DEV)
+
+    def mk():
+        return MelSpectrogramLayer(torch.tensor(float(case["lambd"])), n_mels=case["n_mels"], n_points=case["L"], sample_rate=case["sr"],
+                                   hop_length=case["hop"], device=DEV, optimized=True, log=True).to(DEV)
+
+    la, lb = mk(), mk()
+    oa = LambdAdam([la.lambd], lr=1e-3)
+    ob = torch.optim.Adam([lb.lambd], lr=1e-3, capturable=True)
+
+    def step(lay, o):
+        o.zero_grad(set_to_none=True)
+        (lay(x) * g).sum().backward()
+        o.step()
+
+    step(la, oa); step(lb, ob)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        step(la, oa)
+    for _ in range(20):
+        gr.replay()
+        step(lb, ob)
+    torch.cuda.synchronize()
+    va, vb = float(la.lambd.detach()), float(lb.lambd.detach())
+    assert abs(va - vb) <= 2e-6 * abs(vb) and va != float(case["lambd"])
+    assert float(oa.state[la.lambd]["step"]) == 21.0                        # one eager step + 20 replays (the capture itself executes nothing)
+
+
+def test_lambd_adam_rejects_what_it_is_not_for():
+    from dmel_amd import LambdAdam, capi
+    with pytest.raises(ValueError):
+        LambdAdam([torch.nn.Parameter(torch.zeros(4))])                       # a CPU parameter
+    with pytest.raises(ValueError):
+        LambdAdam([torch.nn.Parameter(torch.zeros(70000, device=DEV))])      # not small
+    with pytest.raises(ValueError):
+        LambdAdam([torch.nn.Parameter(torch.zeros(4, device=DEV))], betas=(1.0, 0.9))
+    t = torch.zeros(4, device=DEV)
+    with pytest.raises(RuntimeError):
+        capi.adam_step(t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), 0, 4, 1e-3, 0.9, 0.999, 1e-8, 0.0, False, 0)
