@@ -176,7 +176,7 @@ def load():
     L.dmel_mailbox_connect.restype = C.c_int
     L.dmel_mailbox_destroy.argtypes = [vp]
     L.dmel_mailbox_destroy.restype = C.c_int
-    L.dmel_adam_step.argtypes = [vp, vp, vp, vp, vp, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, vp]
+    L.dmel_adam_step.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, vp]
     L.dmel_adam_step.restype = C.c_int
     L.dmel_mailbox_allreduce.argtypes = [vp, vp, vp]
     L.dmel_mailbox_allreduce.restype = C.c_int
@@ -225,11 +225,13 @@ def decide_launch(lambd: float, rate: float, stale_forwards: float) -> tuple[int
     return int(n.value), int(g.value)
 
 
-def adam_step(param_ptr: int, grad_ptr: int, exp_avg_ptr: int, exp_avg_sq_ptr: int, step_ptr: int, n: int, lr: float, beta1: float,
-              beta2: float, eps: float, weight_decay: float, maximize: bool, stream: int) -> None:
-    """dmel_adam_step: torch.optim.Adam's update of a small fp32 parameter as one launch on ``stream`` (device pointers)."""
-    _check(load().dmel_adam_step(param_ptr, grad_ptr, exp_avg_ptr, exp_avg_sq_ptr, step_ptr, int(n), C.c_double(float(lr)), C.c_double(float(beta1)),
-                                 C.c_double(float(beta2)), C.c_double(float(eps)), C.c_double(float(weight_decay)), 1 if maximize else 0, stream))
+def adam_step(param_ptr: int, grad_ptr: int, exp_avg_ptr: int, exp_avg_sq_ptr: int, step_ptr: int, ticket_ptr: int, n: int, lr: float,
+              beta1: float, beta2: float, eps: float, weight_decay: float, maximize: bool, stream: int) -> None:
+    """dmel_adam_step: torch.optim.Adam's update of an fp32 parameter as one launch on ``stream`` (device pointers; ``ticket_ptr``
+    = one zeroed device word, may be 0 up to 1024 elements)."""
+    _check(load().dmel_adam_step(param_ptr, grad_ptr, exp_avg_ptr, exp_avg_sq_ptr, step_ptr, ticket_ptr or None, int(n), C.c_double(float(lr)),
+                                 C.c_double(float(beta1)), C.c_double(float(beta2)), C.c_double(float(eps)), C.c_double(float(weight_decay)),
+                                 1 if maximize else 0, stream))
 
 
 def device_count() -> int:

@@ -1457,16 +1457,17 @@ dmel_status dmel_backward_x_spec(dmel_plan* plan, const float* x, int32_t batch,
     return backward_x_impl(plan, x, batch, lambd, n_fft, (flags & DMEL_SPEC_HALF_WINDOW) ? 1 : 0, 1, false, grad_spec, nullptr, grad_x, stream);
 }
 
-dmel_status dmel_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* step, int32_t n,
+dmel_status dmel_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* step, uint32_t* ticket, int64_t n,
                            double lr, double beta1, double beta2, double eps, double weight_decay, int32_t maximize, void* stream)
 {
     if (!param || !grad || !exp_avg || !exp_avg_sq || !step) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_adam_step: NULL pointer");
-    if (n < 0 || n > 65536) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_adam_step: n must be in [0, 65536] (a small parameter)");
+    if (n < 0 || n > (1LL << 31)) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_adam_step: n out of range");
     if (!(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0) || !std::isfinite(lr))
         return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_adam_step: lr / betas / eps out of range");
     if (n == 0) return DMEL_OK;
+    if (!ticket && dmel::adam_grid(n) > 1) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_adam_step: more than 1024 elements need the ticket word");
     dmel::AdamParams ap{};
-    ap.param = param; ap.grad = grad; ap.exp_avg = exp_avg; ap.exp_avg_sq = exp_avg_sq; ap.step = step;
+    ap.param = param; ap.grad = grad; ap.exp_avg = exp_avg; ap.exp_avg_sq = exp_avg_sq; ap.step = step; ap.ticket = ticket;
     ap.n = n; ap.maximize = maximize ? 1 : 0;
     ap.lr = lr; ap.beta1 = beta1; ap.beta2 = beta2; ap.eps = eps; ap.weight_decay = weight_decay;
     DMEL_HIP(dmel::launch_adam(ap, reinterpret_cast<hipStream_t>(stream)));

@@ -307,36 +307,54 @@ hipError_t launch_naive(const NaiveParams& p, hipStream_t s)
     return hipGetLastError();
 }
 
-// ---- Adam on a small parameter (lambd) ---------------------------------------------------------------
-// torch.optim.Adam's update (main.py:52-53; the fused / capturable variant's arithmetic: fp32, step count on the device) as ONE
-// launch instead of torch's two: an opt-in for callers whose step is a few tens of microseconds.  n is small (1 for
-// lambd): one workgroup.
+// ---- Adam on the layer's parameters (lambd; the filterbank matrix) -------------------------------------------
+// torch.optim.Adam's update (main.py:52-53; the fused / capturable variant's arithmetic: fp32 state, step count on the device) as
+// ONE launch of as many workgroups as the parameter needs: torch launches two kernels for the scalar lambd (a quarter of a
+// 33 us step) and puts the 65 664-entry filterbank of config 2 on two workgroups (42 us).  Opt-in.
+// Every workgroup reads the step count before it draws a ticket; the one that draws the last ticket therefore knows that all have
+// read it, writes the new count and re-arms the ticket word for the next launch on the stream.
+constexpr int kAdamPerThread = 4;
 __global__ void __launch_bounds__(256) dmel_adam_kernel(AdamParams p)
 {
-    const float step = *p.step + 1.0f;                            // every thread reads the old count before thread 0 bumps it
-    __syncthreads();
-    if (threadIdx.x == 0) *p.step = step;
+    const float step = *p.step + 1.0f;
     // the hyper-parameters are doubles, as torch passes them to its kernel: 1 - beta is formed in fp64 (in fp32 1 - 0.999f is off by
     // 5e-5 of itself, which the second moment would carry), the state stays fp32
     const float bc1 = (float)(1.0 - pow(p.beta1, (double)step)), bc2 = (float)(1.0 - pow(p.beta2, (double)step));
     const float step_size = (float)(p.lr / (double)bc1), bc2_sqrt = sqrtf(bc2);
-    for (int i = threadIdx.x; i < p.n; i += 256) {
+    const float omb1 = (float)(1.0 - p.beta1), omb2 = (float)(1.0 - p.beta2), b2 = (float)p.beta2, wd = (float)p.weight_decay, eps = (float)p.eps;
+    const long long stride = 256LL * gridDim.x;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.n; i += stride) {
         float g = p.grad[i];
         const float w = p.param[i];
         if (p.maximize) g = -g;
-        if (p.weight_decay != 0.0) g = (float)((double)g + (double)w * p.weight_decay);
+        if (wd != 0.f) g = fmaf(w, wd, g);
         float m = p.exp_avg[i], v = p.exp_avg_sq[i];
-        m = (float)((double)m + (1.0 - p.beta1) * ((double)g - (double)m));            // lerp(m, g, 1 - beta1)
-        v = (float)(p.beta2 * (double)v + (1.0 - p.beta2) * (double)g * (double)g);
-        const float denom = (float)((double)(sqrtf(v) / bc2_sqrt) + p.eps);
+        m = fmaf(omb1, g - m, m);                                  // lerp(m, g, 1 - beta1)
+        v = fmaf(b2, v, omb2 * g * g);
+        const float denom = sqrtf(v) / bc2_sqrt + eps;
         p.param[i] = w - step_size * m / denom;
         p.exp_avg[i] = m; p.exp_avg_sq[i] = v;
     }
+    __syncthreads();                                               // every thread of this workgroup holds the old count
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned t = p.ticket ? __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        if (!p.ticket || t == gridDim.x - 1) {
+            *p.step = step;
+            if (p.ticket) __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+int adam_grid(long long n)
+{
+    const long long wgs = (n + 256 * kAdamPerThread - 1) / (256 * kAdamPerThread);
+    return (int)(wgs < 1 ? 1 : (wgs > 1024 ? 1024 : wgs));
 }
 
 hipError_t launch_adam(const AdamParams& p, hipStream_t s)
 {
-    hipLaunchKernelGGL(dmel_adam_kernel, dim3(1), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(dmel_adam_kernel, dim3((unsigned)adam_grid(p.n)), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 

@@ -350,12 +350,14 @@ struct RepackParams {
 };
 hipError_t launch_repack(const RepackParams& p, hipStream_t s);
 
-// Adam on a small fp32 parameter (dmel_adam_step)
+// Adam on fp32 parameters of the layer (dmel_adam_step)
 struct AdamParams {
     float* param; const float* grad; float* exp_avg; float* exp_avg_sq; float* step;
-    int n, maximize;
+    unsigned* ticket;          // zero between launches; nullptr: one workgroup
+    long long n; int maximize;
     double lr, beta1, beta2, eps, weight_decay;
 };
+int adam_grid(long long n);    // workgroups of one launch (more than one needs the ticket word)
 hipError_t launch_adam(const AdamParams& p, hipStream_t s);
 
 // Peer-to-peer all-reduce of the one scalar this path exchanges (d lambd), folded into the tail of the dot kernel: the workgroup

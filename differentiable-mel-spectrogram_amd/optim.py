@@ -2,7 +2,7 @@
 
 The reference trains ``lambd`` with ``torch.optim.Adam`` (main.py:40-53: one parameter group per learning rate, ``lr_tf`` for the
 spectrogram layer).  On a step of a few tens of microseconds the two kernels torch launches for that ONE scalar are a quarter of
-the step; ``LambdAdam`` applies the same update -- torch's fused / capturable arithmetic: fp32, step count kept on the
+the step, and the trainable filterbank's 65 664 entries land on two workgroups (42 us); ``LambdAdam`` applies the same update -- torch's fused / capturable arithmetic: fp32, step count kept on the
 device, no host synchronisation -- as one launch per parameter through ``dmel_adam_step`` (include/dmel.h).  The rest of the model
 keeps its own optimizer; ``torch.optim.Adam`` on ``lambd`` keeps working and is what bench.py's headline uses.
 
@@ -20,7 +20,7 @@ from . import capi
 
 
 class LambdAdam(torch.optim.Optimizer):
-    """torch.optim.Adam (no amsgrad) for small fp32 CUDA parameters, one launch per parameter."""
+    """torch.optim.Adam (no amsgrad) for the layer's fp32 CUDA parameters (lambd, the trainable filterbank), one launch per parameter."""
 
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0, maximize: bool = False):
         if lr < 0.0 or eps < 0.0 or not (0.0 <= betas[0] < 1.0) or not (0.0 <= betas[1] < 1.0) or weight_decay < 0.0:
@@ -28,8 +28,8 @@ class LambdAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, maximize=maximize))
         for group in self.param_groups:
             for p in group["params"]:
-                if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous() or p.numel() > 65536:
-                    raise ValueError("LambdAdam takes small contiguous fp32 CUDA parameters (the layer's lambd); use torch.optim for the rest")
+                if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous():
+                    raise ValueError("LambdAdam takes contiguous fp32 CUDA parameters (the layer's lambd and mel_fb); use torch.optim for the rest")
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -50,8 +50,9 @@ class LambdAdam(torch.optim.Optimizer):
                     st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["ticket"] = torch.zeros((), dtype=torch.int32, device=p.device)       # re-armed by every launch
                 with torch.cuda.device(p.device):
                     capi.adam_step(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr(),
-                                   p.numel(), group["lr"], b1, b2, group["eps"], group["weight_decay"], group["maximize"],
+                                   st["ticket"].data_ptr(), p.numel(), group["lr"], b1, b2, group["eps"], group["weight_decay"], group["maximize"],
                                    torch.cuda.current_stream(p.device).cuda_stream)
         return loss

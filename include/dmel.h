@@ -327,14 +327,16 @@ dmel_status dmel_mailbox_error(dmel_mailbox* mb, int32_t* failed, uint32_t* step
 dmel_status dmel_mailbox_set_spin_limit(dmel_mailbox* mb, uint32_t polls);
 dmel_status dmel_plan_attach_mailbox(dmel_plan* plan, dmel_mailbox* mb);
 
-/* torch.optim.Adam's update of a SMALL fp32 parameter on the device (main.py:52-53 builds that optimizer; lambd is one scalar) as
- * one launch on `stream`: param, grad, exp_avg, exp_avg_sq are `n` device floats (n <= 65536), `step` one device float that counts
- * the updates (starts at 0; torch's capturable Adam keeps it the same way).  No host synchronisation, capturable.  The hyper-parameters
- * are doubles, as torch hands them to its own kernel (1 - beta is formed in fp64); the state is fp32.  Arithmetic:
+/* torch.optim.Adam's update of an fp32 parameter of the layer on the device (main.py:52-53 builds that optimizer; lambd is one
+ * scalar, the trainable filterbank a (n_fft/2+1, n_mels) matrix) as ONE launch on `stream`: param, grad, exp_avg, exp_avg_sq are `n`
+ * device floats, `step` one device float that counts the updates (starts at 0; torch's capturable Adam keeps it the same way),
+ * `ticket` one zero-initialised device word the launch leaves at zero (needed when n > 1024: several workgroups; may be NULL
+ * below).  No host synchronisation, capturable.  The hyper-parameters are doubles, as torch hands them to its own kernel
+ * (1 - beta is formed in fp64); the state is fp32.  Arithmetic:
  *   step += 1; g = -grad if maximize; g += weight_decay * param; m += (1 - beta1) (g - m); v = beta2 v + (1 - beta2) g^2;
  *   param -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)
- * Opt-in: torch's own optimizer keeps working on the layer's parameter. */
-dmel_status dmel_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* step, int32_t n,
+ * Opt-in: torch's own optimizer keeps working on the layer's parameters. */
+dmel_status dmel_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* step, uint32_t* ticket, int64_t n,
                            double lr, double beta1, double beta2, double eps, double weight_decay, int32_t maximize, void* stream);
 
 /* Introspection for tests / benchmarks */

@@ -15,7 +15,7 @@ def test_lambd_adam_follows_torch_adam(kw):
     """the same gradients through both optimizers, 300 steps: parameters and moments stay within a few ulps"""
     from dmel_amd import LambdAdam
     gen = torch.Generator(device="cpu").manual_seed(3)
-    for shape in ((), (5,), (3, 7)):
+    for shape in ((), (5,), (3, 7), (513, 128)):                                  # the last: many workgroups, the ticket word
         p0 = torch.randn(shape, generator=gen) * 10.0 + 100.0
         a = torch.nn.Parameter(p0.clone().to(DEV))
         b = torch.nn.Parameter(p0.clone().to(DEV))
@@ -26,8 +26,10 @@ def test_lambd_adam_follows_torch_adam(kw):
             ours.step(); ref.step()
         torch.cuda.synchronize()
         assert torch.allclose(a.detach(), b.detach(), rtol=2e-6, atol=1e-6), (shape, float((a - b).abs().max()))
-        assert torch.allclose(ours.state[a]["exp_avg"], ref.state[b]["exp_avg"], rtol=1e-5, atol=1e-7)
-        assert torch.allclose(ours.state[a]["exp_avg_sq"], ref.state[b]["exp_avg_sq"], rtol=1e-5, atol=1e-9)
+        ma, mb = ours.state[a]["exp_avg"], ref.state[b]["exp_avg"]
+        assert torch.allclose(ma, mb, rtol=1e-5, atol=2e-6 * float(mb.abs().max()))           # (a moment near zero is a difference of large terms)
+        va, vb = ours.state[a]["exp_avg_sq"], ref.state[b]["exp_avg_sq"]
+        assert torch.allclose(va, vb, rtol=1e-5, atol=1e-6 * float(vb.abs().max()))
         assert float(ours.state[a]["step"]) == 300.0
 
 
@@ -71,9 +73,12 @@ def test_lambd_adam_rejects_what_it_is_not_for():
     with pytest.raises(ValueError):
         LambdAdam([torch.nn.Parameter(torch.zeros(4))])                       # a CPU parameter
     with pytest.raises(ValueError):
-        LambdAdam([torch.nn.Parameter(torch.zeros(70000, device=DEV))])      # not small
+        LambdAdam([torch.nn.Parameter(torch.zeros(8, device=DEV, dtype=torch.float64))])
     with pytest.raises(ValueError):
         LambdAdam([torch.nn.Parameter(torch.zeros(4, device=DEV))], betas=(1.0, 0.9))
     t = torch.zeros(4, device=DEV)
     with pytest.raises(RuntimeError):
-        capi.adam_step(t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), 0, 4, 1e-3, 0.9, 0.999, 1e-8, 0.0, False, 0)
+        capi.adam_step(t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), 0, 0, 4, 1e-3, 0.9, 0.999, 1e-8, 0.0, False, 0)
+    big = torch.zeros(5000, device=DEV)
+    with pytest.raises(RuntimeError, match="ticket"):
+        capi.adam_step(big.data_ptr(), big.data_ptr(), big.data_ptr(), big.data_ptr(), t.data_ptr(), 0, 5000, 1e-3, 0.9, 0.999, 1e-8, 0.0, False, 0)
