@@ -282,6 +282,58 @@ def test_c2_full_size_properties():
     assert abs(num - ana) <= 2e-2 * abs(ana) + 1e-3
 
 
+@pytest.mark.parametrize("cname,B", [("g2_c2", 256), ("g3_c3", 8)])
+def test_xgrad_full_size_properties(cname, B, monkeypatch):
+    """dL/dx at BASELINE sizes (config 2: n_fft 1024, the kernel adds up its clip itself; config 3: n_fft 2048, partial sums from the
+    prep kernel), through properties that need no oracle pass over the whole batch: the wave-FFT kernels against the LDS radix-2
+    kernels (two independent implementations of the same adjoint), exact linearity in the cotangent, zero sum per clip (the
+    adjoint of the DC removal), independence of the clips, determinism; a few clips against the oracle."""
+    from dmel_amd import synth, capi
+    case = dict(C.BY_NAME[cname])
+    L, hop, M, sr, lam = case["L"], case["hop"], case["n_mels"], case["sr"], case["lambd"]
+    T = L // hop + 1
+    x_np = synth.waveforms(B, L, seed=11)
+    g_np = synth.cotangent((B, 1, M, T), seed=12)
+    x = torch.from_numpy(x_np).to("cuda:0")
+    g = torch.from_numpy(g_np).to("cuda:0")
+    plan = capi.Plan(L, hop, M, sr)
+    st = torch.cuda.current_stream().cuda_stream
+    y = torch.empty((B, 1, M, T), device="cuda:0")
+    plan.forward(x.data_ptr(), B, lam, y.data_ptr(), None, True, 1e-10, st)
+
+    def gx_of(xx, gg, yy, log=True):
+        out = torch.empty_like(xx)
+        plan.backward_x(xx.data_ptr(), xx.shape[0], lam, gg.data_ptr(), yy.data_ptr(), out.data_ptr(), log, st)
+        torch.cuda.synchronize()
+        return out
+
+    gx = gx_of(x, g, y)
+    scale = float(gx.abs().max())
+    assert torch.isfinite(gx).all() and scale > 0
+    # (1) the other implementation of the same adjoint (LDS radix-2 transforms, one row per frame, ordered gather)
+    monkeypatch.setenv("DMEL_XGRAD_LDS", "1")
+    gx_lds = gx_of(x, g, y)
+    monkeypatch.delenv("DMEL_XGRAD_LDS")
+    assert float((gx - gx_lds).abs().max()) <= TOL * scale                        # (two fp32 transforms of different structure: 3e-5 measured)
+    # (2) window and clip mean from the prep kernel instead of the kernel's own prologue (config 2 only takes the latter by default)
+    monkeypatch.setenv("DMEL_XGRAD_PREP", "1")
+    gx_prep = gx_of(x, g, y)
+    monkeypatch.delenv("DMEL_XGRAD_PREP")
+    assert float((gx - gx_prep).abs().max()) <= 0.2 * TOL * scale
+    # (3) linear in the cotangent, and powers of two pass through every step exactly
+    assert torch.equal(gx_of(x, 2.0 * g, y), 2.0 * gx)
+    # (4) zero sum per clip
+    assert float(gx.double().sum(1).abs().max()) <= 1e-4 * float(gx.double().abs().sum(1).max())
+    # (5) clips are independent, run-to-run determinism
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(5)).to("cuda:0")
+    assert torch.equal(gx_of(x[perm].contiguous(), g[perm].contiguous(), y[perm].contiguous()), gx[perm])
+    assert torch.equal(gx_of(x, g, y), gx)
+    # (6) a few clips against the oracle
+    pick = [0, B // 2, B - 1]
+    ref = O.backward_x(x_np[pick], lam, hop, sr, g_np[pick], y.cpu().numpy()[pick], case["f_min"], case["f_max"], case["normalize_window"])
+    assert _gx_err(gx.cpu().numpy()[pick], ref) <= TOL
+
+
 # ---- SURVEY 8(f1): the nets that call the layer, and the two-LR-group training step ---------------
 @pytest.mark.parametrize("net_name", ["MelLinearNet", "MelMlpNet", "MelConvNet"])
 def test_caller_nets_train_step(net_name):
