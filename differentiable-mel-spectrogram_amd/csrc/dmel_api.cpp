@@ -932,7 +932,7 @@ dmel_status dmel_plan_set_filterbank(dmel_plan* plan, int32_t n_fft, const float
 {
     if (!plan) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
     if (n_fft < 1 || n_fft > dmel::kMaxBigFft || (n_fft > 1 && (n_fft & 1)))
-        return fail(DMEL_ERR_INVALID_ARGUMENT, "n_fft must be 1 or an even length up to 262144");
+        return fail(DMEL_ERR_INVALID_ARGUMENT, "n_fft must be 1 or an even length up to 1048576");
     { dmel_status sd = check_device(plan); if (sd != DMEL_OK) return sd; }      // the synchronisation below must be the plan's device's
     std::lock_guard<std::mutex> lock(plan->mu);
     DMEL_HIP(hipDeviceSynchronize());     // tables of this n_fft may be in use by queued kernels
@@ -952,7 +952,7 @@ dmel_status dmel_plan_set_filterbank_dev(dmel_plan* plan, int32_t n_fft, const f
 {
     if (!plan || !fb_dev) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan / fb_dev is NULL");
     if (n_fft < 1 || n_fft > dmel::kMaxBigFft || (n_fft > 1 && (n_fft & 1)))
-        return fail(DMEL_ERR_INVALID_ARGUMENT, "n_fft must be 1 or an even length up to 262144");
+        return fail(DMEL_ERR_INVALID_ARGUMENT, "n_fft must be 1 or an even length up to 1048576");
     { dmel_status sd = check_device(plan); if (sd != DMEL_OK) return sd; }
     std::lock_guard<std::mutex> lock(plan->mu);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -272,7 +272,8 @@ hipError_t launch_naive(const NaiveParams& p, hipStream_t s);
 
 // transforms beyond the LDS kernels: power-of-two n_fft > 16384 (global-memory FFT) and lengths that are not powers of two
 // (Bluestein), dmel_big.hip
-constexpr int kMaxBigFft = 262144;     // largest power-of-two FFT of that path (n_fft itself, or >= 2 n_fft - 1 for Bluestein)
+constexpr int kMaxBigFft = 1048576;    // largest power-of-two FFT of that path (n_fft itself, or >= 2 n_fft - 1 for Bluestein): BASELINE config 5's
+                                       // 220 500-sample clip in the default optimized=False branch is n_fft 441 000 through 2^20-point FFTs
 struct BigParams {
     const float* x; float* out; float* tangent; const float* psum; const float2* win2;
     const float2* tw;        // (Mfft/2): exp(-2 pi i k / Mfft)

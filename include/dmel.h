@@ -33,8 +33,8 @@ extern "C" {
 typedef enum dmel_status {
     DMEL_OK = 0,
     DMEL_ERR_INVALID_ARGUMENT = 1,  /* bad shape / null pointer / negative size          */
-    DMEL_ERR_UNSUPPORTED = 2,       /* a transform that needs an FFT of more than 262144 points (|lambd| > 43690, or an
-                                       optimized=False clip longer than 65536 samples); optional gradients: n_fft > 16384 */
+    DMEL_ERR_UNSUPPORTED = 2,       /* a transform that needs an FFT of more than 1048576 points (|lambd| > 174762, or an
+                                       optimized=False clip longer than 262144 samples); optional gradients: n_fft > 16384 */
     DMEL_ERR_HIP = 3,               /* a HIP runtime call failed (message has the detail) */
     DMEL_ERR_NO_DEVICE = 4,         /* no gfx950 device visible                           */
     DMEL_ERR_OUT_OF_MEMORY = 5,
@@ -103,7 +103,7 @@ dmel_status dmel_plan_release(dmel_plan* plan);
 dmel_status dmel_plan_get_config(const dmel_plan* plan, dmel_config* cfg);
 
 /* Replace the mel filterbank of the plan by a caller-supplied (n_freqs, n_mels) fp32 HOST matrix for
- * the given n_fft (n_freqs = n_fft/2+1; 1 or any even length up to 262144): the contraction of models.py:53 then uses it instead
+ * the given n_fft (n_freqs = n_fft/2+1; 1 or any even length up to 1048576): the contraction of models.py:53 then uses it instead
  * of the HTK table.  Pass fb = NULL to return to the built-in table. */
 dmel_status dmel_plan_set_filterbank(dmel_plan* plan, int32_t n_fft, const float* fb);
 

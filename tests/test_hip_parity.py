@@ -202,7 +202,7 @@ def test_error_behaviour():
         layer(torch.zeros(case["L"], device="cuda:0"))
     with pytest.raises(RuntimeError):
         layer(torch.zeros(2, case["L"]))      # CPU tensor: no fallback
-    big = _layer(dict(case, lambd=50000.0), trainable=False)    # n_fft 524288: beyond the 262144-point FFT of the big path
+    big = _layer(dict(case, lambd=200000.0), trainable=False)   # n_fft 2097152: beyond the 2^20-point FFT of the big path
     big.lambd_sync = True
     with pytest.raises(RuntimeError, match="the HIP path stops at"):
         big(torch.zeros(1, case["L"], device="cuda:0"))
@@ -801,6 +801,24 @@ def test_full_window_branch_up_to_8192_points():
     y_ref, _ = O.forward(x_np, case["lambd"], case["hop"], case["n_mels"], case["sr"], case["f_min"], case["f_max"],
                          case["normalize_window"], apply_log=True, optimized=False)
     assert _log_err(y.detach().cpu().numpy(), y_ref) <= TOL
+
+
+def test_full_window_branch_at_config5_clip_length():
+    """The constructor's DEFAULT branch (models.py:15 optimized=False) on BASELINE config 5's clip: 220 500 samples @ 44.1 kHz ->
+    n_fft 441 000 through Bluestein's identity with 2^20-point FFTs in global memory (missing #4).  Two clips, three
+    frames (hop = half a clip) against the fp64 oracle, output and d lambd."""
+    case = dict(C.BY_NAME["g7_mel_nonopt_8000"], name="nonopt_220500", B=2, L=220500, sr=44100, lambd=9000.0, hop=110250, n_mels=128)
+    x_np = C.make_input(case).astype(np.float32)
+    g_np = C.make_cotangent(case)
+    layer = _layer(case, log=True)
+    y = layer(torch.from_numpy(x_np).to("cuda:0"))
+    assert layer.plan_info()["kernel_path"] == 3 and layer.plan_info()["n_fft"] == 441000
+    (y * torch.from_numpy(g_np).to("cuda:0")).sum().backward()
+    y_ref, t_ref = O.forward(x_np, case["lambd"], case["hop"], case["n_mels"], case["sr"], case["f_min"], case["f_max"],
+                             case["normalize_window"], apply_log=True, optimized=False)
+    assert _log_err(y.detach().cpu().numpy(), y_ref) <= TOL
+    exp_d = O.backward(g_np, t_ref)
+    assert abs(float(layer.lambd.grad) - exp_d) <= _dlam_tol(exp_d, g_np, t_ref)
 
 
 def test_full_window_branch_on_the_compact_layout():
