@@ -1371,9 +1371,10 @@ dmel_status backward_x_impl(dmel_plan* plan, const float* x, int32_t batch, floa
                             const float* grad_out, const float* out, float* grad_x, void* stream)
 {
     const int N = n_over > 0 ? n_over : dmel_n_fft(lambd);
-    if (N > dmel::kMaxNfft || (N & (N - 1)))
-        return fail(DMEL_ERR_UNSUPPORTED, "gradient w.r.t. the waveform: n_fft = " + std::to_string(N) + " is not a power of two <= " +
-                    std::to_string(dmel::kMaxNfft) + " (the chirp-z path has no adjoint yet)");
+    const bool big = N > dmel::kMaxNfft || (N & (N - 1));              // dmel_big.hip: chirp-z / global-memory FFT, both directions
+    if (N < 1 || N > dmel::kMaxBigFft || (big && (N & 1)))
+        return fail(DMEL_ERR_UNSUPPORTED, "gradient w.r.t. the waveform: n_fft = " + std::to_string(N) + " (even lengths up to " +
+                    std::to_string(dmel::kMaxBigFft) + ")");
     { dmel_status sd = check_device(plan); if (sd != DMEL_OK) return sd; }
     std::lock_guard<std::mutex> lock(plan->mu);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -1383,10 +1384,13 @@ dmel_status backward_x_impl(dmel_plan* plan, const float* x, int32_t batch, floa
     if ((st = order_after_last_stream(plan, s)) != DMEL_OK) return st;
     Scratch sc;
     if ((st = ensure_own_scratch(plan, batch, s, &sc)) != DMEL_OK) return st;
+    dmel_plan::BigTab bt;
+    const float2* big_tw = nullptr;
+    if (big && (st = big_tables_for(plan, N, &bt, &big_tw)) != DMEL_OK) return st;
     // n_fft 32 ... 2048: the wave-FFT kernel leaves one overlap-added segment per tile of frames; otherwise one row per frame
     int fpt = 0;
     const int win_n = win_half ? N : N / 2 + 1;             // the plain Gaussian is symmetric about N/2 (the whole-clip window need not be)
-    const bool wave_path = dmel::xgrad_wave_shape(N, spec_mode ? 0 : plan->cfg.n_mels, win_n, &fpt) && std::getenv("DMEL_XGRAD_LDS") == nullptr;
+    const bool wave_path = !big && dmel::xgrad_wave_shape(N, spec_mode ? 0 : plan->cfg.n_mels, win_n, &fpt) && std::getenv("DMEL_XGRAD_LDS") == nullptr;
     const int tiles = wave_path ? (plan->T + fpt - 1) / fpt : 0;
     const long long span = wave_path ? (long long)(fpt - 1) * plan->cfg.hop_length + N : 0;
     if (span > 0x3fffffffLL) return fail(DMEL_ERR_UNSUPPORTED, "gradient w.r.t. the waveform: hop_length too large");
@@ -1400,9 +1404,29 @@ dmel_status backward_x_impl(dmel_plan* plan, const float* x, int32_t batch, floa
         DMEL_HIP(hipMalloc(&plan->fbw, need * sizeof(float)));
         plan->fbw_floats = need;
     }
+    // the big path's window table and (sequences longer than LDS) per-workgroup workspace are plan-owned, like the forward's
+    const long long units = (long long)batch * ((plan->T + 1) / 2);
+    const int big_grid = big ? dmel::big_grid(units, bt.M) : 0;
+    if (big) {
+        const size_t need_z = dmel::big_uses_global(bt.M) ? (size_t)big_grid * bt.M : 0;
+        if ((size_t)N > plan->big_win_n || need_z > plan->big_z_n) {
+            if (is_capturing(s)) return fail(DMEL_ERR_INVALID_ARGUMENT, "workspace must grow but the stream is capturing: run one call eagerly first");
+            DMEL_HIP(hipDeviceSynchronize());
+            if ((size_t)N > plan->big_win_n) {
+                (void)hipFree(plan->big_win); plan->big_win = nullptr; plan->big_win_n = 0;
+                DMEL_HIP(hipMalloc(&plan->big_win, (size_t)N * sizeof(float2)));
+                plan->big_win_n = (size_t)N;
+            }
+            if (need_z > plan->big_z_n) {
+                (void)hipFree(plan->big_z); plan->big_z = nullptr; plan->big_z_n = 0;
+                DMEL_HIP(hipMalloc(&plan->big_z, need_z * sizeof(float2)));
+                plan->big_z_n = need_z;
+            }
+        }
+    }
     // clip sums + window table (the tangent half of the table is not used here)
     dmel::PrepParams pp{};
-    pp.x = x; pp.psum = sc.psum; pp.win2 = sc.win;
+    pp.x = x; pp.psum = sc.psum; pp.win2 = big ? plan->big_win : sc.win;
     pp.B = batch; pp.L = plan->cfg.n_points; pp.nchunks = plan->nchunks; pp.chunk = plan->chunk;
     pp.N = N; pp.normalize = plan->cfg.normalize_window; pp.win_half = win_half;
     pp.center = win_half ? (float)((N / 2) / 2) + (float)(N / 2) / 2.0f : (float)N / 2.0f;      // as launch_forward_n
@@ -1412,7 +1436,8 @@ dmel_status backward_x_impl(dmel_plan* plan, const float* x, int32_t batch, floa
     if (!own_prep) DMEL_HIP(dmel::launch_prep(pp, s));
     dmel::XgradParams xp{};
     xp.own_prep = own_prep ? 1 : 0; xp.win_denom = std::fabs(lambd) + 1e-15f;
-    xp.x = x; xp.psum = sc.psum; xp.win2 = sc.win; xp.tw = tb->tw_long;
+    xp.x = x; xp.psum = sc.psum; xp.win2 = big ? plan->big_win : sc.win; xp.tw = big ? big_tw : tb->tw_long;
+    xp.chirp = big ? bt.chirp : nullptr; xp.hbr = big ? bt.hbr : nullptr; xp.zws = plan->big_z; xp.Mfft = big ? bt.M : 0; xp.logM = big ? bt.logM : 0;
     xp.fb = tb->fb_dense; xp.rowband = tb->rowband; xp.rowpk = tb->rowpk; xp.long_rows = tb->long_rows ? 1 : 0; xp.grad_out = grad_out; xp.out = log ? out : nullptr;
     xp.frames = plan->fbw; xp.grad_x = grad_x;
     xp.csum = reinterpret_cast<double*>(plan->fbw + frame_floats);      // 256-byte aligned: frame_floats is a multiple of 64
@@ -1423,7 +1448,12 @@ dmel_status backward_x_impl(dmel_plan* plan, const float* x, int32_t batch, floa
     xp.tw1 = tb->tw1p; xp.tw2 = tb->tw2p;
     xp.win_n = win_n; xp.tiles = tiles; xp.span = (int)span; xp.tile_step = wave_path ? fpt * plan->cfg.hop_length : 0;
     const size_t m0 = prof_mark(plan, s);
-    DMEL_HIP(dmel::launch_xgrad(xp, s));
+    if (big) {
+        DMEL_HIP(dmel::launch_xgrad_big(xp, big_grid, s));
+        DMEL_HIP(dmel::launch_xgrad_gather(xp, s));
+    } else {
+        DMEL_HIP(dmel::launch_xgrad(xp, s));
+    }
     prof_span(plan, m0, prof_mark(plan, s), 2);
     return DMEL_OK;
 }

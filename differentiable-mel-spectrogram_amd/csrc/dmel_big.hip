@@ -201,6 +201,131 @@ __global__ void __launch_bounds__(kBigThreads) dmel_big_kernel(BigParams p)
     }
 }
 
+// ---- gradient w.r.t. the waveform on the same transforms (dmel_backward_x off the power-of-two lengths <= 16384) ---------------
+// The adjoint written out in dmel_xgrad.hip, one workgroup per PAIR of frames, with the DFT of this file in both directions:
+//   Z = DFT_N(x~_a w + i x~_b w);  per bin  H = c gP X  for both frames, conj(H_a + i H_b) Hermitian-extended in place;
+//   R = DFT_N(that) = conj(dv_a + i dv_b);  windowed frame gradients to the (B, T, N) workspace with one fp64 sum per frame
+// (dmel_xgrad_gather_kernel overlap-adds them in frame order and removes the mean).  A power-of-two N (> 16384) leaves the first
+// transform bit-reversed, which is the input order of the second (DIF then DIT, no permutation); Bluestein's round trip returns
+// natural order, so the second transform is simply another round trip.  A correctness path: the reference never asks for this
+// gradient, torch autograd would provide it (time_frequency.py:41,51 / models.py:171-200 with x.requires_grad).
+template <bool GLOBAL_Z>
+__global__ void __launch_bounds__(kBigThreads) dmel_xgrad_big_kernel(XgradParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ double red[2][kBigThreads / 64];
+    float2* Z = GLOBAL_Z ? p.zws + (size_t)blockIdx.x * p.Mfft : reinterpret_cast<float2*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = p.N, M = p.Mfft, sh = 32 - p.logM, T = p.T, Mm = p.M;
+    float2* twa = reinterpret_cast<float2*>(smem_raw + (size_t)M * sizeof(float2));
+    float2* twb = twa + 64;
+    if (!GLOBAL_Z) {
+        if (tid < 64) twa[tid] = (128 * tid < (M >> 1)) ? p.tw[128 * tid] : make_float2(1.f, 0.f);
+        if (tid >= 64 && tid < 192) twb[tid - 64] = (tid - 64 < (M >> 1)) ? p.tw[tid - 64] : make_float2(1.f, 0.f);
+    }
+    auto twid = [&](int k) -> float2 {
+        if (GLOBAL_Z) return p.tw[k];
+        return c_mul(twa[k >> 7], twb[k & 127]);
+    };
+    const bool blue = p.chirp != nullptr;
+    auto pos = [&](int k) -> unsigned { return blue ? (unsigned)k : (M > 1 ? __brev((unsigned)k) >> sh : 0u); };
+    // DFT_N of the N values in Z[0 .. N) (natural order) by Bluestein's round trip, result in natural order
+    auto bluestein = [&]() {
+        for (int n = tid; n < M; n += kBigThreads) Z[n] = n < N ? c_mul(Z[n], p.chirp[n]) : make_float2(0.f, 0.f);
+        __syncthreads();
+        lds_fft_dif<kBigThreads>(Z, M, p.logM, tid, twid);
+        for (int i = tid; i < M; i += kBigThreads) {
+            const float2 v = c_mul(Z[i], p.hbr[i]);
+            Z[i] = make_float2(v.x, -v.y);
+        }
+        __syncthreads();
+        lds_fft_dit<kBigThreads>(Z, M, p.logM, tid, twid);
+        for (int k = tid; k < N; k += kBigThreads) {
+            const float2 v = Z[k];
+            Z[k] = c_mul(make_float2(v.x, -v.y), p.chirp[k]);
+        }
+        __syncthreads();
+    };
+    const int tiles = (T + 1) / 2;
+    const long long units = (long long)p.B * tiles;
+    for (long long unit = blockIdx.x; unit < units; unit += gridDim.x) {
+        const int b = (int)(unit / tiles), tile = (int)(unit % tiles);
+        const int tA = 2 * tile, tB = tA + 1;
+        const bool hasB = tB < T;
+        const float* xb = p.x + (size_t)b * p.L;
+        float mean = 0.f;
+        {
+            double s = 0.0;
+            for (int c = 0; c < p.nchunks; ++c) s += (double)p.psum[(size_t)b * p.nchunks + c];
+            mean = (float)(s * (double)p.inv_L);
+        }
+        __syncthreads();                                   // the previous unit's readers are done with Z
+        for (int n = tid; n < (blue ? N : M); n += kBigThreads) {
+            const long long ia = (long long)tA * p.hop - N / 2 + n, ib = ia + p.hop;
+            const float va = (ia >= 0 && ia < p.L) ? (xb[ia] - mean) : 0.f;
+            const float vb = (hasB && ib >= 0 && ib < p.L) ? (xb[ib] - mean) : 0.f;
+            const float w = p.win2[n].x;
+            Z[n] = make_float2(va * w, vb * w);
+        }
+        __syncthreads();
+        if (blue) bluestein(); else lds_fft_dif<kBigThreads>(Z, M, p.logM, tid, twid);
+        // bin pass: every thread owns bin k and its mirror image (two addresses nobody else touches)
+        const float* ga = p.grad_out + (size_t)b * Mm * T + tA;
+        const float* ya = p.out ? p.out + (size_t)b * Mm * T + tA : nullptr;
+        for (int k = tid; k <= (N >> 1); k += kBigThreads) {
+            const unsigned ak = pos(k), an = pos((N - k) % N);
+            const float2 zk = Z[ak], zn = Z[an];
+            const float xar = 0.5f * (zk.x + zn.x), xai = 0.5f * (zk.y - zn.y);
+            const float xbr = 0.5f * (zk.y + zn.y), xbi = -0.5f * (zk.x - zn.x);
+            float gpa = 0.f, gpb = 0.f;
+            if (p.spec_mode) {
+                const float* gs = p.grad_out + ((size_t)b * p.F + k) * T + tA;
+                gpa = gs[0];
+                gpb = hasB ? gs[1] : 0.f;
+            } else {
+                const int2 band = p.rowband[k];
+                for (int m = band.x; m < band.y; ++m) {
+                    const float c = p.fb[(size_t)k * Mm + m];
+                    float g0 = ga[(size_t)m * T], g1 = hasB ? ga[(size_t)m * T + 1] : 0.f;
+                    if (ya) { g0 *= expf(-ya[(size_t)m * T]); if (hasB) g1 *= expf(-ya[(size_t)m * T + 1]); }
+                    gpa = fmaf(c, g0, gpa);
+                    gpb = fmaf(c, g1, gpb);
+                }
+            }
+            const bool edge = (k == 0) || (2 * k == N);
+            const float sc = edge ? 2.f : 1.f;
+            const float har = sc * gpa * xar, hai = edge ? 0.f : gpa * xai;
+            const float hbr = sc * gpb * xbr, hbi = edge ? 0.f : gpb * xbi;
+            Z[ak] = make_float2(har - hbi, -(hai + hbr));
+            if (!edge) Z[an] = make_float2(har + hbi, hai - hbr);
+        }
+        __syncthreads();
+        if (blue) bluestein(); else lds_fft_dit<kBigThreads>(Z, M, p.logM, tid, twid);
+        float* fa = p.frames + ((size_t)b * T + tA) * N;
+        double sa = 0.0, sb = 0.0;
+        for (int n = tid; n < N; n += kBigThreads) {
+            const float2 r = Z[n];
+            const float w = p.win2[n].x;
+            const float va = r.x * w, vb = -r.y * w;
+            fa[n] = va;
+            if (hasB) fa[(size_t)N + n] = vb;
+            const long long ia = (long long)tA * p.hop - N / 2 + n, ib = ia + p.hop;
+            if (ia >= 0 && ia < p.L) sa += (double)va;
+            if (hasB && ib >= 0 && ib < p.L) sb += (double)vb;
+        }
+        // fixed order: lanes by the shuffle tree, waves ascending
+        for (int o = 32; o > 0; o >>= 1) { sa += __shfl_xor(sa, o, 64); sb += __shfl_xor(sb, o, 64); }
+        if (lane == 0) { red[0][wave] = sa; red[1][wave] = sb; }
+        __syncthreads();
+        if (tid == 0) {
+            double ta = 0.0, tb2 = 0.0;
+            for (int w = 0; w < kBigThreads / 64; ++w) { ta += red[0][w]; tb2 += red[1][w]; }
+            p.csum[(size_t)b * T + tA] = ta;
+            if (hasB) p.csum[(size_t)b * T + tB] = tb2;
+        }
+    }
+}
+
 constexpr int kBigLdsMax = 16384;          // complex entries: 128 KB
 constexpr int kBigSplitAccBytes = 16384;   // split mode: (n_mels) float2 sums of the even half behind the sequence
 constexpr int kBigTwBytes = (64 + 128) * 8; // the two twiddle factor tables behind that
@@ -210,11 +335,22 @@ bool big_can_split(int m_half, int n_mels) { return m_half <= kBigLdsMax && (lon
 
 hipError_t big_prepare_attributes()
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(dmel_big_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               kBigLdsMax * (int)sizeof(float2) + kBigSplitAccBytes + kBigTwBytes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dmel_big_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       kBigLdsMax * (int)sizeof(float2) + kBigSplitAccBytes + kBigTwBytes);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(dmel_xgrad_big_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               kBigLdsMax * (int)sizeof(float2) + kBigTwBytes);
 }
 
 bool big_uses_global(int m_fft) { return m_fft > kBigLdsMax; }
+
+// frames kernel of dmel_backward_x on this file's transforms; launch_xgrad_gather (dmel_xgrad.hip) finishes the job
+hipError_t launch_xgrad_big(const XgradParams& p, int grid, hipStream_t s)
+{
+    if (big_uses_global(p.Mfft)) hipLaunchKernelGGL(dmel_xgrad_big_kernel<true>, dim3((unsigned)grid), dim3(kBigThreads), 0, s, p);
+    else hipLaunchKernelGGL(dmel_xgrad_big_kernel<false>, dim3((unsigned)grid), dim3(kBigThreads), (size_t)p.Mfft * sizeof(float2) + kBigTwBytes, s, p);
+    return hipGetLastError();
+}
 
 // workgroups of one launch: every unit its own workgroup while the sequence fits LDS, a bounded number of persistent ones
 // (each owns m_fft complex words of the workspace) otherwise

@@ -317,8 +317,12 @@ struct XgradParams {
     float win_denom;                          // |lambd| + 1e-15 (time_frequency.py:24), own_prep only
     int tw2_off;                              // set by launch_xgrad: byte offset of the radix-C twiddles in LDS
     int win_n;                                // window entries kept in LDS: N/2 + 1 (symmetric about N/2) or N
+    // dmel_big.hip path (lengths that are not powers of two, powers of two > 16384): `tw` then belongs to the Mfft-point FFT
+    const float2* chirp; const float2* hbr; float2* zws; int Mfft, logM;
 };
 hipError_t launch_xgrad(const XgradParams& p, hipStream_t s);
+hipError_t launch_xgrad_big(const XgradParams& p, int grid, hipStream_t s);     // frames kernel on the global-memory FFT / chirp-z transforms
+hipError_t launch_xgrad_gather(const XgradParams& p, hipStream_t s);           // ordered overlap-add of the (B, T, N) frame gradients + mean
 hipError_t xgrad_prepare_attributes();
 bool xgrad_wave_shape(int n_fft, int n_mels, int win_n, int* frames_per_tile);   // the wave-FFT kernel takes this shape
 int xgrad_chunks(int L);      // gather chunks per clip (size of XgradParams::csum per clip)

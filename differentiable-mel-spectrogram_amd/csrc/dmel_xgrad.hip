@@ -672,6 +672,11 @@ hipError_t launch_xgrad(const XgradParams& p, hipStream_t s)
     else hipLaunchKernelGGL(dmel_xgrad_frames_kernel<false>, dim3((unsigned)grid), dim3(kXgThreads), lds, s, q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    return launch_xgrad_gather(p, s);
+}
+
+hipError_t launch_xgrad_gather(const XgradParams& p, hipStream_t s)
+{
     const dim3 g2((unsigned)((p.L + kXgChunk - 1) / kXgChunk), (unsigned)p.B);
     hipLaunchKernelGGL(dmel_xgrad_gather_kernel, g2, dim3(256), 0, s, p);
     return hipGetLastError();

@@ -320,9 +320,6 @@ class MelSpectrogramLayer(nn.Module):
             raise RuntimeError(f"input has {n_points} points, the layer was built for n_points={self.n_points}")
         if not x.is_cuda:
             raise RuntimeError("dmel_amd runs on MI355X only: x must be a CUDA/HIP tensor (no CPU fallback)")
-        if x.requires_grad and not self.optimized and (n_points & (n_points - 1) or 2 * n_points > capi.MAX_NFFT):
-            raise NotImplementedError("gradient w.r.t. the waveform with optimized=False needs a power-of-two n_points <= "
-                                      f"{capi.MAX_NFFT // 2} (the chirp-z transform of other lengths has no adjoint kernel yet)")
         if self.lambd.device != x.device:
             raise RuntimeError(f"lambd is on {self.lambd.device} but x is on {x.device}; call layer.to(x.device)")
         # dtype / layout conversions only when needed (each no-op torch call still costs ~2 us of host time); when x requires
@@ -466,9 +463,6 @@ class SpectrogramLayer(nn.Module):
             with torch.cuda.device(x.device):
                 plan = capi.Plan(n_points, self.hop_length, 1, 2, 0.0, 1.0, bool(self.normalize_window))
             self._plans[key] = plan
-        if x.requires_grad and (n_fft & (n_fft - 1) or n_fft > capi.MAX_NFFT):
-            raise NotImplementedError(f"gradient w.r.t. the waveform needs a power-of-two n_fft <= {capi.MAX_NFFT} (this forward uses n_fft = {n_fft}: "
-                                      "the chirp-z transform has no adjoint kernel yet)")
         xf = x if x.dtype == torch.float32 else x.to(torch.float32)
         return _DspecFunction.apply(xf.contiguous(), self.lambd, plan, lam_host, n_fft, half)
 

@@ -34,7 +34,7 @@ typedef enum dmel_status {
     DMEL_OK = 0,
     DMEL_ERR_INVALID_ARGUMENT = 1,  /* bad shape / null pointer / negative size          */
     DMEL_ERR_UNSUPPORTED = 2,       /* a transform that needs an FFT of more than 1048576 points (|lambd| > 174762, or an
-                                       optimized=False clip longer than 262144 samples); optional gradients: n_fft > 16384 */
+                                       optimized=False clip longer than 262144 samples) */
     DMEL_ERR_HIP = 3,               /* a HIP runtime call failed (message has the detail) */
     DMEL_ERR_NO_DEVICE = 4,         /* no gfx950 device visible                           */
     DMEL_ERR_OUT_OF_MEMORY = 5,
@@ -248,15 +248,16 @@ dmel_status dmel_backward_fb_dev(dmel_plan* plan, const float* x, int32_t batch,
  * time_frequency.py:43-53 (zero padding, framing, window, rfft, |.|^2), models.py:53 (mel contraction) and, with
  * DMEL_FLAG_LOG, models.py:73.  The reference never differentiates the waveform; provided for completeness
  * (adversarial / saliency uses).  Arguments as dmel_backward_fb; grad_x: device, (batch, n_points) fp32, overwritten.
- * Power-of-two transforms up to 16384 points: every optimized=True case, and the optimized=False branch (DMEL_FLAG_FULL_WINDOW) on
- * clips of a power-of-two length up to 8192 samples (the chirp-z path has no adjoint yet: DMEL_ERR_UNSUPPORTED).  Deterministic
- * (overlap-add as an ordered gather).  Asynchronous on `stream`; shares the plan-owned workspace with dmel_backward_fb.
+ * Every transform the forward runs: the wave-FFT kernels up to n_fft 2048, LDS transforms up to 16384, and beyond that -- or for
+ * lengths that are not powers of two, i.e. the optimized=False branch (DMEL_FLAG_FULL_WINDOW) on arbitrary clips -- the
+ * global-memory FFT / chirp-z transforms in both directions (a correctness path: one (batch, n_time, n_fft) fp32 workspace).
+ * Deterministic (overlap-add as an ordered gather).  Asynchronous on `stream`; shares the plan-owned workspace with dmel_backward_fb.
  */
 dmel_status dmel_backward_x(dmel_plan* plan, const float* x, int32_t batch, float lambd, uint32_t flags,
                             const float* grad_out, const float* out, float* grad_x, void* stream);
 /* The same through SpectrogramLayer.forward (models.py:171-200; dmel_spectrogram_ex with DMEL_SPEC_REMOVE_DC): grad_spec is the
- * gradient of the power spectrogram, device (batch, n_fft/2+1, n_time) fp32; n_fft and flags as in dmel_spectrogram_ex (power-of-two
- * n_fft up to 16384). */
+ * gradient of the power spectrogram, device (batch, n_fft/2+1, n_time) fp32; n_fft and flags as in dmel_spectrogram_ex (any
+ * even n_fft the forward accepts). */
 dmel_status dmel_backward_x_spec(dmel_plan* plan, const float* x, int32_t batch, float lambd, int32_t n_fft, uint32_t flags,
                                  const float* grad_spec, float* grad_x, void* stream);
 

@@ -196,7 +196,7 @@ def run_panns(models):
     return out
 
 
-XGRAD_CASES = ("g1_c1", "g5_n128", "g6_n256_ragged", "g6_tone_dc", "g6_n32", "g7_mel_nonopt_256", "g7_mel_nonopt_1024n")   # the last two: optimized=False
+XGRAD_CASES = ("g1_c1", "g5_n128", "g6_n256_ragged", "g6_tone_dc", "g6_n32", "g7_mel_nonopt_256", "g7_mel_nonopt_1024n", "g7_mel_nonopt_601", "g7_mel_nonopt_8000")   # the last four: optimized=False (601, 8000: n_fft = 2L is not a power of two)
 
 
 def run_xgrad(models, tf, case):
@@ -271,7 +271,7 @@ def main(argv):
         argv = [a for a in argv if a != "net_keys"]
         if len(argv) == 1 and "net_keys" in sys.argv:
             return
-    names = argv[1:] or [c["name"] for c in C.CASES] + ["g7_dspec", "g7_dspec_100", "g7_dspec_xgrad"] + ["g8_fbgrad_" + n for n in FBGRAD_CASES] + ["g9_panns"] + ["g10_xgrad_" + n for n in XGRAD_CASES] + ["g11_nets"]
+    names = argv[1:] or [c["name"] for c in C.CASES] + ["g7_dspec", "g7_dspec_100", "g7_dspec_xgrad", "g7_dspec_xgrad_100"] + ["g8_fbgrad_" + n for n in FBGRAD_CASES] + ["g9_panns"] + ["g10_xgrad_" + n for n in XGRAD_CASES] + ["g11_nets"]
     for name in names:
         if name == "g7_dspec":
             out = run_dspec(models, tf)
@@ -279,6 +279,8 @@ def main(argv):
             out = run_dspec(models, tf, L=100)
         elif name == "g7_dspec_xgrad":
             out = run_dspec_xgrad(models, tf)
+        elif name == "g7_dspec_xgrad_100":
+            out = run_dspec_xgrad(models, tf, L=100)
         elif name.startswith("g10_xgrad_"):
             out = run_xgrad(models, tf, C.BY_NAME[name[len("g10_xgrad_"):]])
         elif name == "g9_panns":

@@ -737,7 +737,7 @@ def test_backward_fb_rejects_bad_arguments():
     with pytest.raises(capi.DmelError):
         plan.backward_fb(x.data_ptr(), 2, 9.0, g.data_ptr(), None, gfb.data_ptr(), True, st)        # log without the saved output
     with pytest.raises(capi.DmelError):
-        plan.backward_fb(x.data_ptr(), 2, 50000.0, g.data_ptr(), None, gfb.data_ptr(), False, st)   # n_fft 524288: beyond the HIP path
+        plan.backward_fb(x.data_ptr(), 2, 200000.0, g.data_ptr(), None, gfb.data_ptr(), False, st)   # n_fft 2097152: beyond the HIP path
     plan.backward_fb(x.data_ptr(), 0, 9.0, g.data_ptr(), None, gfb.fill_(1.0).data_ptr(), False, st)   # empty batch: zeros
     torch.cuda.synchronize()
     assert float(gfb.abs().max()) == 0.0
@@ -1133,10 +1133,11 @@ def test_config5_training_step_front_end_share():
 
 
 # ---- the optional gradients outside optimized=True (missing #2 and #3) -------------------------------------------------
-@pytest.mark.parametrize("name", ["g7_mel_nonopt_256", "g7_mel_nonopt_1024n"])
+@pytest.mark.parametrize("name", ["g7_mel_nonopt_256", "g7_mel_nonopt_1024n", "g7_mel_nonopt_601", "g7_mel_nonopt_8000"])
 def test_xgrad_full_window_matches_reference_golden(name):
     """x.requires_grad through the optimized=False branch (window = the clip, n_fft = 2 L; time_frequency.py:41,51) against torch
-    autograd through the reference (g10_xgrad_g7_*.npz)."""
+    autograd through the reference (g10_xgrad_g7_*.npz).  601 and 8000 samples: n_fft 1202 / 16000 are not powers of two, both
+    transforms of the adjoint are chirp-z round trips (16000: through 32768-point FFTs in global memory)."""
     import os
     case = C.BY_NAME[name]
     gold = np.load(os.path.join(os.path.dirname(C.__file__), f"g10_xgrad_{name}.npz"))
@@ -1153,14 +1154,18 @@ def test_xgrad_full_window_matches_reference_golden(name):
         assert layer.lambd.grad is not None
 
 
-def test_xgrad_full_window_other_lengths_raise():
-    from dmel_amd import MelSpectrogramLayer
-    lay = MelSpectrogramLayer(torch.tensor(50.0), n_mels=24, n_points=601, sample_rate=8000, hop_length=20, device="cuda:0",
-                              optimized=False).to("cuda:0")
-    x = torch.zeros(2, 601, device="cuda:0", requires_grad=True)
-    with pytest.raises(NotImplementedError):
-        lay(x)
-    assert lay(x.detach()).shape == (2, 1, 24, 31)
+def test_xgrad_long_power_of_two_transform():
+    """dL/dx at n_fft 32768 (lambd 2800: a power of two beyond the LDS kernels): DIF / DIT in global memory, against the oracle"""
+    case = dict(C.BY_NAME["g5_n32768"], B=1)
+    x_np = C.make_input(case).astype(np.float32)
+    g_np = C.make_cotangent(case)
+    x = torch.from_numpy(x_np).to("cuda:0").requires_grad_(True)
+    layer = _layer(case, log=True)
+    y = layer(x)
+    (y * torch.from_numpy(g_np).to("cuda:0")).sum().backward()
+    ref = O.backward_x(x_np, case["lambd"], case["hop"], case["sr"], g_np, y.detach().cpu().numpy(), case["f_min"], case["f_max"],
+                       case["normalize_window"])
+    assert _gx_err(x.grad.cpu().numpy(), ref) <= TOL
 
 
 @pytest.mark.parametrize("name", ["g7_mel_nonopt_256", "g7_mel_nonopt_601"])
@@ -1204,6 +1209,10 @@ def test_dspec_xgrad_matches_reference_golden():
     (s * g).sum().backward()
     assert _gx_err(x.grad.cpu().numpy(), gold["gx"].astype(np.float64)) <= TOL
     assert lay.lambd.grad is not None
-    x100 = torch.zeros(2, 100, device="cuda:0", requires_grad=True)
-    with pytest.raises(NotImplementedError):
-        lay(x100)
+    # L = 100 -> n_fft 200, not a power of two: chirp-z in both directions (g7_dspec_xgrad_100.npz)
+    gold100 = np.load(os.path.join(os.path.dirname(C.__file__), "g7_dspec_xgrad_100.npz"))
+    x100 = torch.from_numpy(synth.waveforms(2, 100, seed=77, scale=1.0)).to("cuda:0").requires_grad_(True)
+    s100 = lay(x100)
+    g100 = torch.from_numpy(synth.cotangent(tuple(s100.shape), seed=78)).to("cuda:0")
+    (s100 * g100).sum().backward()
+    assert _gx_err(x100.grad.cpu().numpy(), gold100["gx"].astype(np.float64)) <= TOL
