@@ -350,7 +350,7 @@ def main():
     if args.mode in ("auto", "graph"):
         # (a graph launch costs ~8-14 us of idle time on the device between two replays -- profiles/r03_step_timeline_c2.json --
         # whatever the graph holds: the more steps one replay carries, the less of it each step pays)
-        ks = [1] + [k for k in (4, 10) if args.steps % k == 0]
+        ks = [1] + [k for k in (4, 10, 20) if args.steps % k == 0]
         for k in ks:
             ok = True
             try:
