@@ -377,13 +377,30 @@ struct __attribute__((packed, aligned(4))) f4u { float v[4]; };       // 16-byte
 // whose rows are padded to 24 floats (the 16 lanes of a ds_read_b128 group then touch 16 different 16-byte slots).  For the log
 // output gm = grad_out * exp(-out) is formed while staging (no pre-pass, no gm workspace).  Same K order in A and B (lane
 // (row, kq) holds t = 16 j + 4 kq + u for k-step u), slices summed in index order by dmel_fbgrad_reduce_kernel: deterministic.
+#ifdef DMEL_STAMPS
+__device__ unsigned long long g_fstamps[1024 * 8 * 8];
+__device__ __forceinline__ void fstamp(int idx)
+{
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const int wg = blockIdx.x + gridDim.x * blockIdx.y;
+    if ((threadIdx.x & 63) == 0 && wg < 1024) g_fstamps[((size_t)wg * 8 + (threadIdx.x >> 6)) * 8 + idx] = t;
+}
+#define FSTAMP(i) fstamp(i)
+#else
+#define FSTAMP(i) do {} while (0)
+#endif
 constexpr int kFbgBF = 64, kFbgBM = 128, kFbgRow = 24, kFbgThreads = 512;     // rows of 24 floats: ds_read_b128 of 16 rows x 4 pieces is conflict-free (20: 2-way)
 
+template <bool LOG, bool TINY>
 __global__ void __launch_bounds__(kFbgThreads) dmel_fbgrad_lds_kernel(FbGradParams p)
 {
-    __shared__ __attribute__((aligned(16))) float lds_a[2][kFbgBF * kFbgRow];
+    __shared__ __attribute__((aligned(16))) float lds_a[2][(kFbgBF + 1) * kFbgRow];     // (+ the folded last row, see `fold`)
     __shared__ __attribute__((aligned(16))) float lds_b[2][kFbgBM * kFbgRow];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    FSTAMP(0);
     const int row = lane & 15, kq = lane >> 4;
     const int wf = wave >> 2, wm = wave & 3;
     const int f0 = blockIdx.x * kFbgBF, m0 = blockIdx.z * kFbgBM;
@@ -391,78 +408,110 @@ __global__ void __launch_bounds__(kFbgThreads) dmel_fbgrad_lds_kernel(FbGradPara
     const int F = p.F, M = p.M, T = p.T;
     // a slice = a run of consecutive K-blocks (16 time steps of one clip) of the batch, cut at block -- not clip -- boundaries:
     // the slices differ by at most one block
-    const int ntc = (T + 15) / 16;
-    const long long all_blocks = (long long)p.B * ntc;
-    const int blk_lo = (int)(all_blocks * split / p.splits), blk_hi = (int)(all_blocks * (split + 1) / p.splits);
-    const int total = blk_hi - blk_lo;
-    const int b_lo = blk_lo / ntc;
+    // (the cuts come from the host as quotient and remainder: 64-bit divisions here cost the workgroup microseconds before its
+    // first request -- 9 k cycles from the first instruction to the first load issued, a quarter of a wave's life at config 2)
+    const int ntc = p.ntc;
+    const int blk_lo = split * p.blk_base + min(split, p.blk_rem);
+    const int total = p.blk_base + (split < p.blk_rem ? 1 : 0);
+    const int b_lo = (int)((unsigned)blk_lo / (unsigned)ntc);
     // staging roles: every thread one 16-byte piece of the B tile (row tid / 4, piece tid % 4), threads 0 .. 255 one of the A tile
     const int srow = tid >> 2, sc = tid & 3;
     const int mrow = min(m0 + srow, M - 1);                       // rows past the edge: valid memory, results never stored
-    const int frow = min(f0 + (srow & (kFbgBF - 1)), F - 1);
-    const bool has_a = tid < 4 * kFbgBF;
+    // n_fft / 2 + 1 rows = a multiple of 64 plus ONE: a ninth tile for the Nyquist row would cost a workgroup slot per slice
+    // (56 of 512 at BASELINE config 2) for 1/64 of a tile's work.  Instead the workgroups of the LAST full tile stage that row as a
+    // 65th row of their A image (threads 256 .. 259, whose A registers are otherwise unused) and carry its 128 dot products on the
+    // vector pipe: four FMAs per thread and K-block, summed over the four threads of a column in a fixed order at the end.
+    const bool fold = p.fold_last_row && blockIdx.x == gridDim.x - 1;
+    const int frow = tid < 4 * kFbgBF ? min(f0 + srow, F - 1) : F - 1;
+    const bool has_a = tid < 4 * kFbgBF || (fold && tid < 4 * kFbgBF + 4);
     // DEPTH blocks of loads in flight per thread (one block ahead left every iteration waiting for a memory round trip).  Blocks are
     // requested strictly in order, so the addresses advance by increments (no division, no 64-bit products per block), and what is
     // loaded is only touched when it is parked in LDS -- exp(-out) included: applied at request time it made every request wait
     // for its own loads (config 3, log output: 143 -> 126 us for the whole gradient).
     constexpr int DEPTH = 3;
     float4 ring_a[DEPTH], ring_g[DEPTH], ring_y[DEPTH];
-    int nb = b_lo, nblk = blk_lo - b_lo * ntc;                      // clip and 16-step block of the NEXT request
+    int nblk = blk_lo - b_lo * ntc;                                 // 16-step block (inside its clip) of the NEXT request
     int left = total;                                               // requests still to be made
     const float* pg = p.grad_out + ((size_t)b_lo * M + mrow) * T;
-    const float* py = p.out ? p.out + ((size_t)b_lo * M + mrow) * T : nullptr;
+    const float* py = LOG ? p.out + ((size_t)b_lo * M + mrow) * T : nullptr;
     const float* pa = p.spec + ((size_t)b_lo * F + frow) * T;
     const size_t step_g = (size_t)M * T, step_a = (size_t)F * T;
-    auto fetch = [&](float4& ra, float4& rg, float4& ry) {
+    // Requests are branch-free 16-byte loads that land in the ring registers themselves: a piece that would cross the end of its row
+    // is read from the row's last four entries instead (always in bounds) and shifted into place when it is PARKED, where the
+    // data is touched anyway.  With a branch around the loads -- element-wise loads for such pieces -- the two paths met in a phi,
+    // the compiler loaded into temporaries and moved them (s_waitcnt vmcnt right behind every request): the ring never held
+    // more than one block in flight, 2 k cycles per request in the prologue alone (tools/fstamps.py).  Every thread requests a
+    // piece of A (threads that park none re-read one row: 16 bytes of L1 traffic).  Rows shorter than a piece: TINY, element-wise.
+    int ring_t[DEPTH];
+    auto fetch = [&](float4& ra, float4& rg, float4& ry, int& rt) {
         if (left <= 0) return;
         --left;
         const int t = nblk * 16 + 4 * sc;
-        if (t + 3 < T) {
-            const f4u g = *reinterpret_cast<const f4u*>(pg + t);
+        rt = t;
+        if constexpr (!TINY) {
+            const int tl = min(t, T - 4);
+            const f4u g = *reinterpret_cast<const f4u*>(pg + tl);
+            const f4u a = *reinterpret_cast<const f4u*>(pa + tl);
             rg = make_float4(g.v[0], g.v[1], g.v[2], g.v[3]);
-            if (py) { const f4u y = *reinterpret_cast<const f4u*>(py + t); ry = make_float4(y.v[0], y.v[1], y.v[2], y.v[3]); }
-            if (has_a) { const f4u a = *reinterpret_cast<const f4u*>(pa + t); ra = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]); }
+            ra = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+            if constexpr (LOG) { const f4u y = *reinterpret_cast<const f4u*>(py + tl); ry = make_float4(y.v[0], y.v[1], y.v[2], y.v[3]); }
         } else {
-            // the last block of a row whose length is not a multiple of 16 (or of 4): element-wise, zero past the end of the row
             float gb[4], yb[4], ga[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const bool ok = t + u < T;
-                const int tt = ok ? t + u : 0;
-                gb[u] = ok ? pg[tt] : 0.f;
-                yb[u] = (ok && py) ? py[tt] : 0.f;
-                ga[u] = (ok && has_a) ? pa[tt] : 0.f;
+                const int tt = min(t + u, T - 1);
+                const float vg = pg[tt], va = pa[tt];
+                gb[u] = ok ? vg : 0.f;
+                ga[u] = ok ? va : 0.f;
+                if constexpr (LOG) { const float vy = py[tt]; yb[u] = ok ? vy : 0.f; } else yb[u] = 0.f;
             }
             rg = make_float4(gb[0], gb[1], gb[2], gb[3]);
             ry = make_float4(yb[0], yb[1], yb[2], yb[3]);
             ra = make_float4(ga[0], ga[1], ga[2], ga[3]);
         }
-        if (++nblk == ntc) { nblk = 0; ++nb; pg += step_g; pa += step_a; if (py) py += step_g; }
+        if (++nblk == ntc) { nblk = 0; pg += step_g; pa += step_a; if constexpr (LOG) py += step_g; }
     };
-    auto park = [&](int buf, const float4& ra, const float4& rg, const float4& ry) {
+    // entries t .. t + 3 of a row of T, of which the request fetched min(t, T - 4) .. : shift left by sh = t - (T - 4), zeros behind
+    auto in_place = [&](float4 v, int t) -> float4 {
+        const int sh = t - (T - 4);
+        if (TINY || sh <= 0) return v;
+        if (sh == 1) return make_float4(v.y, v.z, v.w, 0.f);
+        if (sh == 2) return make_float4(v.z, v.w, 0.f, 0.f);
+        if (sh == 3) return make_float4(v.w, 0.f, 0.f, 0.f);
+        return make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto park = [&](int buf, float4 ra, float4 rg, float4 ry, int t) {
+        ra = in_place(ra, t); rg = in_place(rg, t);
         float4 rb = rg;
-        if (p.out) rb = make_float4(rg.x * expf(-ry.x), rg.y * expf(-ry.y), rg.z * expf(-ry.z), rg.w * expf(-ry.w));     // gm = grad_out * exp(-out)
+        if constexpr (LOG) {
+            ry = in_place(ry, t);                                   // (zeros behind the row: exp(-0) times a zero gradient)
+            rb = make_float4(rg.x * expf(-ry.x), rg.y * expf(-ry.y), rg.z * expf(-ry.z), rg.w * expf(-ry.w));     // gm = grad_out * exp(-out)
+        }
         *reinterpret_cast<float4*>(&lds_b[buf][srow * kFbgRow + 4 * sc]) = rb;
         if (has_a) *reinterpret_cast<float4*>(&lds_a[buf][srow * kFbgRow + 4 * sc]) = ra;
     };
     floatx4_t acc[2][2];
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) acc[i][j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+    float nyq = 0.f;                                                // fold: this thread's quarter of column srow of the last row
     // 16-row / 16-column pieces of this wave's sub-tile that exist (n_fft / 2 + 1 rows: the last tile of 64 holds ONE): a wave
     // with none only stages
     const bool act_f0 = f0 + wf * 32 < F, act_f1 = f0 + wf * 32 + 16 < F;
     const bool act_m0 = m0 + wm * 32 < M, act_m1 = m0 + wm * 32 + 16 < M;
     {
+        // block k waits in ring slot k % DEPTH: blocks 0 .. DEPTH - 1 requested, block 0 parked, block DEPTH requested in its place
         const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 a0 = zero, g0 = zero, y0 = zero;
-        fetch(a0, g0, y0);
-        unrolled<0, DEPTH>([&](auto dd) {                     // block k >= 1 lives in ring slot (k - 1) % DEPTH
+        unrolled<0, DEPTH>([&](auto dd) {
             constexpr int d = decltype(dd)::value;
-            ring_a[d] = zero; ring_g[d] = zero; ring_y[d] = zero;
-            fetch(ring_a[d], ring_g[d], ring_y[d]);
+            ring_a[d] = zero; ring_g[d] = zero; ring_y[d] = zero; ring_t[d] = 0;
+            fetch(ring_a[d], ring_g[d], ring_y[d], ring_t[d]);
         });
-        park(0, a0, g0, y0);
+        FSTAMP(1);   // first requests issued
+        park(0, ring_a[0], ring_g[0], ring_y[0], ring_t[0]);
+        fetch(ring_a[0], ring_g[0], ring_y[0], ring_t[0]);
     }
     __syncthreads();
+    FSTAMP(2);       // first block parked
     for (int c0 = 0; c0 < total; c0 += DEPTH) {
         unrolled<0, DEPTH>([&](auto dd) {
             constexpr int d = decltype(dd)::value;            // compile-time ring slot: the buffers stay in registers
@@ -475,10 +524,16 @@ __global__ void __launch_bounds__(kFbgThreads) dmel_fbgrad_lds_kernel(FbGradPara
                 a[i] = *reinterpret_cast<const float4*>(&lds_a[buf][(wf * 32 + 16 * i + row) * kFbgRow + 4 * kq]);
                 g[i] = *reinterpret_cast<const float4*>(&lds_b[buf][(wm * 32 + 16 * i + row) * kFbgRow + 4 * kq]);
             }
+            if (fold) {
+                const float4 ar = *reinterpret_cast<const float4*>(&lds_a[buf][kFbgBF * kFbgRow + 4 * sc]);
+                const float4 gr = *reinterpret_cast<const float4*>(&lds_b[buf][srow * kFbgRow + 4 * sc]);
+                nyq = fmaf(ar.x, gr.x, nyq); nyq = fmaf(ar.y, gr.y, nyq); nyq = fmaf(ar.z, gr.z, nyq); nyq = fmaf(ar.w, gr.w, nyq);
+            }
             // block c + 1 (requested DEPTH iterations ago) into the other image: nobody reads that image before the barrier below;
             // then block c + 1 + DEPTH is requested into the slot just emptied
-            if (c + 1 < total) park(buf ^ 1, ring_a[d], ring_g[d], ring_y[d]);
-            fetch(ring_a[d], ring_g[d], ring_y[d]);
+            constexpr int dn = (d + 1) % DEPTH;               // slot of block c + 1
+            if (c + 1 < total) park(buf ^ 1, ring_a[dn], ring_g[dn], ring_y[dn], ring_t[dn]);
+            fetch(ring_a[dn], ring_g[dn], ring_y[dn], ring_t[dn]);
             const float av[2][4] = {{a[0].x, a[0].y, a[0].z, a[0].w}, {a[1].x, a[1].y, a[1].z, a[1].w}};
             const float gv[2][4] = {{g[0].x, g[0].y, g[0].z, g[0].w}, {g[1].x, g[1].y, g[1].z, g[1].w}};
             if (act_f1 && act_m1) {
@@ -500,8 +555,17 @@ __global__ void __launch_bounds__(kFbgThreads) dmel_fbgrad_lds_kernel(FbGradPara
             __syncthreads();
         });
     }
+    FSTAMP(3);       // K loop
     // D[4 * (lane >> 4) + r][lane & 15]: rows = freq, columns = mel
     float* part = p.partials + (size_t)split * F * M;
+    if (fold) {
+        // the four quarters of a column sit in one quad: (q0 + q1) + (q2 + q3), the same bits in every lane
+        const float o1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, nyq), 0xB1, 0xF, 0xF, true));
+        const float pr = (sc & 1) ? o1 + nyq : nyq + o1;
+        const float o2 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, pr), 0x4E, 0xF, 0xF, true));
+        const float tot = (sc & 2) ? o2 + pr : pr + o2;
+        if (sc == 0 && m0 + srow < M) part[(size_t)(F - 1) * M + m0 + srow] = tot;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -513,6 +577,7 @@ __global__ void __launch_bounds__(kFbgThreads) dmel_fbgrad_lds_kernel(FbGradPara
                 if (f < F) part[(size_t)f * M + m] = acc[i][j][r];
             }
         }
+    FSTAMP(4);       // partial tile stored (issued)
 }
 
 // Eight waves per 64 elements of grad_fb: wave j adds its eighth of the slices in index order (all of its loads in flight at once
@@ -549,6 +614,10 @@ __global__ void __launch_bounds__(64 * kFbgRedWaves) dmel_fbgrad_reduce_kernel(F
         p.grad_fb[i] = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) + ((part[4][lane] + part[5][lane]) + (part[6][lane] + part[7][lane]));
 }
 
+// row tiles of 64: a single left-over row (n_fft / 2 + 1 of a power-of-two n_fft) is folded into the last full tile
+static bool fbgrad_folds(int F) { return F > kFbgBF && F % kFbgBF == 1; }
+static int fbgrad_row_tiles(int F) { return fbgrad_folds(F) ? F / kFbgBF : (F + kFbgBF - 1) / kFbgBF; }
+
 int fbgrad_splits(int batch, int F, int M, int T)
 {
     // as many slices as keep EVERY workgroup resident at once -- two workgroups of 8 waves per CU -- and never one more: a 513th
@@ -559,7 +628,7 @@ int fbgrad_splits(int batch, int F, int M, int T)
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
         return 2 * cus;
     }();
-    const int tiles = ((F + kFbgBF - 1) / kFbgBF) * ((M + kFbgBM - 1) / kFbgBM);
+    const int tiles = fbgrad_row_tiles(F) * ((M + kFbgBM - 1) / kFbgBM);
     const long long blocks = (long long)batch * ((T + 15) / 16);
     long long s = slots / tiles;
     if (s > blocks) s = blocks;
@@ -570,8 +639,19 @@ hipError_t launch_fbgrad(const FbGradParams& p_in, hipStream_t s)
 {
     FbGradParams p = p_in;
     p.gm = p.grad_out;                 // gm = grad_out * exp(-out) is formed by the kernel while it stages the operand (p.out != nullptr)
-    const dim3 grid((p.F + kFbgBF - 1) / kFbgBF, p.splits, (p.M + kFbgBM - 1) / kFbgBM);
-    hipLaunchKernelGGL(dmel_fbgrad_lds_kernel, grid, dim3(kFbgThreads), 0, s, p);
+    p.fold_last_row = fbgrad_folds(p.F) ? 1 : 0;
+    p.ntc = (p.T + 15) / 16;
+    const long long all_blocks = (long long)p.B * p.ntc;
+    if (all_blocks > 0x7fffffffLL || p.splits < 1) return hipErrorInvalidValue;
+    p.blk_base = (int)(all_blocks / p.splits); p.blk_rem = (int)(all_blocks % p.splits);
+    const dim3 grid(fbgrad_row_tiles(p.F), p.splits, (p.M + kFbgBM - 1) / kFbgBM);
+    if (p.T < 4) {                                    // rows shorter than a 16-byte piece: element-wise requests
+        if (p.out) hipLaunchKernelGGL((dmel_fbgrad_lds_kernel<true, true>), grid, dim3(kFbgThreads), 0, s, p);
+        else hipLaunchKernelGGL((dmel_fbgrad_lds_kernel<false, true>), grid, dim3(kFbgThreads), 0, s, p);
+    } else {
+        if (p.out) hipLaunchKernelGGL((dmel_fbgrad_lds_kernel<true, false>), grid, dim3(kFbgThreads), 0, s, p);
+        else hipLaunchKernelGGL((dmel_fbgrad_lds_kernel<false, false>), grid, dim3(kFbgThreads), 0, s, p);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const size_t n = (size_t)p.F * p.M;
@@ -580,3 +660,10 @@ hipError_t launch_fbgrad(const FbGradParams& p_in, hipStream_t s)
 }
 
 }  // namespace dmel
+
+#ifdef DMEL_STAMPS
+extern "C" int dmel_debug_read_fstamps(unsigned long long* host, int count)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dmel::g_fstamps), sizeof(unsigned long long) * (size_t)count);
+}
+#endif

@@ -339,6 +339,8 @@ struct FbGradParams {
     float* partials;         // (splits, F, M)
     float* grad_fb;          // (F, M)
     int B, F, M, T, splits;
+    int ntc, blk_base, blk_rem;   // set by launch_fbgrad: K-blocks per clip; slice s takes blk_base (+1 for s < blk_rem) consecutive blocks
+    int fold_last_row;       // set by launch_fbgrad: F = 64 k + 1, the last row rides with the last full tile of 64 rows
 };
 hipError_t launch_fbgrad(const FbGradParams& p, hipStream_t s);
 int fbgrad_splits(int batch, int F, int M, int T);      // slices of the batch's K-blocks (= F x M partials) of one launch
