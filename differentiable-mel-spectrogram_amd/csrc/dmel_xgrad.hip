@@ -249,6 +249,9 @@ __global__ void __launch_bounds__((XgPlan<N>::THREADS), (XgPlan<N>::MINW)) dmel_
     const int total = p.spec_mode ? 0 : M * FPT;
     const float* gb = p.grad_out + (size_t)b * M * T;
     const float* yb = p.out ? p.out + (size_t)b * M * T : nullptr;
+    // (requests only: nothing here touches what was loaded -- a select on a loaded value, or a branch around a load, makes the
+    // compiler wait for it on the spot, and vector loads return in order: that wait would also sit out the 2 R sample loads above)
+    const float* ysrc = yb ? yb : gb;                                             // always a valid address; ignored without the log
     auto gm_fetch = [&](int base, float (&v)[4], float (&y)[4]) {
         static_for<0, 4>([&](auto uu) {
             constexpr int u = decltype(uu)::value;
@@ -256,15 +259,17 @@ __global__ void __launch_bounds__((XgPlan<N>::THREADS), (XgPlan<N>::MINW)) dmel_
             const bool ok = idx < total && t < T;
             const unsigned o = ok ? (unsigned)(m * T + t) : 0u;
             v[u] = gb[o];
-            y[u] = yb ? yb[o] : 0.f;
-            if (!ok) v[u] = 0.f;
+            y[u] = ysrc[o];
         });
     };
     auto gm_store = [&](int base, const float (&v)[4], const float (&y)[4]) {
         static_for<0, 4>([&](auto uu) {
             constexpr int u = decltype(uu)::value;
-            const int idx = base + u * THREADS;
-            if (idx < total) gm[idx] = yb ? v[u] * expf(-y[u]) : v[u];
+            const int idx = base + u * THREADS, t = t0 + idx % FPT;
+            if (idx < total) {
+                const float val = yb ? v[u] * expf(-y[u]) : v[u];
+                gm[idx] = t < T ? val : 0.f;
+            }
         });
     };
     float gv[4], gy[4];
