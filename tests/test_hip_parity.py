@@ -963,6 +963,30 @@ def test_xgrad_long_transform_and_finite_difference():
     assert abs(fd - an) <= 2e-2 * abs(an) + 1e-3
 
 
+@pytest.mark.parametrize("hop,T", [(1000, 1), (300, 3), (100, 8), (47, 15), (41, 18)])
+def test_filterbank_gradient_with_short_and_ragged_rows(hop, T):
+    """dL/dfb where the time axis is shorter than one 16-byte piece (T < 4: element-wise requests) or ends inside a piece / a 16-step
+    block (the piece is read from the row's last four entries and shifted into place), linear and log output, against the oracle"""
+    from dmel_amd import capi
+    case = dict(C.BY_NAME["g1_c1"], name=f"fb_T{T}", B=3, L=700, lambd=40.0, hop=hop, n_mels=24)
+    assert case["L"] // hop + 1 == T
+    x_np = C.make_input(case).astype(np.float32)
+    g_np = C.make_cotangent(case)
+    x = torch.from_numpy(x_np).to("cuda:0")
+    g = torch.from_numpy(g_np).to("cuda:0")
+    plan = capi.Plan(case["L"], hop, case["n_mels"], case["sr"])
+    n = capi.n_fft(case["lambd"])
+    st = torch.cuda.current_stream().cuda_stream
+    y = torch.empty((case["B"], 1, case["n_mels"], T), device="cuda:0")
+    plan.forward(x.data_ptr(), case["B"], case["lambd"], y.data_ptr(), None, True, 1e-10, st)
+    y_np = y.cpu().numpy()
+    for log in (False, True):
+        gfb = torch.empty((n // 2 + 1, case["n_mels"]), dtype=torch.float32, device="cuda:0")
+        plan.backward_fb(x.data_ptr(), case["B"], case["lambd"], g.data_ptr(), y.data_ptr(), gfb.data_ptr(), log, st)
+        torch.cuda.synchronize()
+        assert _gfb_err(gfb.cpu().numpy(), O.backward_fb(x_np, case["lambd"], hop, g_np, y_np if log else None)) <= TOL
+
+
 def test_optional_gradients_at_tiny_n_fft():
     """dL/dx and dL/dfb where the forward runs on the direct-DFT kernel (n_fft 16, 2, 1)."""
     from dmel_amd import capi
