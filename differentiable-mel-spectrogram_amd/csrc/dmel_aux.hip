@@ -316,7 +316,7 @@ hipError_t launch_naive(const NaiveParams& p, hipStream_t s)
 constexpr int kAdamPerThread = 4;
 __global__ void __launch_bounds__(256) dmel_adam_kernel(AdamParams p)
 {
-    const float step = *p.step + 1.0f;
+    const float step = __hip_atomic_load(p.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1.0f;
     // the hyper-parameters are doubles, as torch passes them to its kernel: 1 - beta is formed in fp64 (in fp32 1 - 0.999f is off by
     // 5e-5 of itself, which the second moment would carry), the state stays fp32
     const float bc1 = (float)(1.0 - pow(p.beta1, (double)step)), bc2 = (float)(1.0 - pow(p.beta2, (double)step));
@@ -337,11 +337,15 @@ __global__ void __launch_bounds__(256) dmel_adam_kernel(AdamParams p)
     }
     __syncthreads();                                               // every thread of this workgroup holds the old count
     if (threadIdx.x == 0) {
-        __threadfence();
-        const unsigned t = p.ticket ? __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        if (!p.ticket || t == gridDim.x - 1) {
-            *p.step = step;
-            if (p.ticket) __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (relaxed: the ticket orders nothing but itself -- every workgroup's read of the count is complete before its ticket is
+        // drawn because the update above consumed it; a release fence here would write back the XCD's L2 once per workgroup)
+        if (gridDim.x == 1) *p.step = step;
+        else {
+            const unsigned t = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == gridDim.x - 1) {
+                __hip_atomic_store(p.step, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
