@@ -32,6 +32,35 @@ __device__ __forceinline__ float big_wave_sum(float v)
     return v;
 }
 
+// One M-point FFT of the sequence Z.  In LDS: the radix-2 passes of dmel_ldsfft.h.  In global memory (M > 16384): only the stages
+// whose span reaches across blocks of 2^lgb points (an even number of them, so lgb = 14 or 13) run on the global sequence; the
+// 13 or 14 stages inside a block run on one block at a time in LDS (a block = an independent DIF / DIT transform of its own length).
+// Every pass over the whole sequence in global memory moves M * 16 bytes through L2 -- nine of them per transform of 2^18
+// points were what bound the 80 000-point frames of the reference's default branch on ESC-50 clips (340 ms per step); now two
+// and one round trip of the blocks.
+constexpr int kBigBlockLog = 14;
+__device__ __forceinline__ int big_block_log(int logM) { return ((logM - kBigBlockLog) & 1) ? kBigBlockLog - 1 : kBigBlockLog; }
+
+template <bool GLOBAL_Z, bool DIT, class TWG, class TWB>
+__device__ __forceinline__ void big_fft(float2* Z, int M, int logM, float2* lds_block, int tid, TWG&& twid, TWB&& twid_block)
+{
+    if constexpr (!GLOBAL_Z) {
+        if constexpr (DIT) lds_fft_dit<kBigThreads>(Z, M, logM, tid, twid); else lds_fft_dif<kBigThreads>(Z, M, logM, tid, twid);
+    } else {
+        const int lgb = big_block_log(logM), ns = logM - lgb, bl = 1 << lgb;
+        if constexpr (!DIT) lds_fft_dif_head<kBigThreads>(Z, M, ns, tid, twid);
+        for (int blk = 0; blk < (M >> lgb); ++blk) {
+            float2* zb = Z + ((size_t)blk << lgb);
+            for (int i = tid; i < bl; i += kBigThreads) lds_block[i] = zb[i];
+            __syncthreads();
+            if constexpr (DIT) lds_fft_dit<kBigThreads>(lds_block, bl, lgb, tid, twid_block); else lds_fft_dif<kBigThreads>(lds_block, bl, lgb, tid, twid_block);
+            for (int i = tid; i < bl; i += kBigThreads) zb[i] = lds_block[i];
+            __syncthreads();
+        }
+        if constexpr (DIT) lds_fft_dit_tail<kBigThreads>(Z, M, ns, tid, twid);
+    }
+}
+
 template <bool GLOBAL_Z>
 __global__ void __launch_bounds__(kBigThreads) dmel_big_kernel(BigParams p)
 {
@@ -43,12 +72,15 @@ __global__ void __launch_bounds__(kBigThreads) dmel_big_kernel(BigParams p)
     float2* macc = reinterpret_cast<float2*>(smem_raw + (size_t)M * sizeof(float2));     // split mode: mel sums of the even half
     // LDS-resident sequences take their twiddles exp(-2 pi i k / M) as a product of two small LDS tables, k = 128 hi + lo (a
     // global-memory table cost an L2 round trip per butterfly group and pass; the full table does not fit next to the sequence)
-    float2* twa = reinterpret_cast<float2*>(smem_raw + (size_t)M * sizeof(float2) + (p.split ? (size_t)p.M * sizeof(float2) : 0));
+    // (sequence in global memory: LDS holds one block of 2^lgb points and the factor tables of the BLOCK's twiddles, which are every
+    // (M >> lgb)-th entry of the M-point table)
+    const int lgb = big_block_log(p.logM), tsh = GLOBAL_Z ? p.logM - lgb : 0, tlen = GLOBAL_Z ? (1 << lgb) : M;
+    float2* lds_block = reinterpret_cast<float2*>(smem_raw);
+    float2* twa = reinterpret_cast<float2*>(smem_raw + (GLOBAL_Z ? ((size_t)sizeof(float2) << kBigBlockLog) : (size_t)M * sizeof(float2) + (p.split ? (size_t)p.M * sizeof(float2) : 0)));
     float2* twb = twa + 64;
-    if (!GLOBAL_Z) {
-        if (tid < 64) twa[tid] = (128 * tid < (M >> 1)) ? p.tw[128 * tid] : make_float2(1.f, 0.f);
-        if (tid >= 64 && tid < 192) twb[tid - 64] = (tid - 64 < (M >> 1)) ? p.tw[tid - 64] : make_float2(1.f, 0.f);
-    }
+    if (tid < 64) twa[tid] = (128 * tid < (tlen >> 1)) ? p.tw[(128 * tid) << tsh] : make_float2(1.f, 0.f);
+    if (tid >= 64 && tid < 192) twb[tid - 64] = (tid - 64 < (tlen >> 1)) ? p.tw[(tid - 64) << tsh] : make_float2(1.f, 0.f);
+    auto twid_block = [&](int k) -> float2 { return c_mul(twa[k >> 7], twb[k & 127]); };
     auto twid = [&](int k) -> float2 {
         if (GLOBAL_Z) return p.tw[k];
         return c_mul(twa[k >> 7], twb[k & 127]);
@@ -113,7 +145,7 @@ __global__ void __launch_bounds__(kBigThreads) dmel_big_kernel(BigParams p)
             Z[n] = z;
         }
         __syncthreads();
-        lds_fft_dif<kBigThreads>(Z, M, p.logM, tid, twid);
+        big_fft<GLOBAL_Z, false>(Z, M, p.logM, lds_block, tid, twid, twid_block);
         if (blue) {
             // Y H / M at the bit-reversed positions the DIF left, conjugated: a forward DIT of that is the conjugate of the
             // inverse transform, in natural order
@@ -122,7 +154,7 @@ __global__ void __launch_bounds__(kBigThreads) dmel_big_kernel(BigParams p)
                 Z[i] = make_float2(v.x, -v.y);
             }
             __syncthreads();
-            lds_fft_dit<kBigThreads>(Z, M, p.logM, tid, twid);
+            big_fft<GLOBAL_Z, true>(Z, M, p.logM, lds_block, tid, twid, twid_block);
             for (int k = tid; k < NT; k += kBigThreads) {
                 const float2 v = Z[k];
                 Z[k] = c_mul(make_float2(v.x, -v.y), p.chirp[k]);
@@ -217,12 +249,13 @@ __global__ void __launch_bounds__(kBigThreads) dmel_xgrad_big_kernel(XgradParams
     float2* Z = GLOBAL_Z ? p.zws + (size_t)blockIdx.x * p.Mfft : reinterpret_cast<float2*>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = p.N, M = p.Mfft, sh = 32 - p.logM, T = p.T, Mm = p.M;
-    float2* twa = reinterpret_cast<float2*>(smem_raw + (size_t)M * sizeof(float2));
+    const int lgb = big_block_log(p.logM), tsh = GLOBAL_Z ? p.logM - lgb : 0, tlen = GLOBAL_Z ? (1 << lgb) : M;
+    float2* lds_block = reinterpret_cast<float2*>(smem_raw);
+    float2* twa = reinterpret_cast<float2*>(smem_raw + (GLOBAL_Z ? ((size_t)sizeof(float2) << kBigBlockLog) : (size_t)M * sizeof(float2)));
     float2* twb = twa + 64;
-    if (!GLOBAL_Z) {
-        if (tid < 64) twa[tid] = (128 * tid < (M >> 1)) ? p.tw[128 * tid] : make_float2(1.f, 0.f);
-        if (tid >= 64 && tid < 192) twb[tid - 64] = (tid - 64 < (M >> 1)) ? p.tw[tid - 64] : make_float2(1.f, 0.f);
-    }
+    if (tid < 64) twa[tid] = (128 * tid < (tlen >> 1)) ? p.tw[(128 * tid) << tsh] : make_float2(1.f, 0.f);
+    if (tid >= 64 && tid < 192) twb[tid - 64] = (tid - 64 < (tlen >> 1)) ? p.tw[(tid - 64) << tsh] : make_float2(1.f, 0.f);
+    auto twid_block = [&](int k) -> float2 { return c_mul(twa[k >> 7], twb[k & 127]); };
     auto twid = [&](int k) -> float2 {
         if (GLOBAL_Z) return p.tw[k];
         return c_mul(twa[k >> 7], twb[k & 127]);
@@ -233,13 +266,13 @@ __global__ void __launch_bounds__(kBigThreads) dmel_xgrad_big_kernel(XgradParams
     auto bluestein = [&]() {
         for (int n = tid; n < M; n += kBigThreads) Z[n] = n < N ? c_mul(Z[n], p.chirp[n]) : make_float2(0.f, 0.f);
         __syncthreads();
-        lds_fft_dif<kBigThreads>(Z, M, p.logM, tid, twid);
+        big_fft<GLOBAL_Z, false>(Z, M, p.logM, lds_block, tid, twid, twid_block);
         for (int i = tid; i < M; i += kBigThreads) {
             const float2 v = c_mul(Z[i], p.hbr[i]);
             Z[i] = make_float2(v.x, -v.y);
         }
         __syncthreads();
-        lds_fft_dit<kBigThreads>(Z, M, p.logM, tid, twid);
+        big_fft<GLOBAL_Z, true>(Z, M, p.logM, lds_block, tid, twid, twid_block);
         for (int k = tid; k < N; k += kBigThreads) {
             const float2 v = Z[k];
             Z[k] = c_mul(make_float2(v.x, -v.y), p.chirp[k]);
@@ -268,7 +301,7 @@ __global__ void __launch_bounds__(kBigThreads) dmel_xgrad_big_kernel(XgradParams
             Z[n] = make_float2(va * w, vb * w);
         }
         __syncthreads();
-        if (blue) bluestein(); else lds_fft_dif<kBigThreads>(Z, M, p.logM, tid, twid);
+        if (blue) bluestein(); else big_fft<GLOBAL_Z, false>(Z, M, p.logM, lds_block, tid, twid, twid_block);
         // bin pass: every thread owns bin k and its mirror image (two addresses nobody else touches)
         const float* ga = p.grad_out + (size_t)b * Mm * T + tA;
         const float* ya = p.out ? p.out + (size_t)b * Mm * T + tA : nullptr;
@@ -300,7 +333,7 @@ __global__ void __launch_bounds__(kBigThreads) dmel_xgrad_big_kernel(XgradParams
             if (!edge) Z[an] = make_float2(har + hbi, hai - hbr);
         }
         __syncthreads();
-        if (blue) bluestein(); else lds_fft_dit<kBigThreads>(Z, M, p.logM, tid, twid);
+        if (blue) bluestein(); else big_fft<GLOBAL_Z, true>(Z, M, p.logM, lds_block, tid, twid, twid_block);
         float* fa = p.frames + ((size_t)b * T + tA) * N;
         double sa = 0.0, sb = 0.0;
         for (int n = tid; n < N; n += kBigThreads) {
@@ -329,6 +362,7 @@ __global__ void __launch_bounds__(kBigThreads) dmel_xgrad_big_kernel(XgradParams
 constexpr int kBigLdsMax = 16384;          // complex entries: 128 KB
 constexpr int kBigSplitAccBytes = 16384;   // split mode: (n_mels) float2 sums of the even half behind the sequence
 constexpr int kBigTwBytes = (64 + 128) * 8; // the two twiddle factor tables behind that
+constexpr int kBigGlobalLds = (int)(sizeof(float2) << kBigBlockLog) + kBigTwBytes;   // sequence in global memory: one block + the block's tables
 
 // split mode is possible when the half-length transform (its own FFT of m_half points) fits LDS together with the mel sums
 bool big_can_split(int m_half, int n_mels) { return m_half <= kBigLdsMax && (long long)n_mels * 8 <= kBigSplitAccBytes; }
@@ -338,8 +372,12 @@ hipError_t big_prepare_attributes()
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dmel_big_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        kBigLdsMax * (int)sizeof(float2) + kBigSplitAccBytes + kBigTwBytes);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(dmel_xgrad_big_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               kBigLdsMax * (int)sizeof(float2) + kBigTwBytes);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(dmel_xgrad_big_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kBigLdsMax * (int)sizeof(float2) + kBigTwBytes);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(dmel_big_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kBigGlobalLds);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(dmel_xgrad_big_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kBigGlobalLds);
 }
 
 bool big_uses_global(int m_fft) { return m_fft > kBigLdsMax; }
@@ -347,7 +385,7 @@ bool big_uses_global(int m_fft) { return m_fft > kBigLdsMax; }
 // frames kernel of dmel_backward_x on this file's transforms; launch_xgrad_gather (dmel_xgrad.hip) finishes the job
 hipError_t launch_xgrad_big(const XgradParams& p, int grid, hipStream_t s)
 {
-    if (big_uses_global(p.Mfft)) hipLaunchKernelGGL(dmel_xgrad_big_kernel<true>, dim3((unsigned)grid), dim3(kBigThreads), 0, s, p);
+    if (big_uses_global(p.Mfft)) hipLaunchKernelGGL(dmel_xgrad_big_kernel<true>, dim3((unsigned)grid), dim3(kBigThreads), kBigGlobalLds, s, p);
     else hipLaunchKernelGGL(dmel_xgrad_big_kernel<false>, dim3((unsigned)grid), dim3(kBigThreads), (size_t)p.Mfft * sizeof(float2) + kBigTwBytes, s, p);
     return hipGetLastError();
 }
@@ -365,7 +403,7 @@ hipError_t launch_big(const BigParams& p, hipStream_t s)
     const bool pair = (p.mode == kInfer || p.mode == kSpec);
     const long long units = (long long)p.B * (pair ? (p.T + 1) / 2 : p.T);
     const int grid = big_grid(units, p.Mfft);
-    if (big_uses_global(p.Mfft)) hipLaunchKernelGGL(dmel_big_kernel<true>, dim3((unsigned)grid), dim3(kBigThreads), 0, s, p);
+    if (big_uses_global(p.Mfft)) hipLaunchKernelGGL(dmel_big_kernel<true>, dim3((unsigned)grid), dim3(kBigThreads), kBigGlobalLds, s, p);
     else hipLaunchKernelGGL(dmel_big_kernel<false>, dim3((unsigned)grid), dim3(kBigThreads),
                             (size_t)p.Mfft * sizeof(float2) + (p.split ? (size_t)p.M * sizeof(float2) : 0) + kBigTwBytes, s, p);
     return hipGetLastError();
