@@ -61,6 +61,34 @@ __device__ __forceinline__ void big_fft(float2* Z, int M, int logM, float2* lds_
     }
 }
 
+// The middle of Bluestein's round trip -- forward transform, times the filter's transform (conjugated: the inverse transform runs
+// as a forward one), second transform -- for a sequence in global memory: the block stages of the first transform END in LDS and
+// those of the second START there on the same block, so the product is formed in LDS and the sequence makes one round trip per
+// block instead of three.
+template <class TWG, class TWB>
+__device__ __forceinline__ void big_convolve_global(float2* Z, int M, int logM, const float2* __restrict__ hbr, float2* lds_block, int tid,
+                                                    TWG&& twid, TWB&& twid_block)
+{
+    const int lgb = big_block_log(logM), ns = logM - lgb, bl = 1 << lgb;
+    lds_fft_dif_head<kBigThreads>(Z, M, ns, tid, twid);
+    for (int blk = 0; blk < (M >> lgb); ++blk) {
+        float2* zb = Z + ((size_t)blk << lgb);
+        const float2* hb = hbr + ((size_t)blk << lgb);
+        for (int i = tid; i < bl; i += kBigThreads) lds_block[i] = zb[i];
+        __syncthreads();
+        lds_fft_dif<kBigThreads>(lds_block, bl, lgb, tid, twid_block);
+        for (int i = tid; i < bl; i += kBigThreads) {
+            const float2 v = c_mul(lds_block[i], hb[i]);
+            lds_block[i] = make_float2(v.x, -v.y);
+        }
+        __syncthreads();
+        lds_fft_dit<kBigThreads>(lds_block, bl, lgb, tid, twid_block);
+        for (int i = tid; i < bl; i += kBigThreads) zb[i] = lds_block[i];
+        __syncthreads();
+    }
+    lds_fft_dit_tail<kBigThreads>(Z, M, ns, tid, twid);
+}
+
 template <bool GLOBAL_Z>
 __global__ void __launch_bounds__(kBigThreads) dmel_big_kernel(BigParams p)
 {
@@ -145,16 +173,19 @@ __global__ void __launch_bounds__(kBigThreads) dmel_big_kernel(BigParams p)
             Z[n] = z;
         }
         __syncthreads();
-        big_fft<GLOBAL_Z, false>(Z, M, p.logM, lds_block, tid, twid, twid_block);
+        if (GLOBAL_Z && blue) big_convolve_global(Z, M, p.logM, p.hbr, lds_block, tid, twid, twid_block);
+        else big_fft<GLOBAL_Z, false>(Z, M, p.logM, lds_block, tid, twid, twid_block);
         if (blue) {
-            // Y H / M at the bit-reversed positions the DIF left, conjugated: a forward DIT of that is the conjugate of the
-            // inverse transform, in natural order
-            for (int i = tid; i < M; i += kBigThreads) {
-                const float2 v = c_mul(Z[i], p.hbr[i]);
-                Z[i] = make_float2(v.x, -v.y);
+            if (!GLOBAL_Z) {
+                // Y H / M at the bit-reversed positions the DIF left, conjugated: a forward DIT of that is the conjugate of the
+                // inverse transform, in natural order
+                for (int i = tid; i < M; i += kBigThreads) {
+                    const float2 v = c_mul(Z[i], p.hbr[i]);
+                    Z[i] = make_float2(v.x, -v.y);
+                }
+                __syncthreads();
+                big_fft<GLOBAL_Z, true>(Z, M, p.logM, lds_block, tid, twid, twid_block);
             }
-            __syncthreads();
-            big_fft<GLOBAL_Z, true>(Z, M, p.logM, lds_block, tid, twid, twid_block);
             for (int k = tid; k < NT; k += kBigThreads) {
                 const float2 v = Z[k];
                 Z[k] = c_mul(make_float2(v.x, -v.y), p.chirp[k]);
@@ -266,13 +297,16 @@ __global__ void __launch_bounds__(kBigThreads) dmel_xgrad_big_kernel(XgradParams
     auto bluestein = [&]() {
         for (int n = tid; n < M; n += kBigThreads) Z[n] = n < N ? c_mul(Z[n], p.chirp[n]) : make_float2(0.f, 0.f);
         __syncthreads();
-        big_fft<GLOBAL_Z, false>(Z, M, p.logM, lds_block, tid, twid, twid_block);
-        for (int i = tid; i < M; i += kBigThreads) {
-            const float2 v = c_mul(Z[i], p.hbr[i]);
-            Z[i] = make_float2(v.x, -v.y);
+        if constexpr (GLOBAL_Z) big_convolve_global(Z, M, p.logM, p.hbr, lds_block, tid, twid, twid_block);
+        else {
+            big_fft<GLOBAL_Z, false>(Z, M, p.logM, lds_block, tid, twid, twid_block);
+            for (int i = tid; i < M; i += kBigThreads) {
+                const float2 v = c_mul(Z[i], p.hbr[i]);
+                Z[i] = make_float2(v.x, -v.y);
+            }
+            __syncthreads();
+            big_fft<GLOBAL_Z, true>(Z, M, p.logM, lds_block, tid, twid, twid_block);
         }
-        __syncthreads();
-        big_fft<GLOBAL_Z, true>(Z, M, p.logM, lds_block, tid, twid, twid_block);
         for (int k = tid; k < N; k += kBigThreads) {
             const float2 v = Z[k];
             Z[k] = c_mul(make_float2(v.x, -v.y), p.chirp[k]);
