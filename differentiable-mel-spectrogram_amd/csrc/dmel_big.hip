@@ -48,7 +48,7 @@ __device__ __forceinline__ void big_fft(float2* Z, int M, int logM, float2* lds_
         if constexpr (DIT) lds_fft_dit<kBigThreads>(Z, M, logM, tid, twid); else lds_fft_dif<kBigThreads>(Z, M, logM, tid, twid);
     } else {
         const int lgb = big_block_log(logM), ns = logM - lgb, bl = 1 << lgb;
-        if constexpr (!DIT) lds_fft_dif_head<kBigThreads>(Z, M, ns, tid, twid);
+        if constexpr (!DIT) lds_fft_dif_head<kBigThreads>(Z, M, ns, tid, twid, [&](int n) { return Z[n]; });
         for (int blk = 0; blk < (M >> lgb); ++blk) {
             float2* zb = Z + ((size_t)blk << lgb);
             for (int i = tid; i < bl; i += kBigThreads) lds_block[i] = zb[i];
@@ -57,7 +57,7 @@ __device__ __forceinline__ void big_fft(float2* Z, int M, int logM, float2* lds_
             for (int i = tid; i < bl; i += kBigThreads) zb[i] = lds_block[i];
             __syncthreads();
         }
-        if constexpr (DIT) lds_fft_dit_tail<kBigThreads>(Z, M, ns, tid, twid);
+        if constexpr (DIT) lds_fft_dit_tail<kBigThreads>(Z, M, ns, tid, twid, [](int, float2 v) { return v; });
     }
 }
 
@@ -65,12 +65,14 @@ __device__ __forceinline__ void big_fft(float2* Z, int M, int logM, float2* lds_
 // as a forward one), second transform -- for a sequence in global memory: the block stages of the first transform END in LDS and
 // those of the second START there on the same block, so the product is formed in LDS and the sequence makes one round trip per
 // block instead of three.
-template <class TWG, class TWB>
+// `first(n)` = input element n (chirp applied, zero beyond the data: the sequence is never written before the first pass reads
+// it), `last(k, v)` = what output k becomes (conjugate, chirp): the two element-wise passes ride with the transforms' own.
+template <class TWG, class TWB, class LD, class ST>
 __device__ __forceinline__ void big_convolve_global(float2* Z, int M, int logM, const float2* __restrict__ hbr, float2* lds_block, int tid,
-                                                    TWG&& twid, TWB&& twid_block)
+                                                    TWG&& twid, TWB&& twid_block, LD&& first, ST&& last)
 {
     const int lgb = big_block_log(logM), ns = logM - lgb, bl = 1 << lgb;
-    lds_fft_dif_head<kBigThreads>(Z, M, ns, tid, twid);
+    lds_fft_dif_head<kBigThreads>(Z, M, ns, tid, twid, first);
     for (int blk = 0; blk < (M >> lgb); ++blk) {
         float2* zb = Z + ((size_t)blk << lgb);
         const float2* hb = hbr + ((size_t)blk << lgb);
@@ -86,7 +88,7 @@ __device__ __forceinline__ void big_convolve_global(float2* Z, int M, int logM, 
         for (int i = tid; i < bl; i += kBigThreads) zb[i] = lds_block[i];
         __syncthreads();
     }
-    lds_fft_dit_tail<kBigThreads>(Z, M, ns, tid, twid);
+    lds_fft_dit_tail<kBigThreads>(Z, M, ns, tid, twid, last);
 }
 
 template <bool GLOBAL_Z>
@@ -160,6 +162,13 @@ __global__ void __launch_bounds__(kBigThreads) dmel_big_kernel(BigParams p)
         const int npar = p.split ? 2 : 1;
         for (int par = 0; par < npar; ++par) {
         __syncthreads();                                   // the previous unit's / half's readers are done with Z
+        if (GLOBAL_Z && blue) {
+            // (no split mode here: its halves fit LDS by definition) the frame is windowed, chirped and zero-extended as the first
+            // pass of the first transform reads it, and the last pass of the second writes conj(.) * chirp
+            big_convolve_global(Z, M, p.logM, p.hbr, lds_block, tid, twid, twid_block,
+                                [&](int n) -> float2 { return n < N ? c_mul(elem(n), p.chirp[n]) : make_float2(0.f, 0.f); },
+                                [&](int k, float2 v) -> float2 { return k < N ? c_mul(make_float2(v.x, -v.y), p.chirp[k]) : v; });
+        } else {
         for (int n = tid; n < M; n += kBigThreads) {
             float2 z = make_float2(0.f, 0.f);
             if (n < NT) {
@@ -173,10 +182,10 @@ __global__ void __launch_bounds__(kBigThreads) dmel_big_kernel(BigParams p)
             Z[n] = z;
         }
         __syncthreads();
-        if (GLOBAL_Z && blue) big_convolve_global(Z, M, p.logM, p.hbr, lds_block, tid, twid, twid_block);
-        else big_fft<GLOBAL_Z, false>(Z, M, p.logM, lds_block, tid, twid, twid_block);
-        if (blue) {
-            if (!GLOBAL_Z) {
+        big_fft<GLOBAL_Z, false>(Z, M, p.logM, lds_block, tid, twid, twid_block);
+        }
+        if (blue && !GLOBAL_Z) {
+            {
                 // Y H / M at the bit-reversed positions the DIF left, conjugated: a forward DIT of that is the conjugate of the
                 // inverse transform, in natural order
                 for (int i = tid; i < M; i += kBigThreads) {
@@ -295,10 +304,14 @@ __global__ void __launch_bounds__(kBigThreads) dmel_xgrad_big_kernel(XgradParams
     auto pos = [&](int k) -> unsigned { return blue ? (unsigned)k : (M > 1 ? __brev((unsigned)k) >> sh : 0u); };
     // DFT_N of the N values in Z[0 .. N) (natural order) by Bluestein's round trip, result in natural order
     auto bluestein = [&]() {
-        for (int n = tid; n < M; n += kBigThreads) Z[n] = n < N ? c_mul(Z[n], p.chirp[n]) : make_float2(0.f, 0.f);
-        __syncthreads();
-        if constexpr (GLOBAL_Z) big_convolve_global(Z, M, p.logM, p.hbr, lds_block, tid, twid, twid_block);
-        else {
+        if constexpr (GLOBAL_Z) {
+            // chirp and zero extension ride with the first pass of the first transform, conj(.) * chirp with the last of the second
+            big_convolve_global(Z, M, p.logM, p.hbr, lds_block, tid, twid, twid_block,
+                                [&](int n) -> float2 { return n < N ? c_mul(Z[n], p.chirp[n]) : make_float2(0.f, 0.f); },
+                                [&](int k, float2 v) -> float2 { return k < N ? c_mul(make_float2(v.x, -v.y), p.chirp[k]) : v; });
+        } else {
+            for (int n = tid; n < M; n += kBigThreads) Z[n] = n < N ? c_mul(Z[n], p.chirp[n]) : make_float2(0.f, 0.f);
+            __syncthreads();
             big_fft<GLOBAL_Z, false>(Z, M, p.logM, lds_block, tid, twid, twid_block);
             for (int i = tid; i < M; i += kBigThreads) {
                 const float2 v = c_mul(Z[i], p.hbr[i]);
@@ -306,12 +319,12 @@ __global__ void __launch_bounds__(kBigThreads) dmel_xgrad_big_kernel(XgradParams
             }
             __syncthreads();
             big_fft<GLOBAL_Z, true>(Z, M, p.logM, lds_block, tid, twid, twid_block);
+            for (int k = tid; k < N; k += kBigThreads) {
+                const float2 v = Z[k];
+                Z[k] = c_mul(make_float2(v.x, -v.y), p.chirp[k]);
+            }
+            __syncthreads();
         }
-        for (int k = tid; k < N; k += kBigThreads) {
-            const float2 v = Z[k];
-            Z[k] = c_mul(make_float2(v.x, -v.y), p.chirp[k]);
-        }
-        __syncthreads();
     };
     const int tiles = (T + 1) / 2;
     const long long units = (long long)p.B * tiles;

@@ -85,16 +85,19 @@ __device__ __forceinline__ void lds_fft_dit(float2* Z, int N, int logN, int tid,
 // block at a time in LDS.  `ns` (even) = stages outside the blocks; blocks are contiguous runs of N >> ns points.
 // lds_fft_dif_head: the FIRST ns stages of an N-point DIF (spans N/2 ... N >> ns); what remains are 2^ns independent DIF
 // transforms of the blocks, each with the twiddles of its own length.
-template <int THREADS, class TW>
-__device__ __forceinline__ void lds_fft_dif_head(float2* Z, int N, int ns, int tid, TW&& twiddle)
+// `first(n)` supplies element n of the input for the FIRST pass (the sequence need not have been written to Z before).
+template <int THREADS, class TW, class LD>
+__device__ __forceinline__ void lds_fft_dif_head(float2* Z, int N, int ns, int tid, TW&& twiddle, LD&& first)
 {
     int left = ns;
     for (int s = N >> 2; left > 0; s >>= 2, left -= 2) {
         const int ta = N / (4 * s);
+        const bool p0 = left == ns;
         for (int i = tid; i < (N >> 2); i += THREADS) {
             const int j = i & (s - 1);
             const int lo = ((i - j) << 2) + j;
-            const float2 e0 = Z[lo], e1 = Z[lo + s], e2 = Z[lo + 2 * s], e3 = Z[lo + 3 * s];
+            const float2 e0 = p0 ? first(lo) : Z[lo], e1 = p0 ? first(lo + s) : Z[lo + s];
+            const float2 e2 = p0 ? first(lo + 2 * s) : Z[lo + 2 * s], e3 = p0 ? first(lo + 3 * s) : Z[lo + 3 * s];
             const float2 w1 = twiddle(j * ta), w2 = twiddle(2 * j * ta);
             const float2 a0 = c_add(e0, e2), a2 = c_mul(c_sub(e0, e2), w1);
             const float2 a1 = c_add(e1, e3), a3 = c_mul_mi(c_mul(c_sub(e1, e3), w1));
@@ -109,11 +112,13 @@ __device__ __forceinline__ void lds_fft_dif_head(float2* Z, int N, int ns, int t
 
 // lds_fft_dit_tail: the LAST ns stages of an N-point DIT (spans N >> ns ... N/2), after the blocks of N >> ns points have been
 // transformed (DIT, bit-reversed in, natural out) one by one.
-template <int THREADS, class TW>
-__device__ __forceinline__ void lds_fft_dit_tail(float2* Z, int N, int ns, int tid, TW&& twiddle)
+// `last(k, v)` turns output k of the LAST pass into what is stored at Z[k].
+template <int THREADS, class TW, class ST>
+__device__ __forceinline__ void lds_fft_dit_tail(float2* Z, int N, int ns, int tid, TW&& twiddle, ST&& last)
 {
     for (int s = N >> ns; 4 * s <= N; s <<= 2) {
         const int tb = N / (4 * s);
+        const bool pl = 16 * s > N;
         for (int i = tid; i < (N >> 2); i += THREADS) {
             const int j = i & (s - 1);
             const int lo = ((i - j) << 2) + j;
@@ -122,10 +127,11 @@ __device__ __forceinline__ void lds_fft_dit_tail(float2* Z, int N, int ns, int t
             const float2 c1 = c_mul(e1, u1), c3 = c_mul(e3, u1);
             const float2 a0 = c_add(e0, c1), a1 = c_sub(e0, c1), a2 = c_add(e2, c3), a3 = c_sub(e2, c3);
             const float2 d2 = c_mul(a2, v), d3 = c_mul_mi(c_mul(a3, v));
-            Z[lo] = c_add(a0, d2);
-            Z[lo + 2 * s] = c_sub(a0, d2);
-            Z[lo + s] = c_add(a1, d3);
-            Z[lo + 3 * s] = c_sub(a1, d3);
+            const float2 o0 = c_add(a0, d2), o2 = c_sub(a0, d2), o1 = c_add(a1, d3), o3 = c_sub(a1, d3);
+            Z[lo] = pl ? last(lo, o0) : o0;
+            Z[lo + 2 * s] = pl ? last(lo + 2 * s, o2) : o2;
+            Z[lo + s] = pl ? last(lo + s, o1) : o1;
+            Z[lo + 3 * s] = pl ? last(lo + 3 * s, o3) : o3;
         }
         __syncthreads();
     }
