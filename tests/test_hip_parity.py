@@ -821,6 +821,25 @@ def test_full_window_branch_at_config5_clip_length():
     assert abs(float(layer.lambd.grad) - exp_d) <= _dlam_tol(exp_d, g_np, t_ref)
 
 
+@pytest.mark.parametrize("L,n_fft", [(20000, 40000), (40000, 80000)])
+def test_full_window_branch_on_esc50_length_clips(L, n_fft):
+    """optimized=False on clips of 20 000 / 40 000 samples (ESC-50's 5 s at 8 kHz): n_fft 40 000 / 80 000 through Bluestein with
+    2^17 / 2^18-point FFTs whose first and last four stages run on the sequence in global memory and the rest on 8192 / 16384-point
+    blocks in LDS.  Three frames per clip against the fp64 oracle, output and d lambd."""
+    case = dict(C.BY_NAME["g7_mel_nonopt_8000"], name=f"nonopt_{L}", B=2, L=L, sr=8000, lambd=1500.0, hop=L // 2, n_mels=64)
+    x_np = C.make_input(case).astype(np.float32)
+    g_np = C.make_cotangent(case)
+    layer = _layer(case, log=True)
+    y = layer(torch.from_numpy(x_np).to("cuda:0"))
+    assert layer.plan_info()["kernel_path"] == 3 and layer.plan_info()["n_fft"] == n_fft
+    (y * torch.from_numpy(g_np).to("cuda:0")).sum().backward()
+    y_ref, t_ref = O.forward(x_np, case["lambd"], case["hop"], case["n_mels"], case["sr"], case["f_min"], case["f_max"],
+                             case["normalize_window"], apply_log=True, optimized=False)
+    assert _log_err(y.detach().cpu().numpy(), y_ref) <= TOL
+    exp_d = O.backward(g_np, t_ref)
+    assert abs(float(layer.lambd.grad) - exp_d) <= _dlam_tol(exp_d, g_np, t_ref)
+
+
 def test_full_window_branch_on_the_compact_layout():
     """optimized=False at n_points 2048: n_fft 4096 on the fused kernel's compact layout, half-length window from the prep kernel."""
     case = dict(C.BY_NAME["g7_mel_nonopt_1024n"], name="nonopt_2048", L=2048, lambd=-150.0, hop=100, normalize_window=True)
