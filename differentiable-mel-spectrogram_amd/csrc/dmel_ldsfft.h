@@ -85,26 +85,68 @@ __device__ __forceinline__ void lds_fft_dit(float2* Z, int N, int logN, int tid,
 // block at a time in LDS.  `ns` (even) = stages outside the blocks; blocks are contiguous runs of N >> ns points.
 // lds_fft_dif_head: the FIRST ns stages of an N-point DIF (spans N/2 ... N >> ns); what remains are 2^ns independent DIF
 // transforms of the blocks, each with the twiddles of its own length.
+// One radix-4 group of two fused DIF stages (spans 2s and s) on four values, twiddles w1 = W^(j ta), w2 = W^(2 j ta): e[1], e[3]
+// leave multiplied as the in-place code above does.
+__device__ __forceinline__ void dif4(float2& e0, float2& e1, float2& e2, float2& e3, float2 w1, float2 w2)
+{
+    const float2 a0 = c_add(e0, e2), a2 = c_mul(c_sub(e0, e2), w1);
+    const float2 a1 = c_add(e1, e3), a3 = c_mul_mi(c_mul(c_sub(e1, e3), w1));
+    e0 = c_add(a0, a1); e1 = c_mul(c_sub(a0, a1), w2);
+    e2 = c_add(a2, a3); e3 = c_mul(c_sub(a2, a3), w2);
+}
+__device__ __forceinline__ void dit4(float2& e0, float2& e1, float2& e2, float2& e3, float2 u1, float2 v)
+{
+    const float2 c1 = c_mul(e1, u1), c3 = c_mul(e3, u1);
+    const float2 a0 = c_add(e0, c1), a1 = c_sub(e0, c1), a2 = c_add(e2, c3), a3 = c_sub(e2, c3);
+    const float2 d2 = c_mul(a2, v), d3 = c_mul_mi(c_mul(a3, v));
+    e0 = c_add(a0, d2); e2 = c_sub(a0, d2);
+    e1 = c_add(a1, d3); e3 = c_sub(a1, d3);
+}
+
 // `first(n)` supplies element n of the input for the FIRST pass (the sequence need not have been written to Z before).
+// FOUR stages per pass where four are left (16 values per thread: e[a][b] = Z[base + j + a sA + b sB], sA = 4 sB): a pass over a
+// sequence in global memory moves all of it through L2, whatever it computes.
 template <int THREADS, class TW, class LD>
 __device__ __forceinline__ void lds_fft_dif_head(float2* Z, int N, int ns, int tid, TW&& twiddle, LD&& first)
 {
     int left = ns;
-    for (int s = N >> 2; left > 0; s >>= 2, left -= 2) {
+    int nc = N;                                   // length of the independent transforms at this level
+    for (; left >= 4; left -= 4, nc >>= 4) {
+        const int sA = nc >> 2, sB = nc >> 4, tA = N / nc, tB = 4 * tA;
+        const bool p0 = left == ns;
+        for (int i = tid; i < (N >> 4); i += THREADS) {
+            const int j = i & (sB - 1);
+            const int base = ((i - j) << 4) + j;
+            float2 e[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) { const int n = base + a * sA + b * sB; e[a][b] = p0 ? first(n) : Z[n]; }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {             // spans nc/2, nc/4: position inside the transform = j + b sB
+                const int ja = j + b * sB;
+                dif4(e[0][b], e[1][b], e[2][b], e[3][b], twiddle(ja * tA), twiddle(2 * ja * tA));
+            }
+            const float2 w1 = twiddle(j * tB), w2 = twiddle(2 * j * tB);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) dif4(e[a][0], e[a][1], e[a][2], e[a][3], w1, w2);       // spans nc/8, nc/16
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) Z[base + a * sA + b * sB] = e[a][b];
+        }
+        __syncthreads();
+    }
+    for (int s = nc >> 2; left > 0; s >>= 2, left -= 2) {
         const int ta = N / (4 * s);
         const bool p0 = left == ns;
         for (int i = tid; i < (N >> 2); i += THREADS) {
             const int j = i & (s - 1);
             const int lo = ((i - j) << 2) + j;
-            const float2 e0 = p0 ? first(lo) : Z[lo], e1 = p0 ? first(lo + s) : Z[lo + s];
-            const float2 e2 = p0 ? first(lo + 2 * s) : Z[lo + 2 * s], e3 = p0 ? first(lo + 3 * s) : Z[lo + 3 * s];
-            const float2 w1 = twiddle(j * ta), w2 = twiddle(2 * j * ta);
-            const float2 a0 = c_add(e0, e2), a2 = c_mul(c_sub(e0, e2), w1);
-            const float2 a1 = c_add(e1, e3), a3 = c_mul_mi(c_mul(c_sub(e1, e3), w1));
-            Z[lo] = c_add(a0, a1);
-            Z[lo + s] = c_mul(c_sub(a0, a1), w2);
-            Z[lo + 2 * s] = c_add(a2, a3);
-            Z[lo + 3 * s] = c_mul(c_sub(a2, a3), w2);
+            float2 e0 = p0 ? first(lo) : Z[lo], e1 = p0 ? first(lo + s) : Z[lo + s];
+            float2 e2 = p0 ? first(lo + 2 * s) : Z[lo + 2 * s], e3 = p0 ? first(lo + 3 * s) : Z[lo + 3 * s];
+            dif4(e0, e1, e2, e3, twiddle(j * ta), twiddle(2 * j * ta));
+            Z[lo] = e0; Z[lo + s] = e1; Z[lo + 2 * s] = e2; Z[lo + 3 * s] = e3;
         }
         __syncthreads();
     }
@@ -116,22 +158,46 @@ __device__ __forceinline__ void lds_fft_dif_head(float2* Z, int N, int ns, int t
 template <int THREADS, class TW, class ST>
 __device__ __forceinline__ void lds_fft_dit_tail(float2* Z, int N, int ns, int tid, TW&& twiddle, ST&& last)
 {
-    for (int s = N >> ns; 4 * s <= N; s <<= 2) {
-        const int tb = N / (4 * s);
-        const bool pl = 16 * s > N;
+    int left = ns;
+    int nc = N >> ns;                             // length of the transforms already done
+    if (left & 2) {                               // an odd number of stage pairs: the single pair first, the radix-16 passes behind it
+        const int s = nc, tb = N / (4 * s);
+        const bool pl = left == 2;
         for (int i = tid; i < (N >> 2); i += THREADS) {
             const int j = i & (s - 1);
             const int lo = ((i - j) << 2) + j;
-            const float2 e0 = Z[lo], e1 = Z[lo + s], e2 = Z[lo + 2 * s], e3 = Z[lo + 3 * s];
-            const float2 u1 = twiddle(2 * j * tb), v = twiddle(j * tb);
-            const float2 c1 = c_mul(e1, u1), c3 = c_mul(e3, u1);
-            const float2 a0 = c_add(e0, c1), a1 = c_sub(e0, c1), a2 = c_add(e2, c3), a3 = c_sub(e2, c3);
-            const float2 d2 = c_mul(a2, v), d3 = c_mul_mi(c_mul(a3, v));
-            const float2 o0 = c_add(a0, d2), o2 = c_sub(a0, d2), o1 = c_add(a1, d3), o3 = c_sub(a1, d3);
-            Z[lo] = pl ? last(lo, o0) : o0;
-            Z[lo + 2 * s] = pl ? last(lo + 2 * s, o2) : o2;
-            Z[lo + s] = pl ? last(lo + s, o1) : o1;
-            Z[lo + 3 * s] = pl ? last(lo + 3 * s, o3) : o3;
+            float2 e0 = Z[lo], e1 = Z[lo + s], e2 = Z[lo + 2 * s], e3 = Z[lo + 3 * s];
+            dit4(e0, e1, e2, e3, twiddle(2 * j * tb), twiddle(j * tb));
+            Z[lo] = pl ? last(lo, e0) : e0; Z[lo + s] = pl ? last(lo + s, e1) : e1;
+            Z[lo + 2 * s] = pl ? last(lo + 2 * s, e2) : e2; Z[lo + 3 * s] = pl ? last(lo + 3 * s, e3) : e3;
+        }
+        __syncthreads();
+        left -= 2; nc <<= 2;
+    }
+    for (; left >= 4; left -= 4, nc <<= 4) {
+        // e[a][b] = Z[base + j + b sB + a sA], sB = nc (spans nc, 2 nc over b), sA = 4 nc (spans 4 nc, 8 nc over a)
+        const int sB = nc, sA = nc << 2, tB = N / (4 * sB), tA = N / (4 * sA);
+        const bool pl = left == 4;
+        for (int i = tid; i < (N >> 4); i += THREADS) {
+            const int j = i & (sB - 1);
+            const int base = ((i - j) << 4) + j;
+            float2 e[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) e[a][b] = Z[base + a * sA + b * sB];
+            const float2 u1 = twiddle(2 * j * tB), v = twiddle(j * tB);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) dit4(e[a][0], e[a][1], e[a][2], e[a][3], u1, v);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {             // position inside the transform of 4 sA points = j + b sB
+                const int ja = j + b * sB;
+                dit4(e[0][b], e[1][b], e[2][b], e[3][b], twiddle(2 * ja * tA), twiddle(ja * tA));
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) { const int k = base + a * sA + b * sB; Z[k] = pl ? last(k, e[a][b]) : e[a][b]; }
         }
         __syncthreads();
     }
