@@ -455,6 +455,40 @@ def main():
         except Exception as e:                                          # noqa: BLE001
             module_step_info["with_lambd_adam"] = {"error": f"{type(e).__name__}: {e}"[:200]}
 
+    # ---- side figure, never `value`: BASELINE config 2 read literally ("bf16 activations / fp32 grad"): the log-mel output stored
+    # as bf16 and its gradient read as bf16 (arithmetic, tangent and d lambd stay fp32), issued the way the headline was
+    if dist is None and not args.no_other_configs and not args.bf16_activations:
+        try:
+            layer3 = MelSpectrogramLayer(torch.tensor(lam), n_mels=M, n_points=L, sample_rate=sr, hop_length=hop, device=str(dev),
+                                         optimized=True, log=True, out_dtype=torch.bfloat16).to(dev)
+            opt3 = torch.optim.Adam([layer3.lambd], lr=ADAM_LR, fused=True, capturable=True)
+            g16 = g32.to(torch.bfloat16)
+
+            def module_step3():
+                opt3.zero_grad(set_to_none=True)
+                layer3(x).backward(g16)
+                opt3.step()
+
+            for _ in range(3):
+                module_step3()
+            torch.cuda.synchronize()
+            fn3 = module_step3
+            if chosen != "eager":
+                fn3 = GraphedStep(module_step3, [layer3], max_ahead=MAX_AHEAD, steps_per_replay=k_chosen)
+                for _ in range(MAX_AHEAD + 4):
+                    fn3()
+                torch.cuda.synchronize()
+            n3 = max(200, 50 * k_chosen)
+            el3 = min(time_loop(fn3, 8, n3 // k_chosen), time_loop(fn3, 0, n3 // k_chosen))
+            assert layer3.lambd_status()["error"] == 0
+            module_step_info["with_bf16_activations"] = {"ms_per_step": round(1e3 * el3 / n3, 5), "frames_per_s": round(frames_per_rank * n3 / el3, 1),
+                                                         "steps": n3, "issued": chosen,
+                                                         "note": "output and its gradient as bf16 (BASELINE config 2's wording), arithmetic / tangent / "
+                                                                 "d lambd fp32; a side figure: `value` is measured with fp32 activations, the reference's"}
+            del fn3, opt3, layer3
+        except Exception as e:                                          # noqa: BLE001
+            module_step_info["with_bf16_activations"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+
     # ---- the bare kernels through the C ABI (round 1's headline): fused forward + dot, lambd by value, no autograd, no update -
     plan = capi.Plan(L, hop, M, sr, max_batch=B)
     out = torch.empty((B, 1, M, T), dtype=act, device=dev)
