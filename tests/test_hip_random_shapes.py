@@ -128,3 +128,33 @@ def test_random_full_window_configuration_matches_oracle(case):
             yi = _layer(case, log=log, trainable=False)(x)
         oi = yi.cpu().numpy()
         assert (_log_err(oi, o_ref) if log else _rel_err(oi, o_ref)) <= TOL
+
+
+# ---- the optional gradients on the same kind of sweep: dL/dx (wave-FFT kernels up to n_fft 2048, LDS transforms beyond) and dL/dfb ----
+GRAD_CASES = [c for c in _random_cases(60, seed=4711) if c["B"] * (c["L"] // c["hop"] + 1) * O.n_fft(c["lambd"]) <= 1_500_000][:28]
+
+
+@pytest.mark.parametrize("case", GRAD_CASES, ids=[c["name"] for c in GRAD_CASES])
+def test_random_configuration_optional_gradients_match_oracle(case):
+    from dmel_amd import capi
+    from test_hip_parity import _gfb_err, _gx_err
+    x_np = C.make_input(case).astype(np.float32)
+    g_np = C.make_cotangent(case)
+    g = torch.from_numpy(g_np).to("cuda:0")
+    n = capi.n_fft(case["lambd"])
+    for log in (False, True):
+        x = torch.from_numpy(x_np).to("cuda:0").requires_grad_(True)
+        layer = _layer(case, log=log)
+        y = layer(x)
+        (y * g).sum().backward()
+        y_np = y.detach().cpu().numpy()
+        ref_x = O.backward_x(x_np, case["lambd"], case["hop"], case["sr"], g_np, y_np if log else None, case["f_min"], case["f_max"],
+                             case["normalize_window"])
+        assert _gx_err(x.grad.cpu().numpy(), ref_x) <= TOL, case["name"]
+        plan = capi.Plan(case["L"], case["hop"], case["n_mels"], case["sr"], case["f_min"], case["f_max"], case["normalize_window"])
+        gfb = torch.empty((n // 2 + 1, case["n_mels"]), dtype=torch.float32, device="cuda:0")
+        plan.backward_fb(x.detach().data_ptr(), case["B"], case["lambd"], g.data_ptr(), y.detach().data_ptr(), gfb.data_ptr(), log,
+                         torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        ref_fb = O.backward_fb(x_np, case["lambd"], case["hop"], g_np, y_np if log else None, case["normalize_window"])
+        assert _gfb_err(gfb.cpu().numpy(), ref_fb) <= TOL, case["name"]
