@@ -48,7 +48,7 @@ __device__ __forceinline__ void big_fft(float2* Z, int M, int logM, float2* lds_
         if constexpr (DIT) lds_fft_dit<kBigThreads>(Z, M, logM, tid, twid); else lds_fft_dif<kBigThreads>(Z, M, logM, tid, twid);
     } else {
         const int lgb = big_block_log(logM), ns = logM - lgb, bl = 1 << lgb;
-        if constexpr (!DIT) lds_fft_dif_head<kBigThreads>(Z, M, ns, tid, twid, [&](int n) { return Z[n]; });
+        if constexpr (!DIT) lds_fft_dif_head<kBigThreads>(Z, M, ns, tid, twid, [&](int n) { return Z[n]; }, M);
         for (int blk = 0; blk < (M >> lgb); ++blk) {
             float2* zb = Z + ((size_t)blk << lgb);
             for (int i = tid; i < bl; i += kBigThreads) lds_block[i] = zb[i];
@@ -72,7 +72,7 @@ __device__ __forceinline__ void big_convolve_global(float2* Z, int M, int logM, 
                                                     TWG&& twid, TWB&& twid_block, LD&& first, ST&& last)
 {
     const int lgb = big_block_log(logM), ns = logM - lgb, bl = 1 << lgb;
-    lds_fft_dif_head<kBigThreads>(Z, M, ns, tid, twid, first);
+    lds_fft_dif_head<kBigThreads>(Z, M, ns, tid, twid, first, M);
     for (int blk = 0; blk < (M >> lgb); ++blk) {
         float2* zb = Z + ((size_t)blk << lgb);
         const float2* hb = hbr + ((size_t)blk << lgb);

@@ -16,75 +16,6 @@ __device__ __forceinline__ float2 c_sub(float2 a, float2 b) { return make_float2
 __device__ __forceinline__ float2 c_mul(float2 a, float2 w) { return make_float2(fmaf(a.x, w.x, -(a.y * w.y)), fmaf(a.x, w.y, a.y * w.x)); }
 __device__ __forceinline__ float2 c_mul_mi(float2 a) { return make_float2(a.y, -a.x); }          // a * (-i)
 
-template <int THREADS, class TW>
-__device__ __forceinline__ void lds_fft_dif(float2* Z, int N, int logN, int tid, TW&& twiddle)
-{
-    int top = N >> 1;                 // span of the next radix-2 stage
-    if (logN & 1) {                   // odd number of stages: one plain radix-2 stage first
-        for (int i = tid; i < (N >> 1); i += THREADS) {
-            const float2 a = Z[i], c = Z[i + top];
-            Z[i] = c_add(a, c);
-            Z[i + top] = c_mul(c_sub(a, c), twiddle(i));
-        }
-        __syncthreads();
-        top >>= 1;
-    }
-    // fused pairs (span 2s, span s)
-    for (int s = top >> 1; s >= 1; s >>= 2) {
-        const int ta = N / (4 * s);
-        for (int i = tid; i < (N >> 2); i += THREADS) {
-            const int j = i & (s - 1);
-            const int lo = ((i - j) << 2) + j;
-            const float2 e0 = Z[lo], e1 = Z[lo + s], e2 = Z[lo + 2 * s], e3 = Z[lo + 3 * s];
-            const float2 w1 = twiddle(j * ta), w2 = twiddle(2 * j * ta);
-            const float2 a0 = c_add(e0, e2), a2 = c_mul(c_sub(e0, e2), w1);
-            const float2 a1 = c_add(e1, e3), a3 = c_mul_mi(c_mul(c_sub(e1, e3), w1));
-            Z[lo] = c_add(a0, a1);
-            Z[lo + s] = c_mul(c_sub(a0, a1), w2);
-            Z[lo + 2 * s] = c_add(a2, a3);
-            Z[lo + 3 * s] = c_mul(c_sub(a2, a3), w2);
-        }
-        __syncthreads();
-    }
-}
-
-template <int THREADS, class TW>
-__device__ __forceinline__ void lds_fft_dit(float2* Z, int N, int logN, int tid, TW&& twiddle)
-{
-    int s = 1;                        // span of the next radix-2 stage
-    if (logN & 1) {                   // odd number of stages: one plain radix-2 stage (span 1, twiddle 1) first
-        for (int i = tid; i < (N >> 1); i += THREADS) {
-            const float2 a = Z[2 * i], c = Z[2 * i + 1];
-            Z[2 * i] = c_add(a, c);
-            Z[2 * i + 1] = c_sub(a, c);
-        }
-        __syncthreads();
-        s = 2;
-    }
-    // fused pairs (span s, span 2s)
-    for (; 4 * s <= N; s <<= 2) {
-        const int tb = N / (4 * s);
-        for (int i = tid; i < (N >> 2); i += THREADS) {
-            const int j = i & (s - 1);
-            const int lo = ((i - j) << 2) + j;
-            const float2 e0 = Z[lo], e1 = Z[lo + s], e2 = Z[lo + 2 * s], e3 = Z[lo + 3 * s];
-            const float2 u1 = twiddle(2 * j * tb), v = twiddle(j * tb);
-            const float2 c1 = c_mul(e1, u1), c3 = c_mul(e3, u1);
-            const float2 a0 = c_add(e0, c1), a1 = c_sub(e0, c1), a2 = c_add(e2, c3), a3 = c_sub(e2, c3);
-            const float2 d2 = c_mul(a2, v), d3 = c_mul_mi(c_mul(a3, v));
-            Z[lo] = c_add(a0, d2);
-            Z[lo + 2 * s] = c_sub(a0, d2);
-            Z[lo + s] = c_add(a1, d3);
-            Z[lo + 3 * s] = c_sub(a1, d3);
-        }
-        __syncthreads();
-    }
-}
-
-// ---- transforms longer than LDS: the stages whose span reaches across blocks run on the sequence in global memory, the rest on one
-// block at a time in LDS.  `ns` (even) = stages outside the blocks; blocks are contiguous runs of N >> ns points.
-// lds_fft_dif_head: the FIRST ns stages of an N-point DIF (spans N/2 ... N >> ns); what remains are 2^ns independent DIF
-// transforms of the blocks, each with the twiddles of its own length.
 // One radix-4 group of two fused DIF stages (spans 2s and s) on four values, twiddles w1 = W^(j ta), w2 = W^(2 j ta): e[1], e[3]
 // leave multiplied as the in-place code above does.
 __device__ __forceinline__ void dif4(float2& e0, float2& e1, float2& e2, float2& e3, float2 w1, float2 w2)
@@ -103,14 +34,89 @@ __device__ __forceinline__ void dit4(float2& e0, float2& e1, float2& e2, float2&
     e1 = c_add(a1, d3); e3 = c_sub(a1, d3);
 }
 
+template <int THREADS, class TW, class LD>
+__device__ __forceinline__ void lds_fft_dif_head(float2* Z, int N, int ns, int tid, TW&& twiddle, LD&& first, int nc0);
+template <int THREADS, class TW, class ST>
+__device__ __forceinline__ void lds_fft_dit_tail(float2* Z, int N, int ns, int tid, TW&& twiddle, ST&& last);
+
+// R16: four stages per pass where four are left (16 values per thread) -- half the passes and barriers of the two-stage passes:
+// -10 % for the 1024-thread workgroups of dmel_big.hip; the 256-thread workgroups of dmel_xgrad_frames_kernel measured
+// slower with it (74 -> 94 us at BASELINE config 2) and keep two stages per pass.
+template <int THREADS, bool R16 = true, class TW>
+__device__ __forceinline__ void lds_fft_dif(float2* Z, int N, int logN, int tid, TW&& twiddle)
+{
+    int top = N >> 1;                 // span of the next radix-2 stage
+    if (logN & 1) {                   // odd number of stages: one plain radix-2 stage first
+        for (int i = tid; i < (N >> 1); i += THREADS) {
+            const float2 a = Z[i], c = Z[i + top];
+            Z[i] = c_add(a, c);
+            Z[i + top] = c_mul(c_sub(a, c), twiddle(i));
+        }
+        __syncthreads();
+        top >>= 1;
+    }
+    if constexpr (R16) {
+        // the remaining (even number of) stages four at a time where four are left, then one two-stage pass
+        lds_fft_dif_head<THREADS>(Z, N, logN & ~1, tid, twiddle, [&](int n) { return Z[n]; }, top << 1);
+    } else {
+        // fused pairs (span 2s, span s)
+        for (int s = top >> 1; s >= 1; s >>= 2) {
+            const int ta = N / (4 * s);
+            for (int i = tid; i < (N >> 2); i += THREADS) {
+                const int j = i & (s - 1);
+                const int lo = ((i - j) << 2) + j;
+                float2 e0 = Z[lo], e1 = Z[lo + s], e2 = Z[lo + 2 * s], e3 = Z[lo + 3 * s];
+                dif4(e0, e1, e2, e3, twiddle(j * ta), twiddle(2 * j * ta));
+                Z[lo] = e0; Z[lo + s] = e1; Z[lo + 2 * s] = e2; Z[lo + 3 * s] = e3;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int THREADS, bool R16 = true, class TW>
+__device__ __forceinline__ void lds_fft_dit(float2* Z, int N, int logN, int tid, TW&& twiddle)
+{
+    int s = 1;                        // span of the next radix-2 stage
+    if (logN & 1) {                   // odd number of stages: one plain radix-2 stage (span 1, twiddle 1) first
+        for (int i = tid; i < (N >> 1); i += THREADS) {
+            const float2 a = Z[2 * i], c = Z[2 * i + 1];
+            Z[2 * i] = c_add(a, c);
+            Z[2 * i + 1] = c_sub(a, c);
+        }
+        __syncthreads();
+        s = 2;
+    }
+    if constexpr (R16) {
+        lds_fft_dit_tail<THREADS>(Z, N, logN & ~1, tid, twiddle, [](int, float2 v) { return v; });
+    } else {
+        // fused pairs (span s, span 2s)
+        for (; 4 * s <= N; s <<= 2) {
+            const int tb = N / (4 * s);
+            for (int i = tid; i < (N >> 2); i += THREADS) {
+                const int j = i & (s - 1);
+                const int lo = ((i - j) << 2) + j;
+                float2 e0 = Z[lo], e1 = Z[lo + s], e2 = Z[lo + 2 * s], e3 = Z[lo + 3 * s];
+                dit4(e0, e1, e2, e3, twiddle(2 * j * tb), twiddle(j * tb));
+                Z[lo] = e0; Z[lo + s] = e1; Z[lo + 2 * s] = e2; Z[lo + 3 * s] = e3;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---- transforms longer than LDS: the stages whose span reaches across blocks run on the sequence in global memory, the rest on one
+// block at a time in LDS.  `ns` (even) = stages outside the blocks; blocks are contiguous runs of N >> ns points.
+// lds_fft_dif_head: the FIRST ns stages of an N-point DIF (spans N/2 ... N >> ns); what remains are 2^ns independent DIF
+// transforms of the blocks, each with the twiddles of its own length.
 // `first(n)` supplies element n of the input for the FIRST pass (the sequence need not have been written to Z before).
 // FOUR stages per pass where four are left (16 values per thread: e[a][b] = Z[base + j + a sA + b sB], sA = 4 sB): a pass over a
 // sequence in global memory moves all of it through L2, whatever it computes.
 template <int THREADS, class TW, class LD>
-__device__ __forceinline__ void lds_fft_dif_head(float2* Z, int N, int ns, int tid, TW&& twiddle, LD&& first)
+__device__ __forceinline__ void lds_fft_dif_head(float2* Z, int N, int ns, int tid, TW&& twiddle, LD&& first, int nc0)
 {
     int left = ns;
-    int nc = N;                                   // length of the independent transforms at this level
+    int nc = nc0;                                 // length of the independent transforms at this level (N, or less behind earlier stages)
     for (; left >= 4; left -= 4, nc >>= 4) {
         const int sA = nc >> 2, sB = nc >> 4, tA = N / nc, tB = 4 * tA;
         const bool p0 = left == ns;

@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(kXgThreads) dmel_xgrad_frames_kernel(XgradPara
     if constexpr (TWLDS) for (int k = tid; k < (N >> 1); k += kXgThreads) twl[k] = p.tw[k];
     __syncthreads();
     // forward: decimation in frequency, natural order in, bit-reversed order out
-    lds_fft_dif<kXgThreads>(Z, N, p.logN, tid, twiddle);
+    lds_fft_dif<kXgThreads, false>(Z, N, p.logN, tid, twiddle);
     // spectra of the two frames, gradient of the power spectrum, conj(H_a) + i conj(H_b) back in place
     const float* ga = p.grad_out + (size_t)b * M * T + tA;
     const float* ya = p.out ? p.out + (size_t)b * M * T + tA : nullptr;
@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(kXgThreads) dmel_xgrad_frames_kernel(XgradPara
     }
     __syncthreads();
     // decimation in time, bit-reversed order in, natural order out: R = FFT(conj W) = conj(dv_a + i dv_b)
-    lds_fft_dit<kXgThreads>(Z, N, p.logN, tid, twiddle);
+    lds_fft_dit<kXgThreads, false>(Z, N, p.logN, tid, twiddle);
     float* fa = p.frames + ((size_t)b * T + tA) * N;
     double sa = 0.0, sb = 0.0;                                 // what each frame contributes to the sum of the clip's gradient
     for (int n = tid; n < N; n += kXgThreads) {
