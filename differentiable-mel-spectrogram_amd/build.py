@@ -34,19 +34,40 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# csrc/dmel_fwd.hip is compiled FWD_PARTS times (-DDMEL_FWD_SPLIT -DDMEL_FWD_PART=k): its large instantiations in parallel
+FWD_PARTS = 4
+
+
+def _units():
+    """(source path, object path, extra flags) of every translation unit"""
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        stem = os.path.splitext(src)[0]
+        if src == "dmel_fwd.hip":
+            for k in range(FWD_PARTS):
+                yield sp, os.path.join(OBJ_DIR, f"{stem}_part{k}.o"), ["-DDMEL_FWD_SPLIT", f"-DDMEL_FWD_PART={k}"]
+        else:
+            yield sp, os.path.join(OBJ_DIR, stem + ".o"), []
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = _hipcc()
-    objs = []
-    for src in SOURCES:
-        sp = os.path.join(CSRC, src)
-        obj = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".o")
+    objs, running = [], []
+    jobs = max(1, min(int(os.environ.get("DMEL_BUILD_JOBS", "0")) or (os.cpu_count() or 2), 8))
+    for sp, obj, extra in _units():
+        objs.append(obj)
         if force or _stale(obj, [sp] + HEADERS):
-            cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", sp, "-o", obj]
+            cmd = [hipcc] + FLAGS + extra + ["-x", "hip", "-c", sp, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
-        objs.append(obj)
+            while len(running) >= jobs:
+                if running.pop(0).wait() != 0:
+                    raise RuntimeError("hipcc failed")
+            running.append(subprocess.Popen(cmd))
+    for pr in running:
+        if pr.wait() != 0:
+            raise RuntimeError("hipcc failed")
     if force or _stale(LIB_PATH, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-ldl"]
         if verbose:

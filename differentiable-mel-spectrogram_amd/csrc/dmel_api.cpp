@@ -629,6 +629,7 @@ dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dm
     fp.wgs_per_clip = (fp.tiles_per_clip + tpw - 1) / tpw;
     const long long grid = (long long)batch * fp.wgs_per_clip;
     if (grid > 0x7fffffffLL) return fail(DMEL_ERR_INVALID_ARGUMENT, "too many tiles for one launch");
+    if (grid <= dmel::forward_resident_workgroups(N, mode)) fp.flags |= dmel::kFwdEdgeFirst;      // one round: see the kernel's prologue
     DMEL_HIP(dmel::launch_forward(N, mode, tpw, fp, (int)grid, s));
     prof_span(pl, m1, prof_mark(pl, s), 1);
     pl->info.kernel_path = 0; pl->info.frames_per_tile = fpt; pl->info.grid_fwd = (int)grid;

@@ -31,6 +31,10 @@
 namespace dmel {
 
 
+#ifndef DMEL_FWD_PART
+#define DMEL_FWD_PART 0
+#endif
+#if DMEL_FWD_PART == 0
 // ---- prep kernel: per-clip partial sums (DC removal, models.py:38) + window tables -----------
 __global__ void __launch_bounds__(kThreads) dmel_prep_kernel(PrepParams p)
 {
@@ -102,6 +106,8 @@ hipError_t launch_prep(const PrepParams& p, hipStream_t s)
     hipLaunchKernelGGL(dmel_prep_kernel, grid, dim3(kThreads), 0, s, p);
     return hipGetLastError();
 }
+
+#endif   // DMEL_FWD_PART == 0
 
 // ---- fused forward --------------------------------------------------------------------------
 
@@ -184,6 +190,8 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
     int wg = blockIdx.x;
     {
         const int nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7, xcd = wg & 7;
+        // (the two workgroups that share a CU -- local indices i and i + 32 of an XCD's 64 at config 2 -- given the two halves of ONE
+        // clip, so that the second pass over the clip hits L1: 19.99 against 20.05 us, not kept)
         wg = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (wg >> 3);
     }
     const int b = wg / p.wgs_per_clip;
@@ -269,6 +277,9 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
             const int f0 = tA * p.hop - N / 2;                       // first sample of frame tA
             const int f1 = PAIR ? f0 + p.hop : f0;
             inside[ti][pass] = __all((f0 >= 0) && (f1 + N <= p.L));
+#ifdef DMEL_ABLATE
+            if (p.flags & 0x2000u) inside[ti][pass] = true;      // timing only: no edge path (edge frames come out wrong)
+#endif
             const int sA = f0 + lg;
             if (inside[ti][pass]) {
                 static_for<0, R>([&](auto aa) {
@@ -293,6 +304,14 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
     float2 wmid = make_float2(1.f, 0.f);                        // ... and the centre entry
     if (!dbg_skip_fft) {
         load_tile(IC<0>{});
+        // The waves that hold a clip's first / last frames take the slow path (clamped loads, selects at windowing time) and every
+        // other wave of their workgroup waits for them at the barrier before phase 2.  In a launch of ONE round of resident
+        // workgroups (kFwdEdgeFirst, set by the host) they get instruction-issue priority over the waves they share a SIMD with:
+        // 20.1 -> 19.7 us at BASELINE config 2 (training), 14.0 -> 13.7 (inference).  In launches of several rounds the same
+        // priority measured 49.0 -> 52.0 us (config 3) and 73.9 -> 76.7 (config 5): there the waves of different rounds overlap
+        // and a privileged wave only delays them.  (Measured and not kept, config 2: priority by wave index, one workgroup of
+        // each CU first through the transforms, the contraction phase first: 20.1 against 20.1.)
+        if ((p.flags & kFwdEdgeFirst) && !inside[0][0]) __builtin_amdgcn_s_setprio(2);
         STAMP(1);   // loads issued
         // lambd (device scalar or by value) and the check that this launch is the n_fft the device value asks for
         const LamState ls = lam_prologue(p.lam, N, blockIdx.x == 0 && tid == 0);
@@ -1061,20 +1080,32 @@ template <int N> static hipError_t launch_n(int mode, int tpw, const FwdParams& 
     return hipErrorInvalidValue;
 }
 
-// -DDMEL_ONLY_NFFT=<n>: development builds that instantiate one transform size only (tools/build_variant.sh; the whole family
-// takes minutes to compile).  Never defined for libdmel_hip.so.
-#ifdef DMEL_ONLY_NFFT
-#define DMEL_FWD_SIZE(n) ((n) == DMEL_ONLY_NFFT)
+// -DDMEL_ONLY_NFFT=<n>: development builds that instantiate one transform size only (tools/build_variant.sh).  Never defined for
+// libdmel_hip.so.
+// -DDMEL_FWD_SPLIT -DDMEL_FWD_PART=<k>, k = 0..3: build.py compiles this file four times for libdmel_hip.so so that the
+// instantiations of the large transforms -- minutes of compile time each -- build in parallel: part 0 holds everything that is
+// not a template instantiation plus the sizes up to 512, parts 1-3 hold 1024 / 2048 + 16384 / 4096 + 8192 and nothing else.
+// Without DMEL_FWD_SPLIT (the tools' one-command builds) everything is in this one translation unit.
+#ifndef DMEL_FWD_PART
+#define DMEL_FWD_PART 0
+#endif
+constexpr int fwd_part_of(int n) { return n <= 512 ? 0 : n == 1024 ? 1 : (n == 2048 || n == 16384) ? 2 : 3; }
+#if defined(DMEL_ONLY_NFFT)
+#define DMEL_FWD_HERE(n) ((n) == DMEL_ONLY_NFFT)
+#elif defined(DMEL_FWD_SPLIT)
+#define DMEL_FWD_HERE(n) (fwd_part_of(n) == DMEL_FWD_PART)
 #else
-#define DMEL_FWD_SIZE(n) true
+#define DMEL_FWD_HERE(n) true
 #endif
 template <int N> static hipError_t launch_size(int mode, int tpw, const FwdParams& p, int grid, hipStream_t s)
 {
-    if constexpr (DMEL_FWD_SIZE(N)) return launch_n<N>(mode, tpw, p, grid, s);
+    if constexpr (DMEL_FWD_HERE(N)) return launch_n<N>(mode, tpw, p, grid, s);
     else return hipErrorInvalidValue;
 }
 
-hipError_t launch_forward(int n_fft, int mode, int tpw, const FwdParams& p, int grid, hipStream_t s)
+#define DMEL_CAT2(a, b) a##b
+#define DMEL_CAT(a, b) DMEL_CAT2(a, b)
+hipError_t DMEL_CAT(launch_forward_part, DMEL_FWD_PART)(int n_fft, int mode, int tpw, const FwdParams& p, int grid, hipStream_t s)
 {
     switch (n_fft) {
         case 32: return launch_size<32>(mode, tpw, p, grid, s);
@@ -1089,6 +1120,28 @@ hipError_t launch_forward(int n_fft, int mode, int tpw, const FwdParams& p, int 
         case 16384: return launch_size<16384>(mode, tpw, p, grid, s);
     }
     return hipErrorInvalidValue;
+}
+
+#if DMEL_FWD_PART == 0
+#if defined(DMEL_FWD_SPLIT) && !defined(DMEL_ONLY_NFFT)
+#define DMEL_FWD_PARTS 1
+hipError_t launch_forward_part1(int, int, int, const FwdParams&, int, hipStream_t);
+hipError_t launch_forward_part2(int, int, int, const FwdParams&, int, hipStream_t);
+hipError_t launch_forward_part3(int, int, int, const FwdParams&, int, hipStream_t);
+hipError_t forward_prepare_attributes_part1();
+hipError_t forward_prepare_attributes_part2();
+hipError_t forward_prepare_attributes_part3();
+#endif
+hipError_t launch_forward(int n_fft, int mode, int tpw, const FwdParams& p, int grid, hipStream_t s)
+{
+#ifdef DMEL_FWD_PARTS
+    switch (fwd_part_of(n_fft)) {
+        case 1: return launch_forward_part1(n_fft, mode, tpw, p, grid, s);
+        case 2: return launch_forward_part2(n_fft, mode, tpw, p, grid, s);
+        case 3: return launch_forward_part3(n_fft, mode, tpw, p, grid, s);
+    }
+#endif
+    return launch_forward_part0(n_fft, mode, tpw, p, grid, s);
 }
 
 bool forward_window_in_lds(int n_fft) { return n_fft >= kMinFastNfft && n_fft <= kWinLdsMaxNfft; }
@@ -1147,11 +1200,24 @@ bool forward_two_tiles(int n_fft, int mode)
 // the chip holds at once (160 KB of LDS per CU, 256 CUs); a two-tile workgroup lives about 1.9 times as long as a one-tile
 // one (it pays the prologue once: measured 21.97 against 23.1 us at BASELINE config 2 with the 16 x 16 x 4 plan, one round instead of
 // two).  Two tiles are used when that model says the launch gets shorter -- e.g. not for 5 rounds becoming 3 double ones.
+// Workgroups of the (n_fft, mode) instantiation the device holds at once: LDS-limited (160 KB per CU), at most 32 waves per CU
+int forward_resident_workgroups(int n_fft, int mode)
+{
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        return n;
+    }();
+    const int lds = forward_lds_bytes(n_fft, mode), waves = forward_waves(n_fft);
+    int per_cu = (lds > 0 && 163840 / lds > 0) ? 163840 / lds : 1;
+    if (waves > 0 && per_cu * waves > 32) per_cu = 32 / waves;
+    return cus * (per_cu > 0 ? per_cu : 1);
+}
+
 int forward_tiles_per_wg(int n_fft, int mode, int batch, int tiles_per_clip)
 {
     if (!forward_two_tiles(n_fft, mode) || tiles_per_clip < 2 || batch < 1) return 1;
-    const int lds = forward_lds_bytes(n_fft, mode);
-    const long long resident = 256LL * (lds > 0 && 163840 / lds > 0 ? 163840 / lds : 1);
+    const long long resident = forward_resident_workgroups(n_fft, mode);
     const long long wg1 = (long long)batch * tiles_per_clip, wg2 = (long long)batch * ((tiles_per_clip + 1) / 2);
     const long long r1 = (wg1 + resident - 1) / resident, r2 = (wg2 + resident - 1) / resident;
     return 19 * r2 < 10 * r1 ? 2 : 1;
@@ -1172,6 +1238,8 @@ int forward_nbpre(int n_fft)
     return v;
 }
 
+#endif   // DMEL_FWD_PART == 0
+
 template <int N, int MODE, int TPW> static hipError_t set_attr()
 {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&dmel_fwd_kernel<N, MODE, TPW>),
@@ -1186,7 +1254,7 @@ template <int N, int MODE> static hipError_t set_attr_mode()
 }
 template <int N> static hipError_t set_attr_n()
 {
-    if constexpr (!DMEL_FWD_SIZE(N)) return hipSuccess;
+    if constexpr (!DMEL_FWD_HERE(N)) return hipSuccess;
     else {
         static_assert(geom<N, true>().WAVES == geom<N, false>().WAVES && geom<N, true>().NBPRE == geom<N, false>().NBPRE,
                       "both plans of a size share the filterbank fragment layout");
@@ -1198,7 +1266,7 @@ template <int N> static hipError_t set_attr_n()
     }
 }
 
-hipError_t forward_prepare_attributes()
+hipError_t DMEL_CAT(forward_prepare_attributes_part, DMEL_FWD_PART)()
 {
     hipError_t e;
     if ((e = set_attr_n<32>()) != hipSuccess) return e;
@@ -1212,6 +1280,20 @@ hipError_t forward_prepare_attributes()
     if ((e = set_attr_n<8192>()) != hipSuccess) return e;
     return set_attr_n<16384>();
 }
+
+#if DMEL_FWD_PART == 0
+hipError_t forward_prepare_attributes()
+{
+    hipError_t e;
+    if ((e = forward_prepare_attributes_part0()) != hipSuccess) return e;
+#ifdef DMEL_FWD_PARTS
+    if ((e = forward_prepare_attributes_part1()) != hipSuccess) return e;
+    if ((e = forward_prepare_attributes_part2()) != hipSuccess) return e;
+    if ((e = forward_prepare_attributes_part3()) != hipSuccess) return e;
+#endif
+    return hipSuccess;
+}
+#endif
 
 }  // namespace dmel
 

@@ -162,6 +162,10 @@ template <int N, bool PAIR> struct FftPlanSel : FftPlan<N> {};
 template <> struct FftPlanSel<1024, true> { static constexpr int R = 16, C = 4, PASSES = 1, WAVES = 8, NBPRE = 20, MINW = 4, PAIRING = 0, SPLIT = 0; };
 constexpr bool mode_pairs(int mode) { return mode == kInfer || mode == kSpec; }
 
+// internal bit of FwdParams::flags (the public ones are DMEL_FLAG_* of include/dmel.h, the 0x100.. bits belong to -DDMEL_ABLATE builds):
+// the launch fits the chip in ONE round of resident workgroups, see dmel_fwd_kernel's prologue
+constexpr unsigned kFwdEdgeFirst = 0x40u;
+int forward_resident_workgroups(int n_fft, int mode);      // workgroups of this instantiation the device holds at once (LDS-limited)
 constexpr int kWinLdsMaxNfft = 4096;   // (the table in global memory at 4096: 184 us against 171 at the reference's ESC-50 shape)
 constexpr int kRedBytes = 160;         // 16 + 16 partial sums (one per wave), then the tangent scale (word 32) computed once per workgroup
 constexpr int kRedTan = 32;
