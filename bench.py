@@ -397,13 +397,26 @@ def main():
             chosen = order[int(pick.item())]
     elif chosen == "auto":
         chosen = "eager"
-    elapsed = run_mode(chosen, args.warmup, args.steps)                 # <- the timed region: W untimed, exactly K timed steps
+    # The timed region: W untimed steps, then EXACTLY K timed steps between barrier + synchronize on both sides, MAX over ranks.
+    # With the driver's small K such a region is one or two graph launches (well under a millisecond), so it is REPEATED: the
+    # first region is the one the contract describes (W warm-up steps before it), REGIONS - 1 more of exactly K steps follow,
+    # and `ms_per_step` / `value` are the MEDIAN region (min and max beside it) -- not the best one.
+    REGIONS = 11 if args.steps * 0.05 < 50.0 else 3                       # (long regions, > ~50 ms of steps: three)
+    regions = [run_mode(chosen, args.warmup, args.steps)]
+    for _ in range(REGIONS - 1):
+        regions.append(run_mode(chosen, 0, args.steps))
+    elapsed = sorted(regions)[len(regions) // 2]
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * frames_per_rank * args.steps / elapsed
     status = layer.lambd_status()
     lam_end = float(layer.lambd.detach())
     assert status["error"] == 0 and capi.n_fft(lam_end) == capi.n_fft(lam), (status, lam_end)
     module_step_info = {"issued": chosen, "optimizer": f"{opt_kind}, lr {ADAM_LR}", "lambd_end": round(lam_end, 4),
+                        "timed_regions": {"n": len(regions), "steps_each": args.steps, "reported": "median",
+                                          "ms_per_step_min": round(1e3 * min(regions) / args.steps, 5),
+                                          "ms_per_step_median": round(ms_per_step, 5),
+                                          "ms_per_step_max": round(1e3 * max(regions) / args.steps, 5),
+                                          "first_region_ms_per_step": round(1e3 * regions[0] / args.steps, 5)},
                         "trial_ms_per_step": {k: round(1e3 * v, 4) for k, v in trial.items()},
                         "guards_last_call": status["guards"], "graph_unavailable": graph_why or None,
                         "graph_captures": {m: modes[m][0].captures for m in modes if m != "eager"}}
@@ -419,6 +432,88 @@ def main():
             if m != chosen:
                 module_step_info[m.replace(" ", "_") + "_ms_per_step"] = round(1e3 * run_mode(m, 8, 80) / 80, 4)
         module_step_info[chosen.replace(" ", "_") + "_ms_per_step"] = round(ms_per_step, 4)
+
+    # ---- what a training loop would see (train.py:25-49: a NEW batch every step), side figures, never `value` ---------------
+    # loader_fed: INTEGRATION.md's loop -- one graph replay per step (k = 1), each preceded by a device-side copy of the next batch
+    # into the graph's static input (`x_static.copy_(batch)`); the batches come from a pool of POOL resident ones (> 256 MiB in
+    # total, so neither L2 nor the 256 MiB Infinity Cache holds the next one: the copy reads HBM).
+    # cold_inputs: the chosen issue mode with every step of a replay reading a DIFFERENT resident batch of that pool (no copy):
+    # the forward's first touch of x comes from HBM, not from the cache the previous step left.
+    if dist is None and not args.no_other_configs:
+        try:
+            POOL = 24 if B * L * 4 * 24 > (256 << 20) else max(24, (300 << 20) // (B * L * 4) + 1)
+            pool = [torch.from_numpy(synth.waveforms(B, L, seed=1000 + i)).to(dev) for i in range(POOL)]
+            layer4 = MelSpectrogramLayer(torch.tensor(lam), n_mels=M, n_points=L, sample_rate=sr, hop_length=hop, device=str(dev),
+                                         optimized=True, log=True, out_dtype=act).to(dev)
+            opt4 = torch.optim.Adam([layer4.lambd], lr=ADAM_LR, fused=True, capturable=True)
+            x_static = pool[0].clone()
+
+            def module_step4():
+                opt4.zero_grad(set_to_none=True)
+                layer4(x_static).backward(g)
+                opt4.step()
+
+            for _ in range(3):
+                module_step4()
+            torch.cuda.synchronize()
+            gs4 = GraphedStep(module_step4, [layer4], max_ahead=MAX_AHEAD, steps_per_replay=1) if chosen != "eager" else module_step4
+            it = [0]
+
+            def fed_step():
+                x_static.copy_(pool[it[0] % POOL], non_blocking=True)
+                it[0] += 1
+                gs4()
+
+            for _ in range(MAX_AHEAD + 4):
+                fed_step()
+            torch.cuda.synchronize()
+            nfed = 240
+            el4 = sorted(time_loop(fed_step, 8 if r == 0 else 0, nfed) for r in range(5))[2]
+            # the copy alone (same pool rotation), to separate it from the step
+            def copy_only():
+                x_static.copy_(pool[it[0] % POOL], non_blocking=True)
+                it[0] += 1
+            elc = sorted(time_loop(copy_only, 8 if r == 0 else 0, nfed) for r in range(3))[1]
+            assert layer4.lambd_status()["error"] == 0
+            module_step_info["loader_fed"] = {"ms_per_step": round(1e3 * el4 / nfed, 5), "frames_per_s": round(frames_per_rank * nfed / el4, 1),
+                                              "copy_alone_ms": round(1e3 * elc / nfed, 5), "steps": nfed, "pool_batches": POOL,
+                                              "pool_mib": round(POOL * B * L * 4 / 2**20, 1), "median_of": 5,
+                                              "issued": "graph (one step per replay) + x_static.copy_(next batch) per step" if chosen != "eager" else "eager + copy",
+                                              "note": "INTEGRATION.md's training loop (train.py:25-49): a new batch every step through a device-side "
+                                                      "copy into the graph's static input; side figure, never `value`"}
+            del gs4
+            # cold inputs, no copy: k steps per replay, step j of a replay reads pool[j]
+            kc = k_chosen if chosen != "eager" else 1
+            kc = max(kc, 20) if chosen != "eager" else 1
+            jt = [0]
+
+            def module_step5():
+                opt4.zero_grad(set_to_none=True)
+                layer4(pool[jt[0] % POOL]).backward(g)
+                jt[0] += 1
+                opt4.step()
+
+            if chosen != "eager":
+                jt[0] = 0
+                fn5 = GraphedStep(module_step5, [layer4], max_ahead=MAX_AHEAD, steps_per_replay=kc)
+                for _ in range(MAX_AHEAD + 4):
+                    fn5()
+            else:
+                fn5 = module_step5
+            torch.cuda.synchronize()
+            n5 = max(240, 12 * kc)
+            el5 = sorted(time_loop(fn5, 8 if r == 0 else 0, n5 // kc) for r in range(5))[2]
+            assert layer4.lambd_status()["error"] == 0
+            module_step_info["cold_inputs"] = {"ms_per_step": round(1e3 * el5 / (n5 // kc * kc), 5),
+                                               "frames_per_s": round(frames_per_rank * (n5 // kc * kc) / el5, 1),
+                                               "steps_per_replay": kc, "distinct_batches_per_replay": min(kc, POOL), "median_of": 5,
+                                               "note": "every step of a replay reads a different resident batch (pool > 256 MiB): no step finds its input "
+                                                       "in L2 / Infinity Cache; side figure, never `value`"}
+            del fn5, opt4, layer4, pool
+        except Exception as e:                                          # noqa: BLE001
+            module_step_info["loader_fed"] = module_step_info.get("loader_fed") or {"error": f"{type(e).__name__}: {e}"[:300]}
+            module_step_info.setdefault("cold_inputs", {"error": f"{type(e).__name__}: {e}"[:300]})
+        torch.cuda.empty_cache()
 
     # ---- side figure, never `value`: the same step with the opt-in dmel_amd.LambdAdam (torch.optim.Adam's update of lambd as
     # one launch instead of torch's two), issued the way the headline was
@@ -686,6 +781,22 @@ def other_configs(torch, capi, synth, dev, kernel_times):
 
     for name in ("c3", "c5"):
         res[name] = one(name, *CONFIGS[name])
+    # BASELINE config 4's GLOBAL batch (2048 x 16000 = 65 536 frames) on ONE GPU: the many-round regime of the same kernel (a launch
+    # of 8 rounds of resident workgroups: later rounds hide the launch / first-touch / drain of a one-round launch)
+    try:
+        B4 = 8 * CONFIGS["c2"][0]
+        r4 = one("c4_on_one_gpu", B4, *CONFIGS["c2"][1:])
+        r4["ns_per_frame_forward"] = round(1e3 * r4["kernels_us"]["fused_forward"] / r4["frames_per_step"], 4)
+        r4["ns_per_frame_step"] = round(1e3 * r4["step_us"] / r4["frames_per_step"], 4)
+        res["c4_on_one_gpu"] = r4
+    except Exception as e:                                              # noqa: BLE001
+        res["c4_on_one_gpu"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    # config 2 with COLD inputs: the same trains of launches, every forward reading another resident batch of a pool > 256 MiB
+    # (beyond L2 and the Infinity Cache), next to the warm figure (ONE batch replayed: it lives in cache)
+    try:
+        res["c2_cold"] = c2_cold(torch, capi, synth, dev)
+    except Exception as e:                                              # noqa: BLE001
+        res["c2_cold"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     # the shapes of the reference's own experiments (search_spaces.py:4-33 ESC-50, :36-66 Audio-MNIST: 8 kHz, hop 80, 64 mels,
     # init_lambd = 8000 x / 6 for x = 0.01, 0.035, 0.3 -> n_fft 128, 512, 4096) and one lambd the run may drift to (n_fft 8192)
     ref = {}
@@ -702,6 +813,44 @@ def other_configs(torch, capi, synth, dev, kernel_times):
     except Exception as e:                                              # noqa: BLE001
         res["c5"]["train_step"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     return res
+
+
+def c2_cold(torch, capi, synth, dev, pool_n=24, ntrain=120):
+    """Forward-kernel time at config 2 when x comes from HBM: trains of (forward(x_i) + dot) minus trains of the dot alone, x_i rotating
+    over `pool_n` resident batches (24 x 16.4 MB = 393 MB > the 256 MiB Infinity Cache), against the same trains on ONE batch."""
+    B, L, sr, lam, hop, M = CONFIGS["c2"]
+    T = L // hop + 1
+    cur = torch.cuda.current_stream(dev)
+    pool = [torch.from_numpy(synth.waveforms(B, L, seed=2000 + i)).to(dev) for i in range(pool_n)]
+    g = torch.from_numpy(synth.cotangent((B, 1, M, T), seed=9)).to(dev)
+    out, tan, dl = torch.empty((B, 1, M, T), device=dev), torch.empty((B, 1, M, T), device=dev), torch.zeros(1, device=dev)
+    plan = capi.Plan(L, hop, M, sr, max_batch=B)
+    n = out.numel()
+
+    def train(xs, with_fwd=True):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(cur)
+        for i in range(ntrain):
+            if with_fwd:
+                plan.forward(xs[i % len(xs)].data_ptr(), B, lam, out.data_ptr(), tan.data_ptr(), True, 1e-10, cur.cuda_stream)
+            plan.backward(g.data_ptr(), tan.data_ptr(), n, dl.data_ptr(), cur.cuda_stream)
+        ev1.record(cur)
+        torch.cuda.synchronize()
+        return 1e3 * ev0.elapsed_time(ev1) / ntrain
+
+    for _ in range(2):
+        train(pool)
+    dot = sorted(train(pool, False) for _ in range(3))[1]
+    cold = sorted(train(pool) for _ in range(5))[2]
+    warm = sorted(train(pool[:1]) for _ in range(5))[2]
+    alg = 4 * (B * L + 2 * B * M * T)
+    return {"pool_batches": pool_n, "pool_mib": round(pool_n * B * L * 4 / 2**20, 1),
+            "fused_forward_us_cold": round(cold - dot, 2), "fused_forward_us_warm": round(warm - dot, 2), "backward_dot_us": round(dot, 2),
+            "step_us_cold": round(cold, 2), "step_us_warm": round(warm, 2),
+            "frames_per_s_cold": round(B * T / (cold * 1e-6), 1), "frames_per_s_warm": round(B * T / (warm * 1e-6), 1),
+            "hbm_frac_cold": round(alg / ((cold - dot) * 1e-6) / (HBM_PEAK_GBS * 1e9), 4),
+            "note": "trains of forward + dot launches through the C ABI (median of 5); cold: x rotates over the pool so every forward reads "
+                    "its 16.4 MB from HBM; warm: one batch replayed (what the headline's resident batch sees)"}
 
 
 def c5_train_step(torch, synth, dev, steps=8):

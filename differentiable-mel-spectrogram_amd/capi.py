@@ -19,6 +19,7 @@ DMEL_ERR_HIP = 3
 DMEL_ERR_NO_DEVICE = 4
 DMEL_ERR_OUT_OF_MEMORY = 5
 DMEL_ERR_LAMBD_TRACKING = 6
+DMEL_ERR_MAILBOX_TIMEOUT = 7
 DMEL_FLAG_LOG = 1
 DMEL_FLAG_FULL_WINDOW = 2
 DMEL_FLAG_OUT_BF16 = 4
@@ -36,7 +37,7 @@ SYMBOLS = (
     "dmel_plan_lambd_status", "dmel_plan_set_tracking", "dmel_plan_lambd_reset",
     "dmel_plan_retain", "dmel_plan_release", "dmel_plan_lambd_report", "dmel_decide_launch", "dmel_plan_force_launch",
     "dmel_adam_step", "dmel_mailbox_create", "dmel_mailbox_connect", "dmel_mailbox_destroy", "dmel_mailbox_allreduce", "dmel_mailbox_error",
-    "dmel_mailbox_set_spin_limit", "dmel_plan_attach_mailbox", "dmel_backward_x_spec",
+    "dmel_mailbox_set_spin_limit", "dmel_mailbox_set_timeout_ms", "dmel_plan_is_live", "dmel_lambd_ring_size", "dmel_plan_attach_mailbox", "dmel_backward_x_spec",
 )
 TORCH_LIB_PATH = os.path.join(_PKG_DIR, "libdmel_torch.so")
 
@@ -184,6 +185,11 @@ def load():
     L.dmel_mailbox_error.restype = C.c_int
     L.dmel_mailbox_set_spin_limit.argtypes = [vp, C.c_uint32]
     L.dmel_mailbox_set_spin_limit.restype = C.c_int
+    L.dmel_lambd_ring_size.restype = C.c_int32
+    L.dmel_plan_is_live.argtypes = [vp]
+    L.dmel_plan_is_live.restype = C.c_int32
+    L.dmel_mailbox_set_timeout_ms.argtypes = [vp, C.c_uint64]
+    L.dmel_mailbox_set_timeout_ms.restype = C.c_int
     L.dmel_plan_attach_mailbox.argtypes = [vp, vp]
     L.dmel_plan_attach_mailbox.restype = C.c_int
     _lib = L
@@ -211,6 +217,16 @@ def torch_ops():
 def _check(status: int):
     if status != DMEL_OK:
         raise DmelError(status, (load().dmel_last_error() or b"").decode("utf-8", "replace"))
+
+
+def release_handle(handle: int) -> None:
+    """dmel_plan_release of a handle obtained from ``Plan.retain``"""
+    if handle:
+        load().dmel_plan_release(C.c_void_p(int(handle)))
+
+
+def lambd_ring_size() -> int:
+    return int(load().dmel_lambd_ring_size())
 
 
 def n_fft(lambd: float) -> int:
@@ -278,6 +294,15 @@ class Plan:
             self.close()
         except Exception:
             pass
+
+    def retain(self) -> int:
+        """dmel_plan_retain: one more reference; returns the raw handle to give to ``release_handle`` later (it stays valid after
+        this wrapper is gone: what a captured HIP graph needs)"""
+        _check(load().dmel_plan_retain(self._h))
+        return int(self._h.value)
+
+    def is_live(self) -> bool:
+        return bool(self._h.value) and bool(load().dmel_plan_is_live(self._h))
 
     def __deepcopy__(self, memo):
         raise TypeError("a dmel plan is a cache of device tables bound to one GPU: copy the layer, not the plan")
@@ -479,11 +504,17 @@ class Mailbox:
         return (int(step.value), int(miss.value)) if failed.value else None
 
     def set_spin_limit(self, polls: int) -> None:
+        """polls per source rank before an exchange gives up; 0 = no limit on the count (the wall-clock bound holds)"""
         _check(load().dmel_mailbox_set_spin_limit(self._h, int(polls)))
 
+    def set_timeout_ms(self, ms: int) -> None:
+        """wall-clock bound of one exchange (default 120 000 ms; 0 = wait for ever)"""
+        _check(load().dmel_mailbox_set_timeout_ms(self._h, C.c_uint64(int(ms))))
+
     def close(self):
+        """raises while a plan still holds the mailbox (detach or release the plans first: MailboxAllReduce.close does)"""
         if getattr(self, "_h", None) is not None and self._h.value:
-            load().dmel_mailbox_destroy(self._h)
+            _check(load().dmel_mailbox_destroy(self._h))
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -14,6 +14,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 namespace {
@@ -31,6 +32,8 @@ namespace dmel {
 dmel_status set_error(dmel_status st, const std::string& msg) { return fail(st, msg); }   // for dmel_comm.cpp
 bool mailbox_args(const dmel_mailbox* mb, MailboxArgs* out);                              // dmel_comm.cpp
 int mailbox_device(const dmel_mailbox* mb);
+void mailbox_attach_count(dmel_mailbox* mb, int delta);
+unsigned long long mailbox_peek_error(const dmel_mailbox* mb);
 }
 
 namespace {
@@ -638,6 +641,16 @@ dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dm
     return DMEL_OK;
 }
 
+// An exchange of the plan's mailbox that gave up on a rank left NaN in lambd.grad on the ranks that waited: every later call on
+// the plan says so (one pinned word read, no synchronisation) until dmel_mailbox_error has read and cleared the word.
+dmel_status mailbox_status(const dmel_plan* pl)
+{
+    const unsigned long long w = dmel::mailbox_peek_error(pl->mailbox);
+    if (w == 0) return DMEL_OK;
+    return fail(DMEL_ERR_MAILBOX_TIMEOUT, "mailbox all-reduce: rank " + std::to_string((unsigned)(w & 0xffffffffu)) + " never arrived at exchange " +
+                std::to_string((unsigned)(w >> 32)) + ": the reduced gradient of that step was NaN on this rank (dmel_mailbox_error clears this)");
+}
+
 // a plan's tables and scratch live on the device it was created on: launching from a thread whose current device is another
 // one would run the kernels there, on pointers that mean nothing there
 dmel_status check_device(const dmel_plan* pl)
@@ -656,6 +669,7 @@ dmel_status check_forward_args(dmel_plan* pl, const float* x, int batch, const v
     if (batch < 0) return fail(DMEL_ERR_INVALID_ARGUMENT, "batch < 0");
     if (batch > 0 && (!x || !out)) return fail(DMEL_ERR_INVALID_ARGUMENT, "x / out is NULL");
     if (batch > 65534) return fail(DMEL_ERR_INVALID_ARGUMENT, "batch > 65534 (split the call)");
+    if (pl->mailbox) { dmel_status ms = mailbox_status(pl); if (ms != DMEL_OK) return ms; }
     return check_device(pl);
 }
 
@@ -763,7 +777,8 @@ bool lam_observe(dmel_plan* pl)
     return true;
 }
 
-std::mutex g_plans_mu;             // guards dmel_plan::refs
+std::mutex g_plans_mu;             // guards dmel_plan::refs and g_live_plans
+std::unordered_set<const dmel_plan*> g_live_plans;     // every plan between dmel_plan_create and its last release (dmel_plan_is_live)
 
 }  // namespace
 
@@ -886,14 +901,28 @@ dmel_status dmel_plan_create(const dmel_config* cfg, dmel_plan** plan)
         dmel_status st = ensure_own_scratch(pl, std::max(1, cfg->max_batch), nullptr, &sc);
         if (st != DMEL_OK) { dmel_plan_destroy(pl); return st; }
     }
+    {
+        std::lock_guard<std::mutex> lock(g_plans_mu);
+        g_live_plans.insert(pl);
+    }
     *plan = pl;
     return DMEL_OK;
+}
+
+int32_t dmel_lambd_ring_size(void) { return (int32_t)dmel::kLamRing; }
+
+int32_t dmel_plan_is_live(const dmel_plan* plan)
+{
+    if (!plan) return 0;
+    std::lock_guard<std::mutex> lock(g_plans_mu);
+    return g_live_plans.count(plan) ? 1 : 0;
 }
 
 dmel_status dmel_plan_retain(dmel_plan* plan)
 {
     if (!plan) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
     std::lock_guard<std::mutex> lock(g_plans_mu);
+    if (!g_live_plans.count(plan)) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_plan_retain: not a live plan (destroyed, or never created)");
     if (plan->refs < 1) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_plan_retain: the plan has been destroyed");
     ++plan->refs;
     return DMEL_OK;
@@ -905,12 +934,15 @@ dmel_status dmel_plan_release(dmel_plan* plan)
     {
         std::lock_guard<std::mutex> lock(g_plans_mu);
         if (--plan->refs > 0) return DMEL_OK;
+        g_live_plans.erase(plan);          // from here on dmel_plan_is_live says no: a stale integer handle is refused, not dereferenced
     }
     // the last holder is gone.  Work that still reads the tables or writes the report words may be queued (a backward of a
     // graph that outlived its layer, the last launches of a loop): let the device finish before the memory goes away
     int cur = -1;
     const bool switched = hipGetDevice(&cur) == hipSuccess && cur != plan->device && hipSetDevice(plan->device) == hipSuccess;
     (void)hipDeviceSynchronize();
+    dmel::mailbox_attach_count(plan->mailbox, -1);       // after the synchronisation: no queued dot kernel of this plan polls it any more
+    plan->mailbox = nullptr;
     for (auto& kv : plan->tables) kv.second.release();
     for (hipEvent_t e : plan->ev_pool) (void)hipEventDestroy(e);
     (void)hipFree(plan->own_scratch); (void)hipFree(plan->fbw);
@@ -1257,6 +1289,7 @@ dmel_status dmel_backward_scratch(dmel_plan* plan, const void* grad_out, int32_t
     dmel::MailboxArgs mba;
     const bool use_mb = plan->mailbox != nullptr;
     if (use_mb && !dmel::mailbox_args(plan->mailbox, &mba)) return fail(DMEL_ERR_INVALID_ARGUMENT, "the plan's mailbox is not connected");
+    if (use_mb) { dmel_status ms = mailbox_status(plan); if (ms != DMEL_OK) return ms; }
     const size_t m0 = prof_mark(plan, s);
     DMEL_HIP(dmel::launch_dot(grad_out, grad_dtype == DMEL_DTYPE_BF16, tangent, (long long)count, accumulate, sc.partials,
                               sc.counter, kMaxPartials, dlambd, s, use_mb ? &mba : nullptr));
@@ -1269,6 +1302,9 @@ dmel_status dmel_plan_attach_mailbox(dmel_plan* plan, dmel_mailbox* mb)
     if (!plan) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
     if (mb && dmel::mailbox_device(mb) != plan->device) return fail(DMEL_ERR_INVALID_ARGUMENT, "the mailbox and the plan live on different devices");
     std::lock_guard<std::mutex> lock(plan->mu);
+    if (plan->mailbox == mb) return DMEL_OK;
+    dmel::mailbox_attach_count(plan->mailbox, -1);       // the mailbox counts its plans: dmel_mailbox_destroy refuses while any holds it
+    dmel::mailbox_attach_count(mb, +1);
     plan->mailbox = mb;
     return DMEL_OK;
 }
@@ -1493,8 +1529,10 @@ dmel_status dmel_adam_step(float* param, const float* grad, float* exp_avg, floa
 {
     if (!param || !grad || !exp_avg || !exp_avg_sq || !step) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_adam_step: NULL pointer");
     if (n < 0 || n > (1LL << 31)) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_adam_step: n out of range");
-    if (!(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0) || !std::isfinite(lr))
-        return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_adam_step: lr / betas / eps out of range");
+    // the same ranges torch.optim.Adam and dmel_amd.LambdAdam accept
+    if (!(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0) || !std::isfinite(lr) || !(lr >= 0.0) ||
+        !std::isfinite(weight_decay) || !(weight_decay >= 0.0))
+        return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_adam_step: lr / betas / eps / weight_decay out of range");
     if (n == 0) return DMEL_OK;
     if (!ticket && dmel::adam_grid(n) > 1) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_adam_step: more than 1024 elements need the ticket word");
     dmel::AdamParams ap{};

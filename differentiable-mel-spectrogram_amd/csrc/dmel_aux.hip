@@ -74,14 +74,17 @@ __device__ __forceinline__ float mailbox_exchange(const MailboxArgs& mb, float l
         __hip_atomic_store(mb.peer_inbox[r] + par + mb.rank, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     float sum = 0.f;
     bool ok = true;
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();       // 100 MHz, does not change with the shader clock
     for (int r = 0; r < mb.world; ++r) {
         unsigned long long w = 0;
         unsigned spins = 0;
         for (;;) {
             w = __hip_atomic_load(mb.my_inbox + par + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if ((unsigned)(w >> 32) == step) break;
-            if (++spins >= mb.spin_limit) { ok = false; break; }
-            __builtin_amdgcn_s_sleep(2);
+            ++spins;
+            if (mb.spin_limit && spins >= mb.spin_limit) { ok = false; break; }
+            if (mb.timeout_ticks && (spins & 63u) == 0u && __builtin_amdgcn_s_memrealtime() - t_start >= mb.timeout_ticks) { ok = false; break; }
+            if (spins < 4096u) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(32);   // a long wait polls less often
         }
         if (!ok) {
             if (mb.host_error)

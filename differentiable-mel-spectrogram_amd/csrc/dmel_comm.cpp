@@ -15,6 +15,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -179,8 +180,18 @@ struct dmel_mailbox {
     void* peer[DMEL_MAILBOX_MAX_WORLD] = {};    // mapped inboxes (peer[rank] == inbox)
     bool opened[DMEL_MAILBOX_MAX_WORLD] = {};
     bool connected = false;
-    unsigned spin_limit = 1u << 21;
+    unsigned spin_limit = 0;                                  // 0: the wall-clock bound alone
+    unsigned long long timeout_ticks = 120ull * 100000000ull; // 120 s of the 100 MHz s_memrealtime clock
+    int attached = 0;                                         // plans that hold this mailbox (guarded by g_mb_mu)
+    uint8_t handle[DMEL_MAILBOX_HANDLE_BYTES] = {};
 };
+
+namespace {
+// mailboxes created by this process: a handle exported here cannot be opened here (hipIpcOpenMemHandle refuses), so ranks of one
+// process find each other's inbox through this list
+std::mutex g_mb_mu;
+std::vector<dmel_mailbox*> g_mailboxes;
+}
 
 namespace dmel {
 // what dmel_api.cpp needs to launch the dot kernel with the exchange in its tail
@@ -190,11 +201,22 @@ bool mailbox_args(const dmel_mailbox* mb, MailboxArgs* out)
     MailboxArgs a{};
     for (int r = 0; r < mb->world; ++r) a.peer_inbox[r] = static_cast<unsigned long long*>(mb->peer[r]);
     a.my_inbox = mb->inbox; a.step = mb->step; a.host_error = mb->host_error;
-    a.rank = mb->rank; a.world = mb->world; a.spin_limit = mb->spin_limit;
+    a.rank = mb->rank; a.world = mb->world; a.spin_limit = mb->spin_limit; a.timeout_ticks = mb->timeout_ticks;
     *out = a;
     return true;
 }
 int mailbox_device(const dmel_mailbox* mb) { return mb ? mb->device : -1; }
+void mailbox_attach_count(dmel_mailbox* mb, int delta)
+{
+    if (!mb) return;
+    std::lock_guard<std::mutex> lock(g_mb_mu);
+    mb->attached += delta;
+}
+// non-zero: (step << 32) | missing rank of an exchange that timed out (the word stays: dmel_mailbox_error clears it)
+unsigned long long mailbox_peek_error(const dmel_mailbox* mb)
+{
+    return (mb && mb->host_error) ? __atomic_load_n(mb->host_error, __ATOMIC_RELAXED) : 0ull;
+}
 }  // namespace dmel
 
 extern "C" {
@@ -242,6 +264,11 @@ dmel_status dmel_mailbox_create(int32_t rank, int32_t world, dmel_mailbox** out,
         return dmel::set_error(DMEL_ERR_HIP, msg);
     }
     std::memcpy(handle, &h, sizeof(h));
+    std::memcpy(mb->handle, &h, sizeof(h));
+    {
+        std::lock_guard<std::mutex> lock(g_mb_mu);
+        g_mailboxes.push_back(mb);
+    }
     *out = mb;
     return DMEL_OK;
 }
@@ -254,6 +281,31 @@ dmel_status dmel_mailbox_connect(dmel_mailbox* mb, const uint8_t* handles)
         if (r == mb->rank) { mb->peer[r] = mb->inbox; continue; }
         hipIpcMemHandle_t h;
         std::memcpy(&h, handles + (size_t)r * DMEL_MAILBOX_HANDLE_BYTES, sizeof(h));
+        {
+            // a rank of this very process: its pointer is used directly (peer access between the two devices enabled first)
+            dmel_mailbox* local = nullptr;
+            {
+                std::lock_guard<std::mutex> lock(g_mb_mu);
+                for (dmel_mailbox* o : g_mailboxes)
+                    if (o != mb && o->world == mb->world && o->rank == r && std::memcmp(o->handle, &h, sizeof(h)) == 0) { local = o; break; }
+            }
+            if (local) {
+                if (local->device != mb->device) {
+                    int cur = -1;
+                    (void)hipGetDevice(&cur);
+                    hipError_t pe = hipSetDevice(mb->device);
+                    if (pe == hipSuccess) pe = hipDeviceEnablePeerAccess(local->device, 0);
+                    if (pe == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); pe = hipSuccess; }
+                    if (cur >= 0) (void)hipSetDevice(cur);
+                    if (pe != hipSuccess) {
+                        (void)hipGetLastError();
+                        return dmel::set_error(DMEL_ERR_HIP, "dmel_mailbox_connect: peer access to the device of rank " + std::to_string(r) + ": " + hipGetErrorString(pe));
+                    }
+                }
+                mb->peer[r] = local->inbox;
+                continue;
+            }
+        }
         void* p = nullptr;
         const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
         if (e != hipSuccess) {
@@ -269,10 +321,22 @@ dmel_status dmel_mailbox_connect(dmel_mailbox* mb, const uint8_t* handles)
 dmel_status dmel_mailbox_destroy(dmel_mailbox* mb)
 {
     if (!mb) return DMEL_OK;
+    {
+        std::lock_guard<std::mutex> lock(g_mb_mu);
+        if (mb->attached > 0)
+            return dmel::set_error(DMEL_ERR_INVALID_ARGUMENT, "dmel_mailbox_destroy: still attached to " + std::to_string(mb->attached) +
+                                   " plan(s) (dmel_plan_attach_mailbox(plan, NULL) or release them first): their next backward would use freed memory");
+        for (size_t i = 0; i < g_mailboxes.size(); ++i)
+            if (g_mailboxes[i] == mb) { g_mailboxes.erase(g_mailboxes.begin() + (long)i); break; }
+    }
+    // queued kernels may still poll the inbox: the mailbox's OWN device is drained, whichever device is current
+    int cur = -1;
+    const bool switched = hipGetDevice(&cur) == hipSuccess && cur != mb->device && hipSetDevice(mb->device) == hipSuccess;
     (void)hipDeviceSynchronize();
     for (int r = 0; r < mb->world; ++r) if (mb->opened[r]) (void)hipIpcCloseMemHandle(mb->peer[r]);
     (void)hipFree(mb->inbox); (void)hipFree(mb->step);
     if (mb->host_error) (void)hipHostFree(mb->host_error);
+    if (switched) (void)hipSetDevice(cur);
     (void)hipGetLastError();
     delete mb;
     return DMEL_OK;
@@ -298,8 +362,16 @@ dmel_status dmel_mailbox_error(dmel_mailbox* mb, int32_t* failed, uint32_t* step
 
 dmel_status dmel_mailbox_set_spin_limit(dmel_mailbox* mb, uint32_t polls)
 {
-    if (!mb || polls == 0) return dmel::set_error(DMEL_ERR_INVALID_ARGUMENT, "dmel_mailbox_set_spin_limit: bad arguments");
+    if (!mb) return dmel::set_error(DMEL_ERR_INVALID_ARGUMENT, "dmel_mailbox_set_spin_limit: mailbox is NULL");
     mb->spin_limit = polls;
+    return DMEL_OK;
+}
+
+dmel_status dmel_mailbox_set_timeout_ms(dmel_mailbox* mb, uint64_t milliseconds)
+{
+    if (!mb) return dmel::set_error(DMEL_ERR_INVALID_ARGUMENT, "dmel_mailbox_set_timeout_ms: mailbox is NULL");
+    if (milliseconds > (1ull << 40)) return dmel::set_error(DMEL_ERR_INVALID_ARGUMENT, "dmel_mailbox_set_timeout_ms: out of range");
+    mb->timeout_ticks = milliseconds * 100000ull;             // 100 MHz
     return DMEL_OK;
 }
 

@@ -281,7 +281,11 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
             if (p.flags & 0x2000u) inside[ti][pass] = true;      // timing only: no edge path (edge frames come out wrong)
 #endif
             const int sA = f0 + lg;
-            if (inside[ti][pass]) {
+            bool plain_loads = inside[ti][pass];
+#ifdef DMEL_ABLATE
+            if (p.flags & 0x4000u) plain_loads = true;           // timing only: unclamped loads, selects kept
+#endif
+            if (plain_loads) {
                 static_for<0, R>([&](auto aa) {
                     constexpr int a = decltype(aa)::value;
                     xa[ti][pass][a] = buf_f32(rx, (sA + G * a) * 4);
@@ -435,7 +439,11 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
             constexpr int KB = 8;
             if ((reinterpret_cast<uintptr_t>(xc) & 15) == 0) {
                 const float4* x4 = reinterpret_cast<const float4*>(xc);
+#ifdef DMEL_ABLATE
+                const int n4 = (p.flags & 0x40000u) ? p.L / 8 : ((p.flags & 0x80000u) ? p.L / 16 : p.L / 4);   // timing only: part of the clip
+#else
                 const int n4 = p.L / 4;
+#endif
                 for (int base = 0; base < n4; base += THREADS * KB) {
                     float4 v[KB];
                     static_for<0, KB>([&](auto jj) {
@@ -516,7 +524,10 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
                 const int f0 = tA * p.hop - N / 2;                       // first sample of frame tA
                 const int f1 = PAIR ? f0 + p.hop : f0;
                 // zero padding of torch.stft(center=True, pad_mode='constant') applies AFTER the DC removal
-                const bool inside_w = inside[ti][pass];
+                bool inside_w = inside[ti][pass];
+#ifdef DMEL_ABLATE
+                if (p.flags & 0x20000u) inside_w = true;          // timing only: clamped loads kept, no selects
+#endif
                 v2f z[R];
                 // window entries of this lane: one base register + compile-time offsets (ds_read_b64 offset:512a)
                 int wbyte = (WIN_LDS ? g.AUX_OFF : 0) + lg * 8;

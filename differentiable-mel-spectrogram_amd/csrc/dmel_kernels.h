@@ -30,7 +30,7 @@ constexpr unsigned kLamFirst = 1u, kLamLast = 2u, kLamQuiet = 4u;   // quiet: re
 // counts executions, not host calls: a forward replayed from a HIP graph draws a fresh one at every replay, so the host can
 // tell a replay's report from an older eager call's, and can look up the report of one particular execution (what a
 // multi-rank caller needs to take the same decision on every rank).
-constexpr unsigned kLamRing = 64;
+constexpr unsigned kLamRing = 256;     // (64 until round 4: nine replays of twenty steps in flight overran it -- dmel_lambd_ring_size)
 struct LamArgs {
     const float* dev;                 // device scalar (nullptr: use val)
     float val;                        // lambd by value (dmel_forward: the host read it, as the reference does)
@@ -375,8 +375,10 @@ hipError_t launch_adam(const AdamParams& p, hipStream_t s);
 // that draws the last ticket stores (step, local sum) as ONE 8-byte granule into slot `rank` of every rank's inbox -- peer memory
 // mapped over xGMI, system-scope stores -- then polls its own inbox until every rank's granule of this step has arrived and adds
 // them in rank order (the same fp32 sum on every rank).  Two slots per source, by step parity: a rank cannot be two steps ahead
-// of another (it needs the other's granule of step k + 1, written only after that rank has read step k).  Every spin is bounded:
-// a peer that never arrives yields NaN and raises a pinned error word instead of hanging the device.
+// of another (it needs the other's granule of step k + 1, written only after that rank has read step k).  Every spin is bounded
+// by WALL-CLOCK time (s_memrealtime; default 120 s: a straggler -- a checkpoint, an evaluation pass, a data-loader stall on one
+// rank -- is waited for, as RCCL would) and optionally by a poll count: a peer that never arrives yields NaN and raises a sticky
+// pinned error word, which the next call on the plan reports (DMEL_ERR_MAILBOX_TIMEOUT), instead of hanging the device.
 constexpr int kMailboxMaxWorld = 16;
 struct MailboxArgs {
     unsigned long long* peer_inbox[kMailboxMaxWorld];   // inbox of every rank as seen from this device ([2][world] granules each)
@@ -384,7 +386,8 @@ struct MailboxArgs {
     unsigned* step;                   // device word: reduce steps done so far on this rank (identical on all ranks)
     unsigned long long* host_error;   // pinned: (step << 32) | rank that was missing, or nullptr
     int rank, world;
-    unsigned spin_limit;              // polls per source before giving up
+    unsigned spin_limit;              // polls per source before giving up; 0 = no limit on the count (the wall-clock bound below holds)
+    unsigned long long timeout_ticks; // s_memrealtime ticks (100 MHz, constant) one exchange may wait in total; 0 = no wall-clock bound
 };
 
 // g: fp32, or bf16 when g_bf16 != 0 (the gradient of a bf16 output); t (the tangent) is always fp32

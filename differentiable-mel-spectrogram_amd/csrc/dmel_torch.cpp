@@ -27,7 +27,10 @@ namespace {
 inline dmel_plan* as_plan(int64_t h)
 {
     TORCH_CHECK(h != 0, "dmel: plan handle is 0 (closed or never created)");
-    return reinterpret_cast<dmel_plan*>(static_cast<intptr_t>(h));
+    dmel_plan* p = reinterpret_cast<dmel_plan*>(static_cast<intptr_t>(h));
+    // the handle travels as an integer: refuse anything that is not a live plan of this process instead of dereferencing it
+    TORCH_CHECK(dmel_plan_is_live(p) == 1, "dmel: ", h, " is not the handle of a live plan (destroyed, or not a plan at all)");
+    return p;
 }
 
 inline void check(dmel_status st)

@@ -132,6 +132,7 @@ class MailboxAllReduce:
         from . import capi
         self.group = group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self._plans = []
         err, self.mailbox = "", None
         try:
             self.mailbox = capi.Mailbox(self.rank, self.world)
@@ -155,22 +156,40 @@ class MailboxAllReduce:
     def attach(self, layer, device) -> None:
         """``layer``: a MelSpectrogramLayer (its plan for ``device`` is created if needed)."""
         import torch as _t
-        layer._plan_for(_t.device(device)).attach_mailbox(self.mailbox)
+        plan = layer._plan_for(_t.device(device))
+        plan.attach_mailbox(self.mailbox)
+        if not any(p is plan for p in self._plans):
+            self._plans.append(plan)
 
     def detach(self, layer, device) -> None:
         import torch as _t
-        layer._plan_for(_t.device(device)).attach_mailbox(None)
+        plan = layer._plan_for(_t.device(device))
+        plan.attach_mailbox(None)
+        self._plans = [p for p in self._plans if p is not plan]
 
     def reduce(self, grad: torch.Tensor, stream: int) -> None:
         """For gradients that did not come out of an attached layer: grad[0] = sum over ranks (one tiny launch in ``stream``)."""
         self.mailbox.allreduce(grad.data_ptr(), stream)
 
     def check(self) -> None:
+        """Raises if an exchange gave up on a rank since the last call (and clears the error).  Not mandatory: the next forward /
+        backward through an attached layer raises ``DmelError`` (DMEL_ERR_MAILBOX_TIMEOUT) by itself until this has been called."""
         e = self.mailbox.error() if self.mailbox is not None else None
         if e is not None:
             raise RuntimeError(f"mailbox all-reduce: rank {e[1]} never arrived at exchange {e[0]} (the result was NaN)")
 
+    def set_timeout(self, seconds: float) -> None:
+        """wall-clock bound of one exchange (default 120 s; 0 = wait for ever, as RCCL does)"""
+        self.mailbox.set_timeout_ms(int(round(1e3 * float(seconds))))
+
     def close(self):
+        """detaches every plan this object attached (their next backward is local again), then frees the mailbox"""
         if self.mailbox is not None:
+            for plan in self._plans:
+                try:
+                    plan.attach_mailbox(None)
+                except Exception:      # noqa: BLE001 -- a plan that is already gone has detached itself
+                    pass
+            self._plans = []
             self.mailbox.close()
             self.mailbox = None

@@ -25,11 +25,44 @@ class LambdAdam(torch.optim.Optimizer):
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0, maximize: bool = False):
         if lr < 0.0 or eps < 0.0 or not (0.0 <= betas[0] < 1.0) or not (0.0 <= betas[1] < 1.0) or weight_decay < 0.0:
             raise ValueError("LambdAdam: lr / betas / eps / weight_decay out of range")
-        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, maximize=maximize))
+        # capturable=True: torch's Optimizer.load_state_dict then moves state["step"] to the parameter's device as fp32 (its
+        # _process_value_according_to_param_policy); without the key a checkpoint loaded with map_location="cpu" left the step count
+        # on the host and step() handed a host pointer to the kernel
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, maximize=maximize, capturable=True))
+        self._tickets = {}        # id(param) -> int32 device word re-armed by every launch: private, neither saved nor cast by load_state_dict
         for group in self.param_groups:
             for p in group["params"]:
                 if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous():
                     raise ValueError("LambdAdam takes contiguous fp32 CUDA parameters (the layer's lambd and mel_fb); use torch.optim for the rest")
+
+    def _ticket(self, p):
+        t = self._tickets.get(id(p))
+        if t is None or t.device != p.device:
+            t = self._tickets[id(p)] = torch.zeros((), dtype=torch.int32, device=p.device)
+        return t
+
+    def _checked_state(self, p):
+        """the parameter's state, created on first use; whatever load_state_dict left is validated (and repaired where that is exact)
+        before a pointer of it reaches the kernel"""
+        st = self.state[p]
+        st.pop("ticket", None)                           # checkpoints written by round 3 carried the ticket word: drop it
+        if "step" not in st:
+            st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            return st
+        step = st["step"]
+        if not torch.is_tensor(step):
+            step = torch.tensor(float(step), dtype=torch.float32)
+        if step.device != p.device or step.dtype != torch.float32 or step.dim() != 0:
+            st["step"] = step.detach().to(device=p.device, dtype=torch.float32).reshape(())
+        for key in ("exp_avg", "exp_avg_sq"):
+            m = st.get(key)
+            if m is None or m.shape != p.shape:
+                raise RuntimeError(f"LambdAdam: state['{key}'] is missing or does not have the parameter's shape")
+            if m.device != p.device or m.dtype != torch.float32 or not m.is_contiguous():
+                st[key] = m.detach().to(device=p.device, dtype=torch.float32).contiguous()
+        return st
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -45,14 +78,9 @@ class LambdAdam(torch.optim.Optimizer):
                 g = p.grad
                 if g.dtype != torch.float32 or not g.is_contiguous() or g.device != p.device:
                     raise RuntimeError("LambdAdam: the gradient must be a contiguous fp32 tensor on the parameter's device")
-                st = self.state[p]
-                if not st:
-                    st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["ticket"] = torch.zeros((), dtype=torch.int32, device=p.device)       # re-armed by every launch
+                st = self._checked_state(p)
                 with torch.cuda.device(p.device):
                     capi.adam_step(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr(),
-                                   st["ticket"].data_ptr(), p.numel(), group["lr"], b1, b2, group["eps"], group["weight_decay"], group["maximize"],
+                                   self._ticket(p).data_ptr(), p.numel(), group["lr"], b1, b2, group["eps"], group["weight_decay"], group["maximize"],
                                    torch.cuda.current_stream(p.device).cuda_stream)
         return loss

@@ -38,7 +38,9 @@ typedef enum dmel_status {
     DMEL_ERR_HIP = 3,               /* a HIP runtime call failed (message has the detail) */
     DMEL_ERR_NO_DEVICE = 4,         /* no gfx950 device visible                           */
     DMEL_ERR_OUT_OF_MEMORY = 5,
-    DMEL_ERR_LAMBD_TRACKING = 6     /* dmel_forward_dev: lambd changed n_fft faster than the sync-free path covers   */
+    DMEL_ERR_LAMBD_TRACKING = 6,    /* dmel_forward_dev: lambd changed n_fft faster than the sync-free path covers   */
+    DMEL_ERR_MAILBOX_TIMEOUT = 7    /* an exchange of the plan's mailbox gave up on a rank (the gradient it returned was NaN): reported by
+                                       the next forward / backward on the plan, sticky until dmel_mailbox_error reads it */
 } dmel_status;
 
 /* Constructor arguments of the layer: models.py:15-30 (MelSpectrogramLayer.__init__). */
@@ -96,10 +98,18 @@ dmel_status dmel_plan_create(const dmel_config* cfg, dmel_plan** plan);
  * and the plan is freed -- after the device has finished what was queued on it -- when the last one goes.  Whoever keeps a
  * dmel_plan* beyond the owner's lifetime takes a reference: the autograd node of torch.ops.dmel.mel_spectrogram does, so
  * `y = layer(x); del layer; y.backward(g)` is safe (a plain torch module, models.py:33-56, has no such hazard either).
- * A HIP graph that captured launches of a plan does NOT hold one: keep the layer (or a reference) while the graph lives. */
+ * A HIP graph that captured launches of a plan does NOT hold one by itself: keep the layer, or take a reference for the life of the
+ * graph (dmel_amd.GraphedStep does: it retains the plans of its layers at every capture and releases them when the graph goes). */
 dmel_status dmel_plan_destroy(dmel_plan* plan);
 dmel_status dmel_plan_retain(dmel_plan* plan);
 dmel_status dmel_plan_release(dmel_plan* plan);
+/* 1 while `plan` is a plan of this process between dmel_plan_create and its last release, 0 for anything else (never dereferences
+ * the pointer: a registry lookup).  Bindings that pass plans as integers (torch.ops.dmel.*) check this before every use. */
+int32_t dmel_plan_is_live(const dmel_plan* plan);
+/* depth of the pinned ring the executed forwards of a plan report into (dmel_plan_lambd_report finds execution `number` while fewer
+ * than this many later ones have executed): whoever looks reports up late -- dmel_amd.GraphedStep, (max_ahead + 1) replays of
+ * `steps_per_replay` forwards behind -- keeps that distance below it */
+int32_t dmel_lambd_ring_size(void);
 dmel_status dmel_plan_get_config(const dmel_plan* plan, dmel_config* cfg);
 
 /* Replace the mel filterbank of the plan by a caller-supplied (n_freqs, n_mels) fp32 HOST matrix for
@@ -306,14 +316,20 @@ dmel_status dmel_comm_wait(dmel_comm* comm, int32_t ticket, void* stream);
  * ~35 us step (the optimizer update needs the reduced gradient).  With a mailbox the workgroup of dmel_backward's dot kernel
  * that finishes last stores (step, local sum) as one 8-byte granule straight into every rank's inbox (peer memory over xGMI,
  * system-scope stores), polls its own inbox for the other ranks' granules of the same step and adds them in rank order: no
- * extra launch, no ring, the same fp32 result on every rank.  Opt-in; RCCL (dmel_comm_*) stays the default.  Every spin is
- * bounded: a rank that never arrives makes the result NaN and raises the error word instead of hanging the device.
+ * extra launch, no ring, the same fp32 result on every rank.  Opt-in; RCCL (dmel_comm_*) stays the default.  Every wait is
+ * bounded by wall-clock time (default 120 s, dmel_mailbox_set_timeout_ms): an ordinary straggler is waited for; a rank that never
+ * arrives makes the result NaN on the ranks that waited and raises a sticky error word, and the NEXT dmel_forward* / dmel_backward*
+ * on a plan the mailbox is attached to returns DMEL_ERR_MAILBOX_TIMEOUT (until dmel_mailbox_error has read the word) instead of
+ * hanging the device.
  *   1. every rank: dmel_mailbox_create (allocates its inbox on the current device, returns a 64-byte IPC handle)
  *   2. the handles of all ranks, in rank order, travel by any means (dmel_amd.dist uses torch.distributed) to
- *      dmel_mailbox_connect, which maps the peers' inboxes (hipIpcOpenMemHandle; ranks of one process: pass the handle, the
- *      pointer is used directly)
+ *      dmel_mailbox_connect, which maps the peers' inboxes (hipIpcOpenMemHandle; a handle created by THIS process -- several
+ *      ranks of one process, one per device -- is looked up in a process-local registry and its pointer used directly, with
+ *      peer access enabled between the two devices)
  *   3. dmel_plan_attach_mailbox(plan, mb): from then on dmel_backward / dmel_backward_scratch on that plan return the SUM over
- *      ranks (every rank must call them the same number of times, as with any collective); mb = NULL detaches.
+ *      ranks (every rank must call them the same number of times, as with any collective); mb = NULL detaches.  The mailbox
+ *      counts the plans it is attached to: dmel_mailbox_destroy refuses while that count is not zero (a plan that is released
+ *      detaches itself).
  *      dmel_mailbox_allreduce does the same exchange for a value already in memory (one tiny launch on `stream`). */
 #define DMEL_MAILBOX_HANDLE_BYTES 64
 #define DMEL_MAILBOX_MAX_WORLD 16
@@ -324,8 +340,10 @@ dmel_status dmel_mailbox_destroy(dmel_mailbox* mb);
 dmel_status dmel_mailbox_allreduce(dmel_mailbox* mb, float* buf, void* stream);
 /* 0 = no exchange has timed out; otherwise *step / *missing_rank name the first one that did (sticky until read) */
 dmel_status dmel_mailbox_error(dmel_mailbox* mb, int32_t* failed, uint32_t* step, int32_t* missing_rank);
-/* polls per source rank before an exchange gives up (default 1 << 21, a few seconds) */
+/* polls per source rank before an exchange gives up; 0 (the default) = no limit on the count, the wall-clock bound holds */
 dmel_status dmel_mailbox_set_spin_limit(dmel_mailbox* mb, uint32_t polls);
+/* wall-clock bound of one exchange in milliseconds (default 120 000; 0 = wait for ever, as RCCL does) */
+dmel_status dmel_mailbox_set_timeout_ms(dmel_mailbox* mb, uint64_t milliseconds);
 dmel_status dmel_plan_attach_mailbox(dmel_plan* plan, dmel_mailbox* mb);
 
 /* torch.optim.Adam's update of an fp32 parameter of the layer on the device (main.py:52-53 builds that optimizer; lambd is one

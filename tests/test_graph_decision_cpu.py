@@ -36,7 +36,8 @@ def allreduce(v):
 
 
 ncalls = 400
-caps, steps, colls, uncovered = GR.rehearse(GraphedStep, capi.n_fft, capi.decide_launch, allreduce, rank, world, calls=ncalls, k=K)
+MA = int(os.environ.get("MAX_AHEAD", "4"))
+caps, steps, colls, uncovered = GR.rehearse(GraphedStep, capi.n_fft, capi.decide_launch, allreduce, rank, world, calls=ncalls, k=K, max_ahead=MA)
 assert steps == ncalls * K, (steps, ncalls * K)          # every call = exactly K steps, capture calls included
 assert not uncovered, uncovered[:3]
 assert len(caps) >= 3, caps                              # both-guards graph, guard-free graph, boundary crossing(s)
@@ -53,14 +54,16 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("k", [1, 4])
-def test_graphed_step_recaptures_at_the_same_call_on_every_rank(tmp_path, k):
+@pytest.mark.parametrize("k,max_ahead", [(1, 4), (4, 4), (20, 8)])
+def test_graphed_step_recaptures_at_the_same_call_on_every_rank(tmp_path, k, max_ahead):
+    """(20, 8) is bench.py's graph x20: nine replays of twenty forwards would overrun the stand-in's 64-deep report ring; GraphedStep
+    bounds its run-ahead by the ring and the decisions still coincide"""
     port = _free_port()
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT))
     procs = []
     for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1", K=str(k))
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1", K=str(k), MAX_AHEAD=str(max_ahead))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
     for p in procs:

@@ -352,15 +352,17 @@ def test_execution_numbers_and_reports():
     plan = capi.Plan(case["L"], case["hop"], M, case["sr"])
     out = torch.empty((B, 1, M, T), device=DEV)
     s = torch.cuda.current_stream().cuda_stream
-    for i in range(70):
+    ring = capi.lambd_ring_size()                                              # 256 since round 4 (dmel_lambd_ring_size)
+    n = ring + 6
+    for i in range(n):
         plan.forward_dev(x.data_ptr(), B, lam.data_ptr(), out.data_ptr(), None, True, 1e-10, s)
-        lam += 0.01
+        lam += 0.001
     torch.cuda.synchronize()
     st = plan.lambd_status()
-    assert st["seq_seen"] == 70 and st["seq_issued"] == 70 and st["calls"] == 70 and st["error"] == 0
-    assert plan.lambd_report(70) == pytest.approx(64.0 + 0.69, abs=2e-3)
-    assert plan.lambd_report(7) == pytest.approx(64.0 + 0.06, abs=2e-3)       # still in the 64-deep ring
-    assert plan.lambd_report(6) is None and plan.lambd_report(71) is None and plan.lambd_report(0) is None
+    assert st["seq_seen"] == n and st["seq_issued"] == n and st["calls"] == n and st["error"] == 0
+    assert plan.lambd_report(n) == pytest.approx(64.0 + 0.001 * (n - 1), abs=2e-3)
+    assert plan.lambd_report(7) == pytest.approx(64.0 + 0.006, abs=2e-3)      # still in the ring
+    assert plan.lambd_report(6) is None and plan.lambd_report(n + 1) is None and plan.lambd_report(0) is None
     # a captured forward draws a fresh number at every replay
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
@@ -369,10 +371,10 @@ def test_execution_numbers_and_reports():
         g.replay()
     torch.cuda.synchronize()
     st = plan.lambd_status()
-    assert st["seq_seen"] == 75 and st["calls"] == 71 and st["seq_issued"] == 75
-    plan.forward_dev(x.data_ptr(), B, lam.data_ptr(), out.data_ptr(), None, True, 1e-10, s)      # eager again: number 76, not 72
+    assert st["seq_seen"] == n + 5 and st["calls"] == n + 1 and st["seq_issued"] == n + 5
+    plan.forward_dev(x.data_ptr(), B, lam.data_ptr(), out.data_ptr(), None, True, 1e-10, s)      # eager again: number n + 6, not n + 2
     torch.cuda.synchronize()
-    assert plan.lambd_status()["seq_seen"] == 76
+    assert plan.lambd_status()["seq_seen"] == n + 6
 
 
 def test_forced_launches_are_checked_on_the_device():

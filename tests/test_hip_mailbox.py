@@ -69,15 +69,15 @@ def test_one_rank_mailbox_is_the_identity():
 
 
 WORKER = r'''
-import os, sys, json
+import os, sys, json, time
 sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests", "golden"))
 import numpy as np, torch, torch.distributed as dist
 import cases as C
 import dmel_amd
-from dmel_amd import MelSpectrogramLayer, dist as ddist
+from dmel_amd import MelSpectrogramLayer, capi, dist as ddist
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
-DEV = "cuda:0"                      # both ranks on the one GPU of the box
+DEV = "cuda:0"                      # every rank on the one GPU of the box
 case = C.BY_NAME["g2_c2"]
 x = torch.from_numpy(C.make_input(case).astype(np.float32)).to(DEV)
 g = torch.from_numpy(C.make_cotangent(case)).to(DEV)
@@ -90,13 +90,14 @@ def mk():
 
 full, mine = mk(), mk()
 mar = ddist.MailboxAllReduce()
-mar.mailbox.set_spin_limit(1 << 22)
-mar.attach(mine, DEV)
+mar.attach(mine, DEV)                                      # default bound: 120 s of wall clock, no poll count
 opt_full = torch.optim.Adam([full.lambd], lr=0.05)
 opt_mine = torch.optim.Adam([mine.lambd], lr=0.05)
-for step in range(6):
+for step in range(7):                                      # odd and even exchanges: both parity slots of every inbox
     opt_full.zero_grad(set_to_none=True); opt_mine.zero_grad(set_to_none=True)
     full(x).backward(g)                                   # the whole batch on one rank: the reference
+    if step == 3 and rank == world - 1:
+        time.sleep(1.5)                                   # a LATE rank (a checkpoint, a slow loader): the others wait, nobody gets NaN
     mine(x[lo:hi]).backward(g[lo:hi])                     # this rank's shard; the backward's kernel exchanges the partial sums
     torch.cuda.synchronize()
     mar.check()
@@ -111,20 +112,33 @@ v = torch.tensor([float(rank + 1)], device=DEV)
 mar.reduce(v, torch.cuda.current_stream().cuda_stream)
 torch.cuda.synchronize(); mar.check()
 assert float(v) == world * (world + 1) / 2
-# a rank that never arrives: bounded spin, NaN, a loud error -- not a hung device
+# a DEAD rank (the last one never joins this exchange): bounded wait, NaN, and the error reaches the caller BY ITSELF at the next
+# call through the attached layer -- not a hung device, not a silent NaN in lambd
 dist.barrier()
-mar.mailbox.set_spin_limit(20000)
-if rank == 0:
-    w = torch.tensor([1.0], device=DEV)
-    mar.reduce(w, torch.cuda.current_stream().cuda_stream)
+mar.set_timeout(0.4)
+if rank != world - 1:
+    t0 = time.time()
+    mine.lambd.grad = None
+    mine(x[lo:hi]).backward(g[lo:hi])
     torch.cuda.synchronize()
-    assert torch.isnan(w).all()
+    assert 0.3 < time.time() - t0 < 30.0
+    assert torch.isnan(mine.lambd.grad).all()
     try:
-        mar.check(); raise SystemExit("the timeout went unnoticed")
+        mine(x[lo:hi]); raise SystemExit("the timeout went unnoticed")
+    except RuntimeError as e:                             # DMEL_ERR_MAILBOX_TIMEOUT through torch.ops.dmel (a RuntimeError) or ctypes (DmelError)
+        assert "never arrived" in str(e), e
+    try:
+        mar.check(); raise SystemExit("check() did not report the timeout")
     except RuntimeError as e:
         assert "never arrived" in str(e)
+    mine(x[lo:hi])                                        # the error word has been read: the layer works again
 dist.barrier()
+# closing while the layer still holds the mailbox: the plan is detached first (ADVICE r03: a freed mailbox was dereferenced)
 mar.close()
+mine.lambd.grad = None
+mine(x[lo:hi]).backward(g[lo:hi])                          # local again
+torch.cuda.synchronize()
+assert torch.isfinite(mine.lambd.grad).all()
 dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
@@ -134,13 +148,16 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def test_two_ranks_exchange_through_ipc_mapped_inboxes(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_exchange_through_ipc_mapped_inboxes(tmp_path, world):
+    """two and four ranks sharing the one GPU: both parity slots, a late rank (waited for), a dead rank (NaN + DMEL_ERR_MAILBOX_TIMEOUT
+    at the next call), close() with a plan still attached"""
     port = _free_port()
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT))
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
@@ -151,3 +168,17 @@ def test_two_ranks_exchange_through_ipc_mapped_inboxes(tmp_path):
             p.kill(); o, _ = p.communicate()
         outs.append(o.decode())
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+
+
+def test_mailbox_destroy_refuses_while_a_plan_holds_it():
+    from dmel_amd import capi
+    case = C.BY_NAME["g1_c1"]
+    lay = _mk(case)
+    plan = lay._plan_for(torch.device(DEV))
+    mb = capi.Mailbox(0, 1)
+    mb.connect([mb.handle])
+    plan.attach_mailbox(mb)
+    with pytest.raises(capi.DmelError, match="still attached"):
+        mb.close()
+    plan.attach_mailbox(None)
+    mb.close()

@@ -82,3 +82,47 @@ def test_lambd_adam_rejects_what_it_is_not_for():
     big = torch.zeros(5000, device=DEV)
     with pytest.raises(RuntimeError, match="ticket"):
         capi.adam_step(big.data_ptr(), big.data_ptr(), big.data_ptr(), big.data_ptr(), t.data_ptr(), 0, 5000, 1e-3, 0.9, 0.999, 1e-8, 0.0, False, 0)
+
+
+def test_lambd_adam_state_dict_round_trip_through_the_cpu():
+    """save -> torch.load(map_location='cpu') -> load_state_dict -> step (the usual resume): the step count and the moments are back on
+    the parameter's device as fp32 before a pointer of them reaches the kernel (a host pointer went to dmel_adam_kernel),
+    and the resumed run continues exactly where an uninterrupted one is"""
+    import io
+    from dmel_amd import LambdAdam
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    for shape in ((), (513, 128)):
+        p0 = torch.randn(shape, generator=gen) + 50.0
+        grads = [torch.randn(shape, generator=gen).to(DEV) for _ in range(12)]
+        a = torch.nn.Parameter(p0.clone().to(DEV))
+        ref = torch.nn.Parameter(p0.clone().to(DEV))
+        oa, oref = LambdAdam([a], lr=0.01), LambdAdam([ref], lr=0.01)
+        for g in grads[:6]:
+            a.grad = g.clone(); ref.grad = g.clone()
+            oa.step(); oref.step()
+        buf = io.BytesIO()
+        torch.save({"opt": oa.state_dict(), "p": a.detach().cpu()}, buf)
+        buf.seek(0)
+        ck = torch.load(buf, map_location="cpu")
+        assert "ticket" not in next(iter(ck["opt"]["state"].values()))                  # the ticket word is private, not checkpointed
+        b = torch.nn.Parameter(ck["p"].to(DEV))
+        ob = LambdAdam([b], lr=0.01)
+        ob.load_state_dict(ck["opt"])
+        for g in grads[6:]:
+            b.grad = g.clone(); ref.grad = g.clone()
+            ob.step(); oref.step()
+        torch.cuda.synchronize()
+        st = ob.state[b]
+        assert st["step"].device.type == "cuda" and st["step"].dtype == torch.float32 and float(st["step"]) == 12.0
+        assert st["exp_avg"].device.type == "cuda" and st["exp_avg_sq"].device.type == "cuda"
+        assert torch.equal(b.detach(), ref.detach()), shape
+    # a state whose tensors were left on the host by hand (no capturable policy involved) is repaired too
+    c = torch.nn.Parameter(torch.tensor(3.0, device=DEV))
+    oc = LambdAdam([c], lr=0.1)
+    c.grad = torch.tensor(1.0, device=DEV); oc.step()
+    for k in ("step", "exp_avg", "exp_avg_sq"):
+        oc.state[c][k] = oc.state[c][k].cpu()
+    oc.state[c]["ticket"] = torch.zeros((), dtype=torch.float32)                       # what a round-3 checkpoint carried
+    c.grad = torch.tensor(1.0, device=DEV); oc.step()
+    torch.cuda.synchronize()
+    assert float(oc.state[c]["step"]) == 2.0 and oc.state[c]["step"].is_cuda and "ticket" not in oc.state[c]

@@ -1,0 +1,128 @@
+"""GPU soak tests: run-to-run determinism under load (tools/determinism_stress.py as a test) and the hand-off of the dot kernel.
+
+The dot kernel's last-ticket hand-off (csrc/dmel_aux.hip: relaxed agent-scope store of the partial, `s_waitcnt vmcnt(0)`, relaxed
+ticket) follows the guide's recipe but sits outside HIP's formal memory model: it is covered here by
+thousands of repetitions whose results must be bit-identical -- a partial read before it landed would show as a different sum."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_dot_kernel_handoff_is_bitwise_repeatable_under_load():
+    from dmel_amd import capi, synth
+    s = torch.cuda.current_stream().cuda_stream
+    for (B, L, hop, M) in ((256, 16000, 512, 128), (32, 160000, 512, 128), (3, 16000, 256, 64)):
+        T = L // hop + 1
+        plan = capi.Plan(L, hop, M, 16000, max_batch=B)
+        gen = torch.Generator(device="cpu").manual_seed(11)
+        g = torch.randn((B, 1, M, T), generator=gen).to(DEV)
+        t = torch.randn((B, 1, M, T), generator=gen).to(DEV)
+        # another stream keeps the memory system busy while the dot kernels run (the hand-off must not depend on a quiet chip)
+        noise_a, noise_b = torch.empty(1 << 24, device=DEV), torch.empty(1 << 24, device=DEV)
+        side = torch.cuda.Stream()
+        outs = torch.zeros(4096, device=DEV)
+        for r in range(outs.numel()):
+            if r % 64 == 0:
+                with torch.cuda.stream(side):
+                    noise_b.copy_(noise_a, non_blocking=True)
+            plan.backward(g.data_ptr(), t.data_ptr(), g.numel(), outs[r:].data_ptr(), s)
+        torch.cuda.synchronize()
+        ref = (g.double() * t.double()).sum()
+        assert torch.all(outs == outs[0]), (B, L, int((outs != outs[0]).sum()))
+        assert abs(float(outs[0]) - float(ref)) <= 1e-5 * float((g.double() * t.double()).abs().sum())
+
+
+@pytest.mark.parametrize("shape", [(8, 16000, 16000, 128.0, 512, 128, True), (256, 16000, 16000, 128.0, 512, 128, False),
+                                   (256, 16000, 16000, 128.0, 512, 128, True), (8, 16000, 16000, 64.0, 256, 64, True),
+                                   (4, 40000, 16000, 256.0, 512, 128, False)])
+def test_forward_is_bitwise_repeatable_under_load(shape):
+    """the same launch repeated 160 times, every output compared bit for bit with the first (HTK and dense banks, both modes)"""
+    from dmel_amd import capi, synth
+    B, L, sr, lam, hop, M, dense = shape
+    s = torch.cuda.current_stream().cuda_stream
+    T = L // hop + 1
+    x = torch.from_numpy(synth.waveforms(B, L, seed=3)).to(DEV)
+    plan = capi.Plan(L, hop, M, sr, max_batch=B)
+    n = capi.n_fft(lam)
+    if dense:
+        fb = torch.rand((n // 2 + 1, M), device=DEV) + 0.01
+        plan.set_filterbank_dev(n, fb.data_ptr(), s)
+    for train in (True, False):
+        ref_o = torch.empty((B, 1, M, T), device=DEV)
+        ref_t = torch.empty_like(ref_o)
+        plan.forward(x.data_ptr(), B, lam, ref_o.data_ptr(), ref_t.data_ptr() if train else None, True, 1e-10, s)
+        torch.cuda.synchronize()
+        outs = [(torch.empty_like(ref_o), torch.empty_like(ref_o)) for _ in range(8)]
+        bad = 0
+        for r in range(160):
+            o, t = outs[r % 8]
+            plan.forward(x.data_ptr(), B, lam, o.data_ptr(), t.data_ptr() if train else None, True, 1e-10, s)
+            if r % 8 == 7:
+                torch.cuda.synchronize()
+                bad += sum(1 for (oo, tt) in outs if not torch.equal(oo, ref_o) or (train and not torch.equal(tt, ref_t)))
+        assert bad == 0, (shape, train, bad)
+
+
+def test_torch_ops_refuse_a_handle_that_is_not_a_live_plan():
+    """the plan travels through torch.ops.dmel as an integer; anything that is not a live plan of this process is
+    refused by a registry look-up instead of being dereferenced"""
+    import dmel_amd
+    from dmel_amd import MelSpectrogramLayer, capi
+    lay = MelSpectrogramLayer(torch.tensor(64.0), n_mels=64, n_points=16000, sample_rate=16000, hop_length=256, device=DEV, optimized=True).to(DEV)
+    x = torch.randn(2, 16000, device=DEV)
+    y = lay(x)
+    plan = lay._plan_for(torch.device(DEV))
+    h = plan.handle
+    assert plan.is_live()
+    lam = lay.lambd.detach()
+    for bogus in (12345, h + 64):
+        with pytest.raises(RuntimeError, match="not the handle of a live plan"):
+            torch.ops.dmel.forward(x, lam, bogus, 0, 1e-10, False, False, False)
+    extra = plan.retain()                     # a second reference: the plan survives its owner
+    assert extra == h
+    plan.close()
+    assert capi.load().dmel_plan_is_live(extra) == 1
+    o, _ = torch.ops.dmel.forward(x, lam, extra, 0, 1e-10, True, False, False)       # with the tangent: the kernel the layer's training forward ran
+    torch.cuda.synchronize()
+    assert torch.equal(o, y.detach())
+    capi.release_handle(extra)
+    assert capi.load().dmel_plan_is_live(extra) == 0
+    with pytest.raises(RuntimeError, match="not the handle of a live plan"):
+        torch.ops.dmel.forward(x, lam, extra, 0, 1e-10, False, False, False)
+
+
+def test_graphed_step_keeps_its_plans_alive_for_the_life_of_the_graph():
+    """a captured HIP graph launches kernels that read the plan's tables: GraphedStep takes a reference at every capture, so dropping the
+    creator's reference while the graph is still replayed is safe, and close() gives the reference back"""
+    from dmel_amd import GraphedStep, MelSpectrogramLayer, capi
+    lay = MelSpectrogramLayer(torch.tensor(64.0), n_mels=64, n_points=16000, sample_rate=16000, hop_length=256, device=DEV,
+                              optimized=True, log=True).to(DEV)
+    opt = torch.optim.Adam([lay.lambd], lr=1e-3, capturable=True)
+    x = torch.randn(4, 16000, device=DEV)
+    g = torch.randn(4, 1, 64, 63, device=DEV)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        lay(x).backward(g)
+        opt.step()
+
+    for _ in range(3):
+        step()
+    gs = GraphedStep(step, [lay], max_ahead=4, steps_per_replay=2)
+    for _ in range(8):
+        gs()
+    torch.cuda.synchronize()
+    plan = lay._plan_for(torch.device(DEV))
+    h = plan.handle
+    assert gs._held_plans == [h]
+    lib = capi.load()
+    before = float(lay.lambd.detach())
+    plan.close()                                  # the creator's reference goes; the graph's keeps the plan
+    assert lib.dmel_plan_is_live(h) == 1
+    gs.graph.replay()                             # the captured launches still find live tables
+    torch.cuda.synchronize()
+    assert float(lay.lambd.detach()) != before and torch.isfinite(lay.lambd.detach())
+    gs.close()
+    assert lib.dmel_plan_is_live(h) == 0

@@ -6,6 +6,8 @@ from __future__ import annotations
 
 
 class FakePlan:
+    ring_size = 64                            # what dmel_lambd_ring_size() says for this stand-in (GraphedStep bounds its run-ahead by it)
+
     def __init__(self, world_state, n_fft_of, decide, lag=0):
         self.w, self.n_fft_of, self.decide, self.lag = world_state, n_fft_of, decide, int(lag)
         self.execs, self.calls, self.ring, self.forced, self.error = 0, 0, {}, (0, 0), 0
