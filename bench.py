@@ -515,6 +515,64 @@ def main():
             module_step_info.setdefault("cold_inputs", {"error": f"{type(e).__name__}: {e}"[:300]})
         torch.cuda.empty_cache()
 
+    # ---- the N > 1 code path on this one GPU (what DMEL_BENCH_FORCE_DIST=1 runs): a world-1 RCCL group, the ncclAllReduce of
+    # lambd.grad captured inside the step.  The driver's scaling run starts at N = 1 on the plain path; this figure shows that the
+    # path the other N take costs the same step when there is nobody to talk to (within 3 %: DMEL_BENCH_STRICT=1 asserts it).
+    if dist is None and not args.no_other_configs:
+        try:
+            import torch.distributed as tdist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ["MASTER_PORT"] = str(_free_port())
+            # RCCL prints a version banner through C stdio when its first communicator comes up: stdout carries the JSON line only
+            sys.stdout.flush()
+            _flush_c_stdio()
+            saved_fd = os.dup(1)
+            os.dup2(2, 1)
+            tdist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            try:
+                sar1 = ddist.ScalarAllReduce()
+                layer6 = MelSpectrogramLayer(torch.tensor(lam), n_mels=M, n_points=L, sample_rate=sr, hop_length=hop, device=str(dev),
+                                             optimized=True, log=True, out_dtype=act).to(dev)
+                opt6 = torch.optim.Adam([layer6.lambd], lr=ADAM_LR, fused=True, capturable=True)
+
+                def module_step6():
+                    opt6.zero_grad(set_to_none=True)
+                    layer6(x).backward(g)
+                    sar1.reduce(layer6.lambd.grad, torch.cuda.current_stream(dev).cuda_stream)
+                    opt6.step()
+
+                for _ in range(3):
+                    module_step6()
+                torch.cuda.synchronize()
+                fn6 = module_step6
+                if chosen != "eager":
+                    fn6 = GraphedStep(module_step6, [layer6], max_ahead=MAX_AHEAD, steps_per_replay=k_chosen)
+                    for _ in range(MAX_AHEAD + 4):
+                        fn6()
+                    torch.cuda.synchronize()
+                n6 = max(200, 50 * k_chosen)
+                el6 = sorted(time_loop(fn6, 8 if r == 0 else 0, n6 // k_chosen) for r in range(5))[2]
+                ref = sorted(run_mode(chosen, 8 if r == 0 else 0, n6) for r in range(5))[2]         # the plain path, same length, now
+                ratio = (el6 / (n6 // k_chosen * k_chosen)) / (ref / n6)
+                module_step_info["dist_path_world1"] = {"ms_per_step": round(1e3 * el6 / (n6 // k_chosen * k_chosen), 5),
+                                                        "plain_ms_per_step_same_length": round(1e3 * ref / n6, 5), "ratio": round(ratio, 4),
+                                                        "within_3pct": bool(abs(ratio - 1.0) <= 0.03), "steps": n6, "median_of": 5,
+                                                        "reducer": "RCCL ncclAllReduce in the step's stream (" + ("native dmel_comm" if sar1.native else "torch.distributed: " + sar1.why) + "), world 1",
+                                                        "note": "the code path every N > 1 run takes, with nobody to talk to; side figure"}
+                del fn6, opt6, layer6
+                sar1.close()
+            finally:
+                tdist.destroy_process_group()
+                _flush_c_stdio()
+                os.dup2(saved_fd, 1)
+                os.close(saved_fd)
+            if os.environ.get("DMEL_BENCH_STRICT") == "1":
+                assert module_step_info["dist_path_world1"]["within_3pct"], module_step_info["dist_path_world1"]
+        except AssertionError:
+            raise
+        except Exception as e:                                          # noqa: BLE001
+            module_step_info["dist_path_world1"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     # ---- side figure, never `value`: the same step with the opt-in dmel_amd.LambdAdam (torch.optim.Adam's update of lambd as
     # one launch instead of torch's two), issued the way the headline was
     if dist is None and not args.no_other_configs:

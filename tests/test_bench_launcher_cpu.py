@@ -29,6 +29,19 @@ def test_plain_invocation_spawns_its_ranks(n):
     assert rec["value"] > 0 and rec["higher_is_better"] is True
 
 
+def test_eight_ranks_agree_on_every_capture_call():
+    """BASELINE config 4's rank count (the driver's 8-GPU scaling run): `bench.py --gpus 8 --dry-run` rehearses the launcher, the
+    barrier / MAX timing and -- with a real collective in every step -- dmel_amd.GraphedStep's re-capture decisions on eight gloo
+    ranks whose pictures of lambd arrive 0 / 5 / 2 / 7 executions late: identical capture calls everywhere, every forward covered"""
+    rc, lines, err = _run([sys.executable, "bench.py", "--gpus", "8", "--dry-run", "--steps", "4", "--warmup", "1"], timeout=600)
+    assert rc == 0, err
+    assert len(lines) == 1, (lines, err)
+    rec = json.loads(lines[0])
+    reh = rec["config"]["graphed_step_rehearsal"]
+    assert rec["n_gpus"] == 8 and reh["same_on_every_rank"] is True and len(reh["capture_calls"]) >= 3
+    assert reh["collectives"] >= reh["calls"] * reh["steps_per_replay"]
+
+
 def test_under_torch_distributed_run():
     rc, lines, err = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                            "--master-port", "29611", "bench.py", "--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "0"])

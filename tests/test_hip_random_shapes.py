@@ -8,7 +8,7 @@ import torch
 
 import cases as C
 from oracle import dmel_oracle as O
-from test_hip_parity import TOL, _dlam_tol, _layer, _log_err, _rel_err
+from test_hip_parity import TOL, _dlam_tol, _layer, _log_err, _rel_err, assert_parity
 
 pytestmark = pytest.mark.gpu
 
@@ -70,6 +70,11 @@ def test_random_configuration_matches_oracle(case):
                                  case["normalize_window"], apply_log=log)
         o = y.detach().cpu().numpy()
         assert (_log_err(o, o_ref) if log else _rel_err(o, o_ref)) <= TOL
+        # the same comparison with nothing hidden: the PLAIN relative error of every element (no floor)
+        if log:
+            assert_parity("random/" + case["name"] + "/exp_logmel", np.exp(o.astype(np.float64)), np.exp(o_ref.astype(np.float64)), allow_floor=False)
+        else:
+            assert_parity("random/" + case["name"] + "/mel", o, o_ref, allow_floor=False)
         exp_d = O.backward(g_np, t_ref)
         _assert_dlam(float(layer.lambd.grad), exp_d, g_np, t_ref, case["name"])
         with torch.no_grad():

@@ -72,7 +72,7 @@ def test_torch_ops_refuse_a_handle_that_is_not_a_live_plan():
     from dmel_amd import MelSpectrogramLayer, capi
     lay = MelSpectrogramLayer(torch.tensor(64.0), n_mels=64, n_points=16000, sample_rate=16000, hop_length=256, device=DEV, optimized=True).to(DEV)
     x = torch.randn(2, 16000, device=DEV)
-    y = lay(x)
+    y = lay(x).detach()                       # (the autograd node of a live result would hold a plan reference of its own)
     plan = lay._plan_for(torch.device(DEV))
     h = plan.handle
     assert plan.is_live()
@@ -86,7 +86,7 @@ def test_torch_ops_refuse_a_handle_that_is_not_a_live_plan():
     assert capi.load().dmel_plan_is_live(extra) == 1
     o, _ = torch.ops.dmel.forward(x, lam, extra, 0, 1e-10, True, False, False)       # with the tangent: the kernel the layer's training forward ran
     torch.cuda.synchronize()
-    assert torch.equal(o, y.detach())
+    assert torch.equal(o, y)
     capi.release_handle(extra)
     assert capi.load().dmel_plan_is_live(extra) == 0
     with pytest.raises(RuntimeError, match="not the handle of a live plan"):
