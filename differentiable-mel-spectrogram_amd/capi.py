@@ -37,7 +37,7 @@ SYMBOLS = (
     "dmel_plan_lambd_status", "dmel_plan_set_tracking", "dmel_plan_lambd_reset",
     "dmel_plan_retain", "dmel_plan_release", "dmel_plan_lambd_report", "dmel_decide_launch", "dmel_plan_force_launch",
     "dmel_adam_step", "dmel_mailbox_create", "dmel_mailbox_connect", "dmel_mailbox_destroy", "dmel_mailbox_allreduce", "dmel_mailbox_error",
-    "dmel_mailbox_set_spin_limit", "dmel_mailbox_set_timeout_ms", "dmel_plan_is_live", "dmel_lambd_ring_size", "dmel_plan_attach_mailbox", "dmel_backward_x_spec",
+    "dmel_mailbox_set_spin_limit", "dmel_mailbox_set_timeout_ms", "dmel_plan_is_live", "dmel_lambd_ring_size", "dmel_spectrogram_ex_dev", "dmel_backward_x_dev", "dmel_backward_x_spec_dev", "dmel_plan_attach_mailbox", "dmel_backward_x_spec",
 )
 TORCH_LIB_PATH = os.path.join(_PKG_DIR, "libdmel_torch.so")
 
@@ -186,6 +186,12 @@ def load():
     L.dmel_mailbox_set_spin_limit.argtypes = [vp, C.c_uint32]
     L.dmel_mailbox_set_spin_limit.restype = C.c_int
     L.dmel_lambd_ring_size.restype = C.c_int32
+    L.dmel_spectrogram_ex_dev.argtypes = [vp, vp, C.c_int32, vp, C.c_int32, C.c_uint32, vp, vp, vp]
+    L.dmel_spectrogram_ex_dev.restype = C.c_int
+    L.dmel_backward_x_dev.argtypes = [vp, vp, C.c_int32, vp, C.c_int32, C.c_uint32, vp, vp, vp, vp]
+    L.dmel_backward_x_dev.restype = C.c_int
+    L.dmel_backward_x_spec_dev.argtypes = [vp, vp, C.c_int32, vp, C.c_int32, C.c_uint32, vp, vp, vp]
+    L.dmel_backward_x_spec_dev.restype = C.c_int
     L.dmel_plan_is_live.argtypes = [vp]
     L.dmel_plan_is_live.restype = C.c_int32
     L.dmel_mailbox_set_timeout_ms.argtypes = [vp, C.c_uint64]
@@ -337,10 +343,26 @@ class Plan:
                                              float(eps), out_ptr, tangent_ptr, scratch_ptr, stream))
 
     def backward_fb_dev(self, x_ptr: int, batch: int, lambd_ptr: int, n_fft_: int, grad_ptr: int, out_ptr: int | None, grad_fb_ptr: int,
-                        log: bool, stream: int):
+                        log: bool, stream: int, extra_flags: int = 0):
         """dmel_backward_fb_dev: dmel_backward_fb with lambd read on the device."""
-        _check(load().dmel_backward_fb_dev(self._h, x_ptr, batch, lambd_ptr, int(n_fft_), DMEL_FLAG_LOG if log else 0, grad_ptr,
+        _check(load().dmel_backward_fb_dev(self._h, x_ptr, batch, lambd_ptr, int(n_fft_), (DMEL_FLAG_LOG if log else 0) | int(extra_flags), grad_ptr,
                                            out_ptr if log else None, grad_fb_ptr, stream))
+
+    def backward_x_dev(self, x_ptr: int, batch: int, lambd_ptr: int, n_fft_: int, grad_ptr: int, out_ptr: int | None, grad_x_ptr: int,
+                       log: bool, stream: int, extra_flags: int = 0):
+        """dmel_backward_x_dev: dmel_backward_x with lambd read on the device (n_fft_: what this step's forward ran)."""
+        _check(load().dmel_backward_x_dev(self._h, x_ptr, batch, lambd_ptr, int(n_fft_), (DMEL_FLAG_LOG if log else 0) | int(extra_flags), grad_ptr,
+                                          out_ptr if log else None, grad_x_ptr, stream))
+
+    def backward_x_spec_dev(self, x_ptr: int, batch: int, lambd_ptr: int, n_fft_: int, grad_spec_ptr: int, grad_x_ptr: int, stream: int,
+                            half_window: bool = False):
+        _check(load().dmel_backward_x_spec_dev(self._h, x_ptr, batch, lambd_ptr, int(n_fft_), 1 | (2 if half_window else 0),
+                                               grad_spec_ptr, grad_x_ptr, stream))
+
+    def spectrogram_ex_dev(self, x_ptr: int, batch: int, lambd_ptr: int, n_fft_: int, spec_ptr: int, tangent_ptr, stream: int,
+                           remove_dc: bool = True, half_window: bool = False):
+        flags = (1 if remove_dc else 0) | (2 if half_window else 0)
+        _check(load().dmel_spectrogram_ex_dev(self._h, x_ptr, batch, lambd_ptr, int(n_fft_), flags, spec_ptr, tangent_ptr, stream))
 
     def backward_scratch(self, grad_ptr: int, tangent_ptr: int, count: int, dlambd_ptr: int, stream: int, scratch_ptr: int | None,
                          accumulate: bool = False, grad_bf16: bool = False):

@@ -675,14 +675,17 @@ dmel_status check_forward_args(dmel_plan* pl, const float* x, int batch, const v
 
 // lambd by value (the host has read it, as time_frequency.py:39 does): one launch, plan-owned scratch unless given.
 // The plan mutex is held by the caller.
+// lambd_dev != nullptr: the kernels read lambd from the device instead (no host read: capturable); the transform length must then
+// be given (n_fft_override: the lengths that do not depend on lambd -- optimized=False branches, the spectrogram layer).
 dmel_status run_forward_nolock(dmel_plan* pl, const float* x, int batch, float lambd, unsigned flags, double eps,
                         float* out, float* tangent, int mode, int remove_dc, void* stream,
-                        int n_fft_override = 0, int win_half = 0, void* scratch = nullptr)
+                        int n_fft_override = 0, int win_half = 0, void* scratch = nullptr, const float* lambd_dev = nullptr)
 {
     dmel_status st = check_forward_args(pl, x, batch, out);
     if (st != DMEL_OK) return st;
     if (batch == 0) return DMEL_OK;
-    if (!std::isfinite(lambd)) return fail(DMEL_ERR_INVALID_ARGUMENT, "lambd is not finite");
+    if (lambd_dev && n_fft_override <= 0) return fail(DMEL_ERR_INVALID_ARGUMENT, "lambd on the device needs an explicit n_fft");
+    if (!lambd_dev && !std::isfinite(lambd)) return fail(DMEL_ERR_INVALID_ARGUMENT, "lambd is not finite");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int N = n_fft_override > 0 ? n_fft_override : dmel_n_fft(lambd);
     Scratch sc;
@@ -692,7 +695,7 @@ dmel_status run_forward_nolock(dmel_plan* pl, const float* x, int batch, float l
         if ((st = ensure_own_scratch(pl, batch, s, &sc)) != DMEL_OK) return st;
     }
     dmel::LamArgs lam{};
-    lam.dev = nullptr; lam.val = lambd; lam.n_expected = 0;      // N was derived from this very value (or given explicitly)
+    lam.dev = lambd_dev; lam.val = lambd_dev ? 0.f : lambd; lam.n_expected = 0;      // N was derived from this very value (or given explicitly)
     lam.role = dmel::kLamFirst | dmel::kLamLast;
     lam.dot_counter = scratch ? sc.counter : nullptr;            // plan-owned counters are zeroed at allocation and reset themselves
     bool sums_done = false;
@@ -701,11 +704,11 @@ dmel_status run_forward_nolock(dmel_plan* pl, const float* x, int batch, float l
 
 dmel_status run_forward(dmel_plan* pl, const float* x, int batch, float lambd, unsigned flags, double eps,
                         float* out, float* tangent, int mode, int remove_dc, void* stream,
-                        int n_fft_override = 0, int win_half = 0, void* scratch = nullptr)
+                        int n_fft_override = 0, int win_half = 0, void* scratch = nullptr, const float* lambd_dev = nullptr)
 {
     if (!pl) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
     std::lock_guard<std::mutex> lock(pl->mu);
-    return run_forward_nolock(pl, x, batch, lambd, flags, eps, out, tangent, mode, remove_dc, stream, n_fft_override, win_half, scratch);
+    return run_forward_nolock(pl, x, batch, lambd, flags, eps, out, tangent, mode, remove_dc, stream, n_fft_override, win_half, scratch, lambd_dev);
 }
 
 // ---- device-resident lambd ---------------------------------------------------------------------------------------------
@@ -1141,8 +1144,12 @@ dmel_status dmel_forward_dev_fixed(dmel_plan* plan, const float* x, int32_t batc
     dmel_status st = check_forward_args(plan, x, batch, out);
     if (st != DMEL_OK) return st;
     if (!lambd_dev) return fail(DMEL_ERR_INVALID_ARGUMENT, "lambd_dev is NULL");
-    if (flags & DMEL_FLAG_FULL_WINDOW)
-        return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_forward_dev_fixed: DMEL_FLAG_FULL_WINDOW needs lambd by value, use dmel_forward");
+    if (flags & DMEL_FLAG_FULL_WINDOW) {
+        // optimized=False (time_frequency.py:41,51): window = the clip, n_fft = 2 n_points whatever lambd is -- nothing to check on
+        // the device, nothing for the host to read: lambd only shapes the window, which the kernels build from the device value
+        return run_forward(plan, x, batch, 0.f, flags & ~DMEL_FLAG_FULL_WINDOW, eps, static_cast<float*>(out), tangent,
+                           tangent ? dmel::kTrain : dmel::kInfer, 1, stream, 2 * plan->cfg.n_points, 1, scratch, lambd_dev);
+    }
     if (n_fft < 1 || n_fft > dmel::kMaxNfft || (n_fft & (n_fft - 1)))
         return fail(DMEL_ERR_INVALID_ARGUMENT, "n_fft must be a power of two in [1, 16384]");
     std::lock_guard<std::mutex> lock(plan->mu);
@@ -1257,6 +1264,15 @@ dmel_status dmel_spectrogram_ex(dmel_plan* plan, const float* x, int32_t batch, 
                        (flags & DMEL_SPEC_REMOVE_DC) ? 1 : 0, stream, n_fft, (flags & DMEL_SPEC_HALF_WINDOW) ? 1 : 0);
 }
 
+dmel_status dmel_spectrogram_ex_dev(dmel_plan* plan, const float* x, int32_t batch, const float* lambd_dev, int32_t n_fft,
+                                    uint32_t flags, float* spec, float* tangent, void* stream)
+{
+    if (!lambd_dev) return fail(DMEL_ERR_INVALID_ARGUMENT, "lambd_dev is NULL");
+    if (n_fft <= 0) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_spectrogram_ex_dev: n_fft must be given (a length that depends on lambd needs the host value: dmel_spectrogram_ex)");
+    return run_forward(plan, x, batch, 0.f, 0u, 0.0, spec, tangent, tangent ? dmel::kSpecTrain : dmel::kSpec,
+                       (flags & DMEL_SPEC_REMOVE_DC) ? 1 : 0, stream, n_fft, (flags & DMEL_SPEC_HALF_WINDOW) ? 1 : 0, nullptr, lambd_dev);
+}
+
 dmel_status dmel_backward_ex(dmel_plan* plan, const void* grad_out, int32_t grad_dtype, const float* tangent, int64_t count,
                              int32_t accumulate, float* dlambd, void* stream)
 {
@@ -1328,14 +1344,12 @@ dmel_status backward_fb_impl(dmel_plan* plan, const float* x, int32_t batch, flo
     if ((flags & DMEL_FLAG_LOG) && batch > 0 && !out)
         return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_backward_fb: DMEL_FLAG_LOG needs the saved log output");
     if (!lambd_dev && !std::isfinite(lambd)) return fail(DMEL_ERR_INVALID_ARGUMENT, "lambd is not finite");
-    if (lambd_dev && (flags & DMEL_FLAG_FULL_WINDOW))
-        return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_backward_fb_dev: DMEL_FLAG_FULL_WINDOW needs lambd by value, use dmel_backward_fb");
-    if (lambd_dev && (n_fft_dev < 1 || n_fft_dev > dmel::kMaxNfft || (n_fft_dev & (n_fft_dev - 1))))
+    const bool full = (flags & DMEL_FLAG_FULL_WINDOW) != 0;
+    if (lambd_dev && !full && (n_fft_dev < 1 || n_fft_dev > dmel::kMaxNfft || (n_fft_dev & (n_fft_dev - 1))))
         return fail(DMEL_ERR_INVALID_ARGUMENT, "n_fft must be a power of two in [1, 16384]");
     int n_over = 0, win_half = 0;
-    if (flags & DMEL_FLAG_FULL_WINDOW) { n_over = 2 * plan->cfg.n_points; win_half = 1; }     // any clip length: the spectrogram pass takes
-                                                                                            // the chirp-z path where it has to
-    const int N = lambd_dev ? n_fft_dev : (n_over ? n_over : dmel_n_fft(lambd));
+    if (full) { n_over = 2 * plan->cfg.n_points; win_half = 1; }     // any clip length: the spectrogram pass takes the chirp-z path where it has to
+    const int N = n_over ? n_over : (lambd_dev ? n_fft_dev : dmel_n_fft(lambd));
     if (N > dmel::kMaxBigFft)
         return fail(DMEL_ERR_UNSUPPORTED, "n_fft = " + std::to_string(N) + " > " + std::to_string(dmel::kMaxBigFft) + " is not supported by the HIP kernels");
     const int F = N / 2 + 1, M = plan->cfg.n_mels, T = plan->T;
@@ -1360,7 +1374,10 @@ dmel_status backward_fb_impl(dmel_plan* plan, const float* x, int32_t batch, flo
     }
     // the spectrogram the layer contracted at models.py:53 (DC removed, models.py:38): P is recomputed, not saved
     dmel_status st;
-    if (lambd_dev) {
+    if (lambd_dev && full) {
+        // n_fft = 2 n_points does not depend on lambd: the kernels take the window's width from the device value, nothing to check
+        st = run_forward_nolock(plan, x, batch, 0.f, 0u, 0.0, plan->fbw, nullptr, dmel::kSpec, 1, stream, n_over, win_half, nullptr, lambd_dev);
+    } else if (lambd_dev) {
         // lambd read on the device and checked against N: a mismatch (the forward of this step reported it) leaves NaN here too
         Scratch sc;
         if ((st = ensure_own_scratch(plan, batch, s, &sc)) != DMEL_OK) return st;
@@ -1404,9 +1421,12 @@ dmel_status dmel_backward_fb_dev(dmel_plan* plan, const float* x, int32_t batch,
 namespace {
 // gradient w.r.t. the waveform on the power-of-two transforms: the mel layer (spec_mode 0; n_over / win_half describe the
 // optimized=False branch) and the spectrogram layer (spec_mode 1: grad_out is the gradient of the power spectrogram)
+// lambd_dev != nullptr: lambd is read by the kernels (window tables, the wave kernel's own window); the transform length then comes
+// from the caller (n_over), never from a host copy of lambd
 dmel_status backward_x_impl(dmel_plan* plan, const float* x, int32_t batch, float lambd, int n_over, int win_half, int spec_mode, bool log,
-                            const float* grad_out, const float* out, float* grad_x, void* stream)
+                            const float* grad_out, const float* out, float* grad_x, void* stream, const float* lambd_dev = nullptr)
 {
+    if (lambd_dev && n_over <= 0) return fail(DMEL_ERR_INVALID_ARGUMENT, "lambd on the device needs an explicit n_fft");
     const int N = n_over > 0 ? n_over : dmel_n_fft(lambd);
     const bool big = N > dmel::kMaxNfft || (N & (N - 1));              // dmel_big.hip: chirp-z / global-memory FFT, both directions
     if (N < 1 || N > dmel::kMaxBigFft || (big && (N & 1)))
@@ -1467,12 +1487,12 @@ dmel_status backward_x_impl(dmel_plan* plan, const float* x, int32_t batch, floa
     pp.B = batch; pp.L = plan->cfg.n_points; pp.nchunks = plan->nchunks; pp.chunk = plan->chunk;
     pp.N = N; pp.normalize = plan->cfg.normalize_window; pp.win_half = win_half;
     pp.center = win_half ? (float)((N / 2) / 2) + (float)(N / 2) / 2.0f : (float)N / 2.0f;      // as launch_forward_n
-    pp.lam.val = lambd; pp.lam.role = dmel::kLamQuiet;
+    pp.lam.dev = lambd_dev; pp.lam.val = lambd_dev ? 0.f : lambd; pp.lam.role = dmel::kLamQuiet;
     // short clips with the plain Gaussian window: the wave-FFT kernel evaluates the window and adds up its clip itself
     const bool own_prep = wave_path && !win_half && !plan->cfg.normalize_window && plan->cfg.n_points <= 32768 && std::getenv("DMEL_XGRAD_PREP") == nullptr;
     if (!own_prep) DMEL_HIP(dmel::launch_prep(pp, s));
     dmel::XgradParams xp{};
-    xp.own_prep = own_prep ? 1 : 0; xp.win_denom = std::fabs(lambd) + 1e-15f;
+    xp.own_prep = own_prep ? 1 : 0; xp.win_denom = std::fabs(lambd) + 1e-15f; xp.lam_dev = lambd_dev;
     xp.x = x; xp.psum = sc.psum; xp.win2 = big ? plan->big_win : sc.win; xp.tw = big ? big_tw : tb->tw_long;
     xp.chirp = big ? bt.chirp : nullptr; xp.hbr = big ? bt.hbr : nullptr; xp.zws = plan->big_z; xp.Mfft = big ? bt.M : 0; xp.logM = big ? bt.logM : 0;
     xp.fb = tb->fb_dense; xp.rowband = tb->rowband; xp.rowpk = tb->rowpk; xp.long_rows = tb->long_rows ? 1 : 0; xp.grad_out = grad_out; xp.out = log ? out : nullptr;
@@ -1522,6 +1542,34 @@ dmel_status dmel_backward_x_spec(dmel_plan* plan, const float* x, int32_t batch,
     if (!(flags & DMEL_SPEC_REMOVE_DC)) return fail(DMEL_ERR_UNSUPPORTED, "dmel_backward_x_spec: only the DC-removed spectrogram (models.py:187) is differentiated");
     if (!std::isfinite(lambd)) return fail(DMEL_ERR_INVALID_ARGUMENT, "lambd is not finite");
     return backward_x_impl(plan, x, batch, lambd, n_fft, (flags & DMEL_SPEC_HALF_WINDOW) ? 1 : 0, 1, false, grad_spec, nullptr, grad_x, stream);
+}
+
+dmel_status dmel_backward_x_dev(dmel_plan* plan, const float* x, int32_t batch, const float* lambd_dev, int32_t n_fft, uint32_t flags,
+                                const float* grad_out, const float* out, float* grad_x, void* stream)
+{
+    if (!plan) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
+    if (!lambd_dev) return fail(DMEL_ERR_INVALID_ARGUMENT, "lambd_dev is NULL");
+    if (batch < 0) return fail(DMEL_ERR_INVALID_ARGUMENT, "batch < 0");
+    if (batch == 0) return DMEL_OK;
+    if (!x || !grad_out || !grad_x) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_backward_x_dev: x / grad_out / grad_x is NULL");
+    if ((flags & DMEL_FLAG_LOG) && !out) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_backward_x_dev: DMEL_FLAG_LOG needs the saved log output");
+    const bool full = (flags & DMEL_FLAG_FULL_WINDOW) != 0;
+    if (!full && (n_fft < 1 || n_fft > dmel::kMaxNfft || (n_fft & (n_fft - 1))))
+        return fail(DMEL_ERR_INVALID_ARGUMENT, "n_fft must be a power of two in [1, 16384] (the n_fft this step's forward was issued for)");
+    return backward_x_impl(plan, x, batch, 0.f, full ? 2 * plan->cfg.n_points : n_fft, full ? 1 : 0, 0, (flags & DMEL_FLAG_LOG) != 0,
+                           grad_out, out, grad_x, stream, lambd_dev);
+}
+
+dmel_status dmel_backward_x_spec_dev(dmel_plan* plan, const float* x, int32_t batch, const float* lambd_dev, int32_t n_fft, uint32_t flags,
+                                     const float* grad_spec, float* grad_x, void* stream)
+{
+    if (!plan) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
+    if (!lambd_dev) return fail(DMEL_ERR_INVALID_ARGUMENT, "lambd_dev is NULL");
+    if (batch < 0 || n_fft <= 0) return fail(DMEL_ERR_INVALID_ARGUMENT, "batch < 0 or n_fft not given");
+    if (batch == 0) return DMEL_OK;
+    if (!x || !grad_spec || !grad_x) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_backward_x_spec_dev: x / grad_spec / grad_x is NULL");
+    if (!(flags & DMEL_SPEC_REMOVE_DC)) return fail(DMEL_ERR_UNSUPPORTED, "dmel_backward_x_spec_dev: only the DC-removed spectrogram (models.py:187) is differentiated");
+    return backward_x_impl(plan, x, batch, 0.f, n_fft, (flags & DMEL_SPEC_HALF_WINDOW) ? 1 : 0, 1, false, grad_spec, nullptr, grad_x, stream, lambd_dev);
 }
 
 dmel_status dmel_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* step, uint32_t* ticket, int64_t n,

@@ -319,6 +319,7 @@ struct XgradParams {
     int tiles, span, tile_step;               // tiles per clip, (FPT - 1) hop + N, FPT hop
     int own_prep;                             // the kernel evaluates the window and the clip mean itself (no dmel_prep_kernel launch)
     float win_denom;                          // |lambd| + 1e-15 (time_frequency.py:24), own_prep only
+    const float* lam_dev;                     // own_prep only: lambd on the device (then win_denom is derived from it by the kernel), or nullptr
     int tw2_off;                              // set by launch_xgrad: byte offset of the radix-C twiddles in LDS
     int win_n;                                // window entries kept in LDS: N/2 + 1 (symmetric about N/2) or N
     // dmel_big.hip path (lengths that are not powers of two, powers of two > 16384): `tw` then belongs to the Mfft-point FFT

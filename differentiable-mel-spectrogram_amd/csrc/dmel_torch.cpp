@@ -75,10 +75,15 @@ std::tuple<at::Tensor, at::Tensor> dmel_forward_op(const at::Tensor& x, const at
     void* scratch = base + tan_bytes;
     const uint32_t f = (uint32_t)flags | (out_bf16 ? DMEL_FLAG_OUT_BF16 : 0u);
     if (B > 0) {
-        if (lambd_sync || (f & DMEL_FLAG_FULL_WINDOW)) {
+        if (lambd_sync) {
             TORCH_CHECK(lambd.is_cuda() || lambd.is_cpu(), "dmel::forward: lambd on an unsupported device");
             const float lam = lambd.item<float>();                       // the one host read (time_frequency.py:39)
             check(dmel_forward_scratch(plan, x.data_ptr<float>(), (int32_t)B, lam, f, eps, out.data_ptr(), tangent, scratch, stream_of(x)));
+        } else if (f & DMEL_FLAG_FULL_WINDOW) {
+            // optimized=False: n_fft = 2 n_points whatever lambd is -- the kernels take the window's width from the device value
+            TORCH_CHECK(lambd.device() == x.device(), "dmel::forward: lambd is on ", lambd.device(), " but x is on ", x.device());
+            check(dmel_forward_dev_fixed(plan, x.data_ptr<float>(), (int32_t)B, lambd.data_ptr<float>(), 0, f, eps, out.data_ptr(), tangent,
+                                         scratch, stream_of(x)));
         } else {
             TORCH_CHECK(lambd.device() == x.device(), "dmel::forward: lambd is on ", lambd.device(), " but x is on ", x.device());
             check(dmel_forward_dev(plan, x.data_ptr<float>(), (int32_t)B, lambd.data_ptr<float>(), f, eps, out.data_ptr(), tangent, scratch,

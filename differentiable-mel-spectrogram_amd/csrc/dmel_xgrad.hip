@@ -303,12 +303,14 @@ __global__ void __launch_bounds__((XgPlan<N>::THREADS), (XgPlan<N>::MINW)) dmel_
             i0 = n4 * 4;
         }
         for (int i = i0 + tid; i < L; i += THREADS) a0 += xc[i];
+        // lambd by value, or read here from the parameter's storage (a uniform scalar load; dmel_backward_x_dev: no host read)
+        const float win_denom = p.lam_dev ? __builtin_fabsf(*p.lam_dev) + 1e-15f : p.win_denom;
         static_for<0, WPT>([&](auto ww) {
             constexpr int wi = decltype(ww)::value;
             const int n = tid + THREADS * wi;
             if (n < WN) {
                 const float d = (float)n - (float)N / 2.0f;
-                const float tq = d / p.win_denom;
+                const float tq = d / win_denom;
                 win[n] = expf(-0.5f * (tq * tq));
             }
         });

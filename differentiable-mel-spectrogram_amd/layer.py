@@ -122,16 +122,18 @@ class _DmelFunction(torch.autograd.Function):
 
 
 class _DmelFbDevFunction(torch.autograd.Function):
-    """Trainable filterbank with lambd left on the device: dmel_forward_dev_fixed (one launch for the n_fft the matrix was
-    built for; lambd read and checked by the kernel), dmel_backward_scratch (d lambd) and dmel_backward_fb_dev (adjoint of
-    models.py:53).  No host read anywhere: the step queues without waiting and can be captured into a HIP graph."""
+    """The layer with lambd left on the device wherever the transform length does not hang on lambd's host value: a trainable
+    filterbank (its row count fixes n_fft: dmel_forward_dev_fixed checks lambd against it on the device) and the optimized=False
+    branch (n_fft = 2 n_points whatever lambd is), with or without the gradients w.r.t. the filterbank (dmel_backward_fb_dev) and the
+    waveform (dmel_backward_x_dev).  No host read anywhere: the step queues without waiting and can be captured into a HIP graph."""
 
     @staticmethod
-    def forward(ctx, x, lambd, plan, n_fft, log, eps, fb, out_dtype):
+    def forward(ctx, x, lambd, plan, n_fft, log, eps, fb, out_dtype, full_window=False):
         B = x.shape[0]
         want_tangent = ctx.needs_input_grad[1]
-        want_fb = ctx.needs_input_grad[6]
-        round_later = out_dtype == torch.bfloat16 and log and want_fb       # see _DmelFunction.forward
+        want_fb = fb is not None and ctx.needs_input_grad[6]
+        want_x = ctx.needs_input_grad[0]
+        round_later = out_dtype == torch.bfloat16 and log and (want_fb or want_x)       # see _DmelFunction.forward
         kdtype = torch.float32 if round_later else out_dtype
         out = torch.empty((B, 1, plan.n_mels, plan.n_time), dtype=kdtype, device=x.device)
         tangent = torch.empty(out.shape, dtype=torch.float32, device=x.device) if want_tangent else None
@@ -139,18 +141,19 @@ class _DmelFbDevFunction(torch.autograd.Function):
         lam = lambd.detach()
         if lam.dtype != torch.float32:
             lam = lam.to(torch.float32)
+        flags = capi.DMEL_FLAG_FULL_WINDOW if full_window else 0
         with _on_device(x.device):
             plan.forward_dev_fixed(x.data_ptr(), B, lam.data_ptr(), n_fft, out.data_ptr(), tangent.data_ptr() if want_tangent else None,
                                    log, eps, _stream_ptr(x.device), scratch.data_ptr(),
-                                   extra_flags=capi.DMEL_FLAG_OUT_BF16 if kdtype == torch.bfloat16 else 0)
-        ctx.plan, ctx.n_fft, ctx.log = plan, n_fft, bool(log)
+                                   extra_flags=flags | (capi.DMEL_FLAG_OUT_BF16 if kdtype == torch.bfloat16 else 0))
+        ctx.plan, ctx.n_fft, ctx.log, ctx.flags = plan, n_fft, bool(log), flags
         ctx.lambd_shape, ctx.lambd_dtype = lambd.shape, lambd.dtype
-        ctx.want_tangent, ctx.want_fb = want_tangent, want_fb
-        ctx.fb_meta = (tuple(fb.shape), fb.dtype)
+        ctx.want_tangent, ctx.want_fb, ctx.want_x = want_tangent, want_fb, want_x
+        ctx.fb_meta = None if fb is None else (tuple(fb.shape), fb.dtype)
         saved = [scratch]
         if want_tangent:
             saved.append(tangent)
-        if want_fb:
+        if want_fb or want_x:
             saved += [x, lam]
             if log:
                 saved.append(out)
@@ -167,7 +170,7 @@ class _DmelFbDevFunction(torch.autograd.Function):
             g = g.to(torch.float32)
         if not g.is_contiguous():
             g = g.contiguous()
-        dl = gfb = None
+        dl = gfb = gx = None
         with _on_device(g.device):
             if ctx.want_tangent:
                 tangent = saved.pop(0)
@@ -176,16 +179,21 @@ class _DmelFbDevFunction(torch.autograd.Function):
                                           scratch.data_ptr(), grad_bf16=bf16)
                 if ctx.lambd_dtype != torch.float32:
                     dl = dl.to(ctx.lambd_dtype)
-            if ctx.want_fb:
+            if ctx.want_fb or ctx.want_x:
                 x, lam = saved.pop(0), saved.pop(0)
                 out = saved.pop(0).to(torch.float32) if ctx.log else None
                 g32 = g.to(torch.float32)
+            if ctx.want_x:
+                gx = torch.empty_like(x)
+                ctx.plan.backward_x_dev(x.data_ptr(), x.shape[0], lam.data_ptr(), ctx.n_fft, g32.data_ptr(), out.data_ptr() if ctx.log else None,
+                                        gx.data_ptr(), ctx.log, _stream_ptr(g.device), extra_flags=ctx.flags)
+            if ctx.want_fb:
                 fb_shape, fb_dtype = ctx.fb_meta
                 gfb = torch.empty(fb_shape, dtype=torch.float32, device=g.device)
                 ctx.plan.backward_fb_dev(x.data_ptr(), x.shape[0], lam.data_ptr(), ctx.n_fft, g32.data_ptr(),
-                                         out.data_ptr() if ctx.log else None, gfb.data_ptr(), ctx.log, _stream_ptr(g.device))
+                                         out.data_ptr() if ctx.log else None, gfb.data_ptr(), ctx.log, _stream_ptr(g.device), extra_flags=ctx.flags)
                 gfb = gfb.to(fb_dtype)
-        return None, dl, None, None, None, None, gfb, None
+        return gx, dl, None, None, None, None, gfb, None, None
 
 
 _MEL_OP = None
@@ -338,19 +346,26 @@ class MelSpectrogramLayer(nn.Module):
             if lam.dtype != torch.float32:
                 lam = lam.to(torch.float32)
             return _mel_op()(xf, lam, plan.handle, flags, self.eps, self.lambd_sync, self.out_dtype == torch.bfloat16)
-        if fb is not None and self.optimized and not x.requires_grad and not self.lambd_sync:
-            # trainable filterbank, sync-free: the matrix fixes n_fft (its row count), lambd is read and checked on the device;
-            # a lambd that has left that n_fft gives NaN now and a RuntimeError at the next forward (models.py:53 fails on the
-            # shape in the same situation)
-            n = 2 * (fb.shape[0] - 1)
-            if fb.device != x.device:
-                raise RuntimeError(f"mel_fb is on {fb.device} but x is on {x.device}; call layer.to(x.device)")
-            fbd = fb.detach()
-            if fbd.dtype != torch.float32 or not fbd.is_contiguous():
-                fbd = fbd.to(torch.float32).contiguous()
-            with _on_device(x.device):
-                plan.set_filterbank_dev(n, fbd.data_ptr(), _stream_ptr(x.device))
-            return _DmelFbDevFunction.apply(xf, self.lambd, plan, n, self.log, self.eps, fb, self.out_dtype)
+        if not self.lambd_sync and (fb is not None or not self.optimized):
+            # sync-free wherever the transform length does not hang on lambd's HOST value: a trainable filterbank fixes n_fft (its row
+            # count; lambd is read and checked on the device: one that has left that n_fft gives NaN now and a RuntimeError at the next
+            # forward, as models.py:53 fails on the shape), and the optimized=False branch runs n_fft = 2 n_points whatever lambd is.
+            # With or without x.requires_grad.  (What still reads lambd to the host: x.requires_grad on the HTK bank with
+            # optimized=True -- its backward must know which n_fft the forward's guards ended up running -- and lambd_sync=True.)
+            full = not self.optimized
+            n = 2 * self.n_points if full else 2 * (fb.shape[0] - 1)
+            if fb is not None:
+                if fb.shape[0] != n // 2 + 1:
+                    raise RuntimeError(f"mel_fb was built for n_fft={2 * (fb.shape[0] - 1)} but this layer runs n_fft={n}; "
+                                       "a learnable filterbank is tied to one n_fft")
+                if fb.device != x.device:
+                    raise RuntimeError(f"mel_fb is on {fb.device} but x is on {x.device}; call layer.to(x.device)")
+                fbd = fb.detach()
+                if fbd.dtype != torch.float32 or not fbd.is_contiguous():
+                    fbd = fbd.to(torch.float32).contiguous()
+                with _on_device(x.device):
+                    plan.set_filterbank_dev(n, fbd.data_ptr(), _stream_ptr(x.device))
+            return _DmelFbDevFunction.apply(xf, self.lambd, plan, n, self.log, self.eps, fb, self.out_dtype, full)
         lam_host = self._lambd_host()
         if fb is not None:
             n = capi.n_fft(lam_host) if self.optimized else 2 * self.n_points
@@ -381,17 +396,27 @@ class _DspecFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, lambd, plan, lam_host, n_fft, half_window):
+        """lam_host None: lambd is read by the kernels from the parameter's storage (no host read: capturable)"""
         B = x.shape[0]
         out = torch.empty((B, 1, n_fft // 2 + 1, plan.n_time), dtype=torch.float32, device=x.device)
         want_tangent = ctx.needs_input_grad[1]
         tangent = torch.empty_like(out) if want_tangent else None
-        with torch.cuda.device(x.device):
-            plan.spectrogram_ex(x.data_ptr(), B, lam_host, n_fft, out.data_ptr(), tangent.data_ptr() if want_tangent else None,
-                                _stream_ptr(x.device), remove_dc=True, half_window=half_window)
+        lam = None
+        if lam_host is None:
+            lam = lambd.detach()
+            if lam.dtype != torch.float32:
+                lam = lam.to(torch.float32)
+        with _on_device(x.device):
+            if lam is None:
+                plan.spectrogram_ex(x.data_ptr(), B, lam_host, n_fft, out.data_ptr(), tangent.data_ptr() if want_tangent else None,
+                                    _stream_ptr(x.device), remove_dc=True, half_window=half_window)
+            else:
+                plan.spectrogram_ex_dev(x.data_ptr(), B, lam.data_ptr(), n_fft, out.data_ptr(), tangent.data_ptr() if want_tangent else None,
+                                        _stream_ptr(x.device), remove_dc=True, half_window=half_window)
         ctx.plan, ctx.lambd_shape, ctx.lambd_dtype = plan, lambd.shape, lambd.dtype
         ctx.want_tangent, ctx.want_x = want_tangent, ctx.needs_input_grad[0]
         ctx.args = (lam_host, n_fft, half_window)
-        saved = ([tangent] if want_tangent else []) + ([x] if ctx.want_x else [])
+        saved = ([tangent] if want_tangent else []) + ([x] if ctx.want_x else []) + ([lam] if (ctx.want_x and lam is not None) else [])
         ctx.save_for_backward(*saved)
         return out
 
@@ -400,7 +425,7 @@ class _DspecFunction(torch.autograd.Function):
         saved = list(ctx.saved_tensors)
         g = grad_out.to(torch.float32).contiguous()
         dl = gx = None
-        with torch.cuda.device(g.device):
+        with _on_device(g.device):
             if ctx.want_tangent:
                 tangent = saved.pop(0)
                 dl = torch.empty((1,), dtype=torch.float32, device=g.device)
@@ -410,8 +435,13 @@ class _DspecFunction(torch.autograd.Function):
                 x = saved.pop(0)
                 lam_host, n_fft, half_window = ctx.args
                 gx = torch.empty_like(x)
-                ctx.plan.backward_x_spec(x.data_ptr(), x.shape[0], lam_host, n_fft, g.data_ptr(), gx.data_ptr(), _stream_ptr(g.device),
-                                         half_window=half_window)
+                if lam_host is None:
+                    lam = saved.pop(0)
+                    ctx.plan.backward_x_spec_dev(x.data_ptr(), x.shape[0], lam.data_ptr(), n_fft, g.data_ptr(), gx.data_ptr(),
+                                                 _stream_ptr(g.device), half_window=half_window)
+                else:
+                    ctx.plan.backward_x_spec(x.data_ptr(), x.shape[0], lam_host, n_fft, g.data_ptr(), gx.data_ptr(), _stream_ptr(g.device),
+                                             half_window=half_window)
         return gx, dl, None, None, None, None
 
 
@@ -426,8 +456,9 @@ class SpectrogramLayer(nn.Module):
     ``optimized=True``: n_fft = next_pow2(int(6*|lambd|)) and the output must have the shape ``size``.
     """
 
-    def __init__(self, init_lambd, device="cpu", optimized=False, size=(512, 1024), hop_length=1, normalize_window=False):
+    def __init__(self, init_lambd, device="cpu", optimized=False, size=(512, 1024), hop_length=1, normalize_window=False, *, lambd_sync=False):
         super().__init__()
+        self.lambd_sync = bool(lambd_sync)          # True: read lambd to the host at every forward, as the reference does
         if not torch.is_tensor(init_lambd):
             init_lambd = torch.tensor(float(init_lambd), dtype=torch.float32)
         self.hop_length = hop_length
@@ -449,7 +480,12 @@ class SpectrogramLayer(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("dmel_amd runs on MI355X only: x must be a CUDA/HIP tensor (no CPU fallback)")
         batch_size, n_points = x.shape
-        lam_host = float(self.lambd.detach())
+        if self.lambd.device != x.device:
+            raise RuntimeError(f"lambd is on {self.lambd.device} but x is on {x.device}; call layer.to(x.device)")
+        # optimized=False (the reference's only DSPEC configuration, search_spaces.py:71-91): n_fft = 2 n_points whatever lambd is, so
+        # lambd stays on the device -- no host read, the step is HIP-graph capturable.  optimized=True derives n_fft from lambd on the
+        # host like the reference (time_frequency.py:39): the output SHAPE depends on it.
+        lam_host = float(self.lambd.detach()) if (self.optimized or self.lambd_sync) else None
         if self.optimized:
             n_fft, half = capi.n_fft(lam_host), False
             expect = (n_fft // 2 + 1, n_points // self.hop_length + 1)

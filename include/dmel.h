@@ -154,7 +154,7 @@ dmel_status dmel_forward(dmel_plan* plan, const float* x, int32_t batch, float l
  *              dmel_backward_scratch that consumes its tangent (no initialisation needed), or NULL to use the plan's
  *              own (then calls on different streams are serialised by the plan)
  * The first call on a plan (and the first after an error or dmel_plan_lambd_reset) reads lambd once, blocking.
- * DMEL_FLAG_FULL_WINDOW is not accepted (its n_fft does not depend on lambd: use dmel_forward).
+ * DMEL_FLAG_FULL_WINDOW is not accepted (its n_fft does not depend on lambd: use dmel_forward_dev_fixed, which needs no tracking).
  */
 size_t dmel_scratch_bytes(const dmel_plan* plan, int32_t batch);
 /* dmel_forward (lambd by value) with the caller's scratch instead of the plan's */
@@ -166,7 +166,9 @@ dmel_status dmel_forward_dev(dmel_plan* plan, const float* x, int32_t batch, con
  * (dmel_plan_set_filterbank_dev) has n_fft/2+1 rows: exactly one launch for `n_fft`, lambd read and checked on the device, no
  * guard launches, no host picture of lambd (never blocks, capturable from the first call).  If the device value asks for
  * another n_fft the outputs are NaN and the NEXT call returns DMEL_ERR_LAMBD_TRACKING (models.py:42-48 ties the reference's
- * matrix to the n_fft of the forward in the same way: torch.matmul fails on the shape). */
+ * matrix to the n_fft of the forward in the same way: torch.matmul fails on the shape).
+ * With DMEL_FLAG_FULL_WINDOW (the layer's optimized=False branch, time_frequency.py:41,51) the transform is n_fft = 2 n_points
+ * whatever lambd is: `n_fft` is ignored, nothing is checked, lambd only shapes the window the kernels build from the device value. */
 dmel_status dmel_forward_dev_fixed(dmel_plan* plan, const float* x, int32_t batch, const float* lambd_dev, int32_t n_fft,
                                    uint32_t flags, double eps, void* out, float* tangent, void* scratch, void* stream);
 
@@ -249,7 +251,8 @@ dmel_status dmel_backward_scratch(dmel_plan* plan, const void* grad_out, int32_t
 dmel_status dmel_backward_fb(dmel_plan* plan, const float* x, int32_t batch, float lambd, uint32_t flags,
                              const float* grad_out, const float* out, float* grad_fb, void* stream);
 /* dmel_backward_fb with lambd read on the device (the spectrogram recompute checks it against `n_fft`, the one the forward
- * of this step was issued for: dmel_forward_dev_fixed); no host read, capturable.  DMEL_FLAG_FULL_WINDOW is not accepted. */
+ * of this step was issued for: dmel_forward_dev_fixed); no host read, capturable.  With DMEL_FLAG_FULL_WINDOW `n_fft` is ignored
+ * (2 n_points) and nothing is checked. */
 dmel_status dmel_backward_fb_dev(dmel_plan* plan, const float* x, int32_t batch, const float* lambd_dev, int32_t n_fft, uint32_t flags,
                                  const float* grad_out, const float* out, float* grad_fb, void* stream);
 
@@ -270,6 +273,14 @@ dmel_status dmel_backward_x(dmel_plan* plan, const float* x, int32_t batch, floa
  * even n_fft the forward accepts). */
 dmel_status dmel_backward_x_spec(dmel_plan* plan, const float* x, int32_t batch, float lambd, int32_t n_fft, uint32_t flags,
                                  const float* grad_spec, float* grad_x, void* stream);
+/* Both with lambd read on the device (no host read, capturable): `n_fft` is the transform length the forward of this step ran --
+ * fixed by a trainable filterbank (dmel_forward_dev_fixed), 2 n_points with DMEL_FLAG_FULL_WINDOW (then `n_fft` is ignored), or the
+ * spectrogram layer's explicit length.  A lambd that has left `n_fft` made that forward return NaN and raise its error; the
+ * gradient computed here for it is not meaningful either. */
+dmel_status dmel_backward_x_dev(dmel_plan* plan, const float* x, int32_t batch, const float* lambd_dev, int32_t n_fft, uint32_t flags,
+                                const float* grad_out, const float* out, float* grad_x, void* stream);
+dmel_status dmel_backward_x_spec_dev(dmel_plan* plan, const float* x, int32_t batch, const float* lambd_dev, int32_t n_fft, uint32_t flags,
+                                     const float* grad_spec, float* grad_x, void* stream);
 
 /* Power spectrogram only, (batch, n_fft/2+1, n_time) fp32 = time_frequency.differentiable_spectrogram
  * (time_frequency.py:32-58, optimized branch) applied per clip; remove_dc != 0 adds models.py:38. */
@@ -289,6 +300,10 @@ dmel_status dmel_spectrogram(dmel_plan* plan, const float* x, int32_t batch, flo
 #define DMEL_SPEC_HALF_WINDOW 2u    /* window support = middle half of n_fft                          */
 dmel_status dmel_spectrogram_ex(dmel_plan* plan, const float* x, int32_t batch, float lambd, int32_t n_fft,
                                 uint32_t flags, float* spec, float* tangent, void* stream);
+/* the same with lambd read on the device; n_fft must be given (> 0: a length that does not depend on lambd, e.g. the reference's
+ * DSPEC configuration optimized=False, search_spaces.py:71-91): no host read, capturable */
+dmel_status dmel_spectrogram_ex_dev(dmel_plan* plan, const float* x, int32_t batch, const float* lambd_dev, int32_t n_fft,
+                                    uint32_t flags, float* spec, float* tangent, void* stream);
 
 /* ---- the one exchange step: all-reduce of lambd.grad across GPUs (RCCL over xGMI) -------------------
  * The reference has no distributed code; with the batch sharded over one process per GPU the only cross-GPU

@@ -1,0 +1,110 @@
+"""every way the layers are used without the transform length hanging on lambd's HOST value is sync-free -- the step
+(forward, backward to lambd / the waveform / the filterbank, Adam) is captured ONCE into a HIP graph (a host read inside would fail the
+capture) and its replays reproduce, bit for bit, the eagerly issued steps of a layer that reads lambd to the host at every forward
+(lambd_sync=True: the by-value entry points).  models.py:171-200 (DSPEC), models.py:33-56 with optimized=False, x.requires_grad."""
+import numpy as np
+import pytest
+import torch
+
+import cases as C
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _run(make, x0, g, steps, graphed, wants_x):
+    """`steps` Adam steps on a fresh layer; returns (parameters..., grad_x of the last step)"""
+    layer = make(not graphed)                                   # eager reference: lambd_sync=True
+    params = [p for p in layer.parameters()]
+    # (a filterbank entry moves by ~lr per Adam step whatever its gradient: small steps keep mel = P @ fb positive under the log)
+    opt = torch.optim.Adam([{"params": [p], "lr": 0.02 if p.dim() == 0 else 1e-5} for p in params], capturable=True)
+    x = x0.clone().requires_grad_(wants_x)
+    gx = torch.zeros_like(x0)
+
+    def step():
+        opt.zero_grad(set_to_none=False)
+        if x.grad is not None:
+            x.grad.zero_()
+        layer(x).backward(g)
+        if wants_x:
+            gx.copy_(x.grad)
+        opt.step()
+
+    if not graphed:
+        for _ in range(steps):
+            step()
+    else:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                step()                                          # workspaces, optimizer state
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()                                              # any host read of lambd in here fails the capture
+        for _ in range(steps - 2):
+            graph.replay()
+    torch.cuda.synchronize()
+    return [p.detach().clone() for p in params] + [gx.clone()]
+
+
+def _same(a, b):
+    for u, v in zip(a, b):
+        assert torch.equal(u, v), float((u - v).abs().max())
+
+
+@pytest.mark.parametrize("wants_x", [False, True])
+@pytest.mark.parametrize("n_points,hop", [(128, 1), (100, 1), (256, 4)])
+def test_dspec_layer_step_is_sync_free_and_graph_capturable(n_points, hop, wants_x):
+    """SpectrogramLayer in the reference's own configuration (optimized=False, search_spaces.py:71-91): powers of two and the chirp-z
+    length 200"""
+    from dmel_amd import SpectrogramLayer
+    gen = torch.Generator().manual_seed(3)
+    x0 = torch.randn(6, n_points, generator=gen).to(DEV)
+    g = torch.randn(6, 1, n_points + 1, n_points // hop + 1, generator=gen).to(DEV)
+
+    def make(sync):
+        return SpectrogramLayer(torch.tensor(6.38), device=DEV, optimized=False, hop_length=hop, lambd_sync=sync).to(DEV)
+
+    ref = _run(make, x0, g, 6, False, wants_x)
+    got = _run(make, x0, g, 6, True, wants_x)
+    assert abs(float(ref[0]) - 6.38) > 1e-3
+    _same(ref, got)
+
+
+@pytest.mark.parametrize("wants_x,learnable", [(False, False), (True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("log", [False, True])
+def test_mel_layer_full_window_branch_is_sync_free_and_graph_capturable(wants_x, learnable, log):
+    """optimized=False (the constructor's default, time_frequency.py:41,51): n_fft = 2 n_points whatever lambd is; with the waveform's
+    gradient, with a trainable filterbank, with both"""
+    from dmel_amd import MelSpectrogramLayer
+    L, hop, M, sr = 512, 64, 24, 8000
+    gen = torch.Generator().manual_seed(4)
+    x0 = torch.randn(5, L, generator=gen).to(DEV)
+    g = torch.randn(5, 1, M, L // hop + 1, generator=gen).to(DEV)
+
+    def make(sync):
+        return MelSpectrogramLayer(torch.tensor(40.0), n_mels=M, n_points=L, sample_rate=sr, hop_length=hop, device=DEV, optimized=False,
+                                   log=log, learnable_fb=learnable, lambd_sync=sync).to(DEV)
+
+    ref = _run(make, x0, g, 6, False, wants_x)
+    got = _run(make, x0, g, 6, True, wants_x)
+    _same(ref, got)
+
+
+@pytest.mark.parametrize("log", [False, True])
+def test_waveform_gradient_with_a_trainable_filterbank_is_sync_free(log):
+    """optimized=True: the matrix fixes n_fft, so x.requires_grad needs no host value of lambd either (dmel_backward_x_dev)"""
+    from dmel_amd import MelSpectrogramLayer
+    case = C.BY_NAME["g1_c1"]
+    x0 = torch.from_numpy(C.make_input(case).astype(np.float32)).to(DEV)
+    g = torch.from_numpy(C.make_cotangent(case)).to(DEV)
+
+    def make(sync):
+        return MelSpectrogramLayer(torch.tensor(float(case["lambd"])), n_mels=case["n_mels"], n_points=case["L"], sample_rate=case["sr"],
+                                   hop_length=case["hop"], device=DEV, optimized=True, log=log, learnable_fb=True, lambd_sync=sync).to(DEV)
+
+    ref = _run(make, x0, g, 5, False, True)
+    got = _run(make, x0, g, 5, True, True)
+    _same(ref, got)
