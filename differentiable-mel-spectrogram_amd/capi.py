@@ -20,6 +20,7 @@ DMEL_ERR_NO_DEVICE = 4
 DMEL_ERR_OUT_OF_MEMORY = 5
 DMEL_ERR_LAMBD_TRACKING = 6
 DMEL_ERR_MAILBOX_TIMEOUT = 7
+DMEL_FLAG_MFMA_BF16X3 = 8
 DMEL_FLAG_LOG = 1
 DMEL_FLAG_FULL_WINDOW = 2
 DMEL_FLAG_OUT_BF16 = 4
@@ -37,7 +38,7 @@ SYMBOLS = (
     "dmel_plan_lambd_status", "dmel_plan_set_tracking", "dmel_plan_lambd_reset",
     "dmel_plan_retain", "dmel_plan_release", "dmel_plan_lambd_report", "dmel_decide_launch", "dmel_plan_force_launch",
     "dmel_adam_step", "dmel_mailbox_create", "dmel_mailbox_connect", "dmel_mailbox_destroy", "dmel_mailbox_allreduce", "dmel_mailbox_error",
-    "dmel_mailbox_set_spin_limit", "dmel_mailbox_set_timeout_ms", "dmel_plan_is_live", "dmel_lambd_ring_size", "dmel_spectrogram_ex_dev", "dmel_backward_x_dev", "dmel_backward_x_spec_dev", "dmel_plan_attach_mailbox", "dmel_backward_x_spec",
+    "dmel_mailbox_set_spin_limit", "dmel_mailbox_set_timeout_ms", "dmel_plan_is_live", "dmel_lambd_ring_size", "dmel_spectrogram_ex_dev", "dmel_forward_dev_fixed_spec", "dmel_backward_fb_saved", "dmel_backward_x_dev", "dmel_backward_x_spec_dev", "dmel_plan_attach_mailbox", "dmel_backward_x_spec",
 )
 TORCH_LIB_PATH = os.path.join(_PKG_DIR, "libdmel_torch.so")
 
@@ -186,6 +187,10 @@ def load():
     L.dmel_mailbox_set_spin_limit.argtypes = [vp, C.c_uint32]
     L.dmel_mailbox_set_spin_limit.restype = C.c_int
     L.dmel_lambd_ring_size.restype = C.c_int32
+    L.dmel_forward_dev_fixed_spec.argtypes = [vp, vp, C.c_int32, vp, C.c_int32, C.c_uint32, C.c_double, vp, vp, vp, vp, vp]
+    L.dmel_forward_dev_fixed_spec.restype = C.c_int
+    L.dmel_backward_fb_saved.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_uint32, vp, vp, vp, vp]
+    L.dmel_backward_fb_saved.restype = C.c_int
     L.dmel_spectrogram_ex_dev.argtypes = [vp, vp, C.c_int32, vp, C.c_int32, C.c_uint32, vp, vp, vp]
     L.dmel_spectrogram_ex_dev.restype = C.c_int
     L.dmel_backward_x_dev.argtypes = [vp, vp, C.c_int32, vp, C.c_int32, C.c_uint32, vp, vp, vp, vp]
@@ -341,6 +346,17 @@ class Plan:
         """dmel_forward_dev_fixed: one launch for ``n_fft_``, lambd read and checked on the device (trainable filterbank)."""
         _check(load().dmel_forward_dev_fixed(self._h, x_ptr, batch, lambd_ptr, int(n_fft_), (DMEL_FLAG_LOG if log else 0) | int(extra_flags),
                                              float(eps), out_ptr, tangent_ptr, scratch_ptr, stream))
+
+    def forward_dev_fixed_spec(self, x_ptr: int, batch: int, lambd_ptr: int, n_fft_: int, out_ptr: int, tangent_ptr: int, spec_ptr: int,
+                               log: bool, eps: float, stream: int, scratch_ptr: int | None = None, extra_flags: int = 0):
+        """dmel_forward_dev_fixed_spec: the training forward that also writes the (B, F, T) power spectrogram for backward_fb_saved."""
+        _check(load().dmel_forward_dev_fixed_spec(self._h, x_ptr, batch, lambd_ptr, int(n_fft_), (DMEL_FLAG_LOG if log else 0) | int(extra_flags),
+                                                  float(eps), out_ptr, tangent_ptr, spec_ptr, scratch_ptr, stream))
+
+    def backward_fb_saved(self, spec_ptr: int, batch: int, n_fft_: int, grad_ptr: int, out_ptr: int | None, grad_fb_ptr: int, log: bool,
+                          stream: int, extra_flags: int = 0):
+        _check(load().dmel_backward_fb_saved(self._h, spec_ptr, batch, int(n_fft_), (DMEL_FLAG_LOG if log else 0) | int(extra_flags), grad_ptr,
+                                             out_ptr if log else None, grad_fb_ptr, stream))
 
     def backward_fb_dev(self, x_ptr: int, batch: int, lambd_ptr: int, n_fft_: int, grad_ptr: int, out_ptr: int | None, grad_fb_ptr: int,
                         log: bool, stream: int, extra_flags: int = 0):

@@ -493,11 +493,13 @@ dmel_status big_tables_for(dmel_plan* pl, int N, dmel_plan::BigTab* out, const f
 // this call.  Shared by every entry point; the plan mutex is held by the caller.
 dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dmel::LamArgs lam, unsigned flags, double eps,
                              float* out, float* tangent, int mode, int remove_dc, const Scratch& sc, hipStream_t s, int win_half,
-                             bool* sums_done)
+                             bool* sums_done, float* spec_out = nullptr)
 {
     if (N < 1) return fail(DMEL_ERR_UNSUPPORTED, "n_fft = " + std::to_string(N));
     const bool pow2 = (N & (N - 1)) == 0;
     const bool big = !pow2 || N > dmel::kMaxNfft;
+    if (spec_out && (big || N < dmel::kMinFastNfft || mode != dmel::kTrain))
+        return fail(DMEL_ERR_UNSUPPORTED, "the spectrogram is saved by the fused training kernel only (power-of-two n_fft from 32 to 16384, tangent requested)");
     if (big && (N & 1)) return fail(DMEL_ERR_UNSUPPORTED, "n_fft = " + std::to_string(N) + " is odd");
     NfftTables* tb = nullptr;
     dmel_status st = build_tables(pl, N, &tb);
@@ -626,6 +628,7 @@ dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dm
     fp.tiles_per_clip = (pl->T + fpt - 1) / fpt;
     fp.inv_L = inv_L; fp.eps = (float)eps; fp.flags = flags; fp.lam = lam;
     fp.remove_dc = remove_dc; fp.normalize = pl->cfg.normalize_window; fp.win_half = win_half;
+    fp.spec_out = spec_out;
     static const int force_tpw = std::getenv("DMEL_TILES_PER_WG") ? std::atoi(std::getenv("DMEL_TILES_PER_WG")) : 0;   // diagnostics
     int tpw = dmel::forward_tiles_per_wg(N, mode, batch, fp.tiles_per_clip);
     if (force_tpw == 1 || (force_tpw == 2 && dmel::forward_two_tiles(N, mode))) tpw = force_tpw;
@@ -1185,6 +1188,49 @@ dmel_status dmel_forward_dev_fixed(dmel_plan* plan, const float* x, int32_t batc
                             tangent ? dmel::kTrain : dmel::kInfer, /*remove_dc=*/1, sc, s, 0, &sums_done);
 }
 
+dmel_status dmel_forward_dev_fixed_spec(dmel_plan* plan, const float* x, int32_t batch, const float* lambd_dev, int32_t n_fft,
+                                        uint32_t flags, double eps, void* out, float* tangent, float* spec, void* scratch, void* stream)
+{
+    if (!spec) return dmel_forward_dev_fixed(plan, x, batch, lambd_dev, n_fft, flags, eps, out, tangent, scratch, stream);
+    dmel_status st = check_forward_args(plan, x, batch, out);
+    if (st != DMEL_OK) return st;
+    if (!lambd_dev || !tangent) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_forward_dev_fixed_spec: lambd_dev / tangent is NULL (the training forward saves the spectrogram)");
+    if (flags & DMEL_FLAG_FULL_WINDOW) return fail(DMEL_ERR_UNSUPPORTED, "dmel_forward_dev_fixed_spec: not with DMEL_FLAG_FULL_WINDOW");
+    if (n_fft < dmel::kMinFastNfft || n_fft > dmel::kMaxNfft || (n_fft & (n_fft - 1)))
+        return fail(DMEL_ERR_UNSUPPORTED, "dmel_forward_dev_fixed_spec: n_fft must be a power of two in [32, 16384]");
+    std::lock_guard<std::mutex> lock(plan->mu);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const unsigned long long err = __atomic_load_n(&plan->host_words[dmel::kLamRing], __ATOMIC_RELAXED);
+    if (err != 0) {
+        float lam; const unsigned bits = (unsigned)err; std::memcpy(&lam, &bits, 4);
+        __atomic_store_n(&plan->host_words[dmel::kLamRing], 0ull, __ATOMIC_RELAXED);
+        lam_reset(plan);
+        return fail(DMEL_ERR_LAMBD_TRACKING,
+                    "lambd = " + std::to_string(lam) + " asks for n_fft " + std::to_string(dmel_n_fft(lam)) + " but the forward was issued for the "
+                    "fixed n_fft " + std::to_string(n_fft) + " (a learnable filterbank is tied to one n_fft): call " +
+                    std::to_string((unsigned)(err >> 32)) + " produced NaN");
+    }
+    if (batch == 0) return DMEL_OK;
+    Scratch sc;
+    if (scratch) sc = carve(scratch);
+    else {
+        if ((st = order_after_last_stream(plan, s)) != DMEL_OK) return st;
+        if ((st = ensure_own_scratch(plan, batch, s, &sc)) != DMEL_OK) return st;
+    }
+    dmel::LamArgs lam{};
+    lam.dev = lambd_dev; lam.val = 0.f; lam.n_expected = n_fft;
+    lam.role = dmel::kLamFirst | dmel::kLamLast;
+    ++plan->calls;
+    if (!is_capturing(s)) ++plan->issued;
+    lam.exec_counter = plan->exec_counter; lam.handled = sc.handled;
+    lam.host_seen = &plan->host_words[0]; lam.host_error = &plan->host_words[dmel::kLamRing];
+    lam.dot_counter = scratch ? sc.counter : nullptr;
+    plan->last_guards = 0;
+    bool sums_done = false;
+    return launch_forward_n(plan, x, batch, n_fft, lam, flags, eps, static_cast<float*>(out), tangent, dmel::kTrain, /*remove_dc=*/1, sc, s, 0,
+                            &sums_done, spec);
+}
+
 dmel_status dmel_plan_lambd_status(dmel_plan* plan, dmel_lambd_status* status)
 {
     if (!plan || !status) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan / status is NULL");
@@ -1335,21 +1381,23 @@ dmel_status dmel_backward(dmel_plan* plan, const float* grad_out, const float* t
 
 namespace {
 // lambd by value (lambd_dev == nullptr; n_fft derived from it) or on the device with the n_fft the caller's forward was issued for
+// saved_spec != nullptr: the (batch, n_fft_dev/2+1, n_time) power spectrogram the training forward wrote (dmel_forward_dev_fixed_spec):
+// no recompute, x and lambd are not touched
 dmel_status backward_fb_impl(dmel_plan* plan, const float* x, int32_t batch, float lambd, const float* lambd_dev, int32_t n_fft_dev,
-                             uint32_t flags, const float* grad_out, const float* out, float* grad_fb, void* stream)
+                             uint32_t flags, const float* grad_out, const float* out, float* grad_fb, void* stream, const float* saved_spec = nullptr)
 {
     if (!plan) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
     if (batch < 0) return fail(DMEL_ERR_INVALID_ARGUMENT, "batch < 0");
-    if (!grad_fb || (batch > 0 && (!x || !grad_out))) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_backward_fb: x / grad_out / grad_fb is NULL");
+    if (!grad_fb || (batch > 0 && ((!x && !saved_spec) || !grad_out))) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_backward_fb: x / grad_out / grad_fb is NULL");
     if ((flags & DMEL_FLAG_LOG) && batch > 0 && !out)
         return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_backward_fb: DMEL_FLAG_LOG needs the saved log output");
-    if (!lambd_dev && !std::isfinite(lambd)) return fail(DMEL_ERR_INVALID_ARGUMENT, "lambd is not finite");
+    if (!lambd_dev && !saved_spec && !std::isfinite(lambd)) return fail(DMEL_ERR_INVALID_ARGUMENT, "lambd is not finite");
     const bool full = (flags & DMEL_FLAG_FULL_WINDOW) != 0;
     if (lambd_dev && !full && (n_fft_dev < 1 || n_fft_dev > dmel::kMaxNfft || (n_fft_dev & (n_fft_dev - 1))))
         return fail(DMEL_ERR_INVALID_ARGUMENT, "n_fft must be a power of two in [1, 16384]");
     int n_over = 0, win_half = 0;
     if (full) { n_over = 2 * plan->cfg.n_points; win_half = 1; }     // any clip length: the spectrogram pass takes the chirp-z path where it has to
-    const int N = n_over ? n_over : (lambd_dev ? n_fft_dev : dmel_n_fft(lambd));
+    const int N = n_over ? n_over : ((lambd_dev || saved_spec) ? n_fft_dev : dmel_n_fft(lambd));
     if (N > dmel::kMaxBigFft)
         return fail(DMEL_ERR_UNSUPPORTED, "n_fft = " + std::to_string(N) + " > " + std::to_string(dmel::kMaxBigFft) + " is not supported by the HIP kernels");
     const int F = N / 2 + 1, M = plan->cfg.n_mels, T = plan->T;
@@ -1361,7 +1409,7 @@ dmel_status backward_fb_impl(dmel_plan* plan, const float* x, int32_t batch, flo
         if (so != DMEL_OK) return so;
     }
     const int splits = dmel::fbgrad_splits(batch, F, M, T);
-    const size_t spec_floats = ((size_t)batch * F * T + 63) / 64 * 64;
+    const size_t spec_floats = saved_spec ? 0 : ((size_t)batch * F * T + 63) / 64 * 64;
     const size_t part_floats = ((size_t)splits * F * M + 63) / 64 * 64;
     const size_t gm_floats = 0;      // (gm = grad_out * exp(-out) is formed inside the GEMM kernel)
     const size_t need = spec_floats + part_floats + gm_floats;
@@ -1374,7 +1422,9 @@ dmel_status backward_fb_impl(dmel_plan* plan, const float* x, int32_t batch, flo
     }
     // the spectrogram the layer contracted at models.py:53 (DC removed, models.py:38): P is recomputed, not saved
     dmel_status st;
-    if (lambd_dev && full) {
+    if (saved_spec) {
+        st = DMEL_OK;
+    } else if (lambd_dev && full) {
         // n_fft = 2 n_points does not depend on lambd: the kernels take the window's width from the device value, nothing to check
         st = run_forward_nolock(plan, x, batch, 0.f, 0u, 0.0, plan->fbw, nullptr, dmel::kSpec, 1, stream, n_over, win_half, nullptr, lambd_dev);
     } else if (lambd_dev) {
@@ -1390,10 +1440,11 @@ dmel_status backward_fb_impl(dmel_plan* plan, const float* x, int32_t batch, flo
     }
     if (st != DMEL_OK) return st;
     dmel::FbGradParams fp{};
-    fp.spec = plan->fbw; fp.grad_out = grad_out; fp.out = (flags & DMEL_FLAG_LOG) ? out : nullptr;
+    fp.spec = saved_spec ? saved_spec : plan->fbw; fp.grad_out = grad_out; fp.out = (flags & DMEL_FLAG_LOG) ? out : nullptr;
     fp.partials = plan->fbw + spec_floats; fp.grad_fb = grad_fb;
     fp.gm_ws = plan->fbw + spec_floats + part_floats;
     fp.B = batch; fp.F = F; fp.M = M; fp.T = T; fp.splits = splits;
+    fp.bf16x3 = (flags & DMEL_FLAG_MFMA_BF16X3) ? 1 : 0;
     const size_t m0 = prof_mark(plan, s);
     DMEL_HIP(dmel::launch_fbgrad(fp, s));
     prof_span(plan, m0, prof_mark(plan, s), 2);
@@ -1414,6 +1465,15 @@ dmel_status dmel_backward_fb_dev(dmel_plan* plan, const float* x, int32_t batch,
 {
     if (!lambd_dev) return fail(DMEL_ERR_INVALID_ARGUMENT, "lambd_dev is NULL");
     return backward_fb_impl(plan, x, batch, 0.f, lambd_dev, n_fft, flags, grad_out, out, grad_fb, stream);
+}
+
+dmel_status dmel_backward_fb_saved(dmel_plan* plan, const float* spec, int32_t batch, int32_t n_fft, uint32_t flags,
+                                   const float* grad_out, const float* out, float* grad_fb, void* stream)
+{
+    if (!spec) return fail(DMEL_ERR_INVALID_ARGUMENT, "spec is NULL");
+    if (flags & DMEL_FLAG_FULL_WINDOW) return fail(DMEL_ERR_UNSUPPORTED, "dmel_backward_fb_saved: not with DMEL_FLAG_FULL_WINDOW");
+    if (n_fft < 2 || (n_fft & 1)) return fail(DMEL_ERR_INVALID_ARGUMENT, "n_fft must be the (even) transform length the spectrogram was computed with");
+    return backward_fb_impl(plan, nullptr, batch, 0.f, nullptr, n_fft, flags, grad_out, out, grad_fb, stream, spec);
 }
 
 }  // extern "C"

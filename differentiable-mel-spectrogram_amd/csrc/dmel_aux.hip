@@ -401,11 +401,33 @@ __device__ __forceinline__ void fstamp(int idx)
 #endif
 constexpr int kFbgBF = 64, kFbgBM = 128, kFbgRow = 24, kFbgThreads = 512;     // rows of 24 floats: ds_read_b128 of 16 rows x 4 pieces is conflict-free (20: 2-way)
 
-template <bool LOG, bool TINY>
+// BF16X3 (opt-in, DMEL_FLAG_MFMA_BF16X3): the same GEMM on the bf16 matrix pipe, 16 x the fp32 MFMA rate, with both operands split
+// into two bf16 halves as they are parked (hi = bf16(v), lo = bf16(v - hi): v = hi + lo to 2^-17) and three products accumulated in
+// fp32 -- hi hi + lo hi + hi lo; the dropped lo lo term is 2^-16 of a product (1.7e-5 on the mel contraction, against the
+// 1e-4 bar; plain bf16 operands miss it by 60 x).  One v_mfma_f32_32x32x16_bf16 per term covers a wave's 32 x 32 sub-tile and a whole
+// K-block of 16 time steps: 3 instructions of 32 cycles where the exact path issues 16 of 32.  LDS images: rows of 16 bf16 padded to
+// 24 (48 B: the 16 lanes of a ds_read_b128 group -- 16 different rows mod 16 -- touch 16 different 16-byte slots).
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float floatx16_t __attribute__((ext_vector_type(16)));
+constexpr int kFbgRowH = 24;                                       // bf16 entries per row of a BF16X3 image
+__device__ __forceinline__ void split_bf16x4(float4 v, uint2& hi, uint2& lo)
+{
+    // round to nearest even both times (v_cvt_pk_bf16_f32); the bf16 bits of hi widened back are exact
+    const unsigned short h0 = bf16_bits(v.x), h1 = bf16_bits(v.y), h2 = bf16_bits(v.z), h3 = bf16_bits(v.w);
+    hi = make_uint2((unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16));
+    const float r0 = v.x - __uint_as_float((unsigned)h0 << 16), r1 = v.y - __uint_as_float((unsigned)h1 << 16);
+    const float r2 = v.z - __uint_as_float((unsigned)h2 << 16), r3 = v.w - __uint_as_float((unsigned)h3 << 16);
+    lo = make_uint2((unsigned)bf16_bits(r0) | ((unsigned)bf16_bits(r1) << 16), (unsigned)bf16_bits(r2) | ((unsigned)bf16_bits(r3) << 16));
+}
+
+template <bool LOG, bool TINY, bool BF16X3 = false>
 __global__ void __launch_bounds__(kFbgThreads) dmel_fbgrad_lds_kernel(FbGradParams p)
 {
-    __shared__ __attribute__((aligned(16))) float lds_a[2][(kFbgBF + 1) * kFbgRow];     // (+ the folded last row, see `fold`)
-    __shared__ __attribute__((aligned(16))) float lds_b[2][kFbgBM * kFbgRow];
+    // exact path: fp32 images, rows of 24 floats.  BF16X3: [hi | lo] images of bf16, rows of 24 entries -- the same bytes either way
+    constexpr int kImgA = BF16X3 ? (kFbgBF + 1) * kFbgRowH : (kFbgBF + 1) * kFbgRow;     // floats (+ the folded last row, see `fold`)
+    constexpr int kImgB = BF16X3 ? kFbgBM * kFbgRowH : kFbgBM * kFbgRow;
+    __shared__ __attribute__((aligned(16))) float lds_a[2][kImgA];
+    __shared__ __attribute__((aligned(16))) float lds_b[2][kImgB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     FSTAMP(0);
     const int row = lane & 15, kq = lane >> 4;
@@ -495,11 +517,29 @@ __global__ void __launch_bounds__(kFbgThreads) dmel_fbgrad_lds_kernel(FbGradPara
             ry = in_place(ry, t);                                   // (zeros behind the row: exp(-0) times a zero gradient)
             rb = make_float4(rg.x * expf(-ry.x), rg.y * expf(-ry.y), rg.z * expf(-ry.z), rg.w * expf(-ry.w));     // gm = grad_out * exp(-out)
         }
-        *reinterpret_cast<float4*>(&lds_b[buf][srow * kFbgRow + 4 * sc]) = rb;
-        if (has_a) *reinterpret_cast<float4*>(&lds_a[buf][srow * kFbgRow + 4 * sc]) = ra;
+        if constexpr (!BF16X3) {
+            *reinterpret_cast<float4*>(&lds_b[buf][srow * kFbgRow + 4 * sc]) = rb;
+            if (has_a) *reinterpret_cast<float4*>(&lds_a[buf][srow * kFbgRow + 4 * sc]) = ra;
+        } else {
+            // image = [hi rows | lo rows], a row = 24 bf16 = 12 floats; this thread's four time steps are 8 bytes of each
+            unsigned short* ib = reinterpret_cast<unsigned short*>(&lds_b[buf][0]);
+            unsigned short* ia = reinterpret_cast<unsigned short*>(&lds_a[buf][0]);
+            uint2 hi, lo;
+            split_bf16x4(rb, hi, lo);
+            *reinterpret_cast<uint2*>(ib + srow * kFbgRowH + 4 * sc) = hi;
+            *reinterpret_cast<uint2*>(ib + (kFbgBM + srow) * kFbgRowH + 4 * sc) = lo;
+            if (has_a) {
+                split_bf16x4(ra, hi, lo);
+                *reinterpret_cast<uint2*>(ia + srow * kFbgRowH + 4 * sc) = hi;
+                *reinterpret_cast<uint2*>(ia + (kFbgBF + 1 + srow) * kFbgRowH + 4 * sc) = lo;
+            }
+        }
     };
     floatx4_t acc[2][2];
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) acc[i][j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+    floatx16_t acc32;                                               // BF16X3: the wave's 32 x 32 sub-tile as ONE accumulator
+    for (int i = 0; i < 16; ++i) acc32[i] = 0.f;
+    const int r32 = lane & 31, kg = lane >> 5;                      // BF16X3 operand lane: row / column r32, time steps 8 kg .. 8 kg + 7
     float nyq = 0.f;                                                // fold: this thread's quarter of column srow of the last row
     // 16-row / 16-column pieces of this wave's sub-tile that exist (n_fft / 2 + 1 rows: the last tile of 64 holds ONE): a wave
     // with none only stages
@@ -526,21 +566,53 @@ __global__ void __launch_bounds__(kFbgThreads) dmel_fbgrad_lds_kernel(FbGradPara
             if (c >= total) return;
             const int buf = c & 1;
             float4 a[2], g[2];
+            bf16x8_t ah, al, gh, gl;
+            if constexpr (!BF16X3) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[i] = *reinterpret_cast<const float4*>(&lds_a[buf][(wf * 32 + 16 * i + row) * kFbgRow + 4 * kq]);
-                g[i] = *reinterpret_cast<const float4*>(&lds_b[buf][(wm * 32 + 16 * i + row) * kFbgRow + 4 * kq]);
-            }
-            if (fold) {
-                const float4 ar = *reinterpret_cast<const float4*>(&lds_a[buf][kFbgBF * kFbgRow + 4 * sc]);
-                const float4 gr = *reinterpret_cast<const float4*>(&lds_b[buf][srow * kFbgRow + 4 * sc]);
-                nyq = fmaf(ar.x, gr.x, nyq); nyq = fmaf(ar.y, gr.y, nyq); nyq = fmaf(ar.z, gr.z, nyq); nyq = fmaf(ar.w, gr.w, nyq);
+                for (int i = 0; i < 2; ++i) {
+                    a[i] = *reinterpret_cast<const float4*>(&lds_a[buf][(wf * 32 + 16 * i + row) * kFbgRow + 4 * kq]);
+                    g[i] = *reinterpret_cast<const float4*>(&lds_b[buf][(wm * 32 + 16 * i + row) * kFbgRow + 4 * kq]);
+                }
+                if (fold) {
+                    const float4 ar = *reinterpret_cast<const float4*>(&lds_a[buf][kFbgBF * kFbgRow + 4 * sc]);
+                    const float4 gr = *reinterpret_cast<const float4*>(&lds_b[buf][srow * kFbgRow + 4 * sc]);
+                    nyq = fmaf(ar.x, gr.x, nyq); nyq = fmaf(ar.y, gr.y, nyq); nyq = fmaf(ar.z, gr.z, nyq); nyq = fmaf(ar.w, gr.w, nyq);
+                }
+            } else {
+                const unsigned short* ia = reinterpret_cast<const unsigned short*>(&lds_a[buf][0]);
+                const unsigned short* ib = reinterpret_cast<const unsigned short*>(&lds_b[buf][0]);
+                ah = *reinterpret_cast<const bf16x8_t*>(ia + (wf * 32 + r32) * kFbgRowH + 8 * kg);
+                al = *reinterpret_cast<const bf16x8_t*>(ia + (kFbgBF + 1 + wf * 32 + r32) * kFbgRowH + 8 * kg);
+                gh = *reinterpret_cast<const bf16x8_t*>(ib + (wm * 32 + r32) * kFbgRowH + 8 * kg);
+                gl = *reinterpret_cast<const bf16x8_t*>(ib + (kFbgBM + wm * 32 + r32) * kFbgRowH + 8 * kg);
+                if (fold) {
+                    // the folded row on the vector pipe: both operands put together again from their halves (hi + lo: 2^-17 of v)
+                    const uint2 arh = *reinterpret_cast<const uint2*>(ia + kFbgBF * kFbgRowH + 4 * sc);
+                    const uint2 arl = *reinterpret_cast<const uint2*>(ia + (kFbgBF + 1 + kFbgBF) * kFbgRowH + 4 * sc);
+                    const uint2 grh = *reinterpret_cast<const uint2*>(ib + srow * kFbgRowH + 4 * sc);
+                    const uint2 grl = *reinterpret_cast<const uint2*>(ib + (kFbgBM + srow) * kFbgRowH + 4 * sc);
+                    auto wide = [](unsigned h, unsigned l, int odd) {
+                        return __uint_as_float(odd ? (h & 0xffff0000u) : (h << 16)) + __uint_as_float(odd ? (l & 0xffff0000u) : (l << 16));
+                    };
+                    nyq = fmaf(wide(arh.x, arl.x, 0), wide(grh.x, grl.x, 0), nyq); nyq = fmaf(wide(arh.x, arl.x, 1), wide(grh.x, grl.x, 1), nyq);
+                    nyq = fmaf(wide(arh.y, arl.y, 0), wide(grh.y, grl.y, 0), nyq); nyq = fmaf(wide(arh.y, arl.y, 1), wide(grh.y, grl.y, 1), nyq);
+                }
             }
             // block c + 1 (requested DEPTH iterations ago) into the other image: nobody reads that image before the barrier below;
             // then block c + 1 + DEPTH is requested into the slot just emptied
             constexpr int dn = (d + 1) % DEPTH;               // slot of block c + 1
             if (c + 1 < total) park(buf ^ 1, ring_a[dn], ring_g[dn], ring_y[dn], ring_t[dn]);
             fetch(ring_a[dn], ring_g[dn], ring_y[dn], ring_t[dn]);
+            if constexpr (BF16X3) {
+                if (act_f0 && act_m0) {
+                    // smallest term first; rows / columns past the edge hold copies of the last valid row and are never stored
+                    acc32 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, gh, acc32, 0, 0, 0);
+                    acc32 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gl, acc32, 0, 0, 0);
+                    acc32 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gh, acc32, 0, 0, 0);
+                }
+                __syncthreads();
+                return;
+            }
             const float av[2][4] = {{a[0].x, a[0].y, a[0].z, a[0].w}, {a[1].x, a[1].y, a[1].z, a[1].w}};
             const float gv[2][4] = {{g[0].x, g[0].y, g[0].z, g[0].w}, {g[1].x, g[1].y, g[1].z, g[1].w}};
             if (act_f1 && act_m1) {
@@ -572,6 +644,19 @@ __global__ void __launch_bounds__(kFbgThreads) dmel_fbgrad_lds_kernel(FbGradPara
         const float o2 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, pr), 0x4E, 0xF, 0xF, true));
         const float tot = (sc & 2) ? o2 + pr : pr + o2;
         if (sc == 0 && m0 + srow < M) part[(size_t)(F - 1) * M + m0 + srow] = tot;
+    }
+    if constexpr (BF16X3) {
+        // D[8 (v / 4) + 4 (lane >> 5) + v % 4][lane & 31] of the 32 x 32 tile: rows = freq, columns = mel
+        const int m = m0 + wm * 32 + r32;
+        if (m < M) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int f = f0 + wf * 32 + 8 * (v >> 2) + 4 * kg + (v & 3);
+                if (f < F) part[(size_t)f * M + m] = acc32[v];
+            }
+        }
+        FSTAMP(4);
+        return;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -652,7 +737,15 @@ hipError_t launch_fbgrad(const FbGradParams& p_in, hipStream_t s)
     if (all_blocks > 0x7fffffffLL || p.splits < 1) return hipErrorInvalidValue;
     p.blk_base = (int)(all_blocks / p.splits); p.blk_rem = (int)(all_blocks % p.splits);
     const dim3 grid(fbgrad_row_tiles(p.F), p.splits, (p.M + kFbgBM - 1) / kFbgBM);
-    if (p.T < 4) {                                    // rows shorter than a 16-byte piece: element-wise requests
+    if (p.bf16x3) {
+        if (p.T < 4) {
+            if (p.out) hipLaunchKernelGGL((dmel_fbgrad_lds_kernel<true, true, true>), grid, dim3(kFbgThreads), 0, s, p);
+            else hipLaunchKernelGGL((dmel_fbgrad_lds_kernel<false, true, true>), grid, dim3(kFbgThreads), 0, s, p);
+        } else {
+            if (p.out) hipLaunchKernelGGL((dmel_fbgrad_lds_kernel<true, false, true>), grid, dim3(kFbgThreads), 0, s, p);
+            else hipLaunchKernelGGL((dmel_fbgrad_lds_kernel<false, false, true>), grid, dim3(kFbgThreads), 0, s, p);
+        }
+    } else if (p.T < 4) {                             // rows shorter than a 16-byte piece: element-wise requests
         if (p.out) hipLaunchKernelGGL((dmel_fbgrad_lds_kernel<true, true>), grid, dim3(kFbgThreads), 0, s, p);
         else hipLaunchKernelGGL((dmel_fbgrad_lds_kernel<false, true>), grid, dim3(kFbgThreads), 0, s, p);
     } else {

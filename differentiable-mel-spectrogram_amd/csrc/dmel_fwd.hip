@@ -837,6 +837,18 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
 #endif
         float htan = 0.f;
         if constexpr (MODE == kTrain || MODE == kSpecTrain) htan = red[kRedTan];       // see the prologue
+        if constexpr (MODE == kTrain) {
+            // a trainable filterbank's gradient contracts this very spectrogram with the output's gradient (models.py:53): written out
+            // here, (B, F, T) as time_frequency.py:53 lays it out, it saves dmel_backward_fb the recompute.  16 consecutive threads
+            // write 16 consecutive frames of one bin: 64-byte pieces.
+            if (p.spec_out) {
+                for (int idx = tid; idx < SLOTS * F; idx += THREADS) {
+                    const int k = idx / SLOTS, slot = idx % SLOTS;
+                    const int t = t0 + slot;
+                    if (t < p.T) p.spec_out[((size_t)b * F + k) * p.T + t] = 0.25f * (lds + slot * SS)[z_index<R, C>(k)].x;
+                }
+            }
+        }
         if constexpr (IS_SPEC) {
             // power spectrogram (time_frequency.py:53), layout (B, F, T); kSpecTrain also writes d P / d lambd
             for (int idx = tid; idx < SLOTS * F; idx += THREADS) {

@@ -241,6 +241,8 @@ struct FwdParams {
     int remove_dc, normalize;
     int win_half;               // window support = middle half of n_fft (DSPEC: win_length = n_fft / 2)
     int wgs_per_clip;           // ceil(tiles_per_clip / tiles per workgroup)
+    float* spec_out;            // training mode only, or nullptr: the power spectrogram (B, F, T) the contraction consumes is ALSO written
+                                // out (16.8 MB at BASELINE config 2), so that the filterbank gradient need not recompute it (16.5 us)
 };
 
 struct PrepParams {
@@ -346,6 +348,7 @@ struct FbGradParams {
     int B, F, M, T, splits;
     int ntc, blk_base, blk_rem;   // set by launch_fbgrad: K-blocks per clip; slice s takes blk_base (+1 for s < blk_rem) consecutive blocks
     int fold_last_row;       // set by launch_fbgrad: F = 64 k + 1, the last row rides with the last full tile of 64 rows
+    int bf16x3;              // DMEL_FLAG_MFMA_BF16X3: three-term split-bf16 products on the bf16 matrix pipe instead of exact fp32 MFMA
 };
 hipError_t launch_fbgrad(const FbGradParams& p, hipStream_t s);
 int fbgrad_splits(int batch, int F, int M, int T);      // slices of the batch's K-blocks (= F x M partials) of one launch

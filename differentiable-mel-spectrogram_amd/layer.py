@@ -128,11 +128,13 @@ class _DmelFbDevFunction(torch.autograd.Function):
     waveform (dmel_backward_x_dev).  No host read anywhere: the step queues without waiting and can be captured into a HIP graph."""
 
     @staticmethod
-    def forward(ctx, x, lambd, plan, n_fft, log, eps, fb, out_dtype, full_window=False):
+    def forward(ctx, x, lambd, plan, n_fft, log, eps, fb, out_dtype, full_window=False, mfma_flags=0, save_spec=False):
         B = x.shape[0]
         want_tangent = ctx.needs_input_grad[1]
         want_fb = fb is not None and ctx.needs_input_grad[6]
         want_x = ctx.needs_input_grad[0]
+        # the spectrogram the contraction consumes, kept for the filterbank gradient (fused training kernel only)
+        keep_spec = bool(save_spec and want_fb and want_tangent and not full_window and 32 <= n_fft <= 16384 and (n_fft & (n_fft - 1)) == 0)
         round_later = out_dtype == torch.bfloat16 and log and (want_fb or want_x)       # see _DmelFunction.forward
         kdtype = torch.float32 if round_later else out_dtype
         out = torch.empty((B, 1, plan.n_mels, plan.n_time), dtype=kdtype, device=x.device)
@@ -141,12 +143,18 @@ class _DmelFbDevFunction(torch.autograd.Function):
         lam = lambd.detach()
         if lam.dtype != torch.float32:
             lam = lam.to(torch.float32)
-        flags = capi.DMEL_FLAG_FULL_WINDOW if full_window else 0
+        flags = (capi.DMEL_FLAG_FULL_WINDOW if full_window else 0) | int(mfma_flags)
+        spec = torch.empty((B, n_fft // 2 + 1, plan.n_time), dtype=torch.float32, device=x.device) if keep_spec else None
         with _on_device(x.device):
-            plan.forward_dev_fixed(x.data_ptr(), B, lam.data_ptr(), n_fft, out.data_ptr(), tangent.data_ptr() if want_tangent else None,
-                                   log, eps, _stream_ptr(x.device), scratch.data_ptr(),
-                                   extra_flags=flags | (capi.DMEL_FLAG_OUT_BF16 if kdtype == torch.bfloat16 else 0))
-        ctx.plan, ctx.n_fft, ctx.log, ctx.flags = plan, n_fft, bool(log), flags
+            if keep_spec:
+                plan.forward_dev_fixed_spec(x.data_ptr(), B, lam.data_ptr(), n_fft, out.data_ptr(), tangent.data_ptr(), spec.data_ptr(),
+                                            log, eps, _stream_ptr(x.device), scratch.data_ptr(),
+                                            extra_flags=flags | (capi.DMEL_FLAG_OUT_BF16 if kdtype == torch.bfloat16 else 0))
+            else:
+                plan.forward_dev_fixed(x.data_ptr(), B, lam.data_ptr(), n_fft, out.data_ptr(), tangent.data_ptr() if want_tangent else None,
+                                       log, eps, _stream_ptr(x.device), scratch.data_ptr(),
+                                       extra_flags=flags | (capi.DMEL_FLAG_OUT_BF16 if kdtype == torch.bfloat16 else 0))
+        ctx.plan, ctx.n_fft, ctx.log, ctx.flags, ctx.keep_spec = plan, n_fft, bool(log), flags, keep_spec
         ctx.lambd_shape, ctx.lambd_dtype = lambd.shape, lambd.dtype
         ctx.want_tangent, ctx.want_fb, ctx.want_x = want_tangent, want_fb, want_x
         ctx.fb_meta = None if fb is None else (tuple(fb.shape), fb.dtype)
@@ -157,12 +165,15 @@ class _DmelFbDevFunction(torch.autograd.Function):
             saved += [x, lam]
             if log:
                 saved.append(out)
+        if keep_spec:
+            saved.append(spec)
         ctx.save_for_backward(*saved)
         return out.to(torch.bfloat16) if round_later else out
 
     @staticmethod
     def backward(ctx, grad_out):
         saved = list(ctx.saved_tensors)
+        spec = saved.pop() if ctx.keep_spec else None
         scratch = saved.pop(0)
         bf16 = grad_out.dtype == torch.bfloat16
         g = grad_out
@@ -190,10 +201,14 @@ class _DmelFbDevFunction(torch.autograd.Function):
             if ctx.want_fb:
                 fb_shape, fb_dtype = ctx.fb_meta
                 gfb = torch.empty(fb_shape, dtype=torch.float32, device=g.device)
-                ctx.plan.backward_fb_dev(x.data_ptr(), x.shape[0], lam.data_ptr(), ctx.n_fft, g32.data_ptr(),
-                                         out.data_ptr() if ctx.log else None, gfb.data_ptr(), ctx.log, _stream_ptr(g.device), extra_flags=ctx.flags)
+                if spec is not None:
+                    ctx.plan.backward_fb_saved(spec.data_ptr(), x.shape[0], ctx.n_fft, g32.data_ptr(), out.data_ptr() if ctx.log else None,
+                                               gfb.data_ptr(), ctx.log, _stream_ptr(g.device), extra_flags=ctx.flags)
+                else:
+                    ctx.plan.backward_fb_dev(x.data_ptr(), x.shape[0], lam.data_ptr(), ctx.n_fft, g32.data_ptr(),
+                                             out.data_ptr() if ctx.log else None, gfb.data_ptr(), ctx.log, _stream_ptr(g.device), extra_flags=ctx.flags)
                 gfb = gfb.to(fb_dtype)
-        return gx, dl, None, None, None, None, gfb, None, None
+        return gx, dl, None, None, None, None, gfb, None, None, None, None
 
 
 _MEL_OP = None
@@ -226,16 +241,26 @@ class MelSpectrogramLayer(nn.Module):
     include/dmel.h), and one the guards do not cover (e.g. ``lambd`` rewritten by hand to a far value in the middle of a
     run: call ``resync()`` after that) yields NaN outputs and a RuntimeError at the next forward.  ``lambd_sync=True``
     reads ``lambd`` to the host at every forward like the reference (time_frequency.py:39).
+    ``mfma="bf16x3"`` (with ``learnable_fb``): the dense contractions -- the forward through the trained matrix, the filterbank
+    gradient's GEMM -- run on the bf16 matrix pipe as three split-bf16 products per fp32 product (~2e-5 relative, inside the 1e-4
+    bar; default "fp32": exact).  ``save_spec=True`` (with ``learnable_fb``, default): the training forward keeps the power
+    spectrogram for the filterbank gradient instead of recomputing it in the backward.
 
     forward(x: (B, n_points)) -> (B, 1, n_mels, n_points // hop_length + 1) float32.
     """
 
     def __init__(self, init_lambd, n_mels, n_points, sample_rate, f_min=0, f_max=None, hop_length=1,
                  device="cpu", optimized=False, normalize_window=False, *, log=False, eps=1e-10, learnable_fb=False,
-                 out_dtype=torch.float32, lambd_sync=False):
+                 out_dtype=torch.float32, lambd_sync=False, mfma="fp32", save_spec=True):
         super().__init__()
         if not torch.is_tensor(init_lambd):
             init_lambd = torch.tensor(float(init_lambd), dtype=torch.float32)
+        if mfma not in ("fp32", "bf16x3"):
+            raise ValueError("mfma must be 'fp32' (exact fp32 MFMA, the default) or 'bf16x3' (DMEL_FLAG_MFMA_BF16X3: three split-bf16 "
+                             "products per fp32 product on the bf16 matrix pipe, for the DENSE contractions of a trainable filterbank)")
+        self.mfma = mfma
+        self.save_spec = bool(save_spec)      # trainable filterbank: the training forward also writes the (B, F, T) power spectrogram, so
+                                              # that the filterbank gradient skips its recompute (16.8 MB per step at BASELINE config 2)
         self.hop_length = hop_length
         self.lambd = nn.Parameter(init_lambd)                        # models.py:19
         self.device = device
@@ -365,7 +390,8 @@ class MelSpectrogramLayer(nn.Module):
                     fbd = fbd.to(torch.float32).contiguous()
                 with _on_device(x.device):
                     plan.set_filterbank_dev(n, fbd.data_ptr(), _stream_ptr(x.device))
-            return _DmelFbDevFunction.apply(xf, self.lambd, plan, n, self.log, self.eps, fb, self.out_dtype, full)
+            return _DmelFbDevFunction.apply(xf, self.lambd, plan, n, self.log, self.eps, fb, self.out_dtype, full,
+                                            capi.DMEL_FLAG_MFMA_BF16X3 if self.mfma == "bf16x3" else 0, self.save_spec)
         lam_host = self._lambd_host()
         if fb is not None:
             n = capi.n_fft(lam_host) if self.optimized else 2 * self.n_points

@@ -65,6 +65,10 @@ typedef struct dmel_plan dmel_plan;
 #define DMEL_FLAG_OUT_BF16 4u   /* dmel_forward writes `out` as bf16 (round to nearest even of the fp32 result; BASELINE
                                   config 2 "bf16 activations / fp32 grad"): half the output bytes.  The arithmetic, the
                                   tangent and d lambd stay fp32.  The reference's output is fp32 (models.py:36).          */
+#define DMEL_FLAG_MFMA_BF16X3 8u /* opt-in: dense contractions (dmel_backward_fb*: the filterbank gradient's GEMM; dmel_forward* with a
+                                   caller-supplied DENSE filterbank) run on the bf16 matrix pipe as three split-bf16 products per fp32
+                                   product (hi hi + lo hi + hi lo, fp32 accumulate: ~2e-5 relative, inside the 1e-4 bar; 16 x the fp32 MFMA
+                                   rate).  Default: exact fp32 MFMA (v_mfma_f32_16x16x4_f32).  The HTK bank's banded contraction ignores it. */
 #define DMEL_DTYPE_F32 0
 #define DMEL_DTYPE_BF16 1
 
@@ -171,6 +175,12 @@ dmel_status dmel_forward_dev(dmel_plan* plan, const float* x, int32_t batch, con
  * whatever lambd is: `n_fft` is ignored, nothing is checked, lambd only shapes the window the kernels build from the device value. */
 dmel_status dmel_forward_dev_fixed(dmel_plan* plan, const float* x, int32_t batch, const float* lambd_dev, int32_t n_fft,
                                    uint32_t flags, double eps, void* out, float* tangent, void* scratch, void* stream);
+/* dmel_forward_dev_fixed that ALSO writes the power spectrogram the contraction consumed -- spec: device, (batch, n_fft/2+1, n_time) fp32,
+ * the layout of time_frequency.py:53 -- for dmel_backward_fb_saved: the filterbank gradient then skips its recompute of the spectrogram
+ * (16.5 us of 43 at BASELINE config 2, for 16.8 MB more stored here).  Training forward only (tangent != NULL), power-of-two n_fft
+ * from 32 to 16384, not with DMEL_FLAG_FULL_WINDOW; spec = NULL is plain dmel_forward_dev_fixed. */
+dmel_status dmel_forward_dev_fixed_spec(dmel_plan* plan, const float* x, int32_t batch, const float* lambd_dev, int32_t n_fft,
+                                        uint32_t flags, double eps, void* out, float* tangent, float* spec, void* scratch, void* stream);
 
 /* Every forward that EXECUTES on a plan (an eager dmel_forward_dev, or one replay of a captured one) draws the next
  * EXECUTION NUMBER from a device counter and reports (number, lambd as it read it) into a pinned ring of 64 entries. */
@@ -255,6 +265,10 @@ dmel_status dmel_backward_fb(dmel_plan* plan, const float* x, int32_t batch, flo
  * (2 n_points) and nothing is checked. */
 dmel_status dmel_backward_fb_dev(dmel_plan* plan, const float* x, int32_t batch, const float* lambd_dev, int32_t n_fft, uint32_t flags,
                                  const float* grad_out, const float* out, float* grad_fb, void* stream);
+/* dmel_backward_fb on the spectrogram saved by dmel_forward_dev_fixed_spec (same batch, n_fft, plan): the GEMM and the ordered sum of
+ * its slices only.  flags: DMEL_FLAG_LOG (then `out` = the saved log output), DMEL_FLAG_MFMA_BF16X3. */
+dmel_status dmel_backward_fb_saved(dmel_plan* plan, const float* spec, int32_t batch, int32_t n_fft, uint32_t flags,
+                                   const float* grad_out, const float* out, float* grad_fb, void* stream);
 
 /*
  * Backward to the waveform: what torch autograd returns for x.requires_grad through models.py:38 (DC removal),

@@ -103,8 +103,41 @@ def test_waveform_gradient_with_a_trainable_filterbank_is_sync_free(log):
 
     def make(sync):
         return MelSpectrogramLayer(torch.tensor(float(case["lambd"])), n_mels=case["n_mels"], n_points=case["L"], sample_rate=case["sr"],
-                                   hop_length=case["hop"], device=DEV, optimized=True, log=log, learnable_fb=True, lambd_sync=sync).to(DEV)
+                                   hop_length=case["hop"], device=DEV, optimized=True, log=log, learnable_fb=True, lambd_sync=sync,
+                                   save_spec=False).to(DEV)       # (the recomputed spectrogram on both sides: the same bits)
 
     ref = _run(make, x0, g, 5, False, True)
     got = _run(make, x0, g, 5, True, True)
     _same(ref, got)
+
+
+@pytest.mark.parametrize("log", [False, True])
+@pytest.mark.parametrize("mfma", ["fp32", "bf16x3"])
+def test_saved_spectrogram_and_split_bf16_filterbank_gradient(log, mfma):
+    """save_spec=True (the training forward writes the power spectrogram the contraction consumed; dmel_backward_fb_saved skips the
+    recompute) and mfma='bf16x3' (DMEL_FLAG_MFMA_BF16X3: the gradient's GEMM as three split-bf16 products on the bf16 matrix pipe)
+    against the exact, recomputing path: d mel_fb within 1e-4 of its largest entry (the bar of the reference fixtures), d lambd the same
+    bits (the forward is the same kernel), and against the fp64 oracle"""
+    from dmel_amd import MelSpectrogramLayer
+    from oracle import dmel_oracle as O
+    for name in ("g1_c1", "g2_c2"):
+        case = C.BY_NAME[name]
+        x_np = C.make_input(case).astype(np.float32)
+        g_np = C.make_cotangent(case)
+        x, g = torch.from_numpy(x_np).to(DEV), torch.from_numpy(g_np).to(DEV)
+
+        def run(**kw):
+            lay = MelSpectrogramLayer(torch.tensor(float(case["lambd"])), n_mels=case["n_mels"], n_points=case["L"], sample_rate=case["sr"],
+                                      hop_length=case["hop"], device=DEV, optimized=True, log=log, learnable_fb=True, **kw).to(DEV)
+            y = lay(x)
+            y.backward(g)
+            torch.cuda.synchronize()
+            return y.detach(), lay.lambd.grad.clone(), lay.mel_fb.grad.clone()
+
+        y0, dl0, gfb0 = run(save_spec=False)
+        y1, dl1, gfb1 = run(save_spec=True, mfma=mfma)
+        assert torch.equal(dl0, dl1)
+        scale = float(gfb0.abs().max())
+        assert float((gfb1 - gfb0).abs().max()) <= 1e-4 * scale
+        ref = O.backward_fb(x_np, case["lambd"], case["hop"], g_np, y0.cpu().numpy() if log else None, case["normalize_window"])
+        assert float(np.abs(gfb1.cpu().numpy().astype(np.float64) - ref).max()) <= 1e-4 * float(np.abs(ref).max())

@@ -30,16 +30,22 @@ def main():
         n = capi.n_fft(lam)
         gfb = torch.empty(n // 2 + 1, M, device="cuda:0")
         for log in logs:
+          ref = None
+          for mode, fl in (("fp32", 0), ("bf16x3", capi.DMEL_FLAG_MFMA_BF16X3)):
             for _ in range(5):
-                plan.backward_fb(x.data_ptr(), B, lam, g.data_ptr(), y.data_ptr(), gfb.data_ptr(), log, st)
+                plan.backward_fb(x.data_ptr(), B, lam, g.data_ptr(), y.data_ptr(), gfb.data_ptr(), log, st, extra_flags=fl)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(reps):
-                plan.backward_fb(x.data_ptr(), B, lam, g.data_ptr(), y.data_ptr(), gfb.data_ptr(), log, st)
+                plan.backward_fb(x.data_ptr(), B, lam, g.data_ptr(), y.data_ptr(), gfb.data_ptr(), log, st, extra_flags=fl)
             e1.record()
             torch.cuda.synchronize()
-            res[f"{name}_{'log' if log else 'lin'}"] = round(e0.elapsed_time(e1) * 1000 / reps, 2)
+            res[f"{name}_{'log' if log else 'lin'}_{mode}"] = round(e0.elapsed_time(e1) * 1000 / reps, 2)
+            if ref is None:
+                ref = gfb.clone()
+            else:
+                res[f"{name}_{'log' if log else 'lin'}_{mode}_max_err_over_max"] = float((gfb - ref).abs().max() / ref.abs().max())
     print(json.dumps(res))
 
 

@@ -16,9 +16,14 @@ x = torch.from_numpy(synth.waveforms(B, L, seed=0)).to(dev)
 T = L // hop + 1
 g = torch.from_numpy(synth.cotangent((B, 1, M, T), seed=1)).to(dev)
 res = {}
-for name, lfb, native in (("lambd_only", False, False), ("lambd_and_filterbank", True, False), ("lambd_and_filterbank_LambdAdam", True, True)):
+for name, lfb, native, kw in (("lambd_only", False, False, {}),
+                              ("lambd_and_filterbank_recompute_fp32", True, False, dict(save_spec=False)),
+                              ("lambd_and_filterbank", True, False, {}),
+                              ("lambd_and_filterbank_bf16x3", True, False, dict(mfma="bf16x3")),
+                              ("lambd_and_filterbank_LambdAdam", True, True, {}),
+                              ("lambd_and_filterbank_bf16x3_LambdAdam", True, True, dict(mfma="bf16x3"))):
     layer = MelSpectrogramLayer(torch.tensor(lam), n_mels=M, n_points=L, sample_rate=sr, hop_length=hop, device=dev, optimized=True,
-                                log=True, learnable_fb=lfb).to(dev)
+                                log=True, learnable_fb=lfb, **kw).to(dev)
     opt = dmel_amd.LambdAdam(layer.parameters(), lr=1e-9) if native else torch.optim.Adam(layer.parameters(), lr=1e-9, fused=True, capturable=True)
 
     def step():
