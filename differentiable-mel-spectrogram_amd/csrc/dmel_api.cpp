@@ -75,11 +75,13 @@ struct NfftTables {
     int2* rowband = nullptr;     // (F): non-zero column range of every filterbank row (dL/dx)
     float4* rowpk = nullptr;     // (F): (first two non-zero coefficients, first column, columns) of every row (dL/dx, wave-FFT kernel)
     bool long_rows = false;      // some row has more than two columns
+    uint4* ent_h = nullptr;      // caller-supplied (dense) banks, n_fft 64 .. 4096: B fragments of the split-bf16 contraction (FwdParams::ent_h)
+    float* fb_nyq = nullptr;     // ... and the row of bin n_fft/2 (n_mels)
     void release()
     {
         if (tw1p == tw1) tw1p = nullptr;
         if (tw2p == tw2) tw2p = nullptr;
-        void* ptrs[] = {tw1, tw2, tw1p, tw2p, ent_b, ent_pre, tile_ranges, fb_dense, tw_long, fbT, band, rowband, rowpk};
+        void* ptrs[] = {tw1, tw2, tw1p, tw2p, ent_b, ent_pre, tile_ranges, fb_dense, tw_long, fbT, band, rowband, rowpk, ent_h, fb_nyq};
         for (void* q : ptrs) (void)hipFree(q);
         *this = NfftTables();
     }
@@ -320,6 +322,34 @@ dmel_status build_tables(dmel_plan* pl, int N, NfftTables** out)
             }
         }
         tb.ent_b_floats = (int)bfr.size();
+        if ((cit != pl->custom_fb.end() || pl->dense_dev.count(N)) && dmel::forward_has_hsplit(N)) {
+            // the same matrix as B fragments of v_mfma_f32_16x16x32_bf16, split into two bf16 halves (DMEL_FLAG_MFMA_BF16X3):
+            // [(tile * (N/64) + kstep) * 2 + (hi | lo)][lane][8]: lane l holds rows 32 kstep + 8 (l >> 4) + e of column 16 tile + (l & 15)
+            const int ks32 = N / 64;
+            auto bf16_rne = [](float v) -> unsigned short {
+                unsigned u; std::memcpy(&u, &v, 4);
+                if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);      // NaN stays NaN
+                return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+            };
+            std::vector<unsigned short> eh((size_t)tb.NT * ks32 * 2 * 64 * 8);
+            for (int tile = 0; tile < tb.NT; ++tile)
+                for (int ks = 0; ks < ks32; ++ks)
+                    for (int l = 0; l < 64; ++l)
+                        for (int e = 0; e < 8; ++e) {
+                            const int f = 32 * ks + 8 * (l >> 4) + e, m = 16 * tile + (l & 15);
+                            const float v = (m < M) ? fb[(size_t)f * M + m] : 0.f;
+                            const unsigned short hi = bf16_rne(v);
+                            unsigned hu = (unsigned)hi << 16; float hf; std::memcpy(&hf, &hu, 4);
+                            const unsigned short lo = bf16_rne(v - hf);
+                            const size_t base = ((size_t)(tile * ks32 + ks) * 2) * 64 * 8;
+                            eh[base + (size_t)l * 8 + e] = hi;
+                            eh[base + 64 * 8 + (size_t)l * 8 + e] = lo;
+                        }
+            DMEL_HIP(hipMalloc(&tb.ent_h, eh.size() * sizeof(unsigned short)));
+            DMEL_HIP(hipMemcpy(tb.ent_h, eh.data(), eh.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+            DMEL_HIP(hipMalloc(&tb.fb_nyq, (size_t)M * sizeof(float)));
+            DMEL_HIP(hipMemcpy(tb.fb_nyq, fb.data() + (size_t)(tb.F - 1) * M, (size_t)M * sizeof(float), hipMemcpyHostToDevice));
+        }
         {   // register-resident prefix of every run of group 0, at a fixed position per (wave, run)
             const int nbpre = dmel::forward_nbpre(N);
             std::vector<float> pre((size_t)waves * 2 * nbpre * 64, 0.f);
@@ -629,9 +659,14 @@ dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dm
     fp.inv_L = inv_L; fp.eps = (float)eps; fp.flags = flags; fp.lam = lam;
     fp.remove_dc = remove_dc; fp.normalize = pl->cfg.normalize_window; fp.win_half = win_half;
     fp.spec_out = spec_out;
+    fp.ent_h = tb->ent_h; fp.fb_nyq = tb->fb_nyq;
+    // DMEL_FLAG_MFMA_BF16X3: the training forward through a caller-supplied (dense) bank contracts on the bf16 matrix pipe
+    const bool hsplit = (flags & DMEL_FLAG_MFMA_BF16X3) && mode == dmel::kTrain && tb->ent_h != nullptr;
+    if (hsplit) mode = dmel::kTrainH;
     static const int force_tpw = std::getenv("DMEL_TILES_PER_WG") ? std::atoi(std::getenv("DMEL_TILES_PER_WG")) : 0;   // diagnostics
     int tpw = dmel::forward_tiles_per_wg(N, mode, batch, fp.tiles_per_clip);
     if (force_tpw == 1 || (force_tpw == 2 && dmel::forward_two_tiles(N, mode))) tpw = force_tpw;
+    if (hsplit) tpw = 1;
     fp.wgs_per_clip = (fp.tiles_per_clip + tpw - 1) / tpw;
     const long long grid = (long long)batch * fp.wgs_per_clip;
     if (grid > 0x7fffffffLL) return fail(DMEL_ERR_INVALID_ARGUMENT, "too many tiles for one launch");
@@ -1011,6 +1046,7 @@ dmel_status dmel_plan_set_filterbank_dev(dmel_plan* plan, int32_t n_fft, const f
     dmel::RepackParams rp{};
     rp.fb = fb_dev; rp.ent_b = tb->ent_b; rp.ent_pre = tb->ent_pre; rp.tile_ranges = tb->tile_ranges;
     rp.fb_dense = tb->fb_dense; rp.fbT = tb->fbT; rp.rowpk = tb->rowpk; rp.F = tb->F; rp.M = plan->cfg.n_mels;
+    rp.ent_h = tb->ent_h; rp.fb_nyq = tb->fb_nyq; rp.ks32 = tb->ent_h ? n_fft / 64 : 0;
     const bool fast = n_fft >= dmel::kMinFastNfft && n_fft <= dmel::kMaxFastNfft;
     const int waves = fast ? dmel::forward_waves(n_fft) : 0;
     rp.runs = fast ? tb->groups * waves * 2 : 0;

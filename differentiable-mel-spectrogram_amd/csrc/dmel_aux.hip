@@ -188,6 +188,28 @@ __global__ void __launch_bounds__(256) dmel_repack_kernel(RepackParams p)
     if ((int)blockIdx.x >= p.runs) {
         const long long n = (long long)p.F * p.M;
         const long long stride = 256LL * (gridDim.x - p.runs);
+        if (p.ent_h) {
+            // the split-bf16 fragments of kTrainH (build_tables is the host's version of this loop): one 16-byte entry per (block, lane)
+            const int NT = (p.M + 15) / 16;
+            const long long ne = (long long)NT * p.ks32 * 64;
+            for (long long q = (long long)(blockIdx.x - p.runs) * 256 + tid; q < ne; q += stride) {
+                const int l = (int)(q & 63);
+                const long long blk = q >> 6;                              // tile * ks32 + kstep
+                const int tile = (int)(blk / p.ks32), ks = (int)(blk % p.ks32);
+                const int m = 16 * tile + (l & 15), f0 = 32 * ks + 8 * (l >> 4);
+                unsigned hi[4], lo[4];
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const float v0 = m < p.M ? p.fb[(size_t)(f0 + e) * p.M + m] : 0.f, v1 = m < p.M ? p.fb[(size_t)(f0 + e + 1) * p.M + m] : 0.f;
+                    const unsigned short h0 = bf16_bits(v0), h1 = bf16_bits(v1);
+                    hi[e / 2] = (unsigned)h0 | ((unsigned)h1 << 16);
+                    lo[e / 2] = (unsigned)bf16_bits(v0 - __uint_as_float((unsigned)h0 << 16)) | ((unsigned)bf16_bits(v1 - __uint_as_float((unsigned)h1 << 16)) << 16);
+                }
+                p.ent_h[blk * 128 + l] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+                p.ent_h[blk * 128 + 64 + l] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+            }
+            for (long long m = (long long)(blockIdx.x - p.runs) * 256 + tid; m < p.M; m += stride) p.fb_nyq[m] = p.fb[(size_t)(p.F - 1) * p.M + m];
+        }
         for (long long i = (long long)(blockIdx.x - p.runs) * 256 + tid; i < n; i += stride) {
             const float v = p.fb[i];
             p.fb_dense[i] = v;

@@ -156,6 +156,10 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
     constexpr int EXS = g.EX_STRIDE, SS = g.SLOT_STRIDE_F2;
     constexpr bool PAIR = (MODE == kInfer || MODE == kSpec);    // two frames share one complex FFT
     constexpr bool IS_SPEC = (MODE == kSpec || MODE == kSpecTrain);
+    constexpr bool HSPLIT = (MODE == kTrainH);                  // dense contraction on the bf16 matrix pipe: PD kept as four bf16 planes
+    constexpr bool TRAINLIKE = (MODE == kTrain || MODE == kTrainH);
+    constexpr int NHS = hsplit_plane_stride(N);                 // bf16 entries per plane (bins 0 .. N/2 + padding to 16 bytes)
+    static_assert(!HSPLIT || (N >= kHsplitMinNfft && N <= kHsplitMaxNfft), "kTrainH: frames inside one wave, N/2 a multiple of 32");
     constexpr int FPT = PAIR ? 2 * SLOTS : SLOTS;               // frames per tile
     constexpr int F = N / 2 + 1;
 
@@ -336,7 +340,7 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
         }
         // d out / d lambd = htan * (contraction of the scaled tangent spectrum): an fp64 division, done by ONE wave of the
         // workgroup and handed to the epilogue through LDS (every barrier below lies between this store and that load)
-        if constexpr (MODE == kTrain || MODE == kSpecTrain) {
+        if constexpr (TRAINLIKE || MODE == kSpecTrain) {
             if (wave == 0) { const float h = 0.5f * lam_tangent_scale(ls); if (lane == 0) red[kRedTan] = h; }
         }
         if constexpr (TW2_LDS) { if (tid < R * C) tw2l[tid] = p.tw2[tid]; }          // visible after the barrier below
@@ -484,6 +488,20 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
         }
         STAMP(2);   // window table + clip mean done
     }
+
+    // kTrainH: PD[k] of a slot goes out as four bf16 values -- P hi, P lo, D hi, D lo, planes of NHS entries each: hi = bf16(v),
+    // lo = bf16(v - hi), v = hi + lo to 2^-17 -- so that phase 2 reads its A operands (8 consecutive bins of one plane) with one
+    // ds_read_b128 per lane and the three products hi hi + lo hi + hi lo stand for one fp32 product.
+    auto store_h = [&](int slot_bytes, int k, v2f pdv) {
+        const unsigned short ph = bf16_bits(pdv.x), dh = bf16_bits(pdv.y);
+        const unsigned short pl = bf16_bits(pdv.x - __uint_as_float((unsigned)ph << 16)), dl = bf16_bits(pdv.y - __uint_as_float((unsigned)dh << 16));
+        unsigned short* q = reinterpret_cast<unsigned short*>(smem_raw + slot_bytes) + k;
+        q[0] = ph; q[NHS] = pl; q[2 * NHS] = dh; q[3 * NHS] = dl;
+    };
+    auto load_h = [&](int slot_bytes, int plane, int k) -> float {          // hi + lo of one bin of plane pair `plane` (0: P, 1: D)
+        const unsigned short* q = reinterpret_cast<const unsigned short*>(smem_raw + slot_bytes) + 2 * plane * NHS + k;
+        return __uint_as_float((unsigned)q[0] << 16) + __uint_as_float((unsigned)q[NHS] << 16);
+    };
 
     // ================= the tiles of this workgroup ==============================================
     static_for<0, TPW>([&](auto tt) {
@@ -766,6 +784,14 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
                         if constexpr (!PAIR) pdv = v2f{fmaf(sx, sx, sy * sy), fmaf(sx, dy, -(sy * dx))};
                         else pdv = v2f{fmaf(sx, sx, sy * sy), fmaf(dx, dx, dy * dy)};
                         if constexpr (PLANE) pdk[p1] = pdv;
+                        else if constexpr (HSPLIT) {
+                            // the same bins, unpadded, into the bf16 planes of the slot
+                            const int kb_a = qp + RR * p2, kb_b = (R - qp) + R * (R - 1) + RR * p2m;
+                            const int kb0 = dir_a ? kb_a : kb_b, kbs = dir_a ? R : -R;
+                            if constexpr (p1 == 0) { if (w0) store_h(slot_b, nyq ? N / 2 : kb0, pdv); }
+                            else if constexpr (p1 < R / 2) store_h(slot_b, kb0 + kbs * p1, pdv);
+                            else { if (q0 && dir_a) store_h(slot_b, kb_a + R * (R / 2), pdv); }
+                        }
                         else if constexpr (p1 == 0) { if (w0) *reinterpret_cast<v2f*>(smem_raw + addr0) = pdv; }
                         else if constexpr (p1 < R / 2) *reinterpret_cast<v2f*>(smem_raw + obase + ostep * p1) = pdv;
                         else { if (q0 && dir_a) *reinterpret_cast<v2f*>(smem_raw + base_a + R * 8 * (R / 2)) = pdv; }
@@ -824,6 +850,8 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
                     constexpr int i = decltype(ii)::value;
                     constexpr int ck = G * i;
                     v2f* dst = reinterpret_cast<v2f*>(smem_raw + zb + (ck + PADC * (ck / RR)) * 8);
+                    if constexpr (HSPLIT) { if (i < NPAIR - 1 || lg == 0) store_h(slot_b, lg + ck, pd[i]); }
+                    else
                     if (i < NPAIR - 1 || lg == 0) *dst = pd[i];          // the last round holds only the Nyquist bin
                 });
                 }
@@ -836,8 +864,8 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
         if (dbg_skip_gemm) { if (tid == 0 && lds[0].x == 12345.678f) p.out[0] = 0.f; return; }
 #endif
         float htan = 0.f;
-        if constexpr (MODE == kTrain || MODE == kSpecTrain) htan = red[kRedTan];       // see the prologue
-        if constexpr (MODE == kTrain) {
+        if constexpr (TRAINLIKE || MODE == kSpecTrain) htan = red[kRedTan];       // see the prologue
+        if constexpr (TRAINLIKE) {
             // a trainable filterbank's gradient contracts this very spectrogram with the output's gradient (models.py:53): written out
             // here, (B, F, T) as time_frequency.py:53 lays it out, it saves dmel_backward_fb the recompute.  16 consecutive threads
             // write 16 consecutive frames of one bin: 64-byte pieces.
@@ -845,6 +873,8 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
                 for (int idx = tid; idx < SLOTS * F; idx += THREADS) {
                     const int k = idx / SLOTS, slot = idx % SLOTS;
                     const int t = t0 + slot;
+                    if constexpr (HSPLIT) { if (t < p.T) p.spec_out[((size_t)b * F + k) * p.T + t] = 0.25f * load_h(slot * (SS * 8), 0, k); }
+                    else
                     if (t < p.T) p.spec_out[((size_t)b * F + k) * p.T + t] = 0.25f * (lds + slot * SS)[z_index<R, C>(k)].x;
                 }
             }
@@ -877,6 +907,128 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
             const int cg = lane >> 4;      // accumulator row group of this lane (C/D layout)
             const int col = lane & 15;
 
+            const bool do_log = (p.flags & 1u) != 0;
+            const bool out_bf16 = (p.flags & 4u) != 0;
+            // ---- epilogue of one 16-mel tile: accumulators -> (B,1,M,T) -------------------------------
+            auto write_tile = [&](int nt, const floatx4 (&tt)[MT]) {
+                    if (nt < 0) return;
+                    const int m = 16 * nt + col;
+                    if (m >= p.M) return;
+                    const size_t rbase = ((size_t)b * p.M + m) * p.T;
+                    float* orow = p.out + rbase;
+                    unsigned short* orow_h = reinterpret_cast<unsigned short*>(p.out) + rbase;     // DMEL_FLAG_OUT_BF16: out is bf16
+                    float* trow = p.tangent ? p.tangent + rbase : nullptr;
+                    auto put = [&](int t, float v) { if (out_bf16) orow_h[t] = bf16_bits(v); else orow[t] = v; };
+                    static_for<0, MT>([&](auto mm) {
+                        constexpr int mt = decltype(mm)::value;
+                        const floatx4 a = tt[mt];
+                        if constexpr (TRAINLIKE) {
+                            // rows 4cg+i: i=0,1 -> |X|^2 of slots 2cg, 2cg+1; i=2,3 -> d|X|^2 of the same slots
+                            const int tp = t0 + mt * 8 + 2 * cg;
+                            if (((p.T | t0) & 1) == 0 && mt * 8 + 2 * cg + 1 < SLOTS && tp + 1 < p.T) {
+                                // even T: both frames of this lane form one aligned 8-byte store per tensor
+                                float2 o2, t2;
+                                static_for<0, 2>([&](auto ss) {
+                                    constexpr int s = decltype(ss)::value;
+                                    const float mel = 0.25f * a[s];
+                                    const float dmel = htan * a[2 + s];
+                                    const float me = mel + p.eps;
+                                    (s == 0 ? o2.x : o2.y) = do_log ? logf(me) : mel;
+                                    (s == 0 ? t2.x : t2.y) = do_log ? dmel * __builtin_amdgcn_rcpf(me) : dmel;
+                                });
+                                if (out_bf16) *reinterpret_cast<unsigned*>(orow_h + tp) = (unsigned)bf16_bits(o2.x) | ((unsigned)bf16_bits(o2.y) << 16);
+                                else *reinterpret_cast<float2*>(orow + tp) = o2;
+                                if (trow) *reinterpret_cast<float2*>(trow + tp) = t2;
+                            } else
+                            static_for<0, 2>([&](auto ss) {
+                                constexpr int s = decltype(ss)::value;
+                                const int slot = mt * 8 + 2 * cg + s;
+                                const int t = t0 + slot;
+                                if (slot < SLOTS && t < p.T) {
+                                    const float mel = 0.25f * a[s];
+                                    const float dmel = htan * a[2 + s];
+                                    if (do_log) {
+                                        const float me = mel + p.eps;
+                                        put(t, logf(me));
+                                        if (trow) trow[t] = dmel * __builtin_amdgcn_rcpf(me);
+                                    } else {
+                                        put(t, mel);
+                                        if (trow) trow[t] = dmel;
+                                    }
+                                }
+                            });
+                        } else {
+                            // slot holds frames (2*slot, 2*slot+1) as (type 0, type 1)
+                            static_for<0, 4>([&](auto ii) {
+                                constexpr int i = decltype(ii)::value;
+                                const int slot = mt * 8 + 2 * cg + (i & 1);
+                                const int t = t0 + 2 * slot + (i >> 1);
+                                if (slot < SLOTS && t < p.T) {
+                                    const float mel = 0.25f * a[i];
+                                    put(t, do_log ? logf(mel + p.eps) : mel);
+                                }
+                            });
+                        }
+                    });
+                };
+
+            if constexpr (HSPLIT) {
+                // ================= phase 2, dense bank on the bf16 matrix pipe ==============================
+                // One v_mfma_f32_16x16x32_bf16 covers 32 bins: lane (row = lane & 15, kg = lane >> 4) supplies bins 32 ks + 8 kg .. + 7 of
+                // its row's plane (one ds_read_b128 for hi, one for lo) and of its column of the filterbank (two 16-byte loads of the
+                // pre-split table).  Three instructions of 16 cycles per (k-step, row tile) -- lo hi + hi lo + hi hi, smallest first --
+                // against eight exact-fp32 ones of 32: the dense contraction's matrix time falls from ~14 us to ~2.5 us at BASELINE
+                // config 2.  Wave w owns mel tile w of every group whole (a dense bank has no narrow and wide tiles to balance):
+                // no half-tile exchange.  Bin N/2 -- N/2 bins are N/64 steps exactly -- rides on the vector pipe.
+                typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+                constexpr int KS32 = N / 64;
+                const int kgq = lane >> 4;
+                int a_base[MT];
+                static_for<0, MT>([&](auto mm) {
+                    constexpr int mt = decltype(mm)::value;
+                    const int slot = mt * 8 + slot8;
+                    a_base[mt] = (slot < SLOTS ? slot : 0) * (SS * 8) + type * (2 * NHS * 2) + kgq * 16;
+                });
+                constexpr int TPWV = 8 / WAVES;                              // mel tiles of a group per wave (8 waves: 1, 4 waves: 2)
+                for (int grp = 0; grp < p.groups; ++grp) {
+                    static_for<0, TPWV>([&](auto jj) {
+                        const int tile = grp * 8 + wave + WAVES * decltype(jj)::value;
+                        if (16 * tile >= p.M) return;                       // (uniform per wave)
+                        floatx4 acc[MT];
+                        static_for<0, MT>([&](auto mm) { acc[decltype(mm)::value] = floatx4{0.f, 0.f, 0.f, 0.f}; });
+                        const uint4* bt = p.ent_h + (size_t)tile * (KS32 * 2 * 64) + lane;
+                        uint4 bh = bt[0], bl = bt[64];
+                        for (int ks = 0; ks < KS32; ++ks) {
+                            const uint4 ch = bh, cl = bl;
+                            if (ks + 1 < KS32) { bh = bt[(ks + 1) * 128]; bl = bt[(ks + 1) * 128 + 64]; }
+                            const bf16x8 vbh = __builtin_bit_cast(bf16x8, ch), vbl = __builtin_bit_cast(bf16x8, cl);
+                            static_for<0, MT>([&](auto mm) {
+                                constexpr int mt = decltype(mm)::value;
+                                const bool valid = mt * 8 + slot8 < SLOTS;
+                                uint4 ah = *reinterpret_cast<const uint4*>(smem_raw + a_base[mt] + ks * 64);
+                                uint4 al = *reinterpret_cast<const uint4*>(smem_raw + a_base[mt] + NHS * 2 + ks * 64);
+                                if constexpr (SLOTS < 8) { if (!valid) { ah = make_uint4(0, 0, 0, 0); al = ah; } }
+                                const bf16x8 vah = __builtin_bit_cast(bf16x8, ah), val = __builtin_bit_cast(bf16x8, al);
+                                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(val, vbh, acc[mt], 0, 0, 0);
+                                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vah, vbl, acc[mt], 0, 0, 0);
+                                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vah, vbh, acc[mt], 0, 0, 0);
+                            });
+                        }
+                        // bin N/2: rows 4 cg + i of the accumulator layout -> (slot 2 cg + (i & 1), P | D = i >> 1)
+                        const int mcol = 16 * tile + col;
+                        const float fbn = mcol < p.M ? p.fb_nyq[mcol] : 0.f;
+                        static_for<0, MT>([&](auto mm) {
+                            constexpr int mt = decltype(mm)::value;
+                            static_for<0, 4>([&](auto ii) {
+                                constexpr int i = decltype(ii)::value;
+                                const int slot = mt * 8 + 2 * cg + (i & 1);
+                                if (slot < SLOTS) acc[mt][i] = fmaf(load_h(slot * (SS * 8), i >> 1, N / 2), fbn, acc[mt][i]);
+                            });
+                        });
+                        write_tile(tile, acc);
+                    });
+                }
+            } else
             for (int grp = 0; grp < p.groups; ++grp) {
                 // acc[loc][mt][parity]: two accumulators per tile so that consecutive MFMAs never wait on each other
                 floatx4 acc[NLOC][MT][2];
@@ -981,8 +1133,6 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
                 });
                 STAMP(16 * ti + 9);   // MFMA loops
                 // ---- epilogue: accumulators -> (B,1,M,T) ------------------------------------------
-                const bool do_log = (p.flags & 1u) != 0;
-                const bool out_bf16 = (p.flags & 4u) != 0;
                 floatx4 tot[NLOC][MT];
                 static_for<0, NLOC>([&](auto l) { static_for<0, MT>([&](auto m) {
                     tot[decltype(l)::value][decltype(m)::value] = acc[decltype(l)::value][decltype(m)::value][0] + acc[decltype(l)::value][decltype(m)::value][1]; }); });
@@ -1005,69 +1155,7 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
 #ifdef DMEL_ABLATE
                 if (p.flags & 0x400u) continue;                        // timing ablation: skip the epilogue
 #endif
-                static_for<0, NLOC>([&](auto l) {
-                    constexpr int loc = decltype(l)::value;
-                    const int nt = tile_of[loc];
-                    if (nt < 0) return;
-                    const int m = 16 * nt + col;
-                    if (m >= p.M) return;
-                    const size_t rbase = ((size_t)b * p.M + m) * p.T;
-                    float* orow = p.out + rbase;
-                    unsigned short* orow_h = reinterpret_cast<unsigned short*>(p.out) + rbase;     // DMEL_FLAG_OUT_BF16: out is bf16
-                    float* trow = p.tangent ? p.tangent + rbase : nullptr;
-                    auto put = [&](int t, float v) { if (out_bf16) orow_h[t] = bf16_bits(v); else orow[t] = v; };
-                    static_for<0, MT>([&](auto mm) {
-                        constexpr int mt = decltype(mm)::value;
-                        const floatx4 a = tot[loc][mt];
-                        if constexpr (MODE == kTrain) {
-                            // rows 4cg+i: i=0,1 -> |X|^2 of slots 2cg, 2cg+1; i=2,3 -> d|X|^2 of the same slots
-                            const int tp = t0 + mt * 8 + 2 * cg;
-                            if (((p.T | t0) & 1) == 0 && mt * 8 + 2 * cg + 1 < SLOTS && tp + 1 < p.T) {
-                                // even T: both frames of this lane form one aligned 8-byte store per tensor
-                                float2 o2, t2;
-                                static_for<0, 2>([&](auto ss) {
-                                    constexpr int s = decltype(ss)::value;
-                                    const float mel = 0.25f * a[s];
-                                    const float dmel = htan * a[2 + s];
-                                    const float me = mel + p.eps;
-                                    (s == 0 ? o2.x : o2.y) = do_log ? logf(me) : mel;
-                                    (s == 0 ? t2.x : t2.y) = do_log ? dmel * __builtin_amdgcn_rcpf(me) : dmel;
-                                });
-                                if (out_bf16) *reinterpret_cast<unsigned*>(orow_h + tp) = (unsigned)bf16_bits(o2.x) | ((unsigned)bf16_bits(o2.y) << 16);
-                                else *reinterpret_cast<float2*>(orow + tp) = o2;
-                                if (trow) *reinterpret_cast<float2*>(trow + tp) = t2;
-                            } else
-                            static_for<0, 2>([&](auto ss) {
-                                constexpr int s = decltype(ss)::value;
-                                const int slot = mt * 8 + 2 * cg + s;
-                                const int t = t0 + slot;
-                                if (slot < SLOTS && t < p.T) {
-                                    const float mel = 0.25f * a[s];
-                                    const float dmel = htan * a[2 + s];
-                                    if (do_log) {
-                                        const float me = mel + p.eps;
-                                        put(t, logf(me));
-                                        if (trow) trow[t] = dmel * __builtin_amdgcn_rcpf(me);
-                                    } else {
-                                        put(t, mel);
-                                        if (trow) trow[t] = dmel;
-                                    }
-                                }
-                            });
-                        } else {
-                            // slot holds frames (2*slot, 2*slot+1) as (type 0, type 1)
-                            static_for<0, 4>([&](auto ii) {
-                                constexpr int i = decltype(ii)::value;
-                                const int slot = mt * 8 + 2 * cg + (i & 1);
-                                const int t = t0 + 2 * slot + (i >> 1);
-                                if (slot < SLOTS && t < p.T) {
-                                    const float mel = 0.25f * a[i];
-                                    put(t, do_log ? logf(mel + p.eps) : mel);
-                                }
-                            });
-                        }
-                    });
-                });
+                static_for<0, NLOC>([&](auto l) { write_tile(tile_of[decltype(l)::value], tot[decltype(l)::value]); });
                 STAMP(16 * ti + 11);  // epilogue stores issued
             }
         }
@@ -1085,11 +1173,19 @@ template <int N, int MODE, int TPW> static hipError_t launch_one(const FwdParams
 // two tiles per workgroup are built for the sizes whose launches are large enough to use them (forward_tiles_per_wg)
 template <int N, bool PAIR> constexpr bool has_tpw2() { return N >= 256 && (N <= 512 || (N == 1024 && geom<N, PAIR>().G == 64)); }   // (32 x 32 plan at 1024: 16-frame tiles, two of them spill)
 
+// kTrainH (dense contraction on the bf16 matrix pipe) exists for the sizes whose frames live inside one wave, one tile per workgroup
+template <int N> constexpr bool has_hsplit() { return N >= kHsplitMinNfft && N <= kHsplitMaxNfft; }
+
 template <int N, int MODE> static hipError_t launch_mode(int tpw, const FwdParams& p, int grid, hipStream_t s)
 {
-    if constexpr (has_tpw2<N, mode_pairs(MODE)>()) { if (tpw == 2) return launch_one<N, MODE, 2>(p, grid, s); }
-    if (tpw != 1) return hipErrorInvalidValue;
-    return launch_one<N, MODE, 1>(p, grid, s);
+    if constexpr (MODE == kTrainH) {
+        if constexpr (has_hsplit<N>()) { if (tpw == 1) return launch_one<N, MODE, 1>(p, grid, s); }
+        return hipErrorInvalidValue;
+    } else {
+        if constexpr (has_tpw2<N, mode_pairs(MODE)>()) { if (tpw == 2) return launch_one<N, MODE, 2>(p, grid, s); }
+        if (tpw != 1) return hipErrorInvalidValue;
+        return launch_one<N, MODE, 1>(p, grid, s);
+    }
 }
 
 template <int N> static hipError_t launch_n(int mode, int tpw, const FwdParams& p, int grid, hipStream_t s)
@@ -1099,6 +1195,7 @@ template <int N> static hipError_t launch_n(int mode, int tpw, const FwdParams& 
         case kInfer: return launch_mode<N, kInfer>(tpw, p, grid, s);
         case kSpec: return launch_mode<N, kSpec>(tpw, p, grid, s);
         case kSpecTrain: return launch_mode<N, kSpecTrain>(tpw, p, grid, s);
+        case kTrainH: return launch_mode<N, kTrainH>(tpw, p, grid, s);
     }
     return hipErrorInvalidValue;
 }
@@ -1167,6 +1264,7 @@ hipError_t launch_forward(int n_fft, int mode, int tpw, const FwdParams& p, int 
     return launch_forward_part0(n_fft, mode, tpw, p, grid, s);
 }
 
+bool forward_has_hsplit(int n_fft) { return n_fft >= kHsplitMinNfft && n_fft <= kHsplitMaxNfft && (n_fft & (n_fft - 1)) == 0; }
 bool forward_window_in_lds(int n_fft) { return n_fft >= kMinFastNfft && n_fft <= kWinLdsMaxNfft; }
 
 // One place that maps a run-time (n_fft, pair) to the compile-time geometry
@@ -1270,10 +1368,15 @@ template <int N, int MODE, int TPW> static hipError_t set_attr()
 }
 template <int N, int MODE> static hipError_t set_attr_mode()
 {
-    hipError_t e = set_attr<N, MODE, 1>();
-    if (e != hipSuccess) return e;
-    if constexpr (has_tpw2<N, mode_pairs(MODE)>()) return set_attr<N, MODE, 2>();
-    else return hipSuccess;
+    if constexpr (MODE == kTrainH) {
+        if constexpr (has_hsplit<N>()) return set_attr<N, MODE, 1>();
+        else return hipSuccess;
+    } else {
+        hipError_t e = set_attr<N, MODE, 1>();
+        if (e != hipSuccess) return e;
+        if constexpr (has_tpw2<N, mode_pairs(MODE)>()) return set_attr<N, MODE, 2>();
+        else return hipSuccess;
+    }
 }
 template <int N> static hipError_t set_attr_n()
 {
@@ -1285,6 +1388,7 @@ template <int N> static hipError_t set_attr_n()
         if ((e = set_attr_mode<N, kTrain>()) != hipSuccess) return e;
         if ((e = set_attr_mode<N, kInfer>()) != hipSuccess) return e;
         if ((e = set_attr_mode<N, kSpec>()) != hipSuccess) return e;
+        if ((e = set_attr_mode<N, kTrainH>()) != hipSuccess) return e;
         return set_attr_mode<N, kSpecTrain>();
     }
 }

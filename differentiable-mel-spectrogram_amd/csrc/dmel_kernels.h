@@ -15,7 +15,11 @@ constexpr int kMinFastNfft = 32;       // below this the direct-DFT kernel runs
 // fp32 -> bf16 bits, round to nearest even (v_cvt_pk_bf16_f32 on gfx950); outputs only, the arithmetic stays fp32
 __device__ __forceinline__ unsigned short bf16_bits(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
 
-enum Mode : int { kTrain = 0, kInfer = 1, kSpec = 2, kSpecTrain = 3 };   // kSpec*: power spectrogram (B,F,T), no mel stage
+enum Mode : int { kTrain = 0, kInfer = 1, kSpec = 2, kSpecTrain = 3,      // kSpec*: power spectrogram (B,F,T), no mel stage
+                  kTrainH = 4 };   // kTrain with the DENSE contraction on the bf16 matrix pipe (DMEL_FLAG_MFMA_BF16X3): the pairing pass
+                                   // leaves PD as four bf16 planes (P hi, P lo, D hi, D lo), three v_mfma_f32_16x16x32_bf16 per fp32 product
+constexpr int kHsplitMinNfft = 64, kHsplitMaxNfft = 4096;    // sizes kTrainH is built for (frames inside one wave, N/2 a multiple of 32)
+constexpr int hsplit_plane_stride(int n_fft) { return n_fft / 2 + 8; }   // bf16 entries per plane: bins 0 .. N/2, rows stay 16-byte aligned
 
 // ---- where lambd comes from, and what a launch does when it was built for another n_fft ------------------------------
 // The reference derives n_fft from the parameter on the host at every forward (time_frequency.py:39: a device->host
@@ -241,6 +245,9 @@ struct FwdParams {
     int remove_dc, normalize;
     int win_half;               // window support = middle half of n_fft (DSPEC: win_length = n_fft / 2)
     int wgs_per_clip;           // ceil(tiles_per_clip / tiles per workgroup)
+    const uint4* ent_h;         // kTrainH: the filterbank as B fragments of v_mfma_f32_16x16x32_bf16, [(tile * (N/64) + kstep) * 2 + (hi | lo)][lane]:
+                                // lane l holds fb[32 kstep + 8 (l >> 4) + e][16 tile + (l & 15)], e = 0 .. 7, as bf16 (hi) / the bf16 of the rest (lo)
+    const float* fb_nyq;        // kTrainH: (n_mels) fp32, the row of bin N/2 (added on the vector pipe: N/2 bins = N/64 steps of 32 exactly)
     float* spec_out;            // training mode only, or nullptr: the power spectrogram (B, F, T) the contraction consumes is ALSO written
                                 // out (16.8 MB at BASELINE config 2), so that the filterbank gradient need not recompute it (16.5 us)
 };
@@ -263,6 +270,7 @@ int forward_frames_per_tile(int n_fft, int mode);
 int forward_waves(int n_fft);              // waves per workgroup of the fused kernel for this n_fft
 int forward_nbpre(int n_fft);              // k-steps per run kept in registers (layout of FwdParams::ent_pre)
 bool forward_plan_rc(int n_fft, bool pair, int* R, int* C);   // pair: the plan of the modes that pack two frames per FFT
+bool forward_has_hsplit(int n_fft);        // kTrainH is built for this size
 bool forward_window_in_lds(int n_fft);     // the kernel builds its own window table (otherwise dmel_prep_kernel writes FwdParams::win2)   // radix per lane and cross-lane radix of the plan (layout of tw1 / tw2)
 hipError_t forward_prepare_attributes();   // raises the dynamic-LDS limit of every instantiation once
 
@@ -356,6 +364,7 @@ int fbgrad_splits(int batch, int F, int M, int T);      // slices of the batch's
 // device-side refresh of every table that holds filterbank VALUES from an (F, M) fp32 device matrix, for tables built with the
 // dense structure (all 4x16 blocks present): what a trainable filterbank needs after each optimizer step
 struct RepackParams {
+    uint4* ent_h; float* fb_nyq; int ks32;      // kTrainH tables (FwdParams::ent_h / fb_nyq) or nullptr
     const float* fb;            // (F, M) row-major, device
     float* ent_b; float* ent_pre; const int4* tile_ranges;
     float* fb_dense;            // (F, M) copy for the kernels that read the matrix as it is

@@ -136,8 +136,56 @@ def test_saved_spectrogram_and_split_bf16_filterbank_gradient(log, mfma):
 
         y0, dl0, gfb0 = run(save_spec=False)
         y1, dl1, gfb1 = run(save_spec=True, mfma=mfma)
-        assert torch.equal(dl0, dl1)
+        if mfma == "fp32":
+            assert torch.equal(dl0, dl1) and torch.equal(y0, y1)              # the forward is the same kernel
+        else:
+            # the forward's contraction ran as three split-bf16 products too (kTrainH): the output within the 1e-4 bar of the exact one
+            if log:
+                assert float((y1 - y0).abs().max()) <= 1e-4
+            else:
+                assert float(((y1 - y0).abs() / y0.abs().clamp_min(1e-6 * float(y0.abs().max()))).max()) <= 1e-4
+            assert abs(float(dl1) - float(dl0)) <= 1e-4 * abs(float(dl0)) + 2e-8 * float((g.abs()).sum())
         scale = float(gfb0.abs().max())
         assert float((gfb1 - gfb0).abs().max()) <= 1e-4 * scale
         ref = O.backward_fb(x_np, case["lambd"], case["hop"], g_np, y0.cpu().numpy() if log else None, case["normalize_window"])
         assert float(np.abs(gfb1.cpu().numpy().astype(np.float64) - ref).max()) <= 1e-4 * float(np.abs(ref).max())
+
+
+@pytest.mark.parametrize("name", ["g1_c1", "g2_c2", "g5_n128", "g5_n4096", "g6_n2048_short", "g6_n64"])
+def test_dense_bank_forward_on_the_bf16_matrix_pipe(name):
+    """DMEL_FLAG_MFMA_BF16X3 through a caller-supplied DENSE filterbank (what a trained matrix is): output and tangent against the exact
+    fp32-MFMA path of the same kernel family and against the fp64 oracle evaluated with the same matrix; the HTK bank ignores the flag"""
+    from dmel_amd import capi
+    from oracle import dmel_oracle as O
+    case = C.BY_NAME[name]
+    x_np = C.make_input(case).astype(np.float32)
+    x = torch.from_numpy(x_np).to(DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    n = capi.n_fft(case["lambd"])
+    plan = capi.Plan(case["L"], case["hop"], case["n_mels"], case["sr"], case["f_min"], case["f_max"], case["normalize_window"])
+    shape = C.out_shape(case)
+
+    def fwd(flags, log):
+        out = torch.empty(shape, dtype=torch.float32, device=DEV)
+        tan = torch.empty_like(out)
+        plan.forward(x.data_ptr(), case["B"], case["lambd"], out.data_ptr(), tan.data_ptr(), log, 1e-10, st, extra_flags=flags)
+        torch.cuda.synchronize()
+        return out, tan
+
+    # the built-in (banded) bank: the flag changes nothing, bit for bit
+    o0, t0 = fwd(0, True)
+    o1, t1 = fwd(capi.DMEL_FLAG_MFMA_BF16X3, True)
+    assert torch.equal(o0, o1) and torch.equal(t0, t1)
+    gen = torch.Generator().manual_seed(12)
+    fb = (torch.rand((n // 2 + 1, case["n_mels"]), generator=gen) + 0.01).to(DEV)
+    plan.set_filterbank_dev(n, fb.data_ptr(), st)
+    for log in (False, True):
+        oe, te = fwd(0, log)
+        oh, th = fwd(capi.DMEL_FLAG_MFMA_BF16X3, log)
+        assert not torch.equal(oe, oh) or n < 64                                # (n_fft 32: no split path, the exact one runs)
+        if log:
+            assert float((oh - oe).abs().max()) <= 1e-4
+        else:
+            assert float(((oh - oe).abs() / oe.abs()).max()) <= 1e-4               # a dense positive bank: no element near zero
+        tscale = float(te.abs().max())
+        assert float((th - te).abs().max()) <= 1e-4 * tscale
