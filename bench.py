@@ -849,6 +849,13 @@ def other_configs(torch, capi, synth, dev, kernel_times):
         res["c4_on_one_gpu"] = r4
     except Exception as e:                                              # noqa: BLE001
         res["c4_on_one_gpu"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    # the "mel params" of north_star: lambd AND the (513 x 128) filterbank trained together at config 2 (learnable_fb=True): the dense
+    # contraction in the forward, the filterbank gradient's GEMM, both optimizers -- per-step time of the HIP-graph replayed nn.Module
+    # step for the exact fp32-MFMA path (with and without the saved spectrogram) and the split-bf16 path (DMEL_FLAG_MFMA_BF16X3)
+    try:
+        res["trainable_filterbank_c2"] = trainable_filterbank(torch, synth, dev)
+    except Exception as e:                                              # noqa: BLE001
+        res["trainable_filterbank_c2"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     # config 2 with COLD inputs: the same trains of launches, every forward reading another resident batch of a pool > 256 MiB
     # (beyond L2 and the Infinity Cache), next to the warm figure (ONE batch replayed: it lives in cache)
     try:
@@ -871,6 +878,61 @@ def other_configs(torch, capi, synth, dev, kernel_times):
     except Exception as e:                                              # noqa: BLE001
         res["c5"]["train_step"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     return res
+
+
+def trainable_filterbank(torch, synth, dev, k=10, replays=30):
+    """lambd and the filterbank matrix trained together (models.py:42-48 made a parameter) at BASELINE config 2."""
+    import dmel_amd
+    from dmel_amd import GraphedStep, MelSpectrogramLayer
+    B, L, sr, lam, hop, M = CONFIGS["c2"]
+    T = L // hop + 1
+    x = torch.from_numpy(synth.waveforms(B, L, seed=0)).to(dev)
+    g = torch.from_numpy(synth.cotangent((B, 1, M, T), seed=1)).to(dev)
+    out = {}
+    F = 2 ** (int(6 * lam) - 1).bit_length() // 2 + 1
+    flops = 2.0 * B * T * F * M
+    for name, kw, native in (("fp32_mfma_recompute", dict(save_spec=False), False), ("fp32_mfma", {}, False), ("bf16x3", dict(mfma="bf16x3"), False),
+                             ("bf16x3_LambdAdam", dict(mfma="bf16x3"), True)):
+        layer = MelSpectrogramLayer(torch.tensor(lam), n_mels=M, n_points=L, sample_rate=sr, hop_length=hop, device=str(dev), optimized=True,
+                                    log=True, learnable_fb=True, **kw).to(dev)
+        # lr 0: the same kernels and the same work, parameters that stay put (any lr > 0 moves the 65 000 zero entries of the HTK matrix
+        # together, and after a few hundred steps the lowest band -- ONE non-zero bin -- of the quietest frames turns negative under the
+        # log: what torch does with a leaf filterbank too, but not what a timing loop should run into)
+        opt = (dmel_amd.LambdAdam(layer.parameters(), lr=0.0) if native
+               else torch.optim.Adam(layer.parameters(), lr=0.0, fused=True, capturable=True))
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            layer(x).backward(g)
+            opt.step()
+
+        try:
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+        except Exception as e:                                          # noqa: BLE001
+            raise RuntimeError(f"{name}: {e}") from e
+        gs = GraphedStep(step, [layer], max_ahead=4, steps_per_replay=k)
+        for _ in range(8):
+            gs()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(replays):
+                gs()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(1e3 * e0.elapsed_time(e1) / (replays * k))
+        us = sorted(ts)[1]
+        out[name] = {"step_us": round(us, 2), "frames_per_s": round(B * T / (us * 1e-6), 1),
+                     "optimizer": "dmel_amd.LambdAdam (one launch per parameter)" if native else "torch.optim.Adam(fused, capturable) on both parameters"}
+        gs.close()
+        del gs, opt, layer
+    out["note"] = (f"HIP-graph replay of the nn.Module step ({k} steps per replay, median of 3 trains); dense contraction 2 x {flops / 1e9:.3f} GFLOP per step "
+                   "(forward: power + tangent rows; gradient GEMM); default is fp32_mfma (exact); bf16x3 is opt-in (mfma='bf16x3')")
+    return out
 
 
 def c2_cold(torch, capi, synth, dev, pool_n=24, ntrain=120):

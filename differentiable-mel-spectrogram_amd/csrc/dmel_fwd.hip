@@ -344,6 +344,23 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
             if (wave == 0) { const float h = 0.5f * lam_tangent_scale(ls); if (lane == 0) red[kRedTan] = h; }
         }
         if constexpr (TW2_LDS) { if (tid < R * C) tw2l[tid] = p.tw2[tid]; }          // visible after the barrier below
+        // Phase 2 pads every run of k-steps to a multiple of four with zero filterbank blocks and still reads the A operands of the
+        // padding: bins past n_fft/2, i.e. floats 2 F .. of the slot.  In the compact layout those are the end of the transposition
+        // plane -- finite data of this tile, EXCEPT the padding column of a row (row stride EXS = G + 1: one float nobody writes)
+        // -- and the padding of the slot stride.  At n_fft 1024 float 1055 (bin 527, tangent row: read by the HTK bank's last mel
+        // tile) and bins 528 .. 531 (a dense bank) are such holes: whatever an earlier kernel left in LDS -- a NaN pattern -- times
+        // a zero coefficient poisoned the accumulator (found in round 4: a trainable-filterbank run went NaN after a few hundred
+        // steps, and at once on a box whose previous process had left NaNs behind).  Everything from float 2 F to the end of the
+        // slot is zeroed once per workgroup, before the barrier in front of the first transform: what the transposition writes
+        // there later is finite, what it leaves out stays zero.
+        if constexpr (SPLIT && !IS_SPEC) {
+            constexpr int first = 2 * F, count = SS * 2 - first;                                // floats
+            static_assert(count >= 0, "slot stride covers PD[0 .. N/2]");
+            if constexpr (count > 0) {
+                for (int i = tid; i < SLOTS * count; i += THREADS)
+                    reinterpret_cast<float*>(smem_raw + (i / count) * (SS * 8))[first + i % count] = 0.f;
+            }
+        }
         // ---- window table into LDS (time_frequency.py:21-30): every workgroup evaluates the same fp32
         // expression, so the table is identical everywhere; this replaces a separate kernel launch
         if constexpr (WIN_LDS) {

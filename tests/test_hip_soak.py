@@ -126,3 +126,33 @@ def test_graphed_step_keeps_its_plans_alive_for_the_life_of_the_graph():
     assert float(lay.lambd.detach()) != before and torch.isfinite(lay.lambd.detach())
     gs.close()
     assert lib.dmel_plan_is_live(h) == 0
+
+
+def test_dense_bank_forward_does_not_read_what_earlier_kernels_left_in_lds():
+    """Round 4 bug: phase 2 pads runs of k-steps with zero filterbank blocks and reads the A operands of the padding; with a DENSE bank at
+    n_fft 1024 four of those bins lay in slot padding nothing writes, and a NaN pattern left there by an earlier kernel times a zero
+    coefficient poisoned the output (a trainable-filterbank run went NaN after a few hundred steps).  Here every CU's LDS is filled with
+    NaNs first (forwards of other transform sizes on an all-NaN waveform), then the dense forward must still be finite and repeatable."""
+    from dmel_amd import capi
+    s = torch.cuda.current_stream().cuda_stream
+    B, L, hop, M, sr = 256, 16000, 512, 128, 16000
+    T = L // hop + 1
+    x = torch.randn(B, L, device=DEV) * 0.1
+    plan = capi.Plan(L, hop, M, sr, max_batch=B)
+    fb = torch.rand((513, M), device=DEV) + 0.01
+    plan.set_filterbank_dev(1024, fb.data_ptr(), s)
+    out, tan = torch.empty((B, 1, M, T), device=DEV), torch.empty((B, 1, M, T), device=DEV)
+    plan.forward(x.data_ptr(), B, 128.0, out.data_ptr(), tan.data_ptr(), True, 1e-10, s)
+    torch.cuda.synchronize()
+    ref_o, ref_t = out.clone(), tan.clone()
+    poison = capi.Plan(L, hop, M, sr, max_batch=B)
+    xn = torch.full((B, L), float("nan"), device=DEV)
+    po, pt = torch.empty_like(out), torch.empty_like(out)
+    for rep in range(4):
+        for lam in (256.0, 512.0, 64.0, 32.0):                        # n_fft 2048, 4096, 512, 256: other LDS maps, all NaN
+            poison.forward(xn.data_ptr(), B, lam, po.data_ptr(), pt.data_ptr(), True, 1e-10, s)
+        out.zero_(); tan.zero_()
+        plan.forward(x.data_ptr(), B, 128.0, out.data_ptr(), tan.data_ptr(), True, 1e-10, s)
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all() and torch.isfinite(tan).all(), rep
+        assert torch.equal(out, ref_o) and torch.equal(tan, ref_t), rep

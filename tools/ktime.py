@@ -12,7 +12,10 @@ from bench import CONFIGS
 name = sys.argv[1] if len(sys.argv) > 1 else "c2"
 mode = sys.argv[2] if len(sys.argv) > 2 else "train"
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 300
-B, L, sr, lam, hop, M = CONFIGS[name]
+# besides bench.py's configs: BASELINE config 4's global batch on one GPU, and the reference's ESC-50 shape (search_spaces.py:4-33) at its
+# largest starting lambd (n_fft 4096) and one lambd a run drifts to (n_fft 8192)
+EXTRA = {"c4": (2048, 16000, 16000, 128.0, 512, 128), "esc_n4096": (32, 40000, 8000, 400.0, 80, 64), "esc_n8192": (32, 40000, 8000, 700.0, 80, 64)}
+B, L, sr, lam, hop, M = CONFIGS[name] if name in CONFIGS else EXTRA[name]
 T = L // hop + 1
 x = torch.from_numpy(synth.waveforms(B, L, seed=0)).cuda()
 out = torch.empty((B, 1, M, T), device="cuda"); tan = torch.empty_like(out)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Turns the raw rocprofv3 output of one profiling session (tools/profile_session.sh -> gpurun_out/prof_<tag>/{kt,fetch,write,sq1,sq2})
-into the small files committed under profiles/.   usage: python tools/summarize_profile.py gpurun_out/prof_r02 r02"""
+"""Turns the raw rocprofv3 output of one profiling session (tools/profile_session.sh -> gpurun_out/prof_<tag>/...) into the small files
+committed under profiles/.   usage: python tools/summarize_profile.py gpurun_out/prof_r04 r04
+Every part of the session is optional: what is missing is skipped (and said so)."""
 import csv
 import glob
 import hashlib
@@ -11,181 +12,233 @@ import statistics
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "prof_r03")
-tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "prof_r04")
+tag = sys.argv[2] if len(sys.argv) > 2 else "r04"
 out = os.path.join(ROOT, "profiles")
-FWD = "dmel_fwd_kernel<1024, 0"          # the training-mode forward at n_fft 1024 (any tiles-per-workgroup variant)
+FWD_C2 = "dmel_fwd_kernel<1024, 0"          # the training-mode forward at n_fft 1024
 
 
-def one(pattern):
-    hits = glob.glob(os.path.join(src, pattern), recursive=True)
-    assert len(hits) == 1, (pattern, hits)
-    return hits[0]
+def hits(pattern):
+    return glob.glob(os.path.join(src, pattern), recursive=True)
 
 
 def short(name):
     return name.split("(")[0].replace("void ", "")
 
 
-# per-kernel stats + trace summary
-shutil.copy(one("kt/**/*_kernel_stats.csv"), os.path.join(out, f"{tag}_kernel_stats_c2.csv"))
-rows = list(csv.DictReader(open(one("kt/**/*_kernel_trace.csv"))))
-summ = []
-for k in sorted({r["Kernel_Name"] for r in rows}):
-    rs = [r for r in rows if r["Kernel_Name"] == k]
-    if len(rs) < 20:
-        continue
-    d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rs]
-    r0 = rs[0]
-    summ.append(dict(kernel=short(k)[:110], calls=len(d), avg_ns=round(statistics.mean(d), 1), median_ns=statistics.median(d), min_ns=min(d),
-                     max_ns=max(d), vgpr=r0.get("VGPR_Count"), accum_vgpr=r0.get("Accum_VGPR_Count"), sgpr=r0.get("SGPR_Count"),
-                     lds=r0.get("LDS_Block_Size"), scratch=r0.get("Scratch_Size"), wg=r0.get("Workgroup_Size", r0.get("Workgroup_Size_X")), grid=r0.get("Grid_Size", r0.get("Grid_Size_X"))))
-json.dump(summ, open(os.path.join(out, f"{tag}_kernel_trace_summary_c2.json"), "w"), indent=1)
+def last_json(path):
+    if not os.path.exists(path):
+        return None
+    lines = [ln for ln in open(path) if ln.startswith("{")]
+    return json.loads(lines[-1]) if lines else None
 
-# configs 3 and 5 (n_fft 2048): per-kernel summary of the launch trains of tools/ktime.py
-other = {}
-for cfg in ("c3", "c5"):
-    hits = glob.glob(os.path.join(src, f"kt_{cfg}/**/*_kernel_trace.csv"), recursive=True)
-    if len(hits) != 1:
-        continue
-    rws = list(csv.DictReader(open(hits[0])))
-    lst = []
-    for k in sorted({r["Kernel_Name"] for r in rws if "dmel" in r["Kernel_Name"]}):
-        rs = [r for r in rws if r["Kernel_Name"] == k]
-        d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rs]
-        r0 = rs[0]
-        lst.append(dict(kernel=short(k)[:110], calls=len(d), avg_ns=round(statistics.mean(d), 1), median_ns=statistics.median(d), min_ns=min(d),
-                        vgpr=r0.get("VGPR_Count"), lds=r0.get("LDS_Block_Size"), scratch=r0.get("Scratch_Size"),
-                        wg=r0.get("Workgroup_Size", r0.get("Workgroup_Size_X")), grid=r0.get("Grid_Size", r0.get("Grid_Size_X"))))
-    other[cfg] = lst
-if other:
-    json.dump(other, open(os.path.join(out, f"{tag}_kernel_trace_summary_c3_c5.json"), "w"), indent=1)
 
-# optional backward outputs and the big-transform kernel: per-kernel summaries
-for sub, name in (("kt_f2", "f2_backward_extras"), ("kt_big", "big_transforms")):
-    hits = glob.glob(os.path.join(src, f"{sub}/**/*_kernel_trace.csv"), recursive=True)
-    if len(hits) != 1:
-        continue
-    rws = list(csv.DictReader(open(hits[0])))
+def dump(name, obj):
+    json.dump(obj, open(os.path.join(out, name), "w"), indent=1)
+    print("wrote", name)
+
+
+def trace_rows(sub):
+    h = hits(f"{sub}/**/*_kernel_trace.csv")
+    return list(csv.DictReader(open(h[0]))) if len(h) == 1 else None
+
+
+def kernel_summary(rows, only_dmel=True, min_calls=1, by_grid=False):
     lst = []
-    for k in sorted({r["Kernel_Name"] for r in rws if "dmel" in r["Kernel_Name"]}):
-        rs = [r for r in rws if r["Kernel_Name"] == k]
-        # the scripts time several shapes with one kernel name: split by grid size
-        for grid in sorted({r.get("Grid_Size", r.get("Grid_Size_X")) for r in rs}, key=lambda v: int(v)):
-            rg = [r for r in rs if r.get("Grid_Size", r.get("Grid_Size_X")) == grid]
+    names = sorted({r["Kernel_Name"] for r in rows if (not only_dmel or "dmel" in r["Kernel_Name"])})
+    for k in names:
+        rs = [r for r in rows if r["Kernel_Name"] == k]
+        grids = sorted({r.get("Grid_Size", r.get("Grid_Size_X")) for r in rs}, key=lambda v: int(v)) if by_grid else [None]
+        for g in grids:
+            rg = rs if g is None else [r for r in rs if r.get("Grid_Size", r.get("Grid_Size_X")) == g]
+            if len(rg) < min_calls:
+                continue
             d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rg]
             r0 = rg[0]
-            lst.append(dict(kernel=short(k)[:110], grid=grid, calls=len(d), avg_ns=round(statistics.mean(d), 1), median_ns=statistics.median(d), min_ns=min(d),
-                            vgpr=r0.get("VGPR_Count"), lds=r0.get("LDS_Block_Size"), scratch=r0.get("Scratch_Size"), wg=r0.get("Workgroup_Size", r0.get("Workgroup_Size_X"))))
-    json.dump(lst, open(os.path.join(out, f"{tag}_kernel_trace_summary_{name}.json"), "w"), indent=1)
-    log = os.path.join(src, sub + ".log")
-    if os.path.exists(log):
-        lines = [ln for ln in open(log) if ln.startswith("{")]
-        if lines:
-            json.dump(json.loads(lines[-1]), open(os.path.join(out, f"{tag}_{name}_timings.json"), "w"), indent=1)
+            lst.append(dict(kernel=short(k)[:110], calls=len(d), avg_ns=round(statistics.mean(d), 1), median_ns=statistics.median(d), min_ns=min(d),
+                            max_ns=max(d), vgpr=r0.get("VGPR_Count"), accum_vgpr=r0.get("Accum_VGPR_Count"), lds=r0.get("LDS_Block_Size"),
+                            scratch=r0.get("Scratch_Size"), wg=r0.get("Workgroup_Size", r0.get("Workgroup_Size_X")),
+                            grid=r0.get("Grid_Size", r0.get("Grid_Size_X"))))
+    return lst
+
+
+def counters(sub, kernel_sub):
+    """{counter: [values per dispatch]} of the kernels whose name contains kernel_sub"""
+    h = hits(f"{sub}/**/*_counter_collection.csv")
+    if len(h) != 1:
+        return {}
+    acc = {}
+    for r in csv.DictReader(open(h[0])):
+        if kernel_sub in r["Kernel_Name"]:
+            acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    return acc
+
+
+def sq_digest(med):
+    waves = med.get("SQ_WAVES", 0.0) or 1.0
+    d = {"medians_per_launch": med,
+         "per_wave": {k.replace("SQ_INSTS_", "insts_"): round(v / waves, 1) for k, v in med.items() if k.startswith("SQ_INSTS_")}}
+    if "SQ_WAVE_CYCLES" in med:
+        d["shares_of_wave_cycles"] = {k: round(med[k] / med["SQ_WAVE_CYCLES"], 4) for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY") if k in med}
+    if "SQ_LDS_IDX_ACTIVE" in med:
+        d["lds_bank_conflict_share"] = round(med.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(1.0, med["SQ_LDS_IDX_ACTIVE"]), 4)
+    return d
+
+
+sha = hashlib.sha256(open(os.path.join(ROOT, "differentiable-mel-spectrogram_amd", "csrc", "dmel_fwd.hip"), "rb").read()).hexdigest()[:16]
+hbm = {"_how": "rocprofv3 --pmc FETCH_SIZE and, separately, --pmc WRITE_SIZE (tools/profile_session.sh); medians over the dispatches.  gfx950 correction "
+               "(MI355X_MICROARCH.md, HBM): FETCH_SIZE reads 1/2 of streamed bytes -> doubled, calibrated in the config-2 run on dmel_dot_kernel, which "
+               "reads exactly 2 x 4 194 304 B with 16-byte loads.  WRITE_SIZE is taken as it is.  Working sets below the 256 MiB Infinity Cache: fabric-side "
+               "bytes, not necessarily DRAM bytes.  bench.py quotes a number only while csrc/dmel_fwd.hip still hashes to kernel_source_sha16.",
+       "kernel_source_sha16": sha}
+
+# ---- config 2: bench line, kernel trace, timeline, counters ---------------------------------------------------------------
+bench = last_json(os.path.join(src, "bench_c2.json"))
+rows = trace_rows("kt")
+if rows:
+    st = hits("kt/**/*_kernel_stats.csv")
+    if len(st) == 1:
+        shutil.copy(st[0], os.path.join(out, f"{tag}_kernel_stats_c2.csv"))
+    dump(f"{tag}_kernel_trace_summary_c2.json", kernel_summary(rows, only_dmel=False, min_calls=20))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+
+    def tight(i):      # forward, dot and the optimizer's kernels back to back: a graph replay, not the eagerly issued trial
+        if i + 3 >= len(rows) or FWD_C2 not in rows[i]["Kernel_Name"] or "dmel_dot" not in rows[i + 1]["Kernel_Name"]:
+            return False
+        if "multi_tensor_apply" not in rows[i + 2]["Kernel_Name"]:
+            return False
+        return int(rows[i + 2]["Start_Timestamp"]) - int(rows[i]["End_Timestamp"]) < 12000
+    idx = [i for i in range(len(rows)) if tight(i)]
+    if idx:
+        mid = idx[len(idx) * 3 // 4]
+        seq, prev = [], None
+        for r in rows[mid:mid + 12]:
+            s0, e0 = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            seq.append(dict(kernel=short(r["Kernel_Name"])[:80], dur_us=round((e0 - s0) / 1e3, 2), gap_before_us=None if prev is None else round((s0 - prev) / 1e3, 2)))
+            prev = e0
+        dump(f"{tag}_step_timeline_c2.json", seq)
+
+fetch, write = counters("fetch", FWD_C2), counters("write", FWD_C2)
+dfetch = counters("fetch", "dmel_dot_kernel")
+factor = 2.0
+if fetch and write and dfetch:
+    dot_known = 2 * 4 * 256 * 128 * 32
+    f_med, w_med, d_med = statistics.median(fetch["FETCH_SIZE"]), statistics.median(write["WRITE_SIZE"]), statistics.median(dfetch["FETCH_SIZE"])
+    factor = dot_known / (d_med * 1024)
+    traffic = int(round(f_med * 1024 * 2 + w_med * 1024))
+    hbm["c2"] = {"dmel_fwd_kernel_FETCH_SIZE_KiB_raw": f_med, "dmel_fwd_kernel_WRITE_SIZE_KiB": w_med, "dmel_fwd_kernel_bytes_per_launch": traffic,
+                 "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"] if bench else None,
+                 "ratio_to_algorithmic": round(traffic / bench["roofline"]["algorithmic_bytes_per_launch"], 4) if bench else None,
+                 "dispatches": len(fetch["FETCH_SIZE"]), "dmel_dot_kernel_FETCH_SIZE_KiB_raw": d_med, "dmel_dot_kernel_bytes_known": dot_known,
+                 "fetch_calibration_factor": round(factor, 3)}
+    if bench:
+        bench["roofline"]["traffic"] = traffic
+        bench["roofline"]["traffic_source"] = f"profiles/hbm_traffic.json (rocprofv3 --pmc, dmel_fwd.hip sha16 {sha})"
+sq = {}
+for sub in ("sq1", "sq2"):
+    for k, v in counters(sub, FWD_C2).items():
+        sq[k] = statistics.median(v)
+if sq:
+    d = sq_digest(sq)
+    d["_how"] = ("rocprofv3 --pmc, two separate passes (tools/profile_session.sh: sq1, sq2) around `bench.py --steps 30 --warmup 5 --mode eager`; medians over the "
+                 "dispatches of dmel_fwd_kernel<1024, train>; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles")
+    dump(f"{tag}_pmc_sq_c2.json", d)
+if bench:
+    dump(f"{tag}_bench_c2.json", bench)
+
+# ---- the other shapes ------------------------------------------------------------------------------------------------
+ALG = {"c3": 4 * (32 * 160000 + 2 * 32 * 128 * 313), "c5": 4 * (32 * 220500 + 2 * 32 * 128 * 501), "c4": 4 * (2048 * 16000 + 2 * 2048 * 128 * 32),
+       "esc_n4096": 4 * (32 * 40000 + 2 * 32 * 64 * 501), "esc_n8192": 4 * (32 * 40000 + 2 * 32 * 64 * 501)}
+shapes = {}
+ktime = {}
+kt_path = os.path.join(src, "ktime.txt")
+if os.path.exists(kt_path):
+    for ln in open(kt_path):
+        p = ln.split()
+        if len(p) >= 4 and p[0].startswith("libdmel"):
+            ktime[f"{p[1]}_{p[2]}"] = float(p[3])
+for cfg in ("c3", "c5", "c4", "esc_n4096", "esc_n8192"):
+    rws = trace_rows(f"kt_{cfg}")
+    if not rws:
+        continue
+    ent = {"kernels": kernel_summary(rws), "forward_train_us_unprofiled": ktime.get(f"{cfg}_train")}
+    f_, w_ = counters(f"fetch_{cfg}", "dmel_fwd_kernel"), counters(f"write_{cfg}", "dmel_fwd_kernel")
+    if f_ and w_:
+        fm, wm = statistics.median(f_["FETCH_SIZE"]), statistics.median(w_["WRITE_SIZE"])
+        tr = int(round(fm * 1024 * 2 + wm * 1024))
+        ent["traffic"] = {"FETCH_SIZE_KiB_raw": fm, "WRITE_SIZE_KiB": wm, "dmel_fwd_kernel_bytes_per_launch": tr, "algorithmic_bytes_per_launch": ALG[cfg],
+                          "ratio_to_algorithmic": round(tr / ALG[cfg], 4), "dispatches": len(f_["FETCH_SIZE"])}
+        pf, pw = counters(f"fetch_{cfg}", "dmel_prep_kernel"), counters(f"write_{cfg}", "dmel_prep_kernel")
+        if pf and pw:
+            ent["traffic"]["dmel_prep_kernel_bytes_per_launch"] = int(round(statistics.median(pf["FETCH_SIZE"]) * 2048 + statistics.median(pw["WRITE_SIZE"]) * 1024))
+        hbm[cfg] = ent["traffic"]
+    s_ = {k: statistics.median(v) for k, v in counters(f"sq_{cfg}", "dmel_fwd_kernel").items()}
+    if s_:
+        ent["sq"] = sq_digest(s_)
+    shapes[cfg] = ent
+if shapes:
+    shapes["_how"] = ("tools/profile_session.sh `shapes`: per shape a kernel trace of a train of forward launches (tools/ktime.py <cfg> train) and three counter passes "
+                      "(FETCH_SIZE, WRITE_SIZE, SQ) of the same command; c4 = BASELINE config 4's global batch (2048 x 16000) on one GPU; esc_n4096 / esc_n8192 = the "
+                      "reference's ESC-50 shape (32 x 40000 @ 8 kHz, hop 80, 64 mels) at lambd 400 / 700")
+    dump(f"{tag}_shapes.json", shapes)
+if len(hbm) > 2:
+    dump("hbm_traffic.json", hbm)
+for nm, fn in (("reference_shapes", "reference_shapes.json"), ("batch_sweep", "batch_sweep.json")):
+    d = last_json(os.path.join(src, fn))
+    if d:
+        dump(f"{tag}_{nm}.json", {"_how": f"tools/{'time_reference_shapes' if nm == 'reference_shapes' else 'batch_sweep'}.py on the final build of the round", "result": d})
+
+# ---- reducers ---------------------------------------------------------------------------------------------------------
 red = {}
-for nm in ("bench_1rank_rccl", "bench_1rank_mailbox", "bench_2ranks_one_gpu_mailbox"):
-    pth = os.path.join(src, nm + ".json")
-    if os.path.exists(pth):
-        lines = [ln for ln in open(pth) if ln.startswith("{")]
-        if lines:
-            d = json.loads(lines[-1])
-            red[nm] = {"value_frames_per_s": d["value"], "ms_per_step": d["ms_per_step"], "n_ranks": d["n_gpus"], "reducer": d["config"].get("reducer"),
-                       "issued": d["module_step"]["issued"], "trial_ms_per_step": d["module_step"]["trial_ms_per_step"]}
+def red_entry(d):
+    return {"value_frames_per_s": d["value"], "ms_per_step": d["ms_per_step"], "n_ranks": d["n_gpus"], "reducer": d["config"].get("reducer"),
+            "issued": d["module_step"]["issued"], "regions": d["module_step"].get("timed_regions")}
+for nm in ("bench_1rank_plain", "bench_1rank_rccl", "bench_1rank_mailbox", "bench_4ranks_one_gpu_mailbox"):
+    d = last_json(os.path.join(src, nm + ".json"))
+    if d:
+        red[nm] = red_entry(d)
+two = [last_json(os.path.join(src, f"bench_2ranks_one_gpu_mailbox_{i}.json")) for i in range(1, 6)]
+two = [d for d in two if d]
+if two:
+    vals = [d["value"] for d in two]
+    red["bench_2ranks_one_gpu_mailbox"] = {"runs": len(two), "value_frames_per_s": vals, "ms_per_step": [d["ms_per_step"] for d in two],
+                                           "median_frames_per_s": statistics.median(vals), "min_frames_per_s": min(vals), "max_frames_per_s": max(vals),
+                                           "spread_max_over_min": round(max(vals) / min(vals), 3), "issued": [d["module_step"]["issued"] for d in two]}
 if red:
-    json.dump({"_how": "bench.py --steps 200 --warmup 20 with DMEL_BENCH_FORCE_DIST=1 (one rank, the reducer still runs: one-rank RCCL communicator / "
-                       "mailbox addressed to itself) and DMEL_BENCH_SHARE_GPU=1 --gpus 2 --reducer mailbox (two processes on ONE GPU exchanging through "
-                       "IPC-mapped inboxes: the code path of two GPUs, not their speed -- the two ranks' kernels overlap on the one device)", **red},
-              open(os.path.join(out, f"{tag}_reducers.json"), "w"), indent=1)
+    red["_how"] = ("bench.py --steps 200 --warmup 20 --no-other-configs: plain; DMEL_BENCH_FORCE_DIST=1 (one rank, the reducer still runs: one-rank RCCL communicator / "
+                   "mailbox addressed to itself); DMEL_BENCH_SHARE_GPU=1 --gpus 2 / 4 --reducer mailbox (processes on ONE GPU exchanging through IPC-mapped inboxes: the "
+                   "code path of N GPUs, not their speed); the two-rank run repeated five times in fresh processes; ms_per_step is the median of 11 regions")
+    dump(f"{tag}_reducers.json", red)
+
+# ---- optional gradients, trainable filterbank ---------------------------------------------------------------------------
+rws = trace_rows("kt_f2")
+if rws:
+    dump(f"{tag}_kernel_trace_summary_f2_backward_extras.json", kernel_summary(rws, by_grid=True))
+    d = last_json(os.path.join(src, "kt_f2.log"))
+    if d:
+        dump(f"{tag}_f2_backward_extras_timings.json", d)
+tf = {}
+d = last_json(os.path.join(src, "learnable_fb.json"))
+if d:
+    tf["step_us_graph_k1"] = d
+d = last_json(os.path.join(src, "fbgrad.json"))
+if d:
+    tf["dmel_backward_fb_us"] = d
+rws = trace_rows("kt_lfb")
+if rws:
+    tf["kernels_profiled"] = kernel_summary(rws, only_dmel=False, min_calls=50, by_grid=True)
+for kern, key in (("dmel_fwd_kernel<1024, 4", "dmel_fwd_kernel<1024,kTrainH>"), ("dmel_fwd_kernel<1024, 0", "dmel_fwd_kernel<1024,kTrain>"),
+                  ("dmel_fbgrad_lds_kernel<true, false, true>", "dmel_fbgrad_lds_kernel<bf16x3>"), ("dmel_fbgrad_lds_kernel<true, false, false>", "dmel_fbgrad_lds_kernel<fp32>")):
+    c = {k: statistics.median(v) for k, v in counters("sq_lfb", kern).items()}
+    if c:
+        tf.setdefault("counters", {})[key] = c
+if tf:
+    tf["_how"] = ("tools/time_learnable_fb.py (lambd and the 513 x 128 filterbank trained together at config 2, HIP-graph replay of the nn.Module step, ONE step per replay: "
+                  "includes the gap between two graph launches), tools/time_fbgrad.py (dmel_backward_fb alone, fp32 vs bf16x3), kernel trace and SQ counters of the former")
+    dump(f"{tag}_trainable_filterbank.json", tf)
 st = os.path.join(src, "stamps_c2.txt")
 if os.path.exists(st):
     shutil.copy(st, os.path.join(out, f"{tag}_stamps_c2.txt"))
-
-rs_path = os.path.join(src, "reference_shapes.json")
-if os.path.exists(rs_path):
-    lines = [ln for ln in open(rs_path) if ln.startswith("{")]
-    if lines:
-        json.dump({"_how": "tools/time_reference_shapes.py: forward + dot per training step through the C ABI (lambd by value), trains of 50 steps "
-                           "between two HIP events, best of 3; shapes of search_spaces.py:4-33 (ESC-50: 32 x 40000 @ 8 kHz, hop 80, 64 mels) and "
-                           ":36-66 (Audio-MNIST: 64 x 8000); lambd 13.3 / 46.7 / 400 are its init_lambd grid, 200 and 700 values a run may drift to",
-                   "shapes": json.loads(lines[-1])}, open(os.path.join(out, f"{tag}_reference_shapes.json"), "w"), indent=1)
-
-# one steady-state step of the timed region (graph replay): kernels in issue order with gaps
-rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-def tight(i):      # forward, dot and the optimizer's kernels back to back: a graph replay, not the eagerly issued trial
-    if i + 3 >= len(rows) or FWD not in rows[i]["Kernel_Name"] or "dmel_dot" not in rows[i + 1]["Kernel_Name"]:
-        return False
-    if "multi_tensor_apply" not in rows[i + 2]["Kernel_Name"]:
-        return False
-    return int(rows[i + 2]["Start_Timestamp"]) - int(rows[i]["End_Timestamp"]) < 12000
-idx = [i for i in range(len(rows)) if tight(i)]
-mid = idx[len(idx) * 3 // 4]          # a forward that is followed by the optimizer's kernels: inside the graph-replayed module steps
-seq, prev = [], None
-for r in rows[mid:mid + 12]:
-    s0, e0 = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    seq.append(dict(kernel=short(r["Kernel_Name"])[:80], dur_us=round((e0 - s0) / 1e3, 2), gap_before_us=None if prev is None else round((s0 - prev) / 1e3, 2)))
-    prev = e0
-json.dump(seq, open(os.path.join(out, f"{tag}_step_timeline_c2.json"), "w"), indent=1)
-
-# PMC passes
-res, sq = {}, {}
-for name in ("fetch", "write", "sq1", "sq2"):
-    path = one(f"{name}/**/*_counter_collection.csv")
-    keep = [r for r in csv.DictReader(open(path)) if "dmel" in r["Kernel_Name"]]
-    if name in ("fetch", "write"):
-        counter = "FETCH_SIZE" if name == "fetch" else "WRITE_SIZE"
-        with open(os.path.join(out, f"{tag}_pmc_{name}_size_c2.csv"), "w", newline="") as f:
-            w = csv.writer(f)
-            w.writerow(["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "Counter_Name", "Counter_Value"])
-            for r in keep:
-                if r["Counter_Name"] == counter:
-                    w.writerow([r["Dispatch_Id"], short(r["Kernel_Name"]), r["Grid_Size"], r["Workgroup_Size"], r["Counter_Name"], r["Counter_Value"]])
-        for kern, key in ((FWD, "dmel_fwd_kernel"), ("dmel_dot_kernel", "dmel_dot_kernel")):
-            v = [float(r["Counter_Value"]) for r in keep if kern in r["Kernel_Name"] and r["Counter_Name"] == counter]
-            res[f"{key}_{counter}_KiB_raw"] = statistics.median(v)
-            res[f"{key}_{counter}_dispatches"] = len(v)
-    else:
-        for r in keep:
-            if FWD in r["Kernel_Name"]:
-                sq.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-bench = json.loads([ln for ln in open(os.path.join(src, "bench_c2.json")) if ln.startswith("{")][-1])
-alg = bench["roofline"]["algorithmic_bytes_per_launch"]
-dot_known = 2 * 4 * 256 * 128 * 32
-factor = dot_known / (res["dmel_dot_kernel_FETCH_SIZE_KiB_raw"] * 1024)      # calibration on a kernel whose reads are known exactly
-traffic = int(round(res["dmel_fwd_kernel_FETCH_SIZE_KiB_raw"] * 1024 * 2 + res["dmel_fwd_kernel_WRITE_SIZE_KiB_raw"] * 1024))
-sha = hashlib.sha256(open(os.path.join(ROOT, "differentiable-mel-spectrogram_amd", "csrc", "dmel_fwd.hip"), "rb").read()).hexdigest()[:16]
-hbm = {
-    "_how": "rocprofv3 --pmc FETCH_SIZE and, separately, --pmc WRITE_SIZE around `bench.py --steps 30 --warmup 5 --mode eager` (config 2); medians over the "
-            "dispatches; raw per-dispatch values: profiles/%s_pmc_fetch_size_c2.csv, %s_pmc_write_size_c2.csv.  gfx950 correction "
-            "(MI355X_MICROARCH.md, HBM): FETCH_SIZE reads 1/2 of streamed bytes -> doubled.  Calibrated in the same run on dmel_dot_kernel, which "
-            "reads exactly 2 x 4 194 304 B with 16-byte loads: measured factor %.3f (2.0 expected).  WRITE_SIZE is taken as it is.  The working "
-            "set fits the 256 MiB Infinity Cache, so these are fabric-side bytes, not necessarily DRAM bytes.  bench.py quotes the number only "
-            "while csrc/dmel_fwd.hip still hashes to kernel_source_sha16." % (tag, tag, factor),
-    "kernel_source_sha16": sha,
-    "c2": {
-        "dmel_fwd_kernel_FETCH_SIZE_KiB_raw": res["dmel_fwd_kernel_FETCH_SIZE_KiB_raw"],
-        "dmel_fwd_kernel_WRITE_SIZE_KiB": res["dmel_fwd_kernel_WRITE_SIZE_KiB_raw"],
-        "dmel_fwd_kernel_bytes_per_launch": traffic,
-        "algorithmic_bytes_per_launch": alg,
-        "dmel_dot_kernel_FETCH_SIZE_KiB_raw": res["dmel_dot_kernel_FETCH_SIZE_KiB_raw"],
-        "dmel_dot_kernel_bytes_known": dot_known,
-        "fetch_calibration_factor": round(factor, 3),
-    },
-}
-json.dump(hbm, open(os.path.join(out, "hbm_traffic.json"), "w"), indent=1)
-med = {k: statistics.median(v) for k, v in sq.items()}
-waves = med.get("SQ_WAVES", 1.0)
-sqj = {"_how": "rocprofv3 --pmc, two separate passes (tools/profile_session.sh: sq1, sq2) around `bench.py --steps 30 --warmup 5 --mode eager`; medians over the "
-               "dispatches of dmel_fwd_kernel<1024, train>; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles",
-       "medians_per_launch": med,
-       "per_wave": {k.replace("SQ_INSTS_", "insts_"): round(v / waves, 1) for k, v in med.items() if k.startswith("SQ_INSTS_")},
-       "shares_of_wave_cycles": {k: round(med[k] / med["SQ_WAVE_CYCLES"], 4) for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY") if k in med and "SQ_WAVE_CYCLES" in med},
-       "lds_bank_conflict_share": round(med.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(1.0, med.get("SQ_LDS_IDX_ACTIVE", 1.0)), 4)}
-json.dump(sqj, open(os.path.join(out, f"{tag}_pmc_sq_c2.json"), "w"), indent=1)
-bench["roofline"]["traffic"] = traffic
-json.dump(bench, open(os.path.join(out, f"{tag}_bench_c2.json"), "w"), indent=1)
-print(json.dumps([s_ for s_ in summ if "dmel" in s_["kernel"]], indent=1))
-print(json.dumps(other, indent=1))
-print(json.dumps(hbm["c2"], indent=1))
-print(json.dumps(sqj["per_wave"]), json.dumps(sqj["shares_of_wave_cycles"]))
-print({k: bench[k] for k in ("value", "ms_per_step")}, bench["module_step"])
+    print("wrote", f"{tag}_stamps_c2.txt")
+if bench:
+    print({k: bench[k] for k in ("value", "ms_per_step")}, bench["roofline"]["avg_launch_us"], bench["roofline"]["frac"])

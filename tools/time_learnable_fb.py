@@ -24,7 +24,7 @@ for name, lfb, native, kw in (("lambd_only", False, False, {}),
                               ("lambd_and_filterbank_bf16x3_LambdAdam", True, True, dict(mfma="bf16x3"))):
     layer = MelSpectrogramLayer(torch.tensor(lam), n_mels=M, n_points=L, sample_rate=sr, hop_length=hop, device=dev, optimized=True,
                                 log=True, learnable_fb=lfb, **kw).to(dev)
-    opt = dmel_amd.LambdAdam(layer.parameters(), lr=1e-9) if native else torch.optim.Adam(layer.parameters(), lr=1e-9, fused=True, capturable=True)
+    opt = dmel_amd.LambdAdam(layer.parameters(), lr=0.0) if native else torch.optim.Adam(layer.parameters(), lr=0.0, fused=True, capturable=True)
 
     def step():
         opt.zero_grad(set_to_none=False)
