@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DMEL_ABI_VERSION 3
+#define DMEL_ABI_VERSION 4   /* round 4: *_dev variants of the fixed-length paths, saved spectrogram, DMEL_FLAG_MFMA_BF16X3, mailbox time-out, plan registry */
 
 typedef enum dmel_status {
     DMEL_OK = 0,

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert sorted(capi.SYMBOLS) == declared
     for name in declared:
         assert hasattr(L, name), f"libdmel_hip.so does not export {name}"
-    assert L.dmel_abi_version() == 3
+    assert L.dmel_abi_version() == 4
 
 
 def test_n_fft_rule_matches_oracle_and_fixtures():
@@ -102,3 +102,23 @@ def test_filterbank_against_independent_implementation(F, M, sr, fmin, fmax):
     assert float(np.abs(ref - fb).max()) <= 5e-5
     # same support, up to entries that are zero in one and <= 5e-5 in the other
     assert ((ref > 5e-5) <= (fb > 0)).all() and ((fb > 5e-5) <= (ref > 0)).all()
+
+
+def test_every_exported_symbol_is_named_in_integration_md():
+    """INTEGRATION.md shows a maintainer what each entry point replaces in the reference: none may be missing from it"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "dmel.h")).read()
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    names = sorted(set(re.findall(r"^(?:dmel_status|int32_t|size_t|const char\*)\s+(dmel_[a-z0-9_]+)\s*\(", header, flags=re.M)))
+    assert len(names) > 50
+    # `dmel_comm_unique_id / create / ...` style lists name a family by prefix + suffixes
+    def named(n):
+        if n in doc:
+            return True
+        for fam in ("dmel_comm_", "dmel_mailbox_", "dmel_plan_"):
+            if n.startswith(fam) and fam in doc and re.search(r"[/ ]" + re.escape(n[len(fam):]) + r"\b", doc):
+                return True
+        return False
+    missing = [n for n in names if not named(n)]
+    assert not missing, missing

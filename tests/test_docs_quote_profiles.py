@@ -1,0 +1,44 @@
+"""The figures DESIGN.md and profiles/README.md quote from the committed profiles must BE the figures in those files (VERDICT r03 weak #7:
+the documents said 20.77 us where the file said 20.28, and 325 M frames/s where the file said 178.8 M).
+
+`profiles/r04_quoted.json` lists every such figure: the document, the exact text around it (must occur in the document), the file
+and the path inside it, a scale (file units -> quoted units) and a relative tolerance (rounding of the quoted text).  A figure that
+is re-measured changes the file; this test then fails until the document follows."""
+import json
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+QUOTED = json.load(open(os.path.join(ROOT, "profiles", "r04_quoted.json")))
+
+
+def resolve(obj, path):
+    for step in path:
+        if isinstance(step, dict):                              # {"field": "substring"}: first list element whose field contains it
+            (field, sub), = step.items()
+            obj = next(e for e in obj if sub in str(e.get(field, "")))
+        elif isinstance(step, int):
+            obj = obj[step]
+        else:
+            obj = obj[step]
+    return obj
+
+
+@pytest.mark.parametrize("q", QUOTED["quotes"], ids=[f'{q["doc"]}:{q["quote"][:40]}' for q in QUOTED["quotes"]])
+def test_quoted_figure_matches_its_file(q):
+    text = open(os.path.join(ROOT, q["doc"])).read()
+    assert q["quote"] in text, f'{q["doc"]} no longer contains the quoted text {q["quote"]!r}'
+    nums = re.findall(r"-?\d+(?:\.\d+)?", q["quote"].replace(" ", "") if q.get("strip_spaces") else q["quote"])
+    said = float(nums[q.get("which", 0)])
+    data = json.load(open(os.path.join(ROOT, q["file"])))
+    have = float(resolve(data, q["path"])) * q.get("scale", 1.0)
+    tol = q.get("rel_tol", 0.01)
+    assert abs(said - have) <= tol * abs(have) + q.get("abs_tol", 0.0), f'{q["doc"]} says {said} ({q["quote"]!r}) but {q["file"]} {q["path"]} holds {have:.6g}'
+
+
+def test_design_is_short_and_the_notebook_exists():
+    n = len(open(os.path.join(ROOT, "DESIGN.md")).read().splitlines())
+    assert n <= 300, f"DESIGN.md has {n} lines: the current state fits 300, history goes to NOTEBOOK.md"
+    assert os.path.exists(os.path.join(ROOT, "NOTEBOOK.md"))

@@ -145,6 +145,13 @@ def test_dense_bank_forward_does_not_read_what_earlier_kernels_left_in_lds():
     plan.forward(x.data_ptr(), B, 128.0, out.data_ptr(), tan.data_ptr(), True, 1e-10, s)
     torch.cuda.synchronize()
     ref_o, ref_t = out.clone(), tan.clone()
+    # the built-in HTK bank too: its last mel tile's padded k-steps reach bin 527, whose tangent entry is the padding column of the
+    # transposition plane's last row
+    htk = capi.Plan(L, hop, M, sr, max_batch=B)
+    ho, ht = torch.empty_like(out), torch.empty_like(out)
+    htk.forward(x.data_ptr(), B, 128.0, ho.data_ptr(), ht.data_ptr(), True, 1e-10, s)
+    torch.cuda.synchronize()
+    ref_ho, ref_ht = ho.clone(), ht.clone()
     poison = capi.Plan(L, hop, M, sr, max_batch=B)
     xn = torch.full((B, L), float("nan"), device=DEV)
     po, pt = torch.empty_like(out), torch.empty_like(out)
@@ -156,3 +163,9 @@ def test_dense_bank_forward_does_not_read_what_earlier_kernels_left_in_lds():
         torch.cuda.synchronize()
         assert torch.isfinite(out).all() and torch.isfinite(tan).all(), rep
         assert torch.equal(out, ref_o) and torch.equal(tan, ref_t), rep
+        for lam in (256.0, 512.0):
+            poison.forward(xn.data_ptr(), B, lam, po.data_ptr(), pt.data_ptr(), True, 1e-10, s)
+        ho.zero_(); ht.zero_()
+        htk.forward(x.data_ptr(), B, 128.0, ho.data_ptr(), ht.data_ptr(), True, 1e-10, s)
+        torch.cuda.synchronize()
+        assert torch.equal(ho, ref_ho) and torch.equal(ht, ref_ht), rep

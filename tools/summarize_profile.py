@@ -19,7 +19,9 @@ FWD_C2 = "dmel_fwd_kernel<1024, 0"          # the training-mode forward at n_fft
 
 
 def hits(pattern):
-    return glob.glob(os.path.join(src, pattern), recursive=True)
+    """the NEWEST match only: a session directory that was merged from two runs holds one rocprofv3 output per run"""
+    h = glob.glob(os.path.join(src, pattern), recursive=True)
+    return [max(h, key=os.path.getmtime)] if h else []
 
 
 def short(name):
