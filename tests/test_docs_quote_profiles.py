@@ -30,10 +30,15 @@ def resolve(obj, path):
 def test_quoted_figure_matches_its_file(q):
     text = open(os.path.join(ROOT, q["doc"])).read()
     assert q["quote"] in text, f'{q["doc"]} no longer contains the quoted text {q["quote"]!r}'
-    nums = re.findall(r"-?\d+(?:\.\d+)?", q["quote"].replace(" ", "") if q.get("strip_spaces") else q["quote"])
+    pat = r"-?\d+(?:\.\d+)?(?:e-?\d+)?" if q.get("sci") else r"-?\d+(?:\.\d+)?"
+    nums = re.findall(pat, q["quote"].replace(" ", "") if q.get("strip_spaces") else q["quote"])
     said = float(nums[q.get("which", 0)])
     data = json.load(open(os.path.join(ROOT, q["file"])))
     have = float(resolve(data, q["path"])) * q.get("scale", 1.0)
+    if q.get("transform") == "spread_percent":                   # max / min  ->  per cent of spread
+        have = (have - 1.0) * 100.0
+        assert abs(said - have) <= 0.06, (said, have)
+        return
     tol = q.get("rel_tol", 0.01)
     assert abs(said - have) <= tol * abs(have) + q.get("abs_tol", 0.0), f'{q["doc"]} says {said} ({q["quote"]!r}) but {q["file"]} {q["path"]} holds {have:.6g}'
 

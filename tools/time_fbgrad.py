@@ -42,6 +42,20 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             res[f"{name}_{'log' if log else 'lin'}_{mode}"] = round(e0.elapsed_time(e1) * 1000 / reps, 2)
+            # the same on a SAVED spectrogram (dmel_backward_fb_saved: what a layer with save_spec=True runs): no recompute
+            spec = torch.empty(B, n // 2 + 1, T, device="cuda:0")
+            plan.spectrogram(x.data_ptr(), B, lam, spec.data_ptr(), st, remove_dc=True)
+            for _ in range(5):
+                plan.backward_fb_saved(spec.data_ptr(), B, n, g.data_ptr(), y.data_ptr(), gfb.data_ptr(), log, st, extra_flags=fl)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(reps):
+                plan.backward_fb_saved(spec.data_ptr(), B, n, g.data_ptr(), y.data_ptr(), gfb.data_ptr(), log, st, extra_flags=fl)
+            e1.record()
+            torch.cuda.synchronize()
+            res[f"{name}_{'log' if log else 'lin'}_{mode}_saved_spec"] = round(e0.elapsed_time(e1) * 1000 / reps, 2)
+            plan.backward_fb(x.data_ptr(), B, lam, g.data_ptr(), y.data_ptr(), gfb.data_ptr(), log, st, extra_flags=fl)
+            torch.cuda.synchronize()
             if ref is None:
                 ref = gfb.clone()
             else:
