@@ -380,6 +380,11 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
                     const int slot = i / CP, jz = i % CP;
                     if (jz < count) reinterpret_cast<float*>(smem_raw + slot * (SS * 8))[first + jz] = 0.f;
                 }
+                // any thread zeroes any slot: the zeroes must land before the slot's own waves write their transposition there.  With
+                // the window table in LDS the barrier behind it does that; the sizes without one (n_fft >= 8192) had NO barrier
+                // before the first transform -- frames next to a clip's edge came out wrong now and then until this one went in
+                // (caught by tests/test_hip_soak.py::test_no_path_depends_on_what_earlier_kernels_left_in_lds)
+                if constexpr (!WIN_LDS) __syncthreads();
             }
         }
         // ---- window table into LDS (time_frequency.py:21-30): every workgroup evaluates the same fp32

@@ -169,3 +169,68 @@ def test_dense_bank_forward_does_not_read_what_earlier_kernels_left_in_lds():
         htk.forward(x.data_ptr(), B, 128.0, ho.data_ptr(), ht.data_ptr(), True, 1e-10, s)
         torch.cuda.synchronize()
         assert torch.equal(ho, ref_ho) and torch.equal(ht, ref_ht), rep
+
+
+def _poison_lds(reps=2):
+    """leave NaN bit patterns in every CU's LDS: forwards of several transform sizes (different LDS maps) on an all-NaN waveform"""
+    from dmel_amd import capi
+    s = torch.cuda.current_stream().cuda_stream
+    B, L, hop, M, sr = 256, 16000, 512, 128, 16000
+    T = L // hop + 1
+    if not hasattr(_poison_lds, "state"):
+        _poison_lds.state = (capi.Plan(L, hop, M, sr, max_batch=B), torch.full((B, L), float("nan"), device=DEV),
+                             torch.empty((B, 1, M, T), device=DEV), torch.empty((B, 1, M, T), device=DEV))
+    plan, xn, po, pt = _poison_lds.state
+    for _ in range(reps):
+        for lam in (128.0, 256.0, 512.0, 64.0, 32.0, 16.0):            # n_fft 1024, 2048, 4096, 512, 256, 128
+            plan.forward(xn.data_ptr(), B, lam, po.data_ptr(), pt.data_ptr(), True, 1e-10, s)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("lam,L,hop,M", [(16.0, 8000, 80, 64), (40.0, 8000, 80, 64), (64.0, 16000, 256, 64), (128.0, 16000, 512, 128),
+                                         (256.0, 32000, 512, 128), (400.0, 40000, 400, 64), (700.0, 40000, 800, 40)])
+def test_no_path_depends_on_what_earlier_kernels_left_in_lds(lam, L, hop, M):
+    """every kernel family at every plan -- training and inference forward (HTK and dense bank, exact and split-bf16), spectrogram, d/d
+    filterbank, d/d waveform -- must give the same bits whether LDS held zeros or NaNs when it started: nothing may read LDS it (or an
+    earlier phase of the same kernel) has not written, not even behind a zero coefficient"""
+    from dmel_amd import capi
+    s = torch.cuda.current_stream().cuda_stream
+    B, sr = 6, 16000
+    T = L // hop + 1
+    n = capi.n_fft(lam)
+    gen = torch.Generator().manual_seed(int(lam))
+    x = (torch.randn(B, L, generator=gen) * 0.1).to(DEV)
+    g = torch.randn(B, 1, M, T, generator=gen).to(DEV)
+    htk, dense = capi.Plan(L, hop, M, sr, max_batch=B), capi.Plan(L, hop, M, sr, max_batch=B)
+    fb = (torch.rand((n // 2 + 1, M), generator=gen) + 0.01).to(DEV)
+    dense.set_filterbank_dev(n, fb.data_ptr(), s)
+
+    def run_all():
+        res = []
+        for plan in (htk, dense):
+            for flags in (0, capi.DMEL_FLAG_MFMA_BF16X3):
+                out, tan = torch.empty((B, 1, M, T), device=DEV), torch.empty((B, 1, M, T), device=DEV)
+                plan.forward(x.data_ptr(), B, lam, out.data_ptr(), tan.data_ptr(), True, 1e-10, s, extra_flags=flags)
+                res += [out, tan]
+                oi = torch.empty((B, 1, M, T), device=DEV)
+                plan.forward(x.data_ptr(), B, lam, oi.data_ptr(), None, True, 1e-10, s, extra_flags=flags)      # inference: two frames per FFT
+                res.append(oi)
+                gfb = torch.empty((n // 2 + 1, M), device=DEV)
+                plan.backward_fb(x.data_ptr(), B, lam, g.data_ptr(), out.data_ptr(), gfb.data_ptr(), True, s, extra_flags=flags)
+                res.append(gfb)
+            gx = torch.empty_like(x)
+            plan.backward_x(x.data_ptr(), B, lam, g.data_ptr(), res[-4].data_ptr(), gx.data_ptr(), True, s)
+            res.append(gx)
+        spec = torch.empty((B, n // 2 + 1, T), device=DEV)
+        htk.spectrogram(x.data_ptr(), B, lam, spec.data_ptr(), s, remove_dc=True)
+        res.append(spec)
+        torch.cuda.synchronize()
+        return res
+
+    ref = run_all()
+    assert all(torch.isfinite(r).all() for r in ref)
+    for rep in range(2):
+        _poison_lds()
+        got = run_all()
+        for i, (a, b) in enumerate(zip(ref, got)):
+            assert torch.equal(a, b), (rep, i, float((a - b).abs().max()))
