@@ -122,3 +122,31 @@ def test_every_exported_symbol_is_named_in_integration_md():
         return False
     missing = [n for n in names if not named(n)]
     assert not missing, missing
+
+
+def test_argument_checks_of_the_round_four_entry_points_need_no_device():
+    """every new entry point refuses NULL handles / pointers with DMEL_ERR_INVALID_ARGUMENT before it touches a device, and the
+    registry look-up never dereferences what it is given"""
+    import ctypes as ct
+    from dmel_amd import capi
+    L = capi.load()
+    null = ct.c_void_p(None)
+    INVALID = capi.DMEL_ERR_INVALID_ARGUMENT if hasattr(capi, "DMEL_ERR_INVALID_ARGUMENT") else 1
+    assert L.dmel_plan_is_live(null) == 0
+    assert L.dmel_plan_is_live(ct.c_void_p(0x1234)) == 0                     # not a plan: a look-up, no dereference
+    assert L.dmel_lambd_ring_size() >= 64
+    assert L.dmel_plan_retain(ct.c_void_p(0x1234)) == INVALID               # retain checks the registry too
+    assert L.dmel_spectrogram_ex_dev(null, null, 1, null, 256, 1, null, null, null) == INVALID
+    assert L.dmel_backward_x_dev(null, null, 1, null, 1024, 0, null, null, null, null) == INVALID
+    assert L.dmel_backward_x_spec_dev(null, null, 1, null, 256, 1, null, null, null) == INVALID
+    assert L.dmel_forward_dev_fixed_spec(null, null, 1, null, 1024, 0, ct.c_double(1e-10), null, null, null, null, null) == INVALID
+    assert L.dmel_backward_fb_saved(null, null, 1, 1024, 0, null, null, null, null) == INVALID
+    assert L.dmel_mailbox_set_timeout_ms(null, ct.c_uint64(1000)) == INVALID
+    assert L.dmel_mailbox_set_spin_limit(null, 10) == INVALID
+    assert b"NULL" in L.dmel_last_error() or b"null" in L.dmel_last_error().lower()
+    # Adam's argument ranges are torch.optim.Adam's (ADVICE r03: a negative lr was accepted)
+    one = ct.c_void_p(16)       # never dereferenced: the range check comes first
+    assert L.dmel_adam_step(one, one, one, one, one, None, 1, ct.c_double(-1e-3), ct.c_double(0.9), ct.c_double(0.999), ct.c_double(1e-8),
+                            ct.c_double(0.0), 0, None) == INVALID
+    assert L.dmel_adam_step(one, one, one, one, one, None, 1, ct.c_double(1e-3), ct.c_double(0.9), ct.c_double(0.999), ct.c_double(1e-8),
+                            ct.c_double(-0.1), 0, None) == INVALID

@@ -234,3 +234,47 @@ def test_no_path_depends_on_what_earlier_kernels_left_in_lds(lam, L, hop, M):
         got = run_all()
         for i, (a, b) in enumerate(zip(ref, got)):
             assert torch.equal(a, b), (rep, i, float((a - b).abs().max()))
+
+
+def test_results_do_not_depend_on_what_freed_device_memory_held():
+    """outputs, tangents, per-call scratch and the autograd functions' temporaries come from torch's caching allocator uninitialised: the
+    same steps must give the same bits whether the freed blocks they land in held zeros or NaNs (the per-call scratch "needs no
+    initialisation", include/dmel.h)"""
+    from dmel_amd import MelSpectrogramLayer, SpectrogramLayer
+    gen = torch.Generator().manual_seed(21)
+    x = (torch.randn(8, 16000, generator=gen) * 0.1).to(DEV)
+
+    def steps():
+        res = []
+        for kw in (dict(optimized=True), dict(optimized=True, learnable_fb=True), dict(optimized=True, learnable_fb=True, mfma="bf16x3"),
+                   dict(optimized=False)):
+            torch.manual_seed(0)
+            lay = MelSpectrogramLayer(torch.tensor(100.0), n_mels=64, n_points=16000 if kw["optimized"] else 2048, sample_rate=16000,
+                                      hop_length=256, device=DEV, log=True, **kw).to(DEV)
+            xx = (x if kw["optimized"] else x[:, :2048].contiguous()).clone().requires_grad_(True)
+            y = lay(xx)
+            g = torch.ones_like(y) * 0.5
+            y.backward(g)
+            res += [y.detach().clone(), lay.lambd.grad.clone(), xx.grad.clone()] + ([lay.mel_fb.grad.clone()] if kw.get("learnable_fb") else [])
+        sp = SpectrogramLayer(torch.tensor(6.38), device=DEV, optimized=False, hop_length=1).to(DEV)
+        xs = x[:, :128].contiguous().clone().requires_grad_(True)
+        ys = sp(xs)
+        ys.sum().backward()
+        res += [ys.detach().clone(), sp.lambd.grad.clone(), xs.grad.clone()]
+        torch.cuda.synchronize()
+        return res
+
+    def fill_cache(value):
+        blocks = [torch.full((n,), value, device=DEV) for n in (1 << 24, 1 << 22, 1 << 20, 1 << 18, 1 << 16, 1 << 14, 1 << 12, 1 << 10) for _ in range(3)]
+        torch.cuda.synchronize()
+        del blocks
+
+    torch.cuda.empty_cache()
+    fill_cache(0.0)
+    ref = steps()
+    assert all(torch.isfinite(r).all() for r in ref)
+    for value in (float("nan"), 1e30):
+        fill_cache(value)
+        got = steps()
+        for i, (a, b) in enumerate(zip(ref, got)):
+            assert torch.equal(a, b), (value, i, float((a - b).abs().max()))
