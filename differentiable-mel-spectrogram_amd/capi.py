@@ -21,6 +21,7 @@ DMEL_ERR_OUT_OF_MEMORY = 5
 DMEL_ERR_LAMBD_TRACKING = 6
 DMEL_ERR_MAILBOX_TIMEOUT = 7
 DMEL_FLAG_MFMA_BF16X3 = 8
+DMEL_FLAG_CHECK_NFFT = 16
 DMEL_FLAG_LOG = 1
 DMEL_FLAG_FULL_WINDOW = 2
 DMEL_FLAG_OUT_BF16 = 4

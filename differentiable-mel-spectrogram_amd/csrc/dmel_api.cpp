@@ -1520,7 +1520,8 @@ namespace {
 // lambd_dev != nullptr: lambd is read by the kernels (window tables, the wave kernel's own window); the transform length then comes
 // from the caller (n_over), never from a host copy of lambd
 dmel_status backward_x_impl(dmel_plan* plan, const float* x, int32_t batch, float lambd, int n_over, int win_half, int spec_mode, bool log,
-                            const float* grad_out, const float* out, float* grad_x, void* stream, const float* lambd_dev = nullptr)
+                            const float* grad_out, const float* out, float* grad_x, void* stream, const float* lambd_dev = nullptr,
+                            bool check_nfft = false)
 {
     if (lambd_dev && n_over <= 0) return fail(DMEL_ERR_INVALID_ARGUMENT, "lambd on the device needs an explicit n_fft");
     const int N = n_over > 0 ? n_over : dmel_n_fft(lambd);
@@ -1589,6 +1590,7 @@ dmel_status backward_x_impl(dmel_plan* plan, const float* x, int32_t batch, floa
     if (!own_prep) DMEL_HIP(dmel::launch_prep(pp, s));
     dmel::XgradParams xp{};
     xp.own_prep = own_prep ? 1 : 0; xp.win_denom = std::fabs(lambd) + 1e-15f; xp.lam_dev = lambd_dev;
+    xp.check_nfft = (check_nfft && lambd_dev && !big) ? 1 : 0;
     xp.x = x; xp.psum = sc.psum; xp.win2 = big ? plan->big_win : sc.win; xp.tw = big ? big_tw : tb->tw_long;
     xp.chirp = big ? bt.chirp : nullptr; xp.hbr = big ? bt.hbr : nullptr; xp.zws = plan->big_z; xp.Mfft = big ? bt.M : 0; xp.logM = big ? bt.logM : 0;
     xp.fb = tb->fb_dense; xp.rowband = tb->rowband; xp.rowpk = tb->rowpk; xp.long_rows = tb->long_rows ? 1 : 0; xp.grad_out = grad_out; xp.out = log ? out : nullptr;
@@ -1652,8 +1654,10 @@ dmel_status dmel_backward_x_dev(dmel_plan* plan, const float* x, int32_t batch, 
     const bool full = (flags & DMEL_FLAG_FULL_WINDOW) != 0;
     if (!full && (n_fft < 1 || n_fft > dmel::kMaxNfft || (n_fft & (n_fft - 1))))
         return fail(DMEL_ERR_INVALID_ARGUMENT, "n_fft must be a power of two in [1, 16384] (the n_fft this step's forward was issued for)");
+    if ((flags & DMEL_FLAG_CHECK_NFFT) && full)
+        return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_backward_x_dev: DMEL_FLAG_CHECK_NFFT has no meaning with DMEL_FLAG_FULL_WINDOW (n_fft = 2 n_points)");
     return backward_x_impl(plan, x, batch, 0.f, full ? 2 * plan->cfg.n_points : n_fft, full ? 1 : 0, 0, (flags & DMEL_FLAG_LOG) != 0,
-                           grad_out, out, grad_x, stream, lambd_dev);
+                           grad_out, out, grad_x, stream, lambd_dev, (flags & DMEL_FLAG_CHECK_NFFT) != 0);
 }
 
 dmel_status dmel_backward_x_spec_dev(dmel_plan* plan, const float* x, int32_t batch, const float* lambd_dev, int32_t n_fft, uint32_t flags,

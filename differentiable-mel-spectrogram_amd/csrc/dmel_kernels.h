@@ -330,6 +330,8 @@ struct XgradParams {
     int own_prep;                             // the kernel evaluates the window and the clip mean itself (no dmel_prep_kernel launch)
     float win_denom;                          // |lambd| + 1e-15 (time_frequency.py:24), own_prep only
     const float* lam_dev;                     // own_prep only: lambd on the device (then win_denom is derived from it by the kernel), or nullptr
+    int check_nfft;                           // DMEL_FLAG_CHECK_NFFT: every kernel returns at once unless lambd (device) asks for THIS n_fft --
+                                              // grad_x and the workspace stay as they were (the caller issues one call per candidate)
     int tw2_off;                              // set by launch_xgrad: byte offset of the radix-C twiddles in LDS
     int win_n;                                // window entries kept in LDS: N/2 + 1 (symmetric about N/2) or N
     // dmel_big.hip path (lengths that are not powers of two, powers of two > 16384): `tw` then belongs to the Mfft-point FFT

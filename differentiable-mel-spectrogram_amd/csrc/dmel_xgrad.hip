@@ -24,11 +24,19 @@ namespace dmel {
 
 constexpr int kXgThreads = 256;
 
+// DMEL_FLAG_CHECK_NFFT (the optimized=True layer with x.requires_grad and lambd left on the device): the step's forward ran one
+// launch per candidate n_fft and only the one lambd asks for did the work (lam_prologue); the backward does the same
+__device__ __forceinline__ bool xgrad_not_this_nfft(const XgradParams& p)
+{
+    return p.check_nfft && p.lam_dev && lam_n_fft(__builtin_fabsf(*p.lam_dev)) != p.N;
+}
+
 template <bool TWLDS>
 __global__ void __launch_bounds__(kXgThreads) dmel_xgrad_frames_kernel(XgradParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* Z = reinterpret_cast<float2*>(smem_raw);
+    if (xgrad_not_this_nfft(p)) return;
     // twiddle table in LDS behind the sequence when it fits (n_fft <= 8192): every butterfly stage would otherwise wait for
     // a global (L1) load per twiddle, twenty-odd dependent round trips per workgroup
     float2* twl = Z + p.N;                                     // TWLDS only
@@ -127,6 +135,7 @@ constexpr int kXgChunk = 4096;
 __global__ void __launch_bounds__(256) dmel_xgrad_gather_kernel(XgradParams p)
 {
     __shared__ double red[256];
+    if (xgrad_not_this_nfft(p)) return;
     const int tid = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
     const int N = p.N, T = p.T, hop = p.hop, half = N / 2;
     float mean = 0.f;
@@ -204,6 +213,7 @@ __global__ void __launch_bounds__((XgPlan<N>::THREADS), (XgPlan<N>::MINW)) dmel_
     static_assert(G <= 64 && N == R * R * C && RR % G == 0, "one wave (or a part of it) per frame pair");
     static_assert(N + (C - 1) * PADP <= SS, "a plane of frame gradients fits half a slot");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    if (xgrad_not_this_nfft(p)) return;
     v2f* lds = reinterpret_cast<v2f*>(smem_raw);
     float* win = reinterpret_cast<float*>(smem_raw + SLOTS * SS * 8);
     // the window table: entries 0 .. N/2 when it is symmetric about N/2 (the Gaussian of the optimized=True branch), else all N
@@ -537,6 +547,7 @@ __global__ void __launch_bounds__((XgPlan<N>::THREADS), (XgPlan<N>::MINW)) dmel_
 // samples between tile starts); they are added in increasing q and the mean of the clip's gradient is subtracted
 __global__ void __launch_bounds__(256) dmel_xgrad_combine_kernel(XgradParams p)
 {
+    if (xgrad_not_this_nfft(p)) return;
     const int tid = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
     const int tiles = p.tiles, span = p.span, ts = p.tile_step, half = p.N / 2;
     const float* sg = p.frames + (size_t)b * tiles * (size_t)span;

@@ -125,7 +125,11 @@ class _DmelFbDevFunction(torch.autograd.Function):
     """The layer with lambd left on the device wherever the transform length does not hang on lambd's host value: a trainable
     filterbank (its row count fixes n_fft: dmel_forward_dev_fixed checks lambd against it on the device) and the optimized=False
     branch (n_fft = 2 n_points whatever lambd is), with or without the gradients w.r.t. the filterbank (dmel_backward_fb_dev) and the
-    waveform (dmel_backward_x_dev).  No host read anywhere: the step queues without waiting and can be captured into a HIP graph."""
+    waveform (dmel_backward_x_dev).  No host read anywhere: the step queues without waiting and can be captured into a HIP graph.
+
+    ``n_fft == 0`` (HTK bank, optimized=True, x.requires_grad): the tracked forward dmel_forward_dev -- one launch per candidate n_fft,
+    the device value of lambd picks the one that works -- and a waveform gradient issued the same way (DMEL_FLAG_CHECK_NFFT: one
+    dmel_backward_x_dev per candidate over a NaN-filled grad_x; a lambd no launch covered leaves the NaN, as that forward's output is)."""
 
     @staticmethod
     def forward(ctx, x, lambd, plan, n_fft, log, eps, fb, out_dtype, full_window=False, mfma_flags=0, save_spec=False):
@@ -134,6 +138,9 @@ class _DmelFbDevFunction(torch.autograd.Function):
         want_fb = fb is not None and ctx.needs_input_grad[6]
         want_x = ctx.needs_input_grad[0]
         # the spectrogram the contraction consumes, kept for the filterbank gradient (fused training kernel only)
+        tracked = n_fft == 0
+        if tracked and (fb is not None or full_window):
+            raise ValueError("n_fft = 0 (tracked forward) is the HTK bank with optimized=True")
         keep_spec = bool(save_spec and want_fb and want_tangent and not full_window and 32 <= n_fft <= 16384 and (n_fft & (n_fft - 1)) == 0)
         round_later = out_dtype == torch.bfloat16 and log and (want_fb or want_x)       # see _DmelFunction.forward
         kdtype = torch.float32 if round_later else out_dtype
@@ -145,8 +152,16 @@ class _DmelFbDevFunction(torch.autograd.Function):
             lam = lam.to(torch.float32)
         flags = (capi.DMEL_FLAG_FULL_WINDOW if full_window else 0) | int(mfma_flags)
         spec = torch.empty((B, n_fft // 2 + 1, plan.n_time), dtype=torch.float32, device=x.device) if keep_spec else None
+        ctx.cands = None
         with _on_device(x.device):
-            if keep_spec:
+            if tracked:
+                plan.forward_dev(x.data_ptr(), B, lam.data_ptr(), out.data_ptr(), tangent.data_ptr() if want_tangent else None, log, eps,
+                                 _stream_ptr(x.device), scratch.data_ptr(),
+                                 extra_flags=capi.DMEL_FLAG_OUT_BF16 if kdtype == torch.bfloat16 else 0)
+                # what that call launched for (host-side bookkeeping of the plan: no device read)
+                n0, guards = plan.info()["n_fft"], plan.lambd_status()["guards"]
+                ctx.cands = [n0] + ([2 * n0] if guards & 2 else []) + ([n0 // 2] if (guards & 1) and n0 >= 2 else [])
+            elif keep_spec:
                 plan.forward_dev_fixed_spec(x.data_ptr(), B, lam.data_ptr(), n_fft, out.data_ptr(), tangent.data_ptr(), spec.data_ptr(),
                                             log, eps, _stream_ptr(x.device), scratch.data_ptr(),
                                             extra_flags=flags | (capi.DMEL_FLAG_OUT_BF16 if kdtype == torch.bfloat16 else 0))
@@ -194,7 +209,18 @@ class _DmelFbDevFunction(torch.autograd.Function):
                 x, lam = saved.pop(0), saved.pop(0)
                 out = saved.pop(0).to(torch.float32) if ctx.log else None
                 g32 = g.to(torch.float32)
-            if ctx.want_x:
+            if ctx.want_x and ctx.cands is not None:
+                if max(ctx.cands) > 16384:
+                    # transforms beyond the fused kernels have no checked backward: the one case that reads lambd (n_fft >= 16384)
+                    gx = torch.empty_like(x)
+                    ctx.plan.backward_x(x.data_ptr(), x.shape[0], float(lam), g32.data_ptr(), out.data_ptr() if ctx.log else None,
+                                        gx.data_ptr(), ctx.log, _stream_ptr(g.device))
+                else:
+                    gx = torch.full_like(x, float("nan"))
+                    for n in ctx.cands:
+                        ctx.plan.backward_x_dev(x.data_ptr(), x.shape[0], lam.data_ptr(), n, g32.data_ptr(), out.data_ptr() if ctx.log else None,
+                                                gx.data_ptr(), ctx.log, _stream_ptr(g.device), extra_flags=capi.DMEL_FLAG_CHECK_NFFT)
+            elif ctx.want_x:
                 gx = torch.empty_like(x)
                 ctx.plan.backward_x_dev(x.data_ptr(), x.shape[0], lam.data_ptr(), ctx.n_fft, g32.data_ptr(), out.data_ptr() if ctx.log else None,
                                         gx.data_ptr(), ctx.log, _stream_ptr(g.device), extra_flags=ctx.flags)
@@ -371,14 +397,14 @@ class MelSpectrogramLayer(nn.Module):
             if lam.dtype != torch.float32:
                 lam = lam.to(torch.float32)
             return _mel_op()(xf, lam, plan.handle, flags, self.eps, self.lambd_sync, self.out_dtype == torch.bfloat16)
-        if not self.lambd_sync and (fb is not None or not self.optimized):
-            # sync-free wherever the transform length does not hang on lambd's HOST value: a trainable filterbank fixes n_fft (its row
-            # count; lambd is read and checked on the device: one that has left that n_fft gives NaN now and a RuntimeError at the next
-            # forward, as models.py:53 fails on the shape), and the optimized=False branch runs n_fft = 2 n_points whatever lambd is.
-            # With or without x.requires_grad.  (What still reads lambd to the host: x.requires_grad on the HTK bank with
-            # optimized=True -- its backward must know which n_fft the forward's guards ended up running -- and lambd_sync=True.)
+        if not self.lambd_sync:
+            # sync-free: a trainable filterbank fixes n_fft (its row count; lambd is read and checked on the device: one that has left
+            # that n_fft gives NaN now and a RuntimeError at the next forward, as models.py:53 fails on the shape), the optimized=False
+            # branch runs n_fft = 2 n_points whatever lambd is, and the HTK bank with optimized=True and x.requires_grad (n = 0) runs the
+            # tracked forward and a backward that issues the waveform gradient for every n_fft that forward launched for.
+            # (What reads lambd to the host: lambd_sync=True, and the waveform gradient at n_fft >= 16384.)
             full = not self.optimized
-            n = 2 * self.n_points if full else 2 * (fb.shape[0] - 1)
+            n = 2 * self.n_points if full else (2 * (fb.shape[0] - 1) if fb is not None else 0)
             if fb is not None:
                 if fb.shape[0] != n // 2 + 1:
                     raise RuntimeError(f"mel_fb was built for n_fft={2 * (fb.shape[0] - 1)} but this layer runs n_fft={n}; "

@@ -69,6 +69,10 @@ typedef struct dmel_plan dmel_plan;
                                    caller-supplied DENSE filterbank) run on the bf16 matrix pipe as three split-bf16 products per fp32
                                    product (hi hi + lo hi + hi lo, fp32 accumulate: ~2e-5 relative, inside the 1e-4 bar; 16 x the fp32 MFMA
                                    rate).  Default: exact fp32 MFMA (v_mfma_f32_16x16x4_f32).  The HTK bank's banded contraction ignores it. */
+#define DMEL_FLAG_CHECK_NFFT 16u /* dmel_backward_x_dev only: the kernels do their work only if the device value of lambd asks for exactly the
+                                   `n_fft` of this call (time_frequency.py:39,60-65 evaluated on the device) and otherwise leave grad_x
+                                   untouched.  For the optimized=True layer whose forward (dmel_forward_dev) issued one launch per candidate
+                                   n_fft: the caller fills grad_x with NaN and issues one dmel_backward_x_dev per candidate. */
 #define DMEL_DTYPE_F32 0
 #define DMEL_DTYPE_BF16 1
 
@@ -290,7 +294,10 @@ dmel_status dmel_backward_x_spec(dmel_plan* plan, const float* x, int32_t batch,
 /* Both with lambd read on the device (no host read, capturable): `n_fft` is the transform length the forward of this step ran --
  * fixed by a trainable filterbank (dmel_forward_dev_fixed), 2 n_points with DMEL_FLAG_FULL_WINDOW (then `n_fft` is ignored), or the
  * spectrogram layer's explicit length.  A lambd that has left `n_fft` made that forward return NaN and raise its error; the
- * gradient computed here for it is not meaningful either. */
+ * gradient computed here for it is not meaningful either.  With DMEL_FLAG_CHECK_NFFT (dmel_backward_x_dev, n_fft <= 16384, not with
+ * DMEL_FLAG_FULL_WINDOW) the call is a no-op on the device unless lambd asks for `n_fft`: the sync-free backward of the
+ * optimized=True layer, one call per n_fft its forward launched for (dmel_plan_get_info's n_fft and dmel_lambd_status::guards
+ * read right after dmel_forward_dev). */
 dmel_status dmel_backward_x_dev(dmel_plan* plan, const float* x, int32_t batch, const float* lambd_dev, int32_t n_fft, uint32_t flags,
                                 const float* grad_out, const float* out, float* grad_x, void* stream);
 dmel_status dmel_backward_x_spec_dev(dmel_plan* plan, const float* x, int32_t batch, const float* lambd_dev, int32_t n_fft, uint32_t flags,

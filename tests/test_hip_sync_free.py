@@ -112,6 +112,53 @@ def test_waveform_gradient_with_a_trainable_filterbank_is_sync_free(log):
 
 
 @pytest.mark.parametrize("log", [False, True])
+def test_waveform_gradient_of_the_default_layer_is_sync_free(log):
+    """HTK bank, optimized=True, x.requires_grad: the transform length follows lambd, so the forward is the tracked one (one launch per
+    candidate n_fft) and the waveform gradient is issued the same way (DMEL_FLAG_CHECK_NFFT over a NaN-filled grad_x)"""
+    from dmel_amd import MelSpectrogramLayer
+    case = C.BY_NAME["g1_c1"]
+    x0 = torch.from_numpy(C.make_input(case).astype(np.float32)).to(DEV)
+    g = torch.from_numpy(C.make_cotangent(case)).to(DEV)
+
+    def make(sync):
+        return MelSpectrogramLayer(torch.tensor(float(case["lambd"])), n_mels=case["n_mels"], n_points=case["L"], sample_rate=case["sr"],
+                                   hop_length=case["hop"], device=DEV, optimized=True, log=log, lambd_sync=sync).to(DEV)
+
+    ref = _run(make, x0, g, 6, False, True)
+    got = _run(make, x0, g, 6, True, True)
+    assert torch.isfinite(got[-1]).all() and float(got[-1].abs().max()) > 0
+    _same(ref, got)
+
+
+@pytest.mark.parametrize("lam0", [21.42, 21.58])
+def test_waveform_gradient_follows_lambd_across_an_n_fft_boundary_inside_a_graph(lam0):
+    """6 lambd = 129 is the boundary between n_fft 128 and 256 (time_frequency.py:39,60-65).  Adam moves lambd by 0.02 per step from
+    just below / just above it; the captured step holds the launches for n_fft, 2 n_fft and n_fft / 2 and the device value picks --
+    forward AND waveform gradient -- so the replays keep matching the layer that reads lambd at every forward.  One of the two
+    starting points crosses, whichever way the gradient points."""
+    from dmel_amd import MelSpectrogramLayer, capi
+    L, hop, M, sr, B = 2000, 100, 20, 8000, 3
+    gen = torch.Generator().manual_seed(11)
+    x0 = torch.randn(B, L, generator=gen).to(DEV)
+    g = torch.randn(B, 1, M, L // hop + 1, generator=gen).to(DEV)
+
+    def make(sync):
+        return MelSpectrogramLayer(torch.tensor(lam0), n_mels=M, n_points=L, sample_rate=sr, hop_length=hop, device=DEV, optimized=True,
+                                   log=True, lambd_sync=sync).to(DEV)
+
+    ref = _run(make, x0, g, 10, False, True)
+    got = _run(make, x0, g, 10, True, True)
+    assert torch.isfinite(got[-1]).all()
+    _same(ref, got)
+    _CROSSED.append(capi.n_fft(float(got[0])) != capi.n_fft(lam0))
+    if len(_CROSSED) == 2:
+        assert any(_CROSSED), "neither starting point crossed the boundary: the test did not exercise the guards"
+
+
+_CROSSED = []
+
+
+@pytest.mark.parametrize("log", [False, True])
 @pytest.mark.parametrize("mfma", ["fp32", "bf16x3"])
 def test_saved_spectrogram_and_split_bf16_filterbank_gradient(log, mfma):
     """save_spec=True (the training forward writes the power spectrogram the contraction consumed; dmel_backward_fb_saved skips the
