@@ -182,49 +182,67 @@ hipError_t launch_dot(const void* g, int g_bf16, const float* t, long long count
 // ---- filterbank tables from a device matrix -----------------------------------------------------------------
 // grid.x = runs (one (group, wave, run) entry of tile_ranges each) + the workgroups that copy / transpose the matrix (one
 // workgroup doing all of it took 64 us for 513 x 128 entries: the longest kernel of a trainable-filterbank step)
+constexpr int kRepackRunSplit = 8;
 __global__ void __launch_bounds__(256) dmel_repack_kernel(RepackParams p)
 {
     const int tid = threadIdx.x;
-    if ((int)blockIdx.x >= p.runs) {
+    if ((int)blockIdx.x >= p.runs * kRepackRunSplit) {
+        // one kind of work per workgroup, at most four entries per thread: [split-bf16 fragments][plain copy + transpose][packed rows +
+        // Nyquist row] (round 4: 65 workgroups that each walked through all of it in turn took 7 us -- four dependent passes)
+        int blk = (int)blockIdx.x - p.runs * kRepackRunSplit;
         const long long n = (long long)p.F * p.M;
-        const long long stride = 256LL * (gridDim.x - p.runs);
-        if (p.ent_h) {
+        if (blk < p.blocks_h) {
             // the split-bf16 fragments of kTrainH (build_tables is the host's version of this loop): one 16-byte entry per (block, lane)
             const int NT = (p.M + 15) / 16;
             const long long ne = (long long)NT * p.ks32 * 64;
-            for (long long q = (long long)(blockIdx.x - p.runs) * 256 + tid; q < ne; q += stride) {
+            const long long q = (long long)blk * 256 + tid;
+            if (q < ne) {
                 const int l = (int)(q & 63);
-                const long long blk = q >> 6;                              // tile * ks32 + kstep
-                const int tile = (int)(blk / p.ks32), ks = (int)(blk % p.ks32);
+                const long long fblk = q >> 6;                             // tile * ks32 + kstep
+                const int tile = (int)(fblk / p.ks32), ks = (int)(fblk % p.ks32);
                 const int m = 16 * tile + (l & 15), f0 = 32 * ks + 8 * (l >> 4);
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = m < p.M ? p.fb[(size_t)(f0 + e) * p.M + m] : 0.f;
                 unsigned hi[4], lo[4];
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
-                    const float v0 = m < p.M ? p.fb[(size_t)(f0 + e) * p.M + m] : 0.f, v1 = m < p.M ? p.fb[(size_t)(f0 + e + 1) * p.M + m] : 0.f;
-                    const unsigned short h0 = bf16_bits(v0), h1 = bf16_bits(v1);
+                    const unsigned short h0 = bf16_bits(v[e]), h1 = bf16_bits(v[e + 1]);
                     hi[e / 2] = (unsigned)h0 | ((unsigned)h1 << 16);
-                    lo[e / 2] = (unsigned)bf16_bits(v0 - __uint_as_float((unsigned)h0 << 16)) | ((unsigned)bf16_bits(v1 - __uint_as_float((unsigned)h1 << 16)) << 16);
+                    lo[e / 2] = (unsigned)bf16_bits(v[e] - __uint_as_float((unsigned)h0 << 16)) | ((unsigned)bf16_bits(v[e + 1] - __uint_as_float((unsigned)h1 << 16)) << 16);
                 }
-                p.ent_h[blk * 128 + l] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-                p.ent_h[blk * 128 + 64 + l] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+                p.ent_h[fblk * 128 + l] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+                p.ent_h[fblk * 128 + 64 + l] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
             }
-            for (long long m = (long long)(blockIdx.x - p.runs) * 256 + tid; m < p.M; m += stride) p.fb_nyq[m] = p.fb[(size_t)(p.F - 1) * p.M + m];
+            return;
         }
-        for (long long i = (long long)(blockIdx.x - p.runs) * 256 + tid; i < n; i += stride) {
-            const float v = p.fb[i];
-            p.fb_dense[i] = v;
-            if (p.fbT) { const int f = (int)(i / p.M), m = (int)(i % p.M); p.fbT[(size_t)m * p.F + f] = v; }
+        blk -= p.blocks_h;
+        if (blk < p.blocks_c) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const long long i = ((long long)blk * 4 + u) * 256 + tid; v[u] = i < n ? p.fb[i] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long i = ((long long)blk * 4 + u) * 256 + tid;
+                if (i < n) {
+                    p.fb_dense[i] = v[u];
+                    if (p.fbT) { const int f = (int)(i / p.M), m = (int)(i % p.M); p.fbT[(size_t)m * p.F + f] = v[u]; }
+                }
+            }
+            return;
         }
-        // packed rows of the waveform gradient (dense structure: every row starts at column 0 and has M columns)
-        if (p.rowpk)
-            for (long long f = (long long)(blockIdx.x - p.runs) * 256 + tid; f < p.F; f += stride)
-                p.rowpk[f] = make_float4(p.fb[f * p.M], p.M > 1 ? p.fb[f * p.M + 1] : 0.f, __builtin_bit_cast(float, 0), __builtin_bit_cast(float, p.M));
+        blk -= p.blocks_c;
+        // packed rows of the waveform gradient (dense structure: every row starts at column 0 and has M columns); the Nyquist row of kTrainH
+        const long long f = (long long)blk * 256 + tid;
+        if (p.rowpk && f < p.F)
+            p.rowpk[f] = make_float4(p.fb[f * p.M], p.M > 1 ? p.fb[f * p.M + 1] : 0.f, __builtin_bit_cast(float, 0), __builtin_bit_cast(float, p.M));
+        if (p.ent_h && f < p.M) p.fb_nyq[f] = p.fb[(size_t)(p.F - 1) * p.M + f];
         return;
     }
-    const int run = blockIdx.x;
+    const int run = blockIdx.x / kRepackRunSplit, part = blockIdx.x % kRepackRunSplit;       // a run's entries dealt over kRepackRunSplit workgroups
     const int4 tr = p.tile_ranges[run];                 // (first k-step, #k-steps, offset into ent_b, mel tile)
     if (tr.y <= 0 || tr.w < 0) return;
-    for (int i = tid; i < tr.y * 64; i += 256) {
+    for (int i = part * 256 + tid; i < tr.y * 64; i += 256 * kRepackRunSplit) {
         const int ks = tr.x + i / 64, l = i % 64;
         const int f = 4 * ks + (l >> 4), m = 16 * tr.w + (l & 15);
         const float v = (f < p.F && m < p.M) ? p.fb[(size_t)f * p.M + m] : 0.f;
@@ -233,11 +251,15 @@ __global__ void __launch_bounds__(256) dmel_repack_kernel(RepackParams p)
     }
 }
 
-hipError_t launch_repack(const RepackParams& p, hipStream_t s)
+hipError_t launch_repack(const RepackParams& p0, hipStream_t s)
 {
+    RepackParams p = p0;
     const long long n = (long long)p.F * p.M;
-    const int copiers = (int)std::max<long long>(1, std::min<long long>(256, (n + 1023) / 1024));
-    hipLaunchKernelGGL(dmel_repack_kernel, dim3((unsigned)(p.runs + copiers)), dim3(256), 0, s, p);
+    const int NT = (p.M + 15) / 16;
+    p.blocks_h = p.ent_h ? (int)(((long long)NT * p.ks32 * 64 + 255) / 256) : 0;
+    p.blocks_c = (int)((n + 1023) / 1024);
+    const int blocks_r = (std::max(p.F, p.M) + 255) / 256;
+    hipLaunchKernelGGL(dmel_repack_kernel, dim3((unsigned)(p.runs * kRepackRunSplit + p.blocks_h + p.blocks_c + blocks_r)), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 

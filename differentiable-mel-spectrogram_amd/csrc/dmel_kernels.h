@@ -373,6 +373,7 @@ struct RepackParams {
     float* fbT;                 // (M, F) transposed copy (long / big transforms) or nullptr
     float4* rowpk;              // (F) packed rows of XgradParams (dense structure: first column 0, M columns)
     int F, M, runs, nbpre, runs_group0;
+    int blocks_h, blocks_c;     // set by launch_repack: workgroups of the fragment / copy sections
 };
 hipError_t launch_repack(const RepackParams& p, hipStream_t s);
 
