@@ -39,7 +39,7 @@ SYMBOLS = (
     "dmel_plan_lambd_status", "dmel_plan_set_tracking", "dmel_plan_lambd_reset",
     "dmel_plan_retain", "dmel_plan_release", "dmel_plan_lambd_report", "dmel_decide_launch", "dmel_plan_force_launch",
     "dmel_adam_step", "dmel_mailbox_create", "dmel_mailbox_connect", "dmel_mailbox_destroy", "dmel_mailbox_allreduce", "dmel_mailbox_error",
-    "dmel_mailbox_set_spin_limit", "dmel_mailbox_set_timeout_ms", "dmel_plan_is_live", "dmel_lambd_ring_size", "dmel_spectrogram_ex_dev", "dmel_forward_dev_fixed_spec", "dmel_backward_fb_saved", "dmel_backward_x_dev", "dmel_backward_x_spec_dev", "dmel_plan_attach_mailbox", "dmel_backward_x_spec",
+    "dmel_mailbox_set_spin_limit", "dmel_mailbox_set_timeout_ms", "dmel_plan_is_live", "dmel_lambd_ring_size", "dmel_spectrogram_ex_dev", "dmel_forward_dev_fixed_spec", "dmel_backward_fb_saved", "dmel_backward_fb_saved_dl", "dmel_backward_x_dev", "dmel_backward_x_spec_dev", "dmel_plan_attach_mailbox", "dmel_backward_x_spec",
 )
 TORCH_LIB_PATH = os.path.join(_PKG_DIR, "libdmel_torch.so")
 
@@ -192,6 +192,8 @@ def load():
     L.dmel_forward_dev_fixed_spec.restype = C.c_int
     L.dmel_backward_fb_saved.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_uint32, vp, vp, vp, vp]
     L.dmel_backward_fb_saved.restype = C.c_int
+    L.dmel_backward_fb_saved_dl.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_uint32, vp, vp, vp, vp, vp, vp, vp]
+    L.dmel_backward_fb_saved_dl.restype = C.c_int
     L.dmel_spectrogram_ex_dev.argtypes = [vp, vp, C.c_int32, vp, C.c_int32, C.c_uint32, vp, vp, vp]
     L.dmel_spectrogram_ex_dev.restype = C.c_int
     L.dmel_backward_x_dev.argtypes = [vp, vp, C.c_int32, vp, C.c_int32, C.c_uint32, vp, vp, vp, vp]
@@ -358,6 +360,12 @@ class Plan:
                           stream: int, extra_flags: int = 0):
         _check(load().dmel_backward_fb_saved(self._h, spec_ptr, batch, int(n_fft_), (DMEL_FLAG_LOG if log else 0) | int(extra_flags), grad_ptr,
                                              out_ptr if log else None, grad_fb_ptr, stream))
+
+    def backward_fb_saved_dl(self, spec_ptr: int, batch: int, n_fft_: int, grad_ptr: int, out_ptr: int | None, tangent_ptr: int, grad_fb_ptr: int,
+                             dlambd_ptr: int, scratch_ptr: int | None, log: bool, stream: int, extra_flags: int = 0):
+        """dmel_backward_fb_saved_dl: the filterbank gradient on the saved spectrogram and d lambd in one launch (fp32 grad_out)."""
+        _check(load().dmel_backward_fb_saved_dl(self._h, spec_ptr, batch, int(n_fft_), (DMEL_FLAG_LOG if log else 0) | int(extra_flags), grad_ptr,
+                                                out_ptr if log else None, tangent_ptr, grad_fb_ptr, dlambd_ptr, scratch_ptr, stream))
 
     def backward_fb_dev(self, x_ptr: int, batch: int, lambd_ptr: int, n_fft_: int, grad_ptr: int, out_ptr: int | None, grad_fb_ptr: int,
                         log: bool, stream: int, extra_flags: int = 0):

@@ -1419,8 +1419,12 @@ namespace {
 // lambd by value (lambd_dev == nullptr; n_fft derived from it) or on the device with the n_fft the caller's forward was issued for
 // saved_spec != nullptr: the (batch, n_fft_dev/2+1, n_time) power spectrogram the training forward wrote (dmel_forward_dev_fixed_spec):
 // no recompute, x and lambd are not touched
+// d lambd computed in the launch of the filterbank gradient (dmel_backward_fb_saved_dl)
+struct DotRider { const float* tangent; float* dlambd; void* scratch; };
+
 dmel_status backward_fb_impl(dmel_plan* plan, const float* x, int32_t batch, float lambd, const float* lambd_dev, int32_t n_fft_dev,
-                             uint32_t flags, const float* grad_out, const float* out, float* grad_fb, void* stream, const float* saved_spec = nullptr)
+                             uint32_t flags, const float* grad_out, const float* out, float* grad_fb, void* stream, const float* saved_spec = nullptr,
+                             const DotRider* rider = nullptr)
 {
     if (!plan) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
     if (batch < 0) return fail(DMEL_ERR_INVALID_ARGUMENT, "batch < 0");
@@ -1444,7 +1448,20 @@ dmel_status backward_fb_impl(dmel_plan* plan, const float* x, int32_t batch, flo
         dmel_status so = order_after_last_stream(plan, s);       // fbw is shared by every call on the plan
         if (so != DMEL_OK) return so;
     }
-    const int splits = dmel::fbgrad_splits(batch, F, M, T);
+    int splits = dmel::fbgrad_splits(batch, F, M, T);
+    // d lambd rides along unless the plan's reducer lives in the dot kernel (mailbox) or the launch has no room for it
+    Scratch rsc;
+    int dot_wgs = 0, dot_vblocks = 0;
+    const long long dot_count = (long long)batch * M * T;
+    if (rider) {
+        if (rider->scratch) rsc = carve(rider->scratch);
+        else { dmel_status sr = ensure_own_scratch(plan, batch, s, &rsc); if (sr != DMEL_OK) return sr; }
+        if (!plan->mailbox) {
+            dot_vblocks = dmel::dot_blocks_for(dot_count, kMaxPartials);
+            const int left = dmel::fbgrad_fuse_dot(F, M, splits, dot_vblocks, &dot_wgs);
+            if (left > 0) splits = left; else dot_wgs = 0;
+        }
+    }
     const size_t spec_floats = saved_spec ? 0 : ((size_t)batch * F * T + 63) / 64 * 64;
     const size_t part_floats = ((size_t)splits * F * M + 63) / 64 * 64;
     const size_t gm_floats = 0;      // (gm = grad_out * exp(-out) is formed inside the GEMM kernel)
@@ -1481,8 +1498,21 @@ dmel_status backward_fb_impl(dmel_plan* plan, const float* x, int32_t batch, flo
     fp.gm_ws = plan->fbw + spec_floats + part_floats;
     fp.B = batch; fp.F = F; fp.M = M; fp.T = T; fp.splits = splits;
     fp.bf16x3 = (flags & DMEL_FLAG_MFMA_BF16X3) ? 1 : 0;
+    if (dot_wgs > 0) {
+        fp.dot_g = grad_out; fp.dot_t = rider->tangent; fp.dot_count = dot_count; fp.dot_partials = rsc.partials; fp.dot_counter = rsc.counter;
+        fp.dot_result = rider->dlambd; fp.dot_vblocks = dot_vblocks; fp.dot_wgs = dot_wgs; fp.dot_accumulate = 0;
+    }
     const size_t m0 = prof_mark(plan, s);
     DMEL_HIP(dmel::launch_fbgrad(fp, s));
+    if (rider && dot_wgs == 0) {
+        // the stand-alone kernel (dmel_backward_scratch): the mailbox exchange lives there
+        dmel::MailboxArgs mba;
+        const bool use_mb = plan->mailbox != nullptr;
+        if (use_mb && !dmel::mailbox_args(plan->mailbox, &mba)) return fail(DMEL_ERR_INVALID_ARGUMENT, "the plan's mailbox is not connected");
+        if (use_mb) { dmel_status ms = mailbox_status(plan); if (ms != DMEL_OK) return ms; }
+        DMEL_HIP(dmel::launch_dot(grad_out, 0, rider->tangent, dot_count, 0, rsc.partials, rsc.counter, kMaxPartials, rider->dlambd, s,
+                                  use_mb ? &mba : nullptr));
+    }
     prof_span(plan, m0, prof_mark(plan, s), 2);
     return DMEL_OK;
 }
@@ -1510,6 +1540,19 @@ dmel_status dmel_backward_fb_saved(dmel_plan* plan, const float* spec, int32_t b
     if (flags & DMEL_FLAG_FULL_WINDOW) return fail(DMEL_ERR_UNSUPPORTED, "dmel_backward_fb_saved: not with DMEL_FLAG_FULL_WINDOW");
     if (n_fft < 2 || (n_fft & 1)) return fail(DMEL_ERR_INVALID_ARGUMENT, "n_fft must be the (even) transform length the spectrogram was computed with");
     return backward_fb_impl(plan, nullptr, batch, 0.f, nullptr, n_fft, flags, grad_out, out, grad_fb, stream, spec);
+}
+
+dmel_status dmel_backward_fb_saved_dl(dmel_plan* plan, const float* spec, int32_t batch, int32_t n_fft, uint32_t flags,
+                                      const float* grad_out, const float* out, const float* tangent, float* grad_fb, float* dlambd,
+                                      void* scratch, void* stream)
+{
+    if (!spec) return fail(DMEL_ERR_INVALID_ARGUMENT, "spec is NULL");
+    if (!tangent || !dlambd) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_backward_fb_saved_dl: tangent / dlambd is NULL");
+    if (batch <= 0) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_backward_fb_saved_dl: batch must be positive");
+    if (flags & DMEL_FLAG_FULL_WINDOW) return fail(DMEL_ERR_UNSUPPORTED, "dmel_backward_fb_saved_dl: not with DMEL_FLAG_FULL_WINDOW");
+    if (n_fft < 2 || (n_fft & 1)) return fail(DMEL_ERR_INVALID_ARGUMENT, "n_fft must be the (even) transform length the spectrogram was computed with");
+    const DotRider rider{tangent, dlambd, scratch};
+    return backward_fb_impl(plan, nullptr, batch, 0.f, nullptr, n_fft, flags, grad_out, out, grad_fb, stream, spec, &rider);
 }
 
 }  // extern "C"

@@ -160,13 +160,18 @@ __global__ void __launch_bounds__(kDotThreads) dmel_dot_kernel(const void* __res
     }
 }
 
-hipError_t launch_dot(const void* g, int g_bf16, const float* t, long long count, int accumulate, double* partials,
-                      unsigned* counter, int max_partials, float* result, hipStream_t s, const MailboxArgs* mb)
+int dot_blocks_for(long long count, int max_partials)
 {
     // 8192 floats per workgroup and tensor: few workgroups on purpose -- every workgroup ends with one ticket on a single
     // counter (~11 ns each, serialised), which cost more than the loads at 256+ workgroups
-    long long want = (count + 8191) / 8192;
-    int blocks = (int)(want < 1 ? 1 : (want > max_partials ? max_partials : want));
+    const long long want = (count + 8191) / 8192;
+    return (int)(want < 1 ? 1 : (want > max_partials ? max_partials : want));
+}
+
+hipError_t launch_dot(const void* g, int g_bf16, const float* t, long long count, int accumulate, double* partials,
+                      unsigned* counter, int max_partials, float* result, hipStream_t s, const MailboxArgs* mb)
+{
+    const int blocks = dot_blocks_for(count, max_partials);
     const MailboxArgs none{};
     const dim3 gr(blocks), bl(kDotThreads);
     if (mb) {
@@ -464,9 +469,87 @@ __device__ __forceinline__ void split_bf16x4(float4 v, uint2& hi, uint2& lo)
     lo = make_uint2((unsigned)bf16_bits(r0) | ((unsigned)bf16_bits(r1) << 16), (unsigned)bf16_bits(r2) | ((unsigned)bf16_bits(r3) << 16));
 }
 
+// d lambd inside the filterbank gradient's launch (FbGradParams::dot_*): dmel_dot_kernel<false, false> restated for a workgroup of 512
+// threads that plays four of its 256-thread blocks, two at a time.  Same elements per (virtual) thread in the same order, same DPP
+// rows, same 16-entry sums, the same walk over the partials by the workgroup that draws the last ticket: the result has the bits of
+// the stand-alone kernel.  One launch (~4.4 us inside a captured step) less per trainable-filterbank step.
+__device__ __forceinline__ double vblock_sum256(double v, double* red16, int vt)
+{
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    v += dpp_f64<0x141>(v);
+    v += dpp_f64<0x140>(v);
+    if ((vt & 15) == 0) red16[vt >> 4] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int q = 0; q < 16; ++q) s += red16[q];
+    return s;
+}
+
+__device__ void fbgrad_dot_body(const FbGradParams& p, int wg)
+{
+    static_assert(kDotThreads == 256, "the fused dot plays dmel_dot_kernel's 256-thread blocks");
+    __shared__ double dred[2][2][16];
+    __shared__ int is_last;
+    const int tid = threadIdx.x, vt = tid & 255, half = tid >> 8;
+    const float* g = p.dot_g; const float* t = p.dot_t;
+    const long long count = p.dot_count;
+    const long long stride = (long long)p.dot_vblocks * 256;
+    const long long n4 = ((reinterpret_cast<uintptr_t>(g) & 15) | (reinterpret_cast<uintptr_t>(t) & 15)) == 0 ? count / 4 : 0;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    const float4* t4 = reinterpret_cast<const float4*>(t);
+    for (int pass = 0; pass < 2; ++pass) {
+        const int vb = wg * 4 + pass * 2 + half;
+        double acc = 0.0;
+        if (vb < p.dot_vblocks) {
+            long long i = (long long)vb * 256 + vt;
+            for (; i + 3 * stride < n4; i += 4 * stride) {
+                const float4 a0 = g4[i], a1 = g4[i + stride], a2 = g4[i + 2 * stride], a3 = g4[i + 3 * stride];
+                const float4 b0 = t4[i], b1 = t4[i + stride], b2 = t4[i + 2 * stride], b3 = t4[i + 3 * stride];
+                acc += ((double)a0.x * (double)b0.x + (double)a0.y * (double)b0.y) + ((double)a0.z * (double)b0.z + (double)a0.w * (double)b0.w);
+                acc += ((double)a1.x * (double)b1.x + (double)a1.y * (double)b1.y) + ((double)a1.z * (double)b1.z + (double)a1.w * (double)b1.w);
+                acc += ((double)a2.x * (double)b2.x + (double)a2.y * (double)b2.y) + ((double)a2.z * (double)b2.z + (double)a2.w * (double)b2.w);
+                acc += ((double)a3.x * (double)b3.x + (double)a3.y * (double)b3.y) + ((double)a3.z * (double)b3.z + (double)a3.w * (double)b3.w);
+            }
+            for (; i < n4; i += stride) {
+                const float4 a = g4[i], b = t4[i];
+                acc += ((double)a.x * (double)b.x + (double)a.y * (double)b.y) + ((double)a.z * (double)b.z + (double)a.w * (double)b.w);
+            }
+            for (long long k = n4 * 4 + (long long)vb * 256 + vt; k < count; k += stride)
+                acc += (double)g[k] * (double)t[k];
+        }
+        const double bsum = vblock_sum256(acc, dred[pass][half], vt);
+        if (vt == 0 && vb < p.dot_vblocks) {
+            __hip_atomic_store(&p.dot_partials[vb], bsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();                                   // both storing threads have their acknowledgements
+    if (tid == 0) {
+        const unsigned ticket = __hip_atomic_fetch_add(p.dot_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (ticket == (unsigned)p.dot_wgs - 1u);
+    }
+    __syncthreads();
+    if (!is_last) return;
+    double sum = 0.0;
+    if (half == 0)
+        for (int q = vt; q < p.dot_vblocks; q += 256)
+            sum += __hip_atomic_load(&p.dot_partials[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double total = vblock_sum256(sum, dred[0][half], vt);
+    if (tid == 0) {
+        __hip_atomic_store(p.dot_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        p.dot_result[0] = p.dot_accumulate ? (float)((double)p.dot_result[0] + total) : (float)total;
+    }
+}
+
 template <bool LOG, bool TINY, bool BF16X3 = false>
 __global__ void __launch_bounds__(kFbgThreads) dmel_fbgrad_lds_kernel(FbGradParams p)
 {
+    if (p.dot_wgs > 0 && (int)blockIdx.y >= p.splits) {
+        const int wg = ((int)blockIdx.y - p.splits) * (int)gridDim.x + (int)blockIdx.x;
+        if (wg < p.dot_wgs) fbgrad_dot_body(p, wg);
+        return;
+    }
     // exact path: fp32 images, rows of 24 floats.  BF16X3: [hi | lo] images of bf16, rows of 24 entries -- the same bytes either way
     constexpr int kImgA = BF16X3 ? (kFbgBF + 1) * kFbgRowH : (kFbgBF + 1) * kFbgRow;     // floats (+ the folded last row, see `fold`)
     constexpr int kImgB = BF16X3 ? kFbgBM * kFbgRowH : kFbgBM * kFbgRow;
@@ -771,6 +854,19 @@ int fbgrad_splits(int batch, int F, int M, int T)
     return s < 1 ? 1 : (int)s;
 }
 
+// d lambd in the same launch: the slice count that leaves room for the dot's workgroups (four virtual blocks each, whole rows of
+// the grid), or 0 when the launch should not carry it (several column tiles; the dot would take more than an eighth of the slots)
+int fbgrad_fuse_dot(int F, int M, int splits, int vblocks, int* dot_wgs)
+{
+    static_assert(kFbgThreads == 512, "fbgrad_dot_body: two 256-thread virtual blocks per pass");
+    if ((M + kFbgBM - 1) / kFbgBM != 1 || vblocks < 1) return 0;
+    const int row_tiles = fbgrad_row_tiles(F);
+    const int wgs = (vblocks + 3) / 4, rows = (wgs + row_tiles - 1) / row_tiles;
+    if (rows * 8 > splits || splits - rows < 1) return 0;
+    *dot_wgs = wgs;
+    return splits - rows;
+}
+
 hipError_t launch_fbgrad(const FbGradParams& p_in, hipStream_t s)
 {
     FbGradParams p = p_in;
@@ -780,7 +876,9 @@ hipError_t launch_fbgrad(const FbGradParams& p_in, hipStream_t s)
     const long long all_blocks = (long long)p.B * p.ntc;
     if (all_blocks > 0x7fffffffLL || p.splits < 1) return hipErrorInvalidValue;
     p.blk_base = (int)(all_blocks / p.splits); p.blk_rem = (int)(all_blocks % p.splits);
-    const dim3 grid(fbgrad_row_tiles(p.F), p.splits, (p.M + kFbgBM - 1) / kFbgBM);
+    const int row_tiles = fbgrad_row_tiles(p.F);
+    const int dot_rows = p.dot_wgs > 0 ? (p.dot_wgs + row_tiles - 1) / row_tiles : 0;      // (the caller made sure grid.z is 1 then)
+    const dim3 grid(row_tiles, p.splits + dot_rows, (p.M + kFbgBM - 1) / kFbgBM);
     if (p.bf16x3) {
         if (p.T < 4) {
             if (p.out) hipLaunchKernelGGL((dmel_fbgrad_lds_kernel<true, true, true>), grid, dim3(kFbgThreads), 0, s, p);

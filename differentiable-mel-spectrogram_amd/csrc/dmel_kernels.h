@@ -359,7 +359,14 @@ struct FbGradParams {
     int ntc, blk_base, blk_rem;   // set by launch_fbgrad: K-blocks per clip; slice s takes blk_base (+1 for s < blk_rem) consecutive blocks
     int fold_last_row;       // set by launch_fbgrad: F = 64 k + 1, the last row rides with the last full tile of 64 rows
     int bf16x3;              // DMEL_FLAG_MFMA_BF16X3: three-term split-bf16 products on the bf16 matrix pipe instead of exact fp32 MFMA
+    // d lambd = sum(grad_out * tangent) riding in the same launch (dmel_backward_fb_saved_dl): dot_wgs extra workgroups behind the
+    // slices (blockIdx.y >= splits) run dmel_dot_kernel's arithmetic -- dot_vblocks virtual blocks of 256 threads, the same partition,
+    // the same order of additions, the same bits -- four virtual blocks each.  dot_wgs = 0: no such workgroups.
+    const float* dot_g; const float* dot_t; long long dot_count; double* dot_partials; unsigned* dot_counter; float* dot_result;
+    int dot_vblocks, dot_wgs, dot_accumulate;
 };
+int dot_blocks_for(long long count, int max_partials);      // workgroups launch_dot uses for `count` elements
+int fbgrad_fuse_dot(int F, int M, int splits, int vblocks, int* dot_wgs);   // slices left when the launch also carries d lambd (0: do not)
 hipError_t launch_fbgrad(const FbGradParams& p, hipStream_t s);
 int fbgrad_splits(int batch, int F, int M, int T);      // slices of the batch's K-blocks (= F x M partials) of one launch
 

@@ -197,14 +197,15 @@ class _DmelFbDevFunction(torch.autograd.Function):
         if not g.is_contiguous():
             g = g.contiguous()
         dl = gfb = gx = None
+        # d lambd rides in the launch of the filterbank gradient (dmel_backward_fb_saved_dl: one kernel less per step, the same bits)
+        ride = ctx.want_tangent and ctx.want_fb and spec is not None and not bf16 and g.numel() > 0
         with _on_device(g.device):
             if ctx.want_tangent:
                 tangent = saved.pop(0)
                 dl = torch.empty(tuple(ctx.lambd_shape), dtype=torch.float32, device=g.device)
-                ctx.plan.backward_scratch(g.data_ptr(), tangent.data_ptr(), g.numel(), dl.data_ptr(), _stream_ptr(g.device),
-                                          scratch.data_ptr(), grad_bf16=bf16)
-                if ctx.lambd_dtype != torch.float32:
-                    dl = dl.to(ctx.lambd_dtype)
+                if not ride:
+                    ctx.plan.backward_scratch(g.data_ptr(), tangent.data_ptr(), g.numel(), dl.data_ptr(), _stream_ptr(g.device),
+                                              scratch.data_ptr(), grad_bf16=bf16)
             if ctx.want_fb or ctx.want_x:
                 x, lam = saved.pop(0), saved.pop(0)
                 out = saved.pop(0).to(torch.float32) if ctx.log else None
@@ -227,13 +228,19 @@ class _DmelFbDevFunction(torch.autograd.Function):
             if ctx.want_fb:
                 fb_shape, fb_dtype = ctx.fb_meta
                 gfb = torch.empty(fb_shape, dtype=torch.float32, device=g.device)
-                if spec is not None:
+                if ride:
+                    ctx.plan.backward_fb_saved_dl(spec.data_ptr(), x.shape[0], ctx.n_fft, g32.data_ptr(), out.data_ptr() if ctx.log else None,
+                                                  tangent.data_ptr(), gfb.data_ptr(), dl.data_ptr(), scratch.data_ptr(), ctx.log,
+                                                  _stream_ptr(g.device), extra_flags=ctx.flags)
+                elif spec is not None:
                     ctx.plan.backward_fb_saved(spec.data_ptr(), x.shape[0], ctx.n_fft, g32.data_ptr(), out.data_ptr() if ctx.log else None,
                                                gfb.data_ptr(), ctx.log, _stream_ptr(g.device), extra_flags=ctx.flags)
                 else:
                     ctx.plan.backward_fb_dev(x.data_ptr(), x.shape[0], lam.data_ptr(), ctx.n_fft, g32.data_ptr(),
                                              out.data_ptr() if ctx.log else None, gfb.data_ptr(), ctx.log, _stream_ptr(g.device), extra_flags=ctx.flags)
                 gfb = gfb.to(fb_dtype)
+            if dl is not None and ctx.lambd_dtype != torch.float32:
+                dl = dl.to(ctx.lambd_dtype)
         return gx, dl, None, None, None, None, gfb, None, None, None, None
 
 

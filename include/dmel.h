@@ -273,6 +273,15 @@ dmel_status dmel_backward_fb_dev(dmel_plan* plan, const float* x, int32_t batch,
  * its slices only.  flags: DMEL_FLAG_LOG (then `out` = the saved log output), DMEL_FLAG_MFMA_BF16X3. */
 dmel_status dmel_backward_fb_saved(dmel_plan* plan, const float* spec, int32_t batch, int32_t n_fft, uint32_t flags,
                                    const float* grad_out, const float* out, float* grad_fb, void* stream);
+/* dmel_backward_fb_saved and dmel_backward_scratch (d lambd = sum(grad_out * tangent), fp32 grad_out, written to `dlambd`, not
+ * accumulated) in ONE launch: a few extra workgroups of the gradient's GEMM kernel play the dot kernel's blocks -- the same partition
+ * and order of additions, the same bits -- so a trainable-filterbank step (models.py:53 with learnable_fb) issues one kernel less.
+ * `scratch`: the dmel_scratch_bytes area the step's forward was given (NULL: the plan's own).  A plan whose reducer lives in the dot
+ * kernel (dmel_plan_attach_mailbox), or a launch without room for the extra workgroups, runs the two kernels one after the other:
+ * same results. */
+dmel_status dmel_backward_fb_saved_dl(dmel_plan* plan, const float* spec, int32_t batch, int32_t n_fft, uint32_t flags,
+                                      const float* grad_out, const float* out, const float* tangent, float* grad_fb, float* dlambd,
+                                      void* scratch, void* stream);
 
 /*
  * Backward to the waveform: what torch autograd returns for x.requires_grad through models.py:38 (DC removal),

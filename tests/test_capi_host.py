@@ -141,6 +141,7 @@ def test_argument_checks_of_the_round_four_entry_points_need_no_device():
     assert L.dmel_backward_x_spec_dev(null, null, 1, null, 256, 1, null, null, null) == INVALID
     assert L.dmel_forward_dev_fixed_spec(null, null, 1, null, 1024, 0, ct.c_double(1e-10), null, null, null, null, null) == INVALID
     assert L.dmel_backward_fb_saved(null, null, 1, 1024, 0, null, null, null, null) == INVALID
+    assert L.dmel_backward_fb_saved_dl(null, null, 1, 1024, 0, null, null, null, null, null, null, null) == INVALID
     assert L.dmel_mailbox_set_timeout_ms(null, ct.c_uint64(1000)) == INVALID
     assert L.dmel_mailbox_set_spin_limit(null, 10) == INVALID
     assert b"NULL" in L.dmel_last_error() or b"null" in L.dmel_last_error().lower()

@@ -198,6 +198,39 @@ def test_saved_spectrogram_and_split_bf16_filterbank_gradient(log, mfma):
         assert float(np.abs(gfb1.cpu().numpy().astype(np.float64) - ref).max()) <= 1e-4 * float(np.abs(ref).max())
 
 
+@pytest.mark.parametrize("B,L,hop,M,n", [(3, 1000, 100, 7, 64), (2, 2000, 100, 20, 128), (16, 16000, 512, 128, 1024), (256, 16000, 512, 128, 1024),
+                                         (5, 4000, 50, 130, 256)])
+@pytest.mark.parametrize("log", [False, True])
+def test_d_lambd_riding_in_the_filterbank_gradient_launch(B, L, hop, M, n, log):
+    """dmel_backward_fb_saved_dl = dmel_backward_fb_saved + dmel_backward_scratch in one launch: d lambd has the BITS of the stand-alone dot
+    kernel (same partition, same order of additions) whatever the element count (tails that are not multiples of four included) and
+    whether or not the launch has room for the extra workgroups (130 mels: two column tiles, the kernels run one after the other);
+    the filterbank gradient agrees to rounding (the slice count differs by the rows the dot takes)"""
+    from dmel_amd import capi
+    gen = torch.Generator().manual_seed(B * 1000 + M)
+    T, F = L // hop + 1, n // 2 + 1
+    plan = capi.Plan(L, hop, M, 8000, max_batch=B)
+    st = torch.cuda.current_stream().cuda_stream
+    spec = torch.rand(B, F, T, generator=gen).to(DEV)
+    g = torch.randn(B, 1, M, T, generator=gen).to(DEV)
+    tan = torch.randn(B, 1, M, T, generator=gen).to(DEV)
+    out = torch.randn(B, 1, M, T, generator=gen).to(DEV)
+    scratch = torch.zeros(plan.scratch_bytes(B), dtype=torch.uint8, device=DEV)
+    gfb_a, gfb_b = torch.empty(F, M, device=DEV), torch.empty(F, M, device=DEV)
+    dl_a, dl_b = torch.full((1,), 7.0, device=DEV), torch.full((1,), -3.0, device=DEV)
+    for flags in (0, capi.DMEL_FLAG_MFMA_BF16X3):
+        plan.backward_scratch(g.data_ptr(), tan.data_ptr(), g.numel(), dl_a.data_ptr(), st, scratch.data_ptr())
+        plan.backward_fb_saved(spec.data_ptr(), B, n, g.data_ptr(), out.data_ptr(), gfb_a.data_ptr(), log, st, extra_flags=flags)
+        for _ in range(3):                                              # the ticket counter is left at zero every time
+            plan.backward_fb_saved_dl(spec.data_ptr(), B, n, g.data_ptr(), out.data_ptr(), tan.data_ptr(), gfb_b.data_ptr(), dl_b.data_ptr(),
+                                      scratch.data_ptr(), log, st, extra_flags=flags)
+        torch.cuda.synchronize()
+        assert torch.equal(dl_a, dl_b), (float(dl_a), float(dl_b))
+        ref = float((g.double() * tan.double()).sum())
+        assert abs(float(dl_b) - ref) <= 1e-6 * float((g.double() * tan.double()).abs().sum())
+        assert float((gfb_a - gfb_b).abs().max()) <= 2e-6 * float(gfb_a.abs().max())
+
+
 @pytest.mark.parametrize("name", ["g1_c1", "g2_c2", "g5_n128", "g5_n4096", "g6_n2048_short", "g6_n64"])
 def test_dense_bank_forward_on_the_bf16_matrix_pipe(name):
     """DMEL_FLAG_MFMA_BF16X3 through a caller-supplied DENSE filterbank (what a trained matrix is): output and tangent against the exact
