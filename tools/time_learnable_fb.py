@@ -27,7 +27,7 @@ for name, lfb, native, kw in (("lambd_only", False, False, {}),
     opt = dmel_amd.LambdAdam(layer.parameters(), lr=0.0) if native else torch.optim.Adam(layer.parameters(), lr=0.0, fused=True, capturable=True)
 
     def step():
-        opt.zero_grad(set_to_none=False)
+        opt.zero_grad(set_to_none=True)
         layer(x).backward(g)
         opt.step()
     for _ in range(5): step()
