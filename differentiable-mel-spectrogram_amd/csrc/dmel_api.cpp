@@ -270,8 +270,9 @@ dmel_status build_tables(dmel_plan* pl, int N, NfftTables** out)
         }
 
         // Non-zero 4 x 16 blocks of the filterbank as MFMA B-fragments.  Mel tiles are handled in
-        // groups of 8 (128 mel bands); inside a group wave w owns tiles w and 7-w (the HTK bands
-        // widen with frequency, so pairing a narrow and a wide tile balances the four waves).
+        // groups of 8 (128 mel bands); inside a group a 4-wave plan gives wave w tiles w and 7-w (the HTK bands
+        // widen with frequency, so pairing a narrow and a wide tile balances the four waves), an 8-wave plan
+        // deals the k-steps themselves (below).
         tb.KS = (tb.F + 3) / 4;
         tb.NT = (M + 15) / 16;
         tb.groups = (tb.NT + 7) / 8;
@@ -292,32 +293,74 @@ dmel_status build_tables(dmel_plan* pl, int N, NfftTables** out)
         };
         for (int g = 0; g < tb.groups; ++g) {
             const int ntg = std::min(8, tb.NT - 8 * g);
+            // the band of a mel tile is one contiguous run of k-steps: [first, first + nks) in units of 4 k-steps (16 bins)
+            int first_of[8], units[8];
             for (int tl = 0; tl < ntg; ++tl) {
                 const int tile = 8 * g + tl;
-                // the band of a mel tile is one contiguous run of k-steps: [first, last] with a non-zero block
                 int first = tb.KS, last = -1;
                 for (int ks = 0; ks < tb.KS; ++ks)
                     for (int l = 0; l < 64; ++l) {
                         const int f = 4 * ks + (l >> 4), m = 16 * tile + (l & 15);
                         if (f < tb.F && m < M && fb[(size_t)f * M + m] != 0.f) { first = std::min(first, ks); last = std::max(last, ks); }
                     }
-                if (last < first) {     // an all-zero tile still needs its outputs written
-                    if (waves == 8) ranges[(size_t)(g * 8 + tl) * 2] = make_int4(0, 0, 0, tile);
-                    else ranges[(size_t)(g * 4 + (tl < 4 ? tl : 7 - tl)) * 2 + (tl < 4 ? 0 : 1)] = make_int4(0, 0, 0, tile);
-                    continue;
-                }
+                if (last < first) { first_of[tl] = 0; units[tl] = 0; continue; }      // an all-zero tile still needs its outputs written
                 tb.n_entries += last - first + 1;
                 first = first / 4 * 4;                       // groups of 4 k-steps start at multiples of 16 bins
-                const int nks = (last - first + 1 + 3) / 4 * 4;
-                if (waves == 8) {
-                    // owner wave tl takes the first half, wave 7-tl the second (its partial goes through LDS)
-                    const int h = (nks / 4 + 1) / 2 * 4;
-                    ranges[(size_t)(g * 8 + tl) * 2 + 0] = emit(tile, first, first + h);
-                    if (nks > h) ranges[(size_t)(g * 8 + (7 - tl)) * 2 + 1] = emit(tile, first + h, first + nks);
-                } else {
-                    // 4 waves: wave w owns tiles w and 7-w whole
+                first_of[tl] = first; units[tl] = (last - first + 1 + 3) / 4;
+            }
+            if (waves == 8) {
+                // Wave tl owns tile tl (run 0: it writes the tile's outputs).  The HTK bands widen with frequency -- at 128 mels the last
+                // tile has five times the k-steps of the first, at 64 mels four tiles meet eight waves -- so the k-steps of the wide
+                // tiles beyond a common limit L are dealt, in contiguous pieces, to the run 1 of waves with narrow or no tiles of their
+                // own (one piece per wave; their sums reach the owner through LDS, dmel_fwd_kernel's exchange).  L = the smallest
+                // limit for which largest-remainder-first onto largest-spare-first fits.  (Round 3 split every tile in two halves,
+                // wave tl and 7 - tl: the slowest wave carried 24 k-steps at BASELINE config 2 where 19.5 is the mean, 56 / 36.5 at
+                // config 5, 120 / 68 at the reference's ESC-50 shape at n_fft 4096.)
+                int total = 0, umax = 0;
+                for (int tl = 0; tl < ntg; ++tl) { total += units[tl]; umax = std::max(umax, units[tl]); }
+                struct Piece { int wave, tile, a, n; };
+                std::vector<Piece> pieces;
+                int own[8];
+                for (int L = std::max(1, (total + 7) / 8); ; ++L) {
+                    pieces.clear();
+                    int spare[8], rem[8];
+                    bool used[8] = {false, false, false, false, false, false, false, false};
+                    for (int w = 0; w < 8; ++w) {
+                        own[w] = w < ntg ? std::min(units[w], L) : 0;
+                        rem[w] = w < ntg ? units[w] - own[w] : 0;
+                        spare[w] = L - own[w];
+                    }
+                    bool ok = true;
+                    for (;;) {
+                        int t = -1;
+                        for (int tl = 0; tl < ntg; ++tl) if (rem[tl] > 0 && (t < 0 || rem[tl] > rem[t])) t = tl;
+                        if (t < 0) break;
+                        int h = -1;
+                        for (int w = 0; w < 8; ++w) if (!used[w] && w != t && spare[w] > 0 && (h < 0 || spare[w] > spare[h])) h = w;
+                        if (h < 0) { ok = false; break; }
+                        const int n = std::min(spare[h], rem[t]);
+                        pieces.push_back({h, t, units[t] - rem[t], n});
+                        used[h] = true; rem[t] -= n;
+                    }
+                    if (ok || L >= umax) {
+                        if (!ok) { pieces.clear(); for (int w = 0; w < ntg; ++w) own[w] = units[w]; }
+                        break;
+                    }
+                }
+                int mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (const Piece& pc : pieces) mask[pc.tile] |= 1 << pc.wave;
+                for (int tl = 0; tl < ntg; ++tl) {
+                    int4 tr = units[tl] > 0 ? emit(8 * g + tl, first_of[tl], first_of[tl] + 4 * own[tl]) : make_int4(0, 0, 0, 8 * g + tl);
+                    tr.w |= mask[tl] << 16;
+                    ranges[(size_t)(g * 8 + tl) * 2 + 0] = tr;
+                }
+                for (const Piece& pc : pieces)
+                    ranges[(size_t)(g * 8 + pc.wave) * 2 + 1] = emit(8 * g + pc.tile, first_of[pc.tile] + 4 * pc.a, first_of[pc.tile] + 4 * (pc.a + pc.n));
+            } else {
+                // 4 waves: wave w owns tiles w and 7-w whole
+                for (int tl = 0; tl < ntg; ++tl) {
                     const int w = tl < 4 ? tl : 7 - tl, loc = tl < 4 ? 0 : 1;
-                    ranges[(size_t)(g * 4 + w) * 2 + loc] = emit(tile, first, first + nks);
+                    ranges[(size_t)(g * 4 + w) * 2 + loc] = units[tl] > 0 ? emit(8 * g + tl, first_of[tl], first_of[tl] + 4 * units[tl]) : make_int4(0, 0, 0, 8 * g + tl);
                 }
             }
         }

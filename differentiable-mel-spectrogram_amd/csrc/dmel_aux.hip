@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(256) dmel_repack_kernel(RepackParams p)
     if (tr.y <= 0 || tr.w < 0) return;
     for (int i = part * 256 + tid; i < tr.y * 64; i += 256 * kRepackRunSplit) {
         const int ks = tr.x + i / 64, l = i % 64;
-        const int f = 4 * ks + (l >> 4), m = 16 * tr.w + (l & 15);
+        const int f = 4 * ks + (l >> 4), m = 16 * (tr.w & 0xffff) + (l & 15);        // (bits 16-23: the helper mask of dmel_fwd_kernel)
         const float v = (f < p.F && m < p.M) ? p.fb[(size_t)f * p.M + m] : 0.f;
         p.ent_b[tr.z + i] = v;
         if (run < p.runs_group0 && i / 64 < p.nbpre) p.ent_pre[((size_t)run * p.nbpre + i / 64) * 64 + l] = v;

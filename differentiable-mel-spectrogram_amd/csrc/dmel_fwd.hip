@@ -18,7 +18,8 @@
 //   phase 2 (MFMA): the mel contraction of models.py:53.  A operands are plain reads of PD,
 //            B fragments are the non-zero 4x16 blocks of the filterbank (prefetched into registers
 //            before phase 1), v_mfma_f32_16x16x4_f32 accumulates exact fp32.  With 4 waves each wave
-//            owns two mel tiles; with 8 waves each owns two half tiles and the halves meet through LDS.
+//            owns two mel tiles; with 8 waves each owns one tile and the k-steps of the wide tiles are dealt
+//            over the waves with narrow (or no) tiles: their sums reach the owner through LDS.
 //   epilogue: scale, log(mel + eps) (models.py:73), tangent d out / d lambd, straight from the
 //            accumulators into the (B,1,M,T) layout of models.py:36.
 //
@@ -1078,6 +1079,7 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
                 static_for<0, NLOC>([&](auto l) { static_for<0, MT>([&](auto m) { static_for<0, 2>([&](auto e) {
                     acc[decltype(l)::value][decltype(m)::value][decltype(e)::value] = floatx4{0.f, 0.f, 0.f, 0.f}; }); }); });
                 int tile_of[NLOC];
+                int helpers = 0;         // 8 waves: bit w set = wave w's run 1 is a piece of THIS wave's tile (bits 16-23 of run 0's tile word)
                 static_for<0, NLOC>([&](auto l) {
                     constexpr int loc = decltype(l)::value;
                     // (ks0, nks, boff, tile): the filterbank is banded, so the non-zero 4x16 blocks of one mel tile
@@ -1086,7 +1088,11 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
                     if (grp > 0) tr = p.tile_ranges[(grp * WAVES + wave) * NLOC + loc];
                     const int ks0 = __builtin_amdgcn_readfirstlane(tr.x), nks = __builtin_amdgcn_readfirstlane(tr.y);
                     const int boff = __builtin_amdgcn_readfirstlane(tr.z);
-                    tile_of[loc] = __builtin_amdgcn_readfirstlane(tr.w);
+                    {
+                        const int tw = __builtin_amdgcn_readfirstlane(tr.w);
+                        tile_of[loc] = tw < 0 ? -1 : (tw & 0xffff);
+                        if constexpr (loc == 0) helpers = tw < 0 ? 0 : ((tw >> 16) & 0xff);
+                    }
 #ifdef DMEL_ABLATE
                     if (p.flags & 0x800u) return;                       // timing ablation: skip the MFMA loop
 #endif
@@ -1180,16 +1186,21 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
                 static_for<0, NLOC>([&](auto l) { static_for<0, MT>([&](auto m) {
                     tot[decltype(l)::value][decltype(m)::value] = acc[decltype(l)::value][decltype(m)::value][0] + acc[decltype(l)::value][decltype(m)::value][1]; }); });
                 if constexpr (WAVES == 8) {
-                    // run 1 of this wave is the second half of tile 7-wave: hand it to its owner through LDS
+                    // run 1 of a wave is a piece of some OTHER wave's tile (the host deals the k-steps of the wide tiles over the
+                    // waves with narrow or no tiles of their own: build_tables): every wave leaves its run-1 sums in its own slot
+                    // and an owner adds the slots of its helpers in ascending order (fixed order: deterministic)
                     // (one 16-row tile at a time through the same 8 KB: two tiles at once would put the 16-frame workgroup of
                     // n_fft 1024 past half of the CU's LDS)
                     floatx4* xch = reinterpret_cast<floatx4*>(smem_raw + SLOTS * SS * 8);
                     static_for<0, MT>([&](auto mm) {
                         constexpr int mt = decltype(mm)::value;
                         if constexpr (mt > 0) __syncthreads();
-                        xch[(7 - wave) * 64 + lane] = tot[1][mt];
+                        xch[wave * 64 + lane] = tot[1][mt];
                         __syncthreads();
-                        tot[0][mt] += xch[wave * 64 + lane];
+                        static_for<0, 8>([&](auto ss) {
+                            constexpr int sw = decltype(ss)::value;
+                            if (helpers & (1 << sw)) tot[0][mt] += xch[sw * 64 + lane];
+                        });
                     });
                     if (p.groups > 1) __syncthreads();
                     tile_of[1] = -1;

@@ -234,7 +234,8 @@ struct FwdParams {
     const float2* tw1;         // (R, G): w_N^(lg*q)      (of the plan of this launch's mode)
     const float2* tw2;         // (R, C): w_G^(r*p1)
     const float* ent_b;        // 64 floats per 4x16 block, blocks of one mel tile contiguous in k
-    const int4* tile_ranges;   // (groups, WAVES, 2): {first k-step, #k-steps (multiple of 4), offset into ent_b, mel tile or -1}
+    const int4* tile_ranges;   // (groups, WAVES, 2): {first k-step, #k-steps (multiple of 4), offset into ent_b, mel tile or -1}; run 0 of an
+                               // 8-wave plan: bits 16-23 of the tile word = the waves whose run 1 is a piece of this tile
     int ent_b_floats;          // size of ent_b (buffer bounds)
     const float* ent_pre;      // (WAVES, 2, NBPRE, 64): the first NBPRE k-steps of every run of mel group 0, zero padded
     int pre_groups[16];        // per (wave, run): how many groups of 4 k-steps of ent_pre are real (the rest is padding nobody reads)
