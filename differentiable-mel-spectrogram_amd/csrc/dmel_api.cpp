@@ -66,6 +66,7 @@ struct NfftTables {
     float* ent_b = nullptr;
     float* ent_pre = nullptr;
     int pre_groups[16] = {};     // per (wave, run) of group 0: real groups of 4 k-steps inside ent_pre
+    unsigned xch_groups = 0;     // FwdParams::xch_groups
     int ent_b_floats = 0;
     int4* tile_ranges = nullptr;
     float* fb_dense = nullptr;   // (F, M) for the direct-DFT kernel
@@ -308,7 +309,9 @@ dmel_status build_tables(dmel_plan* pl, int N, NfftTables** out)
                 first = first / 4 * 4;                       // groups of 4 k-steps start at multiples of 16 bins
                 first_of[tl] = first; units[tl] = (last - first + 1 + 3) / 4;
             }
-            if (waves == 8) {
+            if (waves == 8 || ntg <= waves) {
+                // (4-wave plans, n_fft <= 512: only when every tile has a wave of its own -- up to 64 mels, the reference's experiments --
+                // since run 1 is then free to carry a piece; with more tiles wave w owns tiles w and 7 - w whole, as before)
                 // Wave tl owns tile tl (run 0: it writes the tile's outputs).  The HTK bands widen with frequency -- at 128 mels the last
                 // tile has five times the k-steps of the first, at 64 mels four tiles meet eight waves -- so the k-steps of the wide
                 // tiles beyond a common limit L are dealt, in contiguous pieces, to the run 1 of waves with narrow or no tiles of their
@@ -321,11 +324,13 @@ dmel_status build_tables(dmel_plan* pl, int N, NfftTables** out)
                 struct Piece { int wave, tile, a, n; };
                 std::vector<Piece> pieces;
                 int own[8];
-                for (int L = std::max(1, (total + 7) / 8); ; ++L) {
+                const int W = waves;
+                for (int L = std::max(1, (total + W - 1) / W); ; ++L) {
                     pieces.clear();
                     int spare[8], rem[8];
                     bool used[8] = {false, false, false, false, false, false, false, false};
                     for (int w = 0; w < 8; ++w) {
+                        if (w >= W) { own[w] = 0; rem[w] = 0; spare[w] = 0; used[w] = true; continue; }
                         own[w] = w < ntg ? std::min(units[w], L) : 0;
                         rem[w] = w < ntg ? units[w] - own[w] : 0;
                         spare[w] = L - own[w];
@@ -352,10 +357,14 @@ dmel_status build_tables(dmel_plan* pl, int N, NfftTables** out)
                 for (int tl = 0; tl < ntg; ++tl) {
                     int4 tr = units[tl] > 0 ? emit(8 * g + tl, first_of[tl], first_of[tl] + 4 * own[tl]) : make_int4(0, 0, 0, 8 * g + tl);
                     tr.w |= mask[tl] << 16;
-                    ranges[(size_t)(g * 8 + tl) * 2 + 0] = tr;
+                    ranges[(size_t)(g * W + tl) * 2 + 0] = tr;
                 }
-                for (const Piece& pc : pieces)
-                    ranges[(size_t)(g * 8 + pc.wave) * 2 + 1] = emit(8 * g + pc.tile, first_of[pc.tile] + 4 * pc.a, first_of[pc.tile] + 4 * (pc.a + pc.n));
+                for (const Piece& pc : pieces) {
+                    int4 tr = emit(8 * g + pc.tile, first_of[pc.tile] + 4 * pc.a, first_of[pc.tile] + 4 * (pc.a + pc.n));
+                    tr.w |= 1 << 30;                                   // a piece: summed into its owner's tile, not written by this wave
+                    ranges[(size_t)(g * W + pc.wave) * 2 + 1] = tr;
+                }
+                if (W != 8 && !pieces.empty() && g < 32) tb.xch_groups |= 1u << g;
             } else {
                 // 4 waves: wave w owns tiles w and 7-w whole
                 for (int tl = 0; tl < ntg; ++tl) {
@@ -696,7 +705,7 @@ dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dm
     fp.tw1 = dmel::mode_pairs(mode) ? tb->tw1p : tb->tw1; fp.tw2 = dmel::mode_pairs(mode) ? tb->tw2p : tb->tw2; fp.ent_b = tb->ent_b; fp.tile_ranges = tb->tile_ranges; fp.ent_b_floats = tb->ent_b_floats; fp.ent_pre = tb->ent_pre;
     for (int i = 0; i < 16; ++i) fp.pre_groups[i] = tb->pre_groups[i];
     fp.B = batch; fp.L = pl->cfg.n_points; fp.T = pl->T; fp.hop = pl->cfg.hop_length; fp.M = pl->cfg.n_mels;
-    fp.nchunks = pl->nchunks; fp.groups = tb->groups;
+    fp.nchunks = pl->nchunks; fp.groups = tb->groups; fp.xch_groups = tb->xch_groups;
     const int fpt = dmel::forward_frames_per_tile(N, mode);
     fp.tiles_per_clip = (pl->T + fpt - 1) / fpt;
     fp.inv_L = inv_L; fp.eps = (float)eps; fp.flags = flags; fp.lam = lam;

@@ -187,7 +187,7 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
     constexpr bool TW2_LDS = (C > 1) && (N <= 2048);
     float2* tw2l = reinterpret_cast<float2*>(smem_raw + g.RED_OFF + kRedBytes);
     // the half-tile exchange of phase 2 (8 waves) lives where the window table does: a second tile needs the table back
-    constexpr bool WIN_ALIASED = WIN_LDS && WAVES == 8;
+    constexpr bool WIN_ALIASED = WIN_LDS;
     // compact layouts (dmel_kernels.h): pairing pass through ds_bpermute, transposition one plane at a time, half window table
     constexpr bool BPERM = g.PAIRING == kPairBperm, PLANE = g.PAIRING == kPairPlane, SPLIT = g.SPLIT != 0, WIN_SYM = g.WIN_SYM != 0;
     constexpr bool KEEPZ = BPERM || PLANE;                      // the spectrum stays in registers until the pairing pass
@@ -1079,7 +1079,8 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
                 static_for<0, NLOC>([&](auto l) { static_for<0, MT>([&](auto m) { static_for<0, 2>([&](auto e) {
                     acc[decltype(l)::value][decltype(m)::value][decltype(e)::value] = floatx4{0.f, 0.f, 0.f, 0.f}; }); }); });
                 int tile_of[NLOC];
-                int helpers = 0;         // 8 waves: bit w set = wave w's run 1 is a piece of THIS wave's tile (bits 16-23 of run 0's tile word)
+                int helpers = 0;         // bit w set = wave w's run 1 is a piece of THIS wave's tile (bits 16-23 of run 0's tile word)
+                bool piece1 = (WAVES == 8);   // run 1 is a piece of another wave's tile (always with 8 waves; bit 30 of its tile word with 4)
                 static_for<0, NLOC>([&](auto l) {
                     constexpr int loc = decltype(l)::value;
                     // (ks0, nks, boff, tile): the filterbank is banded, so the non-zero 4x16 blocks of one mel tile
@@ -1092,6 +1093,7 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
                         const int tw = __builtin_amdgcn_readfirstlane(tr.w);
                         tile_of[loc] = tw < 0 ? -1 : (tw & 0xffff);
                         if constexpr (loc == 0) helpers = tw < 0 ? 0 : ((tw >> 16) & 0xff);
+                        if constexpr (loc == 1 && WAVES != 8) piece1 = tw >= 0 && ((tw >> 30) & 1) != 0;
                     }
 #ifdef DMEL_ABLATE
                     if (p.flags & 0x800u) return;                       // timing ablation: skip the MFMA loop
@@ -1185,7 +1187,7 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
                 floatx4 tot[NLOC][MT];
                 static_for<0, NLOC>([&](auto l) { static_for<0, MT>([&](auto m) {
                     tot[decltype(l)::value][decltype(m)::value] = acc[decltype(l)::value][decltype(m)::value][0] + acc[decltype(l)::value][decltype(m)::value][1]; }); });
-                if constexpr (WAVES == 8) {
+                if (WAVES == 8 || ((p.xch_groups >> (grp & 31)) & 1u)) {
                     // run 1 of a wave is a piece of some OTHER wave's tile (the host deals the k-steps of the wide tiles over the
                     // waves with narrow or no tiles of their own: build_tables): every wave leaves its run-1 sums in its own slot
                     // and an owner adds the slots of its helpers in ascending order (fixed order: deterministic)
@@ -1195,15 +1197,15 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
                     static_for<0, MT>([&](auto mm) {
                         constexpr int mt = decltype(mm)::value;
                         if constexpr (mt > 0) __syncthreads();
-                        xch[wave * 64 + lane] = tot[1][mt];
+                        xch[wave * 64 + lane] = piece1 ? tot[1][mt] : floatx4{0.f, 0.f, 0.f, 0.f};
                         __syncthreads();
-                        static_for<0, 8>([&](auto ss) {
+                        static_for<0, WAVES>([&](auto ss) {
                             constexpr int sw = decltype(ss)::value;
                             if (helpers & (1 << sw)) tot[0][mt] += xch[sw * 64 + lane];
                         });
                     });
                     if (p.groups > 1) __syncthreads();
-                    tile_of[1] = -1;
+                    if (piece1) tile_of[1] = -1;
                 }
                 STAMP(16 * ti + 10);  // half-tile exchange
 #ifdef DMEL_ABLATE

@@ -212,7 +212,7 @@ template <int N, bool PAIR = false> constexpr FftGeom geom()
     // the window table lives in LDS up to n_fft 4096 (half table there: 16 KB next to 8 x 16.6 KB of frames); beyond, in global
     // memory, written by dmel_prep_kernel
     g.WIN_LDS = (N <= kWinLdsMaxNfft) ? 1 : 0;
-    const int xch = (g.WAVES == 8) ? 8 * 64 * 16 : 0;     // the half-tile exchange passes one 16-row tile at a time
+    const int xch = g.WAVES * 64 * 16;                    // the exchange of run-1 sums passes one 16-row tile at a time
     // the Gaussian window is symmetric about N/2: the compact layout keeps entries 0..N/2 only
     g.WIN_SYM = (g.WIN_LDS && P::SPLIT) ? 1 : 0;
     const int win = g.WIN_LDS ? (g.WIN_SYM ? (N / 2 + 1) * 8 : N * 8) : 0;
@@ -246,6 +246,7 @@ struct FwdParams {
     int remove_dc, normalize;
     int win_half;               // window support = middle half of n_fft (DSPEC: win_length = n_fft / 2)
     int wgs_per_clip;           // ceil(tiles_per_clip / tiles per workgroup)
+    unsigned xch_groups;        // 4-wave plans: bit g = mel group g has run-1 pieces that go through the exchange (8-wave plans: always)
     const uint4* ent_h;         // kTrainH: the filterbank as B fragments of v_mfma_f32_16x16x32_bf16, [(tile * (N/64) + kstep) * 2 + (hi | lo)][lane]:
                                 // lane l holds fb[32 kstep + 8 (l >> 4) + e][16 tile + (l & 15)], e = 0 .. 7, as bf16 (hi) / the bf16 of the rest (lo)
     const float* fb_nyq;        // kTrainH: (n_mels) fp32, the row of bin N/2 (added on the vector pipe: N/2 bins = N/64 steps of 32 exactly)
