@@ -335,6 +335,10 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
         // and a privileged wave only delays them.  (Measured and not kept, config 2: priority by wave index, one workgroup of
         // each CU first through the transforms, the contraction phase first: 20.1 against 20.1.)
         if ((p.flags & kFwdEdgeFirst) && !inside[0][0]) __builtin_amdgcn_s_setprio(2);
+        // long clips: the partial sums of dmel_prep_kernel are requested here, next to the samples -- asked for where they are used
+        // (behind the window table's barrier) every workgroup waited a global round trip for 64 floats
+        float ps_early = 0.f;
+        if (p.remove_dc && p.psum != nullptr) ps_early = (lane < p.nchunks) ? p.psum[(size_t)b * p.nchunks + lane] : 0.f;
         STAMP(1);   // loads issued
         // lambd (device scalar or by value) and the check that this launch is the n_fft the device value asks for
         const LamState ls = lam_prologue(p.lam, N, blockIdx.x == 0 && tid == 0);
@@ -526,8 +530,7 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
             if (p.remove_dc) {
                 // long clips: the <= 64 partial sums of the prep kernel, one per lane, one round trip, added
                 // in a fixed butterfly order (deterministic)
-                float ps = (lane < p.nchunks) ? p.psum[(size_t)b * p.nchunks + lane] : 0.f;
-                mean = wave_sum(ps) * p.inv_L;
+                mean = wave_sum(ps_early) * p.inv_L;
             }
         }
         STAMP(2);   // window table + clip mean done
