@@ -30,7 +30,7 @@ MAX_NFFT = 16384          # largest transform of the HIP kernels (kMaxNfft in cs
 
 # every symbol include/dmel.h declares (tests check the library exports exactly these)
 SYMBOLS = (
-    "dmel_abi_version", "dmel_n_fft", "dmel_window_host", "dmel_mel_fbanks_host", "dmel_last_error",
+    "dmel_abi_version", "dmel_n_fft", "dmel_window_host", "dmel_mel_fbanks_host", "dmel_contraction_partition_host", "dmel_last_error",
     "dmel_device_count", "dmel_plan_create", "dmel_plan_destroy", "dmel_plan_set_filterbank",
     "dmel_forward", "dmel_backward", "dmel_backward_ex", "dmel_backward_fb", "dmel_backward_x", "dmel_spectrogram", "dmel_plan_get_info",
     "dmel_plan_set_profiling", "dmel_plan_get_profile", "dmel_spectrogram_ex",
@@ -275,6 +275,19 @@ def window_host(lambd: float, n: int, normalize: bool = False):
     _check(load().dmel_window_host(float(lambd), n, int(normalize), w.ctypes.data_as(C.POINTER(C.c_float)),
                                    dw.ctypes.data_as(C.POINTER(C.c_float))))
     return w, dw
+
+
+def contraction_partition(units, waves: int = 8):
+    """dmel_contraction_partition_host: (own[waves], [(wave, tile, first, units), ...]) for one group of mel tiles"""
+    L = load()
+    i32 = C.c_int32
+    n = len(units)
+    u = (i32 * 8)(*([int(v) for v in units] + [0] * (8 - n)))
+    own, npc = (i32 * 8)(), i32(0)
+    pw, pt, pf, pu = (i32 * 8)(), (i32 * 8)(), (i32 * 8)(), (i32 * 8)()
+    L.dmel_contraction_partition_host.restype = C.c_int
+    _check(L.dmel_contraction_partition_host(u, n, int(waves), own, C.byref(npc), pw, pt, pf, pu))
+    return list(own)[:waves], [(pw[i], pt[i], pf[i], pu[i]) for i in range(npc.value)]
 
 
 def mel_fbanks_host(n_freqs: int, f_min: float, f_max: float, n_mels: int, sample_rate: int):

@@ -168,6 +168,46 @@ void prof_span(dmel_plan* pl, size_t a, size_t b, int kind)
     if (a != (size_t)-1 && b != (size_t)-1) pl->spans.push_back({a, b, kind});
 }
 
+// The contraction phase of an 8-wave plan (and of a 4-wave plan with up to four mel tiles per group): wave tl owns tile tl; the
+// units (4 k-steps = 16 bins) of a tile beyond a common limit L go, in contiguous pieces, to the run 1 of other waves (one piece per
+// wave).  L = the smallest limit for which "largest remainder first onto largest spare first" fits.  own[w]: units wave w takes of its
+// own tile; pieces: (helper wave, tile, first unit, units).  Pure host arithmetic (dmel_contraction_partition_host exposes it to tests).
+struct Piece { int wave, tile, a, n; };
+void deal_ksteps(const int* units, int ntg, int W, int* own, std::vector<Piece>* pieces)
+{
+    int total = 0, umax = 0;
+    for (int tl = 0; tl < ntg; ++tl) { total += units[tl]; umax = std::max(umax, units[tl]); }
+    for (int L = std::max(1, (total + W - 1) / W); ; ++L) {
+        pieces->clear();
+        int spare[8], rem[8];
+        bool used[8] = {false, false, false, false, false, false, false, false};
+        for (int w = 0; w < 8; ++w) {
+            if (w >= W) { own[w] = 0; rem[w] = 0; spare[w] = 0; used[w] = true; continue; }
+            own[w] = w < ntg ? std::min(units[w], L) : 0;
+            rem[w] = w < ntg ? units[w] - own[w] : 0;
+            spare[w] = L - own[w];
+        }
+        bool ok = true;
+        for (;;) {
+            int t = -1;
+            for (int tl = 0; tl < ntg; ++tl) if (rem[tl] > 0 && (t < 0 || rem[tl] > rem[t])) t = tl;
+            if (t < 0) break;
+            int h = -1;
+            for (int w = 0; w < 8; ++w) if (!used[w] && w != t && spare[w] > 0 && (h < 0 || spare[w] > spare[h])) h = w;
+            if (h < 0) { ok = false; break; }
+            const int n = std::min(spare[h], rem[t]);
+            pieces->push_back({h, t, units[t] - rem[t], n});
+            used[h] = true; rem[t] -= n;
+        }
+        if (ok) return;
+        if (L >= umax) {                      // (not reached: at L = umax nothing is left over)
+            pieces->clear();
+            for (int w = 0; w < 8; ++w) own[w] = w < ntg ? units[w] : 0;
+            return;
+        }
+    }
+}
+
 dmel_status build_tables(dmel_plan* pl, int N, NfftTables** out)
 {
     auto it = pl->tables.find(N);
@@ -319,39 +359,10 @@ dmel_status build_tables(dmel_plan* pl, int N, NfftTables** out)
                 // limit for which largest-remainder-first onto largest-spare-first fits.  (Round 3 split every tile in two halves,
                 // wave tl and 7 - tl: the slowest wave carried 24 k-steps at BASELINE config 2 where 19.5 is the mean, 56 / 36.5 at
                 // config 5, 120 / 68 at the reference's ESC-50 shape at n_fft 4096.)
-                int total = 0, umax = 0;
-                for (int tl = 0; tl < ntg; ++tl) { total += units[tl]; umax = std::max(umax, units[tl]); }
-                struct Piece { int wave, tile, a, n; };
-                std::vector<Piece> pieces;
-                int own[8];
                 const int W = waves;
-                for (int L = std::max(1, (total + W - 1) / W); ; ++L) {
-                    pieces.clear();
-                    int spare[8], rem[8];
-                    bool used[8] = {false, false, false, false, false, false, false, false};
-                    for (int w = 0; w < 8; ++w) {
-                        if (w >= W) { own[w] = 0; rem[w] = 0; spare[w] = 0; used[w] = true; continue; }
-                        own[w] = w < ntg ? std::min(units[w], L) : 0;
-                        rem[w] = w < ntg ? units[w] - own[w] : 0;
-                        spare[w] = L - own[w];
-                    }
-                    bool ok = true;
-                    for (;;) {
-                        int t = -1;
-                        for (int tl = 0; tl < ntg; ++tl) if (rem[tl] > 0 && (t < 0 || rem[tl] > rem[t])) t = tl;
-                        if (t < 0) break;
-                        int h = -1;
-                        for (int w = 0; w < 8; ++w) if (!used[w] && w != t && spare[w] > 0 && (h < 0 || spare[w] > spare[h])) h = w;
-                        if (h < 0) { ok = false; break; }
-                        const int n = std::min(spare[h], rem[t]);
-                        pieces.push_back({h, t, units[t] - rem[t], n});
-                        used[h] = true; rem[t] -= n;
-                    }
-                    if (ok || L >= umax) {
-                        if (!ok) { pieces.clear(); for (int w = 0; w < ntg; ++w) own[w] = units[w]; }
-                        break;
-                    }
-                }
+                int own[8];
+                std::vector<Piece> pieces;
+                deal_ksteps(units, ntg, W, own, &pieces);
                 int mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                 for (const Piece& pc : pieces) mask[pc.tile] |= 1 << pc.wave;
                 for (int tl = 0; tl < ntg; ++tl) {
@@ -919,6 +930,24 @@ dmel_status dmel_window_host(float lambd, int32_t n_fft, int32_t normalize, floa
         }
     }
     if (dwindow) for (int n = 0; n < n_fft; ++n) dwindow[n] = (float)dw[n];
+    return DMEL_OK;
+}
+
+dmel_status dmel_contraction_partition_host(const int32_t* units, int32_t n_tiles, int32_t waves, int32_t* own, int32_t* n_pieces,
+                                            int32_t* piece_wave, int32_t* piece_tile, int32_t* piece_first, int32_t* piece_units)
+{
+    if (!units || !own || !n_pieces || !piece_wave || !piece_tile || !piece_first || !piece_units || (waves != 4 && waves != 8) ||
+        n_tiles < 0 || n_tiles > waves)
+        return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_contraction_partition_host: bad arguments");
+    int u[8] = {0, 0, 0, 0, 0, 0, 0, 0}, o[8];
+    for (int t = 0; t < n_tiles; ++t) { if (units[t] < 0) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_contraction_partition_host: negative extent"); u[t] = units[t]; }
+    std::vector<Piece> pieces;
+    deal_ksteps(u, n_tiles, waves, o, &pieces);
+    for (int w = 0; w < 8; ++w) own[w] = o[w];
+    *n_pieces = (int32_t)pieces.size();
+    for (size_t i = 0; i < pieces.size() && i < 8; ++i) {
+        piece_wave[i] = pieces[i].wave; piece_tile[i] = pieces[i].tile; piece_first[i] = pieces[i].a; piece_units[i] = pieces[i].n;
+    }
     return DMEL_OK;
 }
 

@@ -93,6 +93,13 @@ dmel_status dmel_window_host(float lambd, int32_t n_fft, int32_t normalize, floa
 dmel_status dmel_mel_fbanks_host(int32_t n_freqs, double f_min, double f_max, int32_t n_mels,
                                  int32_t sample_rate, float* fb);
 
+/* How the fused forward deals the contraction of models.py:53 over the waves of a workgroup (host arithmetic, for tests and tools):
+ * `units[t]` = the non-zero extent of mel tile t (16 mels) of one group of `n_tiles` <= `waves` tiles, in units of 16 bins; wave t owns
+ * tile t and takes own[t] units from its start, the rest goes in contiguous pieces to other waves -- at most one piece per wave --:
+ * piece i = (piece_wave[i], piece_tile[i], piece_first[i], piece_units[i]).  `waves` is 8 or 4; arrays of 8 entries each. */
+dmel_status dmel_contraction_partition_host(const int32_t* units, int32_t n_tiles, int32_t waves, int32_t* own, int32_t* n_pieces,
+                                            int32_t* piece_wave, int32_t* piece_tile, int32_t* piece_first, int32_t* piece_units);
+
 const char* dmel_last_error(void);
 
 /* ---- device path --------------------------------------------------------------------------- */

@@ -151,3 +151,45 @@ def test_argument_checks_of_the_round_four_entry_points_need_no_device():
                             ct.c_double(0.0), 0, None) == INVALID
     assert L.dmel_adam_step(one, one, one, one, one, None, 1, ct.c_double(1e-3), ct.c_double(0.9), ct.c_double(0.999), ct.c_double(1e-8),
                             ct.c_double(-0.1), 0, None) == INVALID
+
+
+def test_contraction_partition_covers_every_tile_once_and_balances():
+    """dmel_contraction_partition_host (what build_tables uses for the 8-wave plans and for 4-wave plans with up to four tiles): every
+    unit of every tile is taken exactly once, pieces are contiguous behind the owner's share, a wave carries at most one piece and
+    never one of its own tile, and the slowest wave is no slower than with round 3's split in halves (wave t and 7 - t)"""
+    import random
+    from dmel_amd import capi
+    rng = random.Random(5)
+    cases = [([2, 2, 3, 4, 4, 6, 8, 10], 8), ([15, 24, 38, 59], 8), ([2, 2, 4, 5, 8, 11, 16, 25], 8), ([2, 4, 5, 8], 4), ([33] * 8, 8), ([33] * 4, 8),
+             ([0, 0, 7], 8), ([1], 8), ([], 8), ([5], 4), ([40, 1, 1, 1], 4)]
+    for _ in range(300):
+        w = rng.choice([4, 8])
+        n = rng.randint(0, w)
+        cases.append(([rng.choice([0, 1, 2, 3, 5, 8, 13, 40, 100]) if rng.random() < 0.5 else rng.randint(0, 60) for _ in range(n)], w))
+    for units, waves in cases:
+        own, pieces = capi.contraction_partition(units, waves)
+        load = [own[w] for w in range(waves)]
+        taken = [own[t] if t < len(units) else 0 for t in range(waves)]
+        helpers = set()
+        nxt = {t: own[t] for t in range(len(units))}
+        for (w, t, a, n) in pieces:
+            assert 0 <= w < waves and 0 <= t < len(units) and w != t and n > 0, (units, waves, pieces)
+            assert w not in helpers, (units, pieces)                       # one piece per wave
+            helpers.add(w)
+            assert a == nxt[t], (units, pieces)                           # contiguous, in order
+            nxt[t] += n
+            taken[t] += n
+            load[w] += n
+        for t, u in enumerate(units):
+            assert taken[t] == u and 0 <= own[t] <= u and (own[t] > 0 or u == 0), (units, waves, own, pieces)
+        assert all(own[w] == 0 for w in range(len(units), waves))
+        total = sum(units)
+        if total:
+            assert max(load) <= max(units), (units, load)
+            if waves == 8:
+                old = [0] * 8
+                for t, u in enumerate(units):
+                    h = (u + 1) // 2
+                    old[t] += h
+                    old[7 - t] += u - h
+                assert max(load) <= max(old), (units, load, old)
