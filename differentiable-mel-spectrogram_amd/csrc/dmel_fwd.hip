@@ -325,6 +325,7 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
     float mean = 0.f;
     float2 wkeep[WPT];                                          // this thread's window entries (TPW > 1: written back per tile)
     float2 wmid = make_float2(1.f, 0.f);                        // ... and the centre entry
+    const float lam_raw = lam_load(p.lam);                       // a scalar load: see lam_load
     if (!dbg_skip_fft) {
         load_tile(IC<0>{});
         // The waves that hold a clip's first / last frames take the slow path (clamped loads, selects at windowing time) and every
@@ -341,7 +342,7 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
         if (p.remove_dc && p.psum != nullptr) ps_early = (lane < p.nchunks) ? p.psum[(size_t)b * p.nchunks + lane] : 0.f;
         STAMP(1);   // loads issued
         // lambd (device scalar or by value) and the check that this launch is the n_fft the device value asks for
-        const LamState ls = lam_prologue(p.lam, N, blockIdx.x == 0 && tid == 0);
+        const LamState ls = lam_prologue(p.lam, N, blockIdx.x == 0 && tid == 0, lam_raw);
         if (ls.action != kLamRun) {
             if (ls.action == kLamPoison) {
                 // no launch of this forward matched the device lambd: NaN instead of stale memory (the host raises too)

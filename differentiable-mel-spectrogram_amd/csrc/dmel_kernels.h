@@ -70,11 +70,27 @@ __device__ __forceinline__ int lam_n_fft(float a)
     return bits > 30 ? 0x40000000 : (1 << bits);
 }
 
+// lambd itself: by value, or one load from the parameter's storage
+__device__ __forceinline__ float lam_load(const LamArgs& la)
+{
+    // The device value through a CONSTANT-address-space pointer: a scalar load (lgkmcnt), not a vector one.  No kernel of a forward writes lambd
+    // (the optimizer's kernel, earlier in the stream, did; the scalar cache is invalidated at every kernel start, as it must be for
+    // the kernel arguments themselves), so the qualifier tells the truth.  A select between a device pointer and the generic address
+    // of `la.val` compiled to a FLAT load followed by `s_waitcnt vmcnt(0)`: every wave of dmel_fwd_kernel waited for all of its sample
+    // loads before it could start on the window table (found in round 4 in the assembly; vector loads complete in order).
+    // (Only the DEVICE pointer is re-qualified: `la.val` is read as it is -- in a kernel whose argument struct the compiler copies to
+    // private memory its address is not a global address, and a scalar load from it faults.)
+    typedef const __attribute__((address_space(4))) float cfloat;
+    float v = la.val;
+    if (la.dev) v = *(cfloat*)la.dev;
+    return v;
+}
+
 // `leader` = one thread of the whole grid.  n_launch = the n_fft this kernel instance computes.
-__device__ __forceinline__ LamState lam_prologue(const LamArgs& la, int n_launch, bool leader)
+__device__ __forceinline__ LamState lam_prologue(const LamArgs& la, int n_launch, bool leader, float lam_value)
 {
     LamState st;
-    st.lam = la.dev ? *la.dev : la.val;                               // uniform address: a scalar load
+    st.lam = lam_value;
     st.a = __builtin_fabsf(st.lam);
     st.denom = st.a + 1e-15f;
     int e = __builtin_amdgcn_readfirstlane(st.a > 1e-30f ? __builtin_amdgcn_frexp_expf(st.a) : 1);
@@ -112,6 +128,11 @@ __device__ __forceinline__ LamState lam_prologue(const LamArgs& la, int n_launch
         }
     }
     return st;
+}
+
+__device__ __forceinline__ LamState lam_prologue(const LamArgs& la, int n_launch, bool leader)
+{
+    return lam_prologue(la, n_launch, leader, lam_load(la));
 }
 
 // sign(lambd) 2^(2e) / (|lambd| + 1e-15)^3: what turns the contraction of the scaled tangent window into d / d lambd
