@@ -28,7 +28,7 @@ constexpr int kXgThreads = 256;
 // launch per candidate n_fft and only the one lambd asks for did the work (lam_prologue); the backward does the same
 __device__ __forceinline__ bool xgrad_not_this_nfft(const XgradParams& p)
 {
-    return p.check_nfft && p.lam_dev && lam_n_fft(__builtin_fabsf(*p.lam_dev)) != p.N;
+    return p.check_nfft && p.lam_dev && lam_n_fft(__builtin_fabsf(*(const __attribute__((address_space(4))) float*)p.lam_dev)) != p.N;
 }
 
 template <bool TWLDS>
@@ -314,7 +314,8 @@ __global__ void __launch_bounds__((XgPlan<N>::THREADS), (XgPlan<N>::MINW)) dmel_
         }
         for (int i = i0 + tid; i < L; i += THREADS) a0 += xc[i];
         // lambd by value, or read here from the parameter's storage (a uniform scalar load; dmel_backward_x_dev: no host read)
-        const float win_denom = p.lam_dev ? __builtin_fabsf(*p.lam_dev) + 1e-15f : p.win_denom;
+        float win_denom = p.win_denom;
+        if (p.lam_dev) win_denom = __builtin_fabsf(*(const __attribute__((address_space(4))) float*)p.lam_dev) + 1e-15f;   // scalar load: see lam_load
         static_for<0, WPT>([&](auto ww) {
             constexpr int wi = decltype(ww)::value;
             const int n = tid + THREADS * wi;
