@@ -278,3 +278,52 @@ def test_results_do_not_depend_on_what_freed_device_memory_held():
         got = steps()
         for i, (a, b) in enumerate(zip(ref, got)):
             assert torch.equal(a, b), (value, i, float((a - b).abs().max()))
+
+
+def test_two_tiles_per_workgroup_give_the_same_bits(tmp_path):
+    """The TPW = 2 instantiations (n_fft 256 / 512, and 1024 for the modes that pack two frames per transform) run when a launch is large
+    enough for them (forward_tiles_per_wg); the suite's shapes are small, so they are forced here (DMEL_TILES_PER_WG=2, read once per
+    process: subprocesses) and must reproduce the one-tile kernels bit for bit -- the second tile rewrites the window table over the
+    exchange region, with 64 mels run 1 carries a piece of another wave's tile (round 4)."""
+    import os
+    import subprocess
+    import sys
+    import numpy as np
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import dmel_amd
+from dmel_amd import capi
+out = {}
+st = torch.cuda.current_stream().cuda_stream
+for (L, hop, M, lam, train) in [(4000, 50, 64, 40.0, True), (4000, 50, 64, 80.0, True), (4000, 50, 128, 80.0, True), (6000, 100, 40, 35.0, True),
+                                (16000, 512, 128, 128.0, False), (4000, 50, 64, 80.0, False)]:
+    B = 3
+    T = L // hop + 1
+    x = torch.from_numpy(np.random.default_rng(L + M).standard_normal((B, L)).astype(np.float32)).cuda()
+    plan = capi.Plan(L, hop, M, 8000, max_batch=B)
+    o = torch.empty((B, 1, M, T), device="cuda"); t = torch.empty_like(o)
+    plan.forward(x.data_ptr(), B, lam, o.data_ptr(), t.data_ptr() if train else None, True, 1e-10, st)
+    torch.cuda.synchronize()
+    key = f"{L}_{hop}_{M}_{lam}_{train}"
+    out["o_" + key] = o.cpu().numpy()
+    out["g_" + key] = np.array(plan.info()["grid_fwd"])
+    if train:
+        out["t_" + key] = t.cpu().numpy()
+np.savez(sys.argv[2], **out)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, force in (("one", "1"), ("two", "2")):
+        env = dict(os.environ, DMEL_TILES_PER_WG=force)
+        path = str(tmp_path / f"{tag}.npz")
+        p = subprocess.run([sys.executable, "-c", code, root, path], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[tag] = np.load(path)
+    assert set(res["one"].files) == set(res["two"].files) and len(res["one"].files) == 16
+    for k in res["one"].files:
+        a, b = res["one"][k], res["two"][k]
+        if k.startswith("g_"):
+            assert int(b) < int(a), (k, int(a), int(b))                 # the forced launches really used two-tile workgroups
+        else:
+            assert np.isfinite(a).all() and np.array_equal(a, b), (k, float(np.abs(a - b).max()))
