@@ -297,7 +297,7 @@ from dmel_amd import capi
 out = {}
 st = torch.cuda.current_stream().cuda_stream
 for (L, hop, M, lam, train) in [(4000, 50, 64, 40.0, True), (4000, 50, 64, 80.0, True), (4000, 50, 128, 80.0, True), (6000, 100, 40, 35.0, True),
-                                (16000, 512, 128, 128.0, False), (4000, 50, 64, 80.0, False)]:
+                                (4000, 50, 130, 80.0, True), (16000, 512, 128, 128.0, False), (4000, 50, 64, 80.0, False)]:
     B = 3
     T = L // hop + 1
     x = torch.from_numpy(np.random.default_rng(L + M).standard_normal((B, L)).astype(np.float32)).cuda()
@@ -320,7 +320,7 @@ np.savez(sys.argv[2], **out)
         p = subprocess.run([sys.executable, "-c", code, root, path], env=env, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]
         res[tag] = np.load(path)
-    assert set(res["one"].files) == set(res["two"].files) and len(res["one"].files) == 16
+    assert set(res["one"].files) == set(res["two"].files) and len(res["one"].files) == 19
     for k in res["one"].files:
         a, b = res["one"][k], res["two"][k]
         if k.startswith("g_"):
