@@ -270,9 +270,26 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
     const int qp = lg / C, r = lg % C;
     // exchange among the lanes of one frame: a wave-level fence, or a workgroup barrier when the frame has several waves
     // (every wave of the workgroup runs the same sequence of them)
+    // Frames of several waves (n_fft 8192: two, 16384: four): their waves meet at a counter in LDS -- one word per frame, words
+    // 36 .. 39 of the sums' region, zeroed in the prologue -- instead of at a workgroup barrier: each wave adds one and waits until
+    // the word has reached (number of meetings so far) x WPF.  A frame's waves are resident together (one workgroup), so the wait ends;
+    // the frames of a workgroup no longer wait for one another between the transposition and pairing steps (nine meetings per tile).
+    unsigned* fctr = reinterpret_cast<unsigned*>(red) + 36;
+    unsigned fmeet = 0;
+    static_assert(WPF == 1 || (WAVES / WPF <= 4 && 36 + 4 <= kRedBytes / 4), "one counter per frame of the workgroup");
     auto sync_frame = [&]() {
-        if constexpr (WPF > 1) __syncthreads();
-        else {
+        if constexpr (WPF > 1) {
+            fmeet += WPF;
+            unsigned* c = fctr + wave / WPF;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // this wave's LDS writes are issued (LDS executes a wave's operations in order)
+            if (lane == 0) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (;;) {
+                const unsigned v = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if ((int)((unsigned)__builtin_amdgcn_readfirstlane((int)v) - fmeet) >= 0) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        } else {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -357,6 +374,10 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
                 }
             }
             return;
+        }
+        if constexpr (WPF > 1) {
+            if (tid < 4) fctr[tid] = 0u;                                  // the frames' meeting counters (sync_frame)
+            __syncthreads();
         }
         // d out / d lambd = htan * (contraction of the scaled tangent spectrum): an fp64 division, done by ONE wave of the
         // workgroup and handed to the epilogue through LDS (every barrier below lies between this store and that load)
