@@ -78,11 +78,15 @@ struct NfftTables {
     bool long_rows = false;      // some row has more than two columns
     uint4* ent_h = nullptr;      // caller-supplied (dense) banks, n_fft 64 .. 4096: B fragments of the split-bf16 contraction (FwdParams::ent_h)
     float* fb_nyq = nullptr;     // ... and the row of bin n_fft/2 (n_mels)
+    float4* wl_b4 = nullptr;     // kTrainW (wave-local contraction, FwdParams::wl_*): B operands, lane table, phase lengths
+    int2* wl_lane = nullptr;
+    int wl_phases = 0, wl_total4 = 0;
+    int wl_len4[dmel::kWlMaxPhases] = {};
     void release()
     {
         if (tw1p == tw1) tw1p = nullptr;
         if (tw2p == tw2) tw2p = nullptr;
-        void* ptrs[] = {tw1, tw2, tw1p, tw2p, ent_b, ent_pre, tile_ranges, fb_dense, tw_long, fbT, band, rowband, rowpk, ent_h, fb_nyq};
+        void* ptrs[] = {tw1, tw2, tw1p, tw2p, ent_b, ent_pre, tile_ranges, fb_dense, tw_long, fbT, band, rowband, rowpk, ent_h, fb_nyq, wl_b4, wl_lane};
         for (void* q : ptrs) (void)hipFree(q);
         *this = NfftTables();
     }
@@ -413,6 +417,55 @@ dmel_status build_tables(dmel_plan* pl, int N, NfftTables** out)
             DMEL_HIP(hipMalloc(&tb.fb_nyq, (size_t)M * sizeof(float)));
             DMEL_HIP(hipMemcpy(tb.fb_nyq, fb.data() + (size_t)(tb.F - 1) * M, (size_t)M * sizeof(float), hipMemcpyHostToDevice));
         }
+        if (dmel::forward_has_wlc(N) && (M + 3) / 4 <= 16 * dmel::kWlMaxPhases) {
+            // kTrainW: the schedule of the wave-local contraction (FwdParams::wl_*).  A quad = 4 consecutive mel bands; its band =
+            // the bins where any of them is non-zero.  Quads sorted by band width, 16 per phase (block b of the 4x4x1 MFMA takes the
+            // b-th of them); a phase is as long as its widest band, rounded up to 4 steps; block b starts at k0 = the band's first
+            // bin, moved down where the padded run would pass bin F - 1 (the coefficients outside the band are zero).
+            const int Q = (M + 3) / 4;
+            std::vector<int> first(Q, 0), width(Q, 0), order(Q);
+            for (int q = 0; q < Q; ++q) {
+                int lo = tb.F, hi = -1;
+                for (int f = 0; f < tb.F; ++f)
+                    for (int j = 0; j < 4 && 4 * q + j < M; ++j)
+                        if (fb[(size_t)f * M + 4 * q + j] != 0.f) { lo = std::min(lo, f); hi = std::max(hi, f); }
+                first[q] = hi >= lo ? lo : 0; width[q] = hi >= lo ? hi - lo + 1 : 0;
+                order[q] = q;
+            }
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return width[a] < width[b]; });
+            tb.wl_phases = (Q + 15) / 16;
+            std::vector<int2> lanes((size_t)tb.wl_phases * 64);
+            std::vector<float4> b4;
+            tb.wl_total4 = 0;
+            for (int ph = 0; ph < tb.wl_phases; ++ph) {
+                int len = 0;
+                for (int b = 0; b < 16 && 16 * ph + b < Q; ++b) len = std::max(len, width[order[16 * ph + b]]);
+                const int n4 = (len + 3) / 4;
+                tb.wl_len4[ph] = n4;
+                const size_t base = b4.size();
+                b4.resize(base + (size_t)n4 * 64, make_float4(0.f, 0.f, 0.f, 0.f));
+                for (int b = 0; b < 16; ++b) {
+                    const int q = 16 * ph + b < Q ? order[16 * ph + b] : -1;
+                    const int k0 = q < 0 ? 0 : std::max(0, std::min(first[q], tb.F - 4 * n4));
+                    for (int j = 0; j < 4; ++j) {
+                        const int m = q < 0 ? -1 : 4 * q + j;
+                        lanes[(size_t)ph * 64 + 4 * b + j] = make_int2(8 * k0, (m >= 0 && m < M) ? m : -1);
+                        if (m < 0 || m >= M) continue;
+                        for (int st = 0; st < 4 * n4; ++st) {
+                            const int f = k0 + st;
+                            const float v = f < tb.F ? fb[(size_t)f * M + m] : 0.f;
+                            float4& e = b4[base + (size_t)(st / 4) * 64 + 4 * b + j];
+                            (st % 4 == 0 ? e.x : st % 4 == 1 ? e.y : st % 4 == 2 ? e.z : e.w) = v;
+                        }
+                    }
+                }
+                tb.wl_total4 += n4;
+            }
+            DMEL_HIP(hipMalloc(&tb.wl_lane, lanes.size() * sizeof(int2)));
+            DMEL_HIP(hipMemcpy(tb.wl_lane, lanes.data(), lanes.size() * sizeof(int2), hipMemcpyHostToDevice));
+            DMEL_HIP(hipMalloc(&tb.wl_b4, std::max<size_t>(b4.size(), 64) * sizeof(float4)));
+            if (!b4.empty()) DMEL_HIP(hipMemcpy(tb.wl_b4, b4.data(), b4.size() * sizeof(float4), hipMemcpyHostToDevice));
+        }
         {   // register-resident prefix of every run of group 0, at a fixed position per (wave, run)
             const int nbpre = dmel::forward_nbpre(N);
             std::vector<float> pre((size_t)waves * 2 * nbpre * 64, 0.f);
@@ -726,6 +779,13 @@ dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dm
     // DMEL_FLAG_MFMA_BF16X3: the training forward through a caller-supplied (dense) bank contracts on the bf16 matrix pipe
     const bool hsplit = (flags & DMEL_FLAG_MFMA_BF16X3) && mode == dmel::kTrain && tb->ent_h != nullptr;
     if (hsplit) mode = dmel::kTrainH;
+    // the wave-local contraction where it is built (n_fft 1024 / 2048 / 4096, up to 512 mel bands): DMEL_WLC=0 keeps the round-4 kernel (diagnostics)
+    static const bool wlc_off = std::getenv("DMEL_WLC") && std::atoi(std::getenv("DMEL_WLC")) == 0;
+    if (mode == dmel::kTrain && tb->wl_b4 != nullptr && !wlc_off) {
+        mode = dmel::kTrainW;
+        fp.wl_b4 = tb->wl_b4; fp.wl_lane = tb->wl_lane; fp.wl_phases = tb->wl_phases;
+        for (int i = 0; i < dmel::kWlMaxPhases; ++i) fp.wl_len4[i] = tb->wl_len4[i];
+    }
     static const int force_tpw = std::getenv("DMEL_TILES_PER_WG") ? std::atoi(std::getenv("DMEL_TILES_PER_WG")) : 0;   // diagnostics
     int tpw = dmel::forward_tiles_per_wg(N, mode, batch, fp.tiles_per_clip);
     if (force_tpw == 1 || (force_tpw == 2 && dmel::forward_two_tiles(N, mode))) tpw = force_tpw;
@@ -1128,6 +1188,8 @@ dmel_status dmel_plan_set_filterbank_dev(dmel_plan* plan, int32_t n_fft, const f
     rp.fb = fb_dev; rp.ent_b = tb->ent_b; rp.ent_pre = tb->ent_pre; rp.tile_ranges = tb->tile_ranges;
     rp.fb_dense = tb->fb_dense; rp.fbT = tb->fbT; rp.rowpk = tb->rowpk; rp.F = tb->F; rp.M = plan->cfg.n_mels;
     rp.ent_h = tb->ent_h; rp.fb_nyq = tb->fb_nyq; rp.ks32 = tb->ent_h ? n_fft / 64 : 0;
+    rp.wl_b4 = tb->wl_b4; rp.wl_lane = tb->wl_lane; rp.wl_total4 = tb->wl_total4; rp.wl_phases = tb->wl_phases;
+    for (int i = 0; i < dmel::kWlMaxPhases; ++i) rp.wl_len4[i] = tb->wl_len4[i];
     const bool fast = n_fft >= dmel::kMinFastNfft && n_fft <= dmel::kMaxFastNfft;
     const int waves = fast ? dmel::forward_waves(n_fft) : 0;
     rp.runs = fast ? tb->groups * waves * 2 : 0;

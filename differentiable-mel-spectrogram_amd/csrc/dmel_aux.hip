@@ -222,6 +222,24 @@ __global__ void __launch_bounds__(256) dmel_repack_kernel(RepackParams p)
             return;
         }
         blk -= p.blocks_h;
+        if (blk < p.blocks_w) {
+            // the B operands of kTrainW (build_tables is the host's version): one 16-byte entry = four steps of one lane
+            const long long q = (long long)blk * 256 + tid;
+            if (q < (long long)p.wl_total4 * 64) {
+                const int l = (int)(q & 63);
+                int s4 = (int)(q >> 6), ph = 0;
+                while (ph + 1 < p.wl_phases && s4 >= p.wl_len4[ph]) { s4 -= p.wl_len4[ph]; ++ph; }
+                const int2 li = p.wl_lane[ph * 64 + l];
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                if (li.y >= 0) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const int f = li.x / 8 + 4 * s4 + u; v[u] = f < p.F ? p.fb[(size_t)f * p.M + li.y] : 0.f; }
+                }
+                p.wl_b4[q] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            return;
+        }
+        blk -= p.blocks_w;
         if (blk < p.blocks_c) {
             float v[4];
 #pragma unroll
@@ -262,9 +280,10 @@ hipError_t launch_repack(const RepackParams& p0, hipStream_t s)
     const long long n = (long long)p.F * p.M;
     const int NT = (p.M + 15) / 16;
     p.blocks_h = p.ent_h ? (int)(((long long)NT * p.ks32 * 64 + 255) / 256) : 0;
+    p.blocks_w = p.wl_b4 ? (int)(((long long)p.wl_total4 * 64 + 255) / 256) : 0;
     p.blocks_c = (int)((n + 1023) / 1024);
     const int blocks_r = (std::max(p.F, p.M) + 255) / 256;
-    hipLaunchKernelGGL(dmel_repack_kernel, dim3((unsigned)(p.runs * kRepackRunSplit + p.blocks_h + p.blocks_c + blocks_r)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(dmel_repack_kernel, dim3((unsigned)(p.runs * kRepackRunSplit + p.blocks_h + p.blocks_w + p.blocks_c + blocks_r)), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 

@@ -126,6 +126,17 @@ hipError_t launch_prep(const PrepParams& p, hipStream_t s)
 
 // ---- fused forward --------------------------------------------------------------------------
 
+// log(me), me = mel + eps, for the fused epilogue (models.py:73).  With the reference's eps (1e-10, any eps >= 1e-30) the argument is a
+// normal number: v_log_f32 (log2, 1 ulp) times ln 2 -- 2 instructions against ~12 of logf(), whose extra work is the scaling of
+// denormal arguments; absolute error <= 3e-6 at |log| = 23 (the 1e-4 bar of the path is absolute in the log domain).  eps below
+// that (or negative): logf().  The choice is uniform over the launch.
+__device__ __attribute__((noinline)) float slow_log(float me) { return logf(me); }   // (a call: the compiler does not fold the two paths into a select)
+__device__ __forceinline__ float fast_log(float me, float eps)
+{
+    if (eps >= 1e-30f) return __builtin_amdgcn_logf(me) * 0.69314718055994530942f;
+    return slow_log(me);
+}
+
 #ifdef DMEL_STAMPS
 // Diagnostic build only (tools/stamps.py): s_memtime stamps of every wave at the phase boundaries of the
 // fused kernel, kept in a buffer nothing else reads.  Never compiled into libdmel_hip.so.
@@ -172,7 +183,8 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
     constexpr bool PAIR = (MODE == kInfer || MODE == kSpec);    // two frames share one complex FFT
     constexpr bool IS_SPEC = (MODE == kSpec || MODE == kSpecTrain);
     constexpr bool HSPLIT = (MODE == kTrainH);                  // dense contraction on the bf16 matrix pipe: PD kept as four bf16 planes
-    constexpr bool TRAINLIKE = (MODE == kTrain || MODE == kTrainH);
+    constexpr bool WLC = (MODE == kTrainW);                     // wave-local contraction: see phase 2
+    constexpr bool TRAINLIKE = (MODE == kTrain || MODE == kTrainH || MODE == kTrainW);
     constexpr int NHS = hsplit_plane_stride(N);                 // bf16 entries per plane (bins 0 .. N/2 + padding to 16 bytes)
     static_assert(!HSPLIT || (N >= kHsplitMinNfft && N <= kHsplitMaxNfft), "kTrainH: frames inside one wave, N/2 a multiple of 32");
     constexpr int FPT = PAIR ? 2 * SLOTS : SLOTS;               // frames per tile
@@ -197,6 +209,7 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
     static_assert(!WIN_SYM || G <= 64, "half window table: frames inside one wave");
     static_assert(WPF == 1 || (PLANE && SPLIT && PASSES == 1 && !WIN_LDS), "frames spread over several waves exchange through planes");
     static_assert(!PLANE || G >= 64, "plane pairing: whole waves per frame");
+    static_assert(!WLC || (BPERM && WPF == 1 && PASSES == 1 && TPW == 1 && wlc_size(N) && FPW <= 2), "kTrainW: whole frames inside one wave, at most four (frame, P | D) rows per wave");
     constexpr int WPT = (N / 2 + THREADS - 1) / THREADS;       // window entries a thread computes (and keeps when TPW > 1)
 
     const int tid = threadIdx.x;
@@ -235,7 +248,7 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
     int4 tr0[NLOC];
     float bpre[NLOC][NBPRE];
     auto fetch_bpre = [&]() {
-        if constexpr (!IS_SPEC) {
+        if constexpr (!IS_SPEC && !WLC) {
             static_for<0, NLOC>([&](auto l) {
                 constexpr int loc = decltype(l)::value;
                 tr0[loc] = p.tile_ranges[wave * NLOC + loc];
@@ -656,7 +669,7 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
                     });
                 }
                 STAMP(16 * ti + 3);   // samples arrived, windowed
-                fft_reg<R>(z);
+                fft_reg_dit<R>(z);
                 STAMP(16 * ti + 4);   // radix-R #1
                 // twiddle w_N^(lg*q), transposition through LDS: S[q][lg]
                 v2f u[R];
@@ -747,7 +760,7 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
                     tw2_fetch(IC<0>{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                fft_reg<R>(u);
+                fft_reg_dit<R>(u);
                 STAMP(16 * ti + 6);   // radix-R #2
                 // twiddle w_G^(r*p1), radix-C across adjacent lanes, spectrum to LDS in natural order
                 const v2f rot_f = splat((C == 4 && r == 3) ? 0.f : 1.f);
@@ -829,7 +842,8 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
                     const int obase = dir_a ? base_a : base_b;
                     const int ostep = dir_a ? R * 8 : -R * 8;
                     const bool nyq = q0 && (2 * p2 == C);                        // k = N/2 (C > 1: round 0; C = 1: the extra round)
-                    const int addr0 = nyq ? slot_b + (N / 2 + PADC * (C / 2)) * 8 : obase;
+                    // (kTrainW reads PD[k] at 8 k for every k <= N/2: its Nyquist bin sits at the unpadded position)
+                    const int addr0 = nyq ? slot_b + (N / 2 + (WLC ? 0 : PADC * (C / 2))) * 8 : obase;
                     const bool w0 = dir_a || !q0 || nyq;
                     static_for<0, R / 2 + 1>([&](auto pp1) {
                         constexpr int p1 = decltype(pp1)::value;
@@ -927,7 +941,13 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
             });
         }
         STAMP(16 * ti + 7);   // twiddle + cross-lane radix-C + spectrum to LDS + pairing pass
-        __syncthreads();
+        if constexpr (WLC) {
+            // every wave goes on with the frames it transformed itself: its own LDS writes are all it waits for
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (p.spec_out) __syncthreads();          // (the saved spectrogram is written by all threads from all slots)
+        } else __syncthreads();
         STAMP(16 * ti + 8);   // barrier
 #ifdef DMEL_ABLATE
         if (dbg_skip_gemm) { if (tid == 0 && lds[0].x == 12345.678f) p.out[0] = 0.f; return; }
@@ -944,7 +964,7 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
                     const int t = t0 + slot;
                     if constexpr (HSPLIT) { if (t < p.T) p.spec_out[((size_t)b * F + k) * p.T + t] = 0.25f * load_h(slot * (SS * 8), 0, k); }
                     else
-                    if (t < p.T) p.spec_out[((size_t)b * F + k) * p.T + t] = 0.25f * (lds + slot * SS)[z_index<R, C>(k)].x;
+                    if (t < p.T) p.spec_out[((size_t)b * F + k) * p.T + t] = 0.25f * (lds + slot * SS)[WLC ? k : z_index<R, C>(k)].x;
                 }
             }
         }
@@ -966,6 +986,91 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
                         if (p.tangent) p.tangent[o] = htan * pdv.y;
                     }
                 }
+            }
+        } else if constexpr (WLC) {
+            // ================= phase 2, wave-local: v_mfma_f32_4x4x1_16b_f32 ==========================
+            // One instruction multiplies 16 independent (4 x 1) (1 x 4) blocks.  Block b works for one quad of mel bands; its four
+            // rows are this wave's (frame, P | D) pairs -- two frames of a 32-lane plan, or one frame (rows 2, 3 repeat 0, 1 and are
+            // dropped) -- and a step feeds it ONE bin: lane 4 b + i supplies PD of row i at the block's current bin (one ds_read_b32,
+            // consecutive steps are consecutive bins: immediate offsets), lane 4 b + j the filterbank coefficient of column j (four
+            // steps per 16-byte load of a table every wave of the grid shares).  The HTK bank has at most two non-zeros per bin: a
+            // quad's band is 5 .. 66 bins wide at n_fft 1024 and the 16 blocks of a phase (quads of similar width) walk their bands in
+            // lock step -- 88 eight-cycle instructions per wave against 39 of 32 cycles for the banded 16 x 16 x 4 tiles, no workgroup
+            // barrier in front (a wave needs nobody else's frames), no exchange of partial sums, the same work in every wave.
+            const bool do_log = (p.flags & 1u) != 0;
+            const bool out_bf16 = (p.flags & 4u) != 0;
+            const int row = lane & 3;
+            const int fr = (FPW == 2) ? (row & 1) : 0, typ = (FPW == 2) ? (row >> 1) : (row & 1);
+            const int a_lane = (wave * FPW + fr) * (SS * 8) + typ * 4;
+            const int tA = t0 + wave * FPW;                                    // first frame of this wave
+            int off4 = 0;
+            for (int ph = 0; ph < p.wl_phases; ++ph) {
+                const int n4 = p.wl_len4[ph];
+                const int2 li = p.wl_lane[ph * 64 + lane];
+                const float4* bp = p.wl_b4 + ((size_t)off4 * 64 + lane);
+                off4 += n4;
+                int aaddr = a_lane + li.x;
+                floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                // B operands: a ring of DEPTH groups of four steps in flight (16-byte loads from a table the whole grid shares: L1 / L2
+                // hits); A operands: the next group's four bins are requested before this group's MFMAs are issued (reads past the
+                // end of a phase land on finite data of the slot and are not used)
+                constexpr int DEPTH = 4;
+                float4 br[DEPTH];
+                static_for<0, DEPTH>([&](auto dd) { constexpr int d = decltype(dd)::value; br[d] = bp[(d < n4 ? d : 0) * 64]; });
+                float a_cur[4];
+                static_for<0, 4>([&](auto uu) { constexpr int u = decltype(uu)::value; a_cur[u] = *reinterpret_cast<const float*>(smem_raw + aaddr + 8 * u); });
+                auto group = [&](auto dd, bool refill, int nx) {
+                    constexpr int d = decltype(dd)::value;
+                    float a_nxt[4];
+                    static_for<0, 4>([&](auto uu) { constexpr int u = decltype(uu)::value; a_nxt[u] = *reinterpret_cast<const float*>(smem_raw + aaddr + 32 * (d + 1) + 8 * u); });
+                    const float4 bq = br[d];
+                    if (refill) br[d] = bp[(nx < n4 ? nx : n4 - 1) * 64];
+                    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cur[0], bq.x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cur[1], bq.y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cur[2], bq.z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cur[3], bq.w, acc1, 0, 0, 0);
+                    static_for<0, 4>([&](auto uu) { constexpr int u = decltype(uu)::value; a_cur[u] = a_nxt[u]; });
+                };
+                int s4 = 0;
+                for (; s4 + DEPTH <= n4; s4 += DEPTH) {
+                    static_for<0, DEPTH>([&](auto dd) { group(dd, true, s4 + decltype(dd)::value + DEPTH); });
+                    aaddr += DEPTH * 32;
+                }
+                static_for<0, DEPTH - 1>([&](auto dd) { if (s4 + decltype(dd)::value < n4) group(dd, false, 0); });
+                const floatx4 tot = acc0 + acc1;
+                // ---- epilogue: column j of block b = mel band li.y, rows = (frame, P | D) ----------------
+                const int m = li.y;
+                if (m < 0) continue;
+                const size_t rbase = ((size_t)b * p.M + m) * p.T;
+                float* orow = p.out + rbase;
+                unsigned short* orow_h = reinterpret_cast<unsigned short*>(p.out) + rbase;
+                float* trow = p.tangent ? p.tangent + rbase : nullptr;
+                float ov[FPW], tv[FPW];
+                static_for<0, FPW>([&](auto ff) {
+                    constexpr int f = decltype(ff)::value;
+                    const float mel = 0.25f * tot[(FPW == 2) ? f : 0];
+                    const float dmel = htan * tot[(FPW == 2) ? 2 + f : 1];
+                    const float me = mel + p.eps;
+                    ov[f] = do_log ? fast_log(me, p.eps) : mel;
+                    tv[f] = do_log ? dmel * __builtin_amdgcn_rcpf(me) : dmel;
+                });
+                if constexpr (FPW == 2) {
+                    if ((p.T & 1) == 0 && tA + 1 < p.T) {
+                        // even T (tA is even): both frames of the wave as one aligned 8-byte store per tensor
+                        if (out_bf16) *reinterpret_cast<unsigned*>(orow_h + tA) = (unsigned)bf16_bits(ov[0]) | ((unsigned)bf16_bits(ov[1]) << 16);
+                        else *reinterpret_cast<float2*>(orow + tA) = make_float2(ov[0], ov[1]);
+                        if (trow) *reinterpret_cast<float2*>(trow + tA) = make_float2(tv[0], tv[1]);
+                        continue;
+                    }
+                }
+                static_for<0, FPW>([&](auto ff) {
+                    constexpr int f = decltype(ff)::value;
+                    const int t = tA + f;
+                    if (t < p.T) {
+                        if (out_bf16) orow_h[t] = bf16_bits(ov[f]); else orow[t] = ov[f];
+                        if (trow) trow[t] = tv[f];
+                    }
+                });
             }
         } else {
             // ================= phase 2: mel contraction on the matrix cores ======================
@@ -1262,6 +1367,9 @@ template <int N, int MODE> static hipError_t launch_mode(int tpw, const FwdParam
     if constexpr (MODE == kTrainH) {
         if constexpr (has_hsplit<N>()) { if (tpw == 1) return launch_one<N, MODE, 1>(p, grid, s); }
         return hipErrorInvalidValue;
+    } else if constexpr (MODE == kTrainW) {
+        if constexpr (wlc_size(N)) { if (tpw == 1) return launch_one<N, MODE, 1>(p, grid, s); }
+        return hipErrorInvalidValue;
     } else {
         if constexpr (has_tpw2<N, mode_pairs(MODE)>()) { if (tpw == 2) return launch_one<N, MODE, 2>(p, grid, s); }
         if (tpw != 1) return hipErrorInvalidValue;
@@ -1277,6 +1385,7 @@ template <int N> static hipError_t launch_n(int mode, int tpw, const FwdParams& 
         case kSpec: return launch_mode<N, kSpec>(tpw, p, grid, s);
         case kSpecTrain: return launch_mode<N, kSpecTrain>(tpw, p, grid, s);
         case kTrainH: return launch_mode<N, kTrainH>(tpw, p, grid, s);
+        case kTrainW: return launch_mode<N, kTrainW>(tpw, p, grid, s);
     }
     return hipErrorInvalidValue;
 }
@@ -1346,6 +1455,7 @@ hipError_t launch_forward(int n_fft, int mode, int tpw, const FwdParams& p, int 
 }
 
 bool forward_has_hsplit(int n_fft) { return n_fft >= kHsplitMinNfft && n_fft <= kHsplitMaxNfft && (n_fft & (n_fft - 1)) == 0; }
+bool forward_has_wlc(int n_fft) { return wlc_size(n_fft); }
 bool forward_window_in_lds(int n_fft) { return n_fft >= kMinFastNfft && n_fft <= kWinLdsMaxNfft; }
 
 // One place that maps a run-time (n_fft, pair) to the compile-time geometry
@@ -1452,6 +1562,9 @@ template <int N, int MODE> static hipError_t set_attr_mode()
     if constexpr (MODE == kTrainH) {
         if constexpr (has_hsplit<N>()) return set_attr<N, MODE, 1>();
         else return hipSuccess;
+    } else if constexpr (MODE == kTrainW) {
+        if constexpr (wlc_size(N)) return set_attr<N, MODE, 1>();
+        else return hipSuccess;
     } else {
         hipError_t e = set_attr<N, MODE, 1>();
         if (e != hipSuccess) return e;
@@ -1470,6 +1583,7 @@ template <int N> static hipError_t set_attr_n()
         if ((e = set_attr_mode<N, kInfer>()) != hipSuccess) return e;
         if ((e = set_attr_mode<N, kSpec>()) != hipSuccess) return e;
         if ((e = set_attr_mode<N, kTrainH>()) != hipSuccess) return e;
+        if ((e = set_attr_mode<N, kTrainW>()) != hipSuccess) return e;
         return set_attr_mode<N, kSpecTrain>();
     }
 }

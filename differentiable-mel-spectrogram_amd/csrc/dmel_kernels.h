@@ -16,8 +16,14 @@ constexpr int kMinFastNfft = 32;       // below this the direct-DFT kernel runs
 __device__ __forceinline__ unsigned short bf16_bits(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
 
 enum Mode : int { kTrain = 0, kInfer = 1, kSpec = 2, kSpecTrain = 3,      // kSpec*: power spectrogram (B,F,T), no mel stage
-                  kTrainH = 4 };   // kTrain with the DENSE contraction on the bf16 matrix pipe (DMEL_FLAG_MFMA_BF16X3): the pairing pass
+                  kTrainH = 4,     // kTrain with the DENSE contraction on the bf16 matrix pipe (DMEL_FLAG_MFMA_BF16X3): the pairing pass
                                    // leaves PD as four bf16 planes (P hi, P lo, D hi, D lo), three v_mfma_f32_16x16x32_bf16 per fp32 product
+                  kTrainW = 5 };   // kTrain with the WAVE-LOCAL contraction (round 5): every wave contracts the frames it transformed itself with
+                                   // v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4 blocks: rows = the wave's (frame, P | D) pairs, one block per
+                                   // quad of mel bands) -- no workgroup barrier between transform and contraction, no exchange of partial sums
+// sizes kTrainW is built for: whole frames inside one wave, compact layout (FftPlan::PAIRING == kPairBperm)
+constexpr bool wlc_size(int n_fft) { return n_fft == 1024; }    // (2048 / 4096: one frame per wave fills two of the four rows -- measured -1 % ... +8 % with the first schedule)
+constexpr int kWlMaxPhases = 8;    // phases of 16 mel quads each: up to 512 mel bands (more: the host falls back to kTrain)
 constexpr int kHsplitMinNfft = 64, kHsplitMaxNfft = 4096;    // sizes kTrainH is built for (frames inside one wave, N/2 a multiple of 32)
 constexpr int hsplit_plane_stride(int n_fft) { return n_fft / 2 + 8; }   // bf16 entries per plane: bins 0 .. N/2, rows stay 16-byte aligned
 
@@ -273,6 +279,14 @@ struct FwdParams {
     const float* fb_nyq;        // kTrainH: (n_mels) fp32, the row of bin N/2 (added on the vector pipe: N/2 bins = N/64 steps of 32 exactly)
     float* spec_out;            // training mode only, or nullptr: the power spectrogram (B, F, T) the contraction consumes is ALSO written
                                 // out (16.8 MB at BASELINE config 2), so that the filterbank gradient need not recompute it (16.5 us)
+    // kTrainW.  The mel quads (4 consecutive bands) are sorted by the width of their band of bins and taken 16 at a time: phase p gives
+    // quad (p, b) to block b of the 4x4x1 MFMA; all 16 blocks walk their bands in lock step, wl_len4[p] groups of 4 bins (zero
+    // coefficients where a band is shorter).  Lane 4 b + j supplies row j of block b (A: PD of its frame at bin k0(p, b) + step)
+    // and column j (B: fb[k0 + step][4 quad + j]) and receives column j of the block's 4 x 4 result.
+    const float4* wl_b4;        // [(steps/4 so far + step/4) * 64 + lane]: the B operands of four consecutive steps
+    const int2* wl_lane;        // [phase * 64 + lane]: (8 k0(p, b): byte offset of PD[k0] inside a frame slot, mel band 4 quad + j or -1)
+    int wl_phases;
+    int wl_len4[kWlMaxPhases];
 };
 
 struct PrepParams {
@@ -294,6 +308,7 @@ int forward_waves(int n_fft);              // waves per workgroup of the fused k
 int forward_nbpre(int n_fft);              // k-steps per run kept in registers (layout of FwdParams::ent_pre)
 bool forward_plan_rc(int n_fft, bool pair, int* R, int* C);   // pair: the plan of the modes that pack two frames per FFT
 bool forward_has_hsplit(int n_fft);        // kTrainH is built for this size
+bool forward_has_wlc(int n_fft);           // kTrainW is built for this size
 bool forward_window_in_lds(int n_fft);     // the kernel builds its own window table (otherwise dmel_prep_kernel writes FwdParams::win2)   // radix per lane and cross-lane radix of the plan (layout of tw1 / tw2)
 hipError_t forward_prepare_attributes();   // raises the dynamic-LDS limit of every instantiation once
 
@@ -397,6 +412,9 @@ int fbgrad_splits(int batch, int F, int M, int T);      // slices of the batch's
 // dense structure (all 4x16 blocks present): what a trainable filterbank needs after each optimizer step
 struct RepackParams {
     uint4* ent_h; float* fb_nyq; int ks32;      // kTrainH tables (FwdParams::ent_h / fb_nyq) or nullptr
+    float4* wl_b4; const int2* wl_lane; int wl_total4;   // kTrainW tables (FwdParams::wl_b4, its lane table, sum of wl_len4) or nullptr
+    int wl_len4[kWlMaxPhases]; int wl_phases;
+    int blocks_w;               // set by launch_repack: workgroups of the kTrainW section
     const float* fb;            // (F, M) row-major, device
     float* ent_b; float* ent_pre; const int4* tile_ranges;
     float* fb_dense;            // (F, M) copy for the kernels that read the matrix as it is
