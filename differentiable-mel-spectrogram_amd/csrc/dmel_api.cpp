@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -438,19 +439,62 @@ dmel_status build_tables(dmel_plan* pl, int N, NfftTables** out)
             std::vector<float4> b4;
             tb.wl_total4 = 0;
             for (int ph = 0; ph < tb.wl_phases; ++ph) {
-                int len = 0;
-                for (int b = 0; b < 16 && 16 * ph + b < Q; ++b) len = std::max(len, width[order[16 * ph + b]]);
-                const int n4 = (len + 3) / 4;
+                const int nq = std::min(16, Q - 16 * ph);
+                int wmax = 0;
+                for (int i = 0; i < nq; ++i) wmax = std::max(wmax, width[order[16 * ph + i]]);
+                // Bank conflicts of the A operand reads (dmel_kernels.h, slot_stride_f2): the 8 blocks of each 32-lane group must sit
+                // at bins that differ modulo 8.  A block may start anywhere in [lo, hi] -- the band must fit into the phase's L steps
+                // and the run must not pass bin F - 1 -- so each quad is matched to one of the 16 (group, residue) places it can
+                // reach (augmenting paths; 16 x 16); if that fails the phase gets four more steps.
+                int L = std::max(4, (wmax + 3) / 4 * 4), slot_of[16], k0_of[16];
+                for (;; L += 4) {
+                    int lo[16], hi[16], owner[16];
+                    for (int i = 0; i < nq; ++i) {
+                        const int q = order[16 * ph + i];
+                        hi[i] = std::max(0, std::min(first[q], tb.F - L));
+                        lo[i] = std::min(hi[i], std::max(0, first[q] + width[q] - L));
+                    }
+                    auto can = [&](int i, int r) { for (int k = hi[i]; k >= lo[i] && k > hi[i] - 8; --k) if ((k & 7) == r) return true; return false; };
+                    std::fill(owner, owner + 16, -1);
+                    bool seen[16];
+                    std::function<bool(int)> place = [&](int i) -> bool {
+                        for (int sl = 0; sl < 16; ++sl) {
+                            if (seen[sl] || !can(i, sl & 7)) continue;
+                            seen[sl] = true;
+                            if (owner[sl] < 0 || place(owner[sl])) { owner[sl] = i; return true; }
+                        }
+                        return false;
+                    };
+                    bool ok = true;
+                    for (int i = nq - 1; i >= 0 && ok; --i) {          // widest (least freedom) first
+                        std::fill(seen, seen + 16, false);
+                        ok = place(i);
+                    }
+                    if (!ok && L < wmax + 64) continue;
+                    std::fill(slot_of, slot_of + 16, -1);
+                    if (ok) { for (int sl = 0; sl < 16; ++sl) if (owner[sl] >= 0) slot_of[owner[sl]] = sl; }
+                    else {                                        // (not reached with 16 places for 16 quads: any residue has two)
+                        bool used[16] = {};
+                        for (int i = 0; i < nq; ++i) for (int sl = 0; sl < 16; ++sl) if (!used[sl]) { used[sl] = true; slot_of[i] = sl; break; }
+                    }
+                    for (int i = 0; i < nq; ++i) {
+                        k0_of[i] = hi[i];
+                        for (int k = hi[i]; k >= lo[i] && k > hi[i] - 8; --k) if ((k & 7) == (slot_of[i] & 7)) { k0_of[i] = k; break; }
+                    }
+                    break;
+                }
+                const int n4 = wmax > 0 ? L / 4 : 0;
                 tb.wl_len4[ph] = n4;
                 const size_t base = b4.size();
                 b4.resize(base + (size_t)n4 * 64, make_float4(0.f, 0.f, 0.f, 0.f));
-                for (int b = 0; b < 16; ++b) {
-                    const int q = 16 * ph + b < Q ? order[16 * ph + b] : -1;
-                    const int k0 = q < 0 ? 0 : std::max(0, std::min(first[q], tb.F - 4 * n4));
+                for (int sl = 0; sl < 16; ++sl)                  // places nobody took: no mel band, a bin of their residue
+                    for (int j = 0; j < 4; ++j) lanes[(size_t)ph * 64 + 4 * sl + j] = make_int2(8 * (sl & 7), -1);
+                for (int i = 0; i < nq; ++i) {
+                    const int q = order[16 * ph + i], b = slot_of[i], k0 = k0_of[i];
                     for (int j = 0; j < 4; ++j) {
-                        const int m = q < 0 ? -1 : 4 * q + j;
-                        lanes[(size_t)ph * 64 + 4 * b + j] = make_int2(8 * k0, (m >= 0 && m < M) ? m : -1);
-                        if (m < 0 || m >= M) continue;
+                        const int m = 4 * q + j;
+                        lanes[(size_t)ph * 64 + 4 * b + j] = make_int2(8 * k0, m < M ? m : -1);
+                        if (m >= M) continue;
                         for (int st = 0; st < 4 * n4; ++st) {
                             const int f = k0 + st;
                             const float v = f < tb.F ? fb[(size_t)f * M + m] : 0.f;
@@ -783,7 +827,7 @@ dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dm
     static const bool wlc_off = std::getenv("DMEL_WLC") && std::atoi(std::getenv("DMEL_WLC")) == 0;
     if (mode == dmel::kTrain && tb->wl_b4 != nullptr && !wlc_off) {
         mode = dmel::kTrainW;
-        fp.wl_b4 = tb->wl_b4; fp.wl_lane = tb->wl_lane; fp.wl_phases = tb->wl_phases;
+        fp.wl_b4 = tb->wl_b4; fp.wl_lane = tb->wl_lane; fp.wl_phases = tb->wl_phases; fp.wl_total4 = tb->wl_total4;
         for (int i = 0; i < dmel::kWlMaxPhases; ++i) fp.wl_len4[i] = tb->wl_len4[i];
     }
     static const int force_tpw = std::getenv("DMEL_TILES_PER_WG") ? std::atoi(std::getenv("DMEL_TILES_PER_WG")) : 0;   // diagnostics

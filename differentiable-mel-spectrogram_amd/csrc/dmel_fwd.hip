@@ -173,9 +173,9 @@ __device__ __forceinline__ void stamp_place(int wgid, int wave, int lane)
 // are requested while the first is transformed, and a launch needs half the workgroups (one round of resident workgroups
 // instead of two at BASELINE config 2).
 template <int N, int MODE, int TPW>
-__global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N, mode_pairs(MODE)>().MINW)) dmel_fwd_kernel(FwdParams p)
+__global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, MODE>().MINW)) dmel_fwd_kernel(FwdParams p)
 {
-    constexpr FftGeom g = geom<N, mode_pairs(MODE)>();
+    constexpr FftGeom g = geom_mode<N, MODE>();
     constexpr int R = g.R, C = g.C, G = g.G, FPW = g.FPW, PASSES = g.PASSES, SLOTS = g.SLOTS, MT = g.MT;
     constexpr int WAVES = g.WAVES, NLOC = g.NLOC, THREADS = g.THREADS;
     constexpr int LB = ilog2(R);
@@ -274,6 +274,41 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
                     }
                 });
             });
+        }
+    };
+
+    // kTrainW: what its phase 2 needs from global memory -- the lane table of the first two phases and the first groups of B operands
+    // of phase 0 -- is requested where fetch_bpre() is (behind the second radix stage: the pairing pass covers the round trips); the
+    // ring is refilled for the next phase in front of each phase's epilogue.  (Asked for where they are used, each phase began
+    // with two dependent round trips: 5 400 cycles per wave for 88 MFMAs and two epilogues, tools/stamps.py.)
+#ifndef DMEL_WL_DEPTH
+#define DMEL_WL_DEPTH 6
+#endif
+#ifndef DMEL_WL_EARLY
+#define DMEL_WL_EARLY 0
+#endif
+#ifndef DMEL_WL_NEXT
+#define DMEL_WL_NEXT 1
+#endif
+    constexpr int WL_DEPTH = DMEL_WL_DEPTH;                     // groups of four steps (16 bytes per lane) in the ring
+    constexpr int WL_EARLY = DMEL_WL_EARLY;                     // 1: lane tables requested before the pairing pass, 2: the ring of phase 0 too
+    floatx4 wl_ring[WLC ? WL_DEPTH : 1];
+    int2 wl_li[2];
+    const __amdgpu_buffer_rsrc_t rbw = make_rsrc(WLC ? (const void*)p.wl_b4 : (const void*)p.x, WLC ? (unsigned)p.wl_total4 * 1024u : 0u);
+    // BUFFER loads on purpose: with plain loads InstCombine folds the ring's phi(load, load) into load(phi(address)) at the loop
+    // header and every group waits a cache round trip in front of its first use; an intrinsic call is not folded.  Groups past the
+    // end of a phase re-read its last group.
+    auto wl_bload = [&](floatx4& dst, int grp, int n4, int boff4) {
+        if (grp < n4) dst = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rbw, lane * 16, (boff4 + __builtin_amdgcn_readfirstlane(grp)) * 1024, 0));
+    };
+    auto wl_ring_init = [&](int n4, int boff4) {
+        if constexpr (WLC) static_for<0, WL_DEPTH>([&](auto dd) { constexpr int d = decltype(dd)::value; wl_ring[d] = floatx4{0.f, 0.f, 0.f, 0.f}; wl_bload(wl_ring[d], d, n4, boff4); });
+    };
+    auto wl_prefetch = [&]() {
+        if constexpr (WLC && WL_EARLY >= 1) {
+            wl_li[0] = p.wl_lane[lane];
+            wl_li[1] = p.wl_lane[(p.wl_phases > 1 ? 64 : 0) + lane];
+            if constexpr (WL_EARLY >= 2) wl_ring_init(p.wl_len4[0], 0);
         }
     };
 
@@ -889,7 +924,7 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
                         });
                     }
                     // the filterbank fragments of phase 2: requested once the spectrum registers are dead
-                    if constexpr (pass == PASSES - 1) { __builtin_amdgcn_sched_barrier(0); fetch_bpre(); }
+                    if constexpr (pass == PASSES - 1) { __builtin_amdgcn_sched_barrier(0); fetch_bpre(); wl_prefetch(); }
                 } else {
                 // the filterbank fragments of phase 2 are requested here: the registers of the FFT are free, and the pairing
                 // pass plus the barrier behind it cover the round trip
@@ -1004,47 +1039,53 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
             const int a_lane = (wave * FPW + fr) * (SS * 8) + typ * 4;
             const int tA = t0 + wave * FPW;                                    // first frame of this wave
             int off4 = 0;
+            // one 64-bit base per tensor and clip in scalar registers, 32-bit element offsets per lane (M T < 2^31)
+            float* const out_clip = p.out + (size_t)b * p.M * p.T;
+            unsigned short* const outh_clip = reinterpret_cast<unsigned short*>(p.out) + (size_t)b * p.M * p.T;
+            float* const tan_clip = p.tangent ? p.tangent + (size_t)b * p.M * p.T : nullptr;
             for (int ph = 0; ph < p.wl_phases; ++ph) {
                 const int n4 = p.wl_len4[ph];
-                const int2 li = p.wl_lane[ph * 64 + lane];
-                const float4* bp = p.wl_b4 + ((size_t)off4 * 64 + lane);
+                int2 li = wl_li[ph & 1];
+                if (ph >= 2 || WL_EARLY < 1) li = p.wl_lane[ph * 64 + lane];
+                if ((WL_EARLY < 2 && ph == 0) || (!DMEL_WL_NEXT && ph > 0)) wl_ring_init(n4, off4 - n4);
                 off4 += n4;
                 int aaddr = a_lane + li.x;
                 floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                // B operands: a ring of DEPTH groups of four steps in flight (16-byte loads from a table the whole grid shares: L1 / L2
-                // hits); A operands: the next group's four bins are requested before this group's MFMAs are issued (reads past the
-                // end of a phase land on finite data of the slot and are not used)
-                constexpr int DEPTH = 4;
-                float4 br[DEPTH];
-                static_for<0, DEPTH>([&](auto dd) { constexpr int d = decltype(dd)::value; br[d] = bp[(d < n4 ? d : 0) * 64]; });
+                // A operands: the next group's four bins are requested before this group's MFMAs are issued (reads past the end of a
+                // phase land on finite data of the slot and are not used).  B operands: the ring (see wl_bload).
                 float a_cur[4];
                 static_for<0, 4>([&](auto uu) { constexpr int u = decltype(uu)::value; a_cur[u] = *reinterpret_cast<const float*>(smem_raw + aaddr + 8 * u); });
-                auto group = [&](auto dd, bool refill, int nx) {
+                auto group = [&](auto dd) {
                     constexpr int d = decltype(dd)::value;
                     float a_nxt[4];
                     static_for<0, 4>([&](auto uu) { constexpr int u = decltype(uu)::value; a_nxt[u] = *reinterpret_cast<const float*>(smem_raw + aaddr + 32 * (d + 1) + 8 * u); });
-                    const float4 bq = br[d];
-                    if (refill) br[d] = bp[(nx < n4 ? nx : n4 - 1) * 64];
-                    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cur[0], bq.x, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cur[1], bq.y, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cur[2], bq.z, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cur[3], bq.w, acc1, 0, 0, 0);
+                    const floatx4 bq = wl_ring[d];
+                    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cur[0], bq[0], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cur[1], bq[1], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cur[2], bq[2], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cur[3], bq[3], acc1, 0, 0, 0);
                     static_for<0, 4>([&](auto uu) { constexpr int u = decltype(uu)::value; a_cur[u] = a_nxt[u]; });
                 };
                 int s4 = 0;
-                for (; s4 + DEPTH <= n4; s4 += DEPTH) {
-                    static_for<0, DEPTH>([&](auto dd) { group(dd, true, s4 + decltype(dd)::value + DEPTH); });
-                    aaddr += DEPTH * 32;
+                for (; s4 + WL_DEPTH <= n4; s4 += WL_DEPTH) {
+                    static_for<0, WL_DEPTH>([&](auto dd) {
+                        constexpr int d = decltype(dd)::value;
+                        group(dd);
+                        wl_bload(wl_ring[d], s4 + d + WL_DEPTH, n4, off4 - n4);
+                    });
+                    aaddr += WL_DEPTH * 32;
                 }
-                static_for<0, DEPTH - 1>([&](auto dd) { if (s4 + decltype(dd)::value < n4) group(dd, false, 0); });
+                static_for<0, WL_DEPTH - 1>([&](auto dd) { if (s4 + decltype(dd)::value < n4) group(dd); });
+                // the next phase's first groups: in flight under this phase's epilogue
+                if (DMEL_WL_NEXT && ph + 1 < p.wl_phases) wl_ring_init(p.wl_len4[ph + 1], off4);
                 const floatx4 tot = acc0 + acc1;
                 // ---- epilogue: column j of block b = mel band li.y, rows = (frame, P | D) ----------------
                 const int m = li.y;
                 if (m < 0) continue;
-                const size_t rbase = ((size_t)b * p.M + m) * p.T;
-                float* orow = p.out + rbase;
-                unsigned short* orow_h = reinterpret_cast<unsigned short*>(p.out) + rbase;
-                float* trow = p.tangent ? p.tangent + rbase : nullptr;
+                const unsigned rbase = (unsigned)m * (unsigned)p.T;
+                float* orow = out_clip + rbase;
+                unsigned short* orow_h = outh_clip + rbase;
+                float* trow = tan_clip ? tan_clip + rbase : nullptr;
                 float ov[FPW], tv[FPW];
                 static_for<0, FPW>([&](auto ff) {
                     constexpr int f = decltype(ff)::value;
@@ -1072,6 +1113,7 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
                     }
                 });
             }
+            STAMP(16 * ti + 9); STAMP(16 * ti + 10); STAMP(16 * ti + 11);   // contraction and epilogue of all phases (no exchange)
         } else {
             // ================= phase 2: mel contraction on the matrix cores ======================
             const int row16 = lane & 15;
@@ -1350,7 +1392,7 @@ __global__ void __launch_bounds__((geom<N, mode_pairs(MODE)>().THREADS), (geom<N
 
 template <int N, int MODE, int TPW> static hipError_t launch_one(const FwdParams& p, int grid, hipStream_t s)
 {
-    constexpr FftGeom g = geom<N, mode_pairs(MODE)>();
+    constexpr FftGeom g = geom_mode<N, MODE>();
     constexpr int lds = g.LDS_BYTES;
     hipLaunchKernelGGL((dmel_fwd_kernel<N, MODE, TPW>), dim3(grid), dim3(g.THREADS), lds, s, p);
     return hipGetLastError();
@@ -1486,6 +1528,13 @@ int forward_lds_bytes(int n_fft, int mode)
 {
     int v = -1;
     with_geom(n_fft, mode_pairs(mode), [&](const FftGeom& g) { v = g.LDS_BYTES; });
+    if (mode == kTrainW) {
+        switch (n_fft) {                                   // (the sizes kTrainW may be built for)
+            case 1024: v = geom<1024, false, true>().LDS_BYTES; break;
+            case 2048: v = geom<2048, false, true>().LDS_BYTES; break;
+            case 4096: v = geom<4096, false, true>().LDS_BYTES; break;
+        }
+    }
     return v;
 }
 
@@ -1555,7 +1604,7 @@ int forward_nbpre(int n_fft)
 template <int N, int MODE, int TPW> static hipError_t set_attr()
 {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&dmel_fwd_kernel<N, MODE, TPW>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, geom<N, mode_pairs(MODE)>().LDS_BYTES);
+                               hipFuncAttributeMaxDynamicSharedMemorySize, geom_mode<N, MODE>().LDS_BYTES);
 }
 template <int N, int MODE> static hipError_t set_attr_mode()
 {

@@ -207,7 +207,7 @@ struct FftGeom {
 
 constexpr int ex_stride(int G, int C) { return G + (G >= 32 ? C : 1); }
 constexpr int z_index_host(int k, int R, int C) { return C == 1 ? k : k + (k / (R * R)) * 4; }
-constexpr int slot_stride_f2(int N, int R, int C, int pairing = 0, int split = 0)
+constexpr int slot_stride_f2(int N, int R, int C, int pairing = 0, int split = 0, bool wl = false)
 {
     const int G = N / R;
     const int a = R * ex_stride(G, C) * (split ? 4 : 8);                           // transposition: complex entries, or one plane of floats
@@ -217,10 +217,15 @@ constexpr int slot_stride_f2(int N, int R, int C, int pairing = 0, int split = 0
     // (128 B) in two 32-lane groups: each group touches 16 B per slot, so the 8 slots must start 16 B apart modulo 128
     // (a stride = 32 mod 256 put slots s and s+4 on the same banks: 2-way conflicts, SQ_LDS_BANK_CONFLICT = 25 % of the
     // LDS-active cycles).  48 rather than 16 keeps the two frames a wave exchanges at n_fft 32 / 64 apart as before.
+    // kTrainW reads its A operands with ds_read_b32 too, but lane 4 b + i of a 32-lane group takes row i = (frame, P | D) of
+    // block b's current bin: dwords {2 k, 2 k + 1} of the two slots of a wave.  With the slots 64 bytes apart modulo 128 a block
+    // covers the bank pairs {k, k + 8} (mod 16): conflict-free as soon as the 8 blocks of a group sit at bins that differ
+    // modulo 8, which the host's schedule arranges (build_tables).  (12 dwords apart, as above: 5 500 cycles per wave for 88 MFMAs.)
+    if (wl) return ((need + 127) / 128 * 128 + 64) / 8;
     return ((need + 127) / 128 * 128 + 48) / 8;
 }
 
-template <int N, bool PAIR = false> constexpr FftGeom geom()
+template <int N, bool PAIR = false, bool WL = false> constexpr FftGeom geom()
 {
     using P = FftPlanSel<N, PAIR>;
     FftGeom g{};
@@ -234,7 +239,7 @@ template <int N, bool PAIR = false> constexpr FftGeom geom()
     g.MT = g.SLOTS >= 8 ? g.SLOTS / 8 : 1;
     g.EX_STRIDE = ex_stride(g.G, g.C);
     g.PAIRING = P::PAIRING; g.SPLIT = P::SPLIT;
-    g.SLOT_STRIDE_F2 = slot_stride_f2(N, P::R, P::C, P::PAIRING, P::SPLIT);
+    g.SLOT_STRIDE_F2 = slot_stride_f2(N, P::R, P::C, P::PAIRING, P::SPLIT, WL);
     // LDS map: [FFT slots][aux: window table (phase 1) aliased with the half-tile exchange (phase 2)][8 sums]
     // the window table lives in LDS up to n_fft 4096 (half table there: 16 KB next to 8 x 16.6 KB of frames); beyond, in global
     // memory, written by dmel_prep_kernel
@@ -249,6 +254,9 @@ template <int N, bool PAIR = false> constexpr FftGeom geom()
     g.LDS_BYTES = g.RED_OFF + kRedBytes + ((P::C > 1 && N <= 2048) ? P::R * P::C * 8 : 0);
     return g;
 }
+
+// the geometry of a kernel instantiation (kTrainW has its own slot stride)
+template <int N, int MODE> constexpr FftGeom geom_mode() { return geom<N, mode_pairs(MODE), MODE == kTrainW>(); }
 
 // One 4(k) x 16(mel) block of the filterbank, pre-arranged as the B operand of
 // v_mfma_f32_16x16x4_f32: lane l holds fb[4*ks + (l >> 4)][16*tile + (l & 15)].
@@ -285,7 +293,7 @@ struct FwdParams {
     // and column j (B: fb[k0 + step][4 quad + j]) and receives column j of the block's 4 x 4 result.
     const float4* wl_b4;        // [(steps/4 so far + step/4) * 64 + lane]: the B operands of four consecutive steps
     const int2* wl_lane;        // [phase * 64 + lane]: (8 k0(p, b): byte offset of PD[k0] inside a frame slot, mel band 4 quad + j or -1)
-    int wl_phases;
+    int wl_phases, wl_total4;   // phases; sum of wl_len4 (size of wl_b4 in 1 KB entries)
     int wl_len4[kWlMaxPhases];
 };
 
