@@ -814,22 +814,25 @@ dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dm
     for (int i = 0; i < 16; ++i) fp.pre_groups[i] = tb->pre_groups[i];
     fp.B = batch; fp.L = pl->cfg.n_points; fp.T = pl->T; fp.hop = pl->cfg.hop_length; fp.M = pl->cfg.n_mels;
     fp.nchunks = pl->nchunks; fp.groups = tb->groups; fp.xch_groups = tb->xch_groups;
+    // DMEL_FLAG_MFMA_BF16X3: the training forward through a caller-supplied (dense) bank contracts on the bf16 matrix pipe
+    const bool hsplit = (flags & DMEL_FLAG_MFMA_BF16X3) && mode == dmel::kTrain && tb->ent_h != nullptr;
+    if (hsplit) mode = dmel::kTrainH;
+    // the wave-local contraction where it is built (n_fft 1024, up to 512 mel bands): DMEL_WLC=0 keeps the round-4 kernel, DMEL_WLC=1
+    // the 8-wave workgroups, DMEL_WLC=2 the 16-wave ones where they are built (diagnostics).
+    static const int wlc_env = std::getenv("DMEL_WLC") ? std::atoi(std::getenv("DMEL_WLC")) : -1;
+    if (mode == dmel::kTrain && tb->wl_b4 != nullptr && wlc_env != 0) {
+        const int wide_fpt = dmel::forward_has_wlc_wide(N) ? dmel::forward_frames_per_tile(N, dmel::kTrainWW) : 0;
+        const bool wide = wide_fpt > 0 && wlc_env == 2;      // (16-wave workgroups: measured slower, dmel_kernels.h; built only on request)
+        mode = wide ? dmel::kTrainWW : dmel::kTrainW;
+        fp.wl_b4 = tb->wl_b4; fp.wl_lane = tb->wl_lane; fp.wl_phases = tb->wl_phases; fp.wl_total4 = tb->wl_total4;
+        for (int i = 0; i < dmel::kWlMaxPhases; ++i) fp.wl_len4[i] = tb->wl_len4[i];
+    }
     const int fpt = dmel::forward_frames_per_tile(N, mode);
     fp.tiles_per_clip = (pl->T + fpt - 1) / fpt;
     fp.inv_L = inv_L; fp.eps = (float)eps; fp.flags = flags; fp.lam = lam;
     fp.remove_dc = remove_dc; fp.normalize = pl->cfg.normalize_window; fp.win_half = win_half;
     fp.spec_out = spec_out;
     fp.ent_h = tb->ent_h; fp.fb_nyq = tb->fb_nyq;
-    // DMEL_FLAG_MFMA_BF16X3: the training forward through a caller-supplied (dense) bank contracts on the bf16 matrix pipe
-    const bool hsplit = (flags & DMEL_FLAG_MFMA_BF16X3) && mode == dmel::kTrain && tb->ent_h != nullptr;
-    if (hsplit) mode = dmel::kTrainH;
-    // the wave-local contraction where it is built (n_fft 1024 / 2048 / 4096, up to 512 mel bands): DMEL_WLC=0 keeps the round-4 kernel (diagnostics)
-    static const bool wlc_off = std::getenv("DMEL_WLC") && std::atoi(std::getenv("DMEL_WLC")) == 0;
-    if (mode == dmel::kTrain && tb->wl_b4 != nullptr && !wlc_off) {
-        mode = dmel::kTrainW;
-        fp.wl_b4 = tb->wl_b4; fp.wl_lane = tb->wl_lane; fp.wl_phases = tb->wl_phases; fp.wl_total4 = tb->wl_total4;
-        for (int i = 0; i < dmel::kWlMaxPhases; ++i) fp.wl_len4[i] = tb->wl_len4[i];
-    }
     static const int force_tpw = std::getenv("DMEL_TILES_PER_WG") ? std::atoi(std::getenv("DMEL_TILES_PER_WG")) : 0;   // diagnostics
     int tpw = dmel::forward_tiles_per_wg(N, mode, batch, fp.tiles_per_clip);
     if (force_tpw == 1 || (force_tpw == 2 && dmel::forward_two_tiles(N, mode))) tpw = force_tpw;

@@ -183,8 +183,17 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
     constexpr bool PAIR = (MODE == kInfer || MODE == kSpec);    // two frames share one complex FFT
     constexpr bool IS_SPEC = (MODE == kSpec || MODE == kSpecTrain);
     constexpr bool HSPLIT = (MODE == kTrainH);                  // dense contraction on the bf16 matrix pipe: PD kept as four bf16 planes
-    constexpr bool WLC = (MODE == kTrainW);                     // wave-local contraction: see phase 2
-    constexpr bool TRAINLIKE = (MODE == kTrain || MODE == kTrainH || MODE == kTrainW);
+#ifndef DMEL_DIT_MASK
+#define DMEL_DIT_MASK (~0)
+#endif
+    // register radix core: decimation in time with Linzer-Feig butterflies (194 packed operations per 32 points) or the round-4
+    // decimation in frequency (228); bit log2(N) of DMEL_DIT_MASK selects (diagnostic builds)
+    // (measured, training: n_fft 4096 145.2 -> 138.5 us at the reference's ESC-50 shape, n_fft 1024 -1 % in many-round launches; n_fft 2048
+    // with the round-4 contraction 48.0 -> 49.0 us at config 3, 70.2 -> 72.4 at config 5 -- eight spilled registers -- but 46.9 -> 46.0 and
+    // 71.9 -> 70.3 with the wave-local contraction: there it stays)
+    constexpr bool WLC = mode_wlc(MODE);                        // wave-local contraction: see phase 2
+    constexpr bool USE_DIT = ((DMEL_DIT_MASK >> ilog2(N)) & 1) != 0 && (N != 2048 || WLC);
+    constexpr bool TRAINLIKE = (MODE == kTrain || MODE == kTrainH || WLC);
     constexpr int NHS = hsplit_plane_stride(N);                 // bf16 entries per plane (bins 0 .. N/2 + padding to 16 bytes)
     static_assert(!HSPLIT || (N >= kHsplitMinNfft && N <= kHsplitMaxNfft), "kTrainH: frames inside one wave, N/2 a multiple of 32");
     constexpr int FPT = PAIR ? 2 * SLOTS : SLOTS;               // frames per tile
@@ -238,6 +247,15 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
     constexpr bool dbg_skip_fft = false;
 #endif
 
+#ifdef DMEL_ABLATE
+    // timing experiment: the workgroups of the first round whose CU-local slot is odd start late by (flags >> 24) x 1024 cycles, so that
+    // the two workgroups a CU holds stay out of step for the rest of a many-round launch
+    if ((p.flags & 0x400000u) && blockIdx.x < 512u) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        if ((hw >> 16) & 1u) for (unsigned i = 0; i < (p.flags >> 24) * 16u; ++i) __builtin_amdgcn_s_sleep(1);
+    }
+#endif
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (size_t)b * p.L, (unsigned)p.L * 4u);
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.ent_b, (unsigned)p.ent_b_floats * 4u);
 
@@ -299,6 +317,9 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
     // header and every group waits a cache round trip in front of its first use; an intrinsic call is not folded.  Groups past the
     // end of a phase re-read its last group.
     auto wl_bload = [&](floatx4& dst, int grp, int n4, int boff4) {
+#ifdef DMEL_ABLATE
+        if (p.flags & 0x10000u) return;                          // timing only: no B operand loads
+#endif
         if (grp < n4) dst = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rbw, lane * 16, (boff4 + __builtin_amdgcn_readfirstlane(grp)) * 1024, 0));
     };
     auto wl_ring_init = [&](int n4, int boff4) {
@@ -386,7 +407,8 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
     };
 
     // ================= prologue, once per workgroup ============================================
-    constexpr bool TW1_POW = (R >= 16);     // first-stage twiddles by powers: see phase 1
+    constexpr bool TW1_LDS = g.TW1_OFF != 0;                    // first-stage twiddles from a table in LDS (kTrainW where it fits)
+    constexpr bool TW1_POW = (R >= 16) && !TW1_LDS;             // first-stage twiddles by powers: see phase 1
     float mean = 0.f;
     float2 wkeep[WPT];                                          // this thread's window entries (TPW > 1: written back per tile)
     float2 wmid = make_float2(1.f, 0.f);                        // ... and the centre entry
@@ -433,6 +455,12 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
             if (wave == 0) { const float h = 0.5f * lam_tangent_scale(ls); if (lane == 0) red[kRedTan] = h; }
         }
         if constexpr (TW2_LDS) { if (tid < R * C) tw2l[tid] = p.tw2[tid]; }          // visible after the barrier below
+        if constexpr (TW1_LDS) {
+            // rows q = 1 .. R - 1 of the first-stage twiddle table, 16 bytes per thread (visible after the window table's barrier)
+            constexpr int n16 = (R - 1) * G / 2;
+            for (int i = tid; i < n16; i += THREADS)
+                reinterpret_cast<float4*>(smem_raw + g.TW1_OFF)[i] = reinterpret_cast<const float4*>(p.tw1 + G)[i];
+        }
         // Phase 2 pads every run of k-steps to a multiple of four with zero filterbank blocks and still reads the A operands of the
         // padding: bins past n_fft/2, i.e. floats 2 F .. of the slot.  In the compact layout those are the end of the transposition
         // plane -- finite data of this tile, EXCEPT the padding column of a row (row stride EXS = G + 1: one float nobody writes)
@@ -704,7 +732,7 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
                     });
                 }
                 STAMP(16 * ti + 3);   // samples arrived, windowed
-                fft_reg_dit<R>(z);
+                if constexpr (USE_DIT) fft_reg_dit<R>(z); else fft_reg<R>(z);
                 STAMP(16 * ti + 4);   // radix-R #1
                 // twiddle w_N^(lg*q), transposition through LDS: S[q][lg]
                 v2f u[R];
@@ -721,9 +749,12 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
                     wb[1] = v2f{w1.x, w1.y};
                     static_for<2, 8>([&](auto bb) { constexpr int b = decltype(bb)::value; wb[b] = cmul(wb[b - 1], w1); });
                 }
+                int tw1b = g.TW1_OFF + lg * 8;                               // one base register, compile-time offsets (ds_read_b64 offset: 8 G (q - 1))
+                asm volatile("" : "+v"(tw1b));
                 auto twiddled = [&](auto qq, v2f v) -> v2f {
                     constexpr int q = decltype(qq)::value;
                     if constexpr (q == 0) return v;
+                    else if constexpr (TW1_LDS) return cmul(v, *reinterpret_cast<const float2*>(smem_raw + tw1b + (q - 1) * (G * 8)));
                     else if constexpr (!TW1_POW) return cmul(v, p.tw1[q * G + lg]);
                     else {
                         constexpr int a8 = q / 8, b8 = q % 8;
@@ -795,7 +826,7 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
                     tw2_fetch(IC<0>{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                fft_reg_dit<R>(u);
+                if constexpr (USE_DIT) fft_reg_dit<R>(u); else fft_reg<R>(u);
                 STAMP(16 * ti + 6);   // radix-R #2
                 // twiddle w_G^(r*p1), radix-C across adjacent lanes, spectrum to LDS in natural order
                 const v2f rot_f = splat((C == 4 && r == 3) ? 0.f : 1.f);
@@ -1043,11 +1074,23 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
             float* const out_clip = p.out + (size_t)b * p.M * p.T;
             unsigned short* const outh_clip = reinterpret_cast<unsigned short*>(p.out) + (size_t)b * p.M * p.T;
             float* const tan_clip = p.tangent ? p.tangent + (size_t)b * p.M * p.T : nullptr;
+            // Staged epilogue (two phases at most -- 128 mel bands --, fp32 output, rows of whole 16-byte pieces): a lane's results --
+            // 8 bytes per tensor and mel band, 64 different rows per store instruction -- are kept until the wave's last phase, written
+            // over the wave's OWN frame slots (its spectra are dead by then), and after ONE workgroup barrier every thread stores
+            // 16 bytes of a row: 4 lanes cover the tile's 16 frames of one (tensor, mel band), 64 contiguous bytes.  Measured with the
+            // store pattern alone (tools/xtime.py 0x20000): config 2 18.8 -> 17.0 us, config 4's batch 117.7 -> 108.2 -- the scattered
+            // 8-byte stores cost the memory pipeline a request per lane.
+#ifndef DMEL_WL_STAGE
+#define DMEL_WL_STAGE 1
+#endif
+            const bool staged = DMEL_WL_STAGE && p.wl_phases <= 2 && p.M <= SS && !out_bf16 && (p.T & 3) == 0 && p.tangent != nullptr && SLOTS % 4 == 0;
+            float sv[2][2 * FPW];
+            int sm[2] = {-1, -1};
             for (int ph = 0; ph < p.wl_phases; ++ph) {
                 const int n4 = p.wl_len4[ph];
                 int2 li = wl_li[ph & 1];
                 if (ph >= 2 || WL_EARLY < 1) li = p.wl_lane[ph * 64 + lane];
-                if ((WL_EARLY < 2 && ph == 0) || (!DMEL_WL_NEXT && ph > 0)) wl_ring_init(n4, off4 - n4);
+                if ((WL_EARLY < 2 && ph == 0) || (!DMEL_WL_NEXT && ph > 0)) wl_ring_init(n4, off4);      // (off4: still this phase's first group)
                 off4 += n4;
                 int aaddr = a_lane + li.x;
                 floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -1060,6 +1103,9 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
                     float a_nxt[4];
                     static_for<0, 4>([&](auto uu) { constexpr int u = decltype(uu)::value; a_nxt[u] = *reinterpret_cast<const float*>(smem_raw + aaddr + 32 * (d + 1) + 8 * u); });
                     const floatx4 bq = wl_ring[d];
+#ifdef DMEL_ABLATE
+                    if (p.flags & 0x800u) { acc0[0] += a_cur[0] + a_cur[1] + a_cur[2] + a_cur[3] + bq[0] + bq[1] + bq[2] + bq[3]; static_for<0, 4>([&](auto uu) { constexpr int u = decltype(uu)::value; a_cur[u] = a_nxt[u]; }); return; }   // timing only: no MFMAs
+#endif
                     acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cur[0], bq[0], acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cur[1], bq[1], acc1, 0, 0, 0);
                     acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cur[2], bq[2], acc0, 0, 0, 0);
@@ -1082,6 +1128,17 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
                 // ---- epilogue: column j of block b = mel band li.y, rows = (frame, P | D) ----------------
                 const int m = li.y;
                 if (m < 0) continue;
+#ifdef DMEL_ABLATE
+                if (p.flags & 0x400u) { if (tot[0] == 12345.678f) out_clip[0] = tot[1] + tot[2] + tot[3]; continue; }   // timing only: no epilogue
+                if (p.flags & 0x20000u) {
+                    // timing only (values are wrong): the store pattern of a staged epilogue -- wave w writes rows 16 w .. 16 w + 15 of one
+                    // tensor per phase, 64 contiguous bytes per row (this tile's 16 frames), 16 bytes per lane
+                    const int mrow = 16 * wave + (lane >> 2);
+                    float* q = (ph == 0 ? out_clip : (tan_clip ? tan_clip : out_clip)) + (unsigned)mrow * (unsigned)p.T + t0 + 4 * (lane & 3);
+                    if (ph < 2 && mrow < p.M) *reinterpret_cast<float4*>(q) = make_float4(tot[0], tot[1], tot[2], tot[3]);
+                    continue;
+                }
+#endif
                 const unsigned rbase = (unsigned)m * (unsigned)p.T;
                 float* orow = out_clip + rbase;
                 unsigned short* orow_h = outh_clip + rbase;
@@ -1095,12 +1152,26 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
                     ov[f] = do_log ? fast_log(me, p.eps) : mel;
                     tv[f] = do_log ? dmel * __builtin_amdgcn_rcpf(me) : dmel;
                 });
+                if (staged) {
+                    static_for<0, 2>([&](auto pp) {
+                        if (decltype(pp)::value == ph) {
+                            sm[decltype(pp)::value] = m;
+                            static_for<0, FPW>([&](auto ff) { constexpr int f = decltype(ff)::value; sv[decltype(pp)::value][f] = ov[f]; sv[decltype(pp)::value][FPW + f] = tv[f]; });
+                        }
+                    });
+                    continue;
+                }
                 if constexpr (FPW == 2) {
                     if ((p.T & 1) == 0 && tA + 1 < p.T) {
                         // even T (tA is even): both frames of the wave as one aligned 8-byte store per tensor
                         if (out_bf16) *reinterpret_cast<unsigned*>(orow_h + tA) = (unsigned)bf16_bits(ov[0]) | ((unsigned)bf16_bits(ov[1]) << 16);
+#ifdef DMEL_WL_NT
+                        else __builtin_nontemporal_store(v2f{ov[0], ov[1]}, reinterpret_cast<v2f*>(orow + tA));
+                        if (trow) __builtin_nontemporal_store(v2f{tv[0], tv[1]}, reinterpret_cast<v2f*>(trow + tA));
+#else
                         else *reinterpret_cast<float2*>(orow + tA) = make_float2(ov[0], ov[1]);
                         if (trow) *reinterpret_cast<float2*>(trow + tA) = make_float2(tv[0], tv[1]);
+#endif
                         continue;
                     }
                 }
@@ -1113,7 +1184,44 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
                     }
                 });
             }
-            STAMP(16 * ti + 9); STAMP(16 * ti + 10); STAMP(16 * ti + 11);   // contraction and epilogue of all phases (no exchange)
+            STAMP(16 * ti + 9);   // contraction and epilogue arithmetic of all phases
+            if (staged) {
+                float* const stg = reinterpret_cast<float*>(smem_raw + wave * FPW * (SS * 8));          // [tensor][mel band][frame of this wave]
+                static_for<0, 2>([&](auto pp) {
+                    constexpr int q = decltype(pp)::value;
+                    if (sm[q] >= 0) {
+                        static_for<0, 2>([&](auto tt2) {
+                            constexpr int pl = decltype(tt2)::value;
+                            float* d = stg + ((pl * p.M + sm[q]) * FPW);
+                            if constexpr (FPW == 2) *reinterpret_cast<float2*>(d) = make_float2(sv[q][pl * FPW], sv[q][pl * FPW + 1]);
+                            else d[0] = sv[q][pl * FPW];
+                        });
+                    }
+                });
+                __syncthreads();
+                STAMP(16 * ti + 10);
+                constexpr int QPR = SLOTS / 4;                               // 16-byte pieces per row of the tile
+                const int total = 2 * p.M * QPR;
+                for (int idx = tid; idx < total; idx += THREADS) {
+                    const int rw = idx / QPR, c = idx % QPR;
+                    const int pl = rw >= p.M ? 1 : 0, mm = rw - pl * p.M;
+                    float4 v;
+                    if constexpr (FPW == 2) {
+                        const float2 lo = *reinterpret_cast<const float2*>(smem_raw + (2 * c) * FPW * (SS * 8) + ((pl * p.M + mm) * FPW) * 4);
+                        const float2 hi = *reinterpret_cast<const float2*>(smem_raw + (2 * c + 1) * FPW * (SS * 8) + ((pl * p.M + mm) * FPW) * 4);
+                        v = make_float4(lo.x, lo.y, hi.x, hi.y);
+                    } else {
+                        float e[4];
+                        static_for<0, 4>([&](auto uu) { constexpr int u = decltype(uu)::value; e[u] = *reinterpret_cast<const float*>(smem_raw + (4 * c + u) * (SS * 8) + (pl * p.M + mm) * 4); });
+                        v = make_float4(e[0], e[1], e[2], e[3]);
+                    }
+                    float* dst = (pl ? tan_clip : out_clip) + (unsigned)mm * (unsigned)p.T + t0 + 4 * c;
+                    const int t = t0 + 4 * c;
+                    if (t + 3 < p.T) *reinterpret_cast<float4*>(dst) = v;
+                    else { if (t < p.T) dst[0] = v.x; if (t + 1 < p.T) dst[1] = v.y; if (t + 2 < p.T) dst[2] = v.z; }
+                }
+            }
+            STAMP(16 * ti + 11);
         } else {
             // ================= phase 2: mel contraction on the matrix cores ======================
             const int row16 = lane & 15;
@@ -1412,6 +1520,9 @@ template <int N, int MODE> static hipError_t launch_mode(int tpw, const FwdParam
     } else if constexpr (MODE == kTrainW) {
         if constexpr (wlc_size(N)) { if (tpw == 1) return launch_one<N, MODE, 1>(p, grid, s); }
         return hipErrorInvalidValue;
+    } else if constexpr (MODE == kTrainWW) {
+        if constexpr (wlc_wide_size(N)) { if (tpw == 1) return launch_one<N, MODE, 1>(p, grid, s); }
+        return hipErrorInvalidValue;
     } else {
         if constexpr (has_tpw2<N, mode_pairs(MODE)>()) { if (tpw == 2) return launch_one<N, MODE, 2>(p, grid, s); }
         if (tpw != 1) return hipErrorInvalidValue;
@@ -1428,6 +1539,7 @@ template <int N> static hipError_t launch_n(int mode, int tpw, const FwdParams& 
         case kSpecTrain: return launch_mode<N, kSpecTrain>(tpw, p, grid, s);
         case kTrainH: return launch_mode<N, kTrainH>(tpw, p, grid, s);
         case kTrainW: return launch_mode<N, kTrainW>(tpw, p, grid, s);
+        case kTrainWW: return launch_mode<N, kTrainWW>(tpw, p, grid, s);
     }
     return hipErrorInvalidValue;
 }
@@ -1498,6 +1610,7 @@ hipError_t launch_forward(int n_fft, int mode, int tpw, const FwdParams& p, int 
 
 bool forward_has_hsplit(int n_fft) { return n_fft >= kHsplitMinNfft && n_fft <= kHsplitMaxNfft && (n_fft & (n_fft - 1)) == 0; }
 bool forward_has_wlc(int n_fft) { return wlc_size(n_fft); }
+bool forward_has_wlc_wide(int n_fft) { return wlc_wide_size(n_fft); }
 bool forward_window_in_lds(int n_fft) { return n_fft >= kMinFastNfft && n_fft <= kWinLdsMaxNfft; }
 
 // One place that maps a run-time (n_fft, pair) to the compile-time geometry
@@ -1528,6 +1641,7 @@ int forward_lds_bytes(int n_fft, int mode)
 {
     int v = -1;
     with_geom(n_fft, mode_pairs(mode), [&](const FftGeom& g) { v = g.LDS_BYTES; });
+    if (mode == kTrainWW && n_fft == 1024 && wlc_wide_size(1024)) return geom<1024, false, true, true>().LDS_BYTES;
     if (mode == kTrainW) {
         switch (n_fft) {                                   // (the sizes kTrainW may be built for)
             case 1024: v = geom<1024, false, true>().LDS_BYTES; break;
@@ -1540,6 +1654,7 @@ int forward_lds_bytes(int n_fft, int mode)
 
 int forward_frames_per_tile(int n_fft, int mode)
 {
+    if (mode == kTrainWW && n_fft == 1024 && wlc_wide_size(1024)) return geom<1024, false, true, true>().SLOTS;
     int slots = -1;
     with_geom(n_fft, mode_pairs(mode), [&](const FftGeom& g) { slots = g.SLOTS; });
     if (slots < 0) return -1;
@@ -1614,6 +1729,9 @@ template <int N, int MODE> static hipError_t set_attr_mode()
     } else if constexpr (MODE == kTrainW) {
         if constexpr (wlc_size(N)) return set_attr<N, MODE, 1>();
         else return hipSuccess;
+    } else if constexpr (MODE == kTrainWW) {
+        if constexpr (wlc_wide_size(N)) return set_attr<N, MODE, 1>();
+        else return hipSuccess;
     } else {
         hipError_t e = set_attr<N, MODE, 1>();
         if (e != hipSuccess) return e;
@@ -1633,6 +1751,7 @@ template <int N> static hipError_t set_attr_n()
         if ((e = set_attr_mode<N, kSpec>()) != hipSuccess) return e;
         if ((e = set_attr_mode<N, kTrainH>()) != hipSuccess) return e;
         if ((e = set_attr_mode<N, kTrainW>()) != hipSuccess) return e;
+        if ((e = set_attr_mode<N, kTrainWW>()) != hipSuccess) return e;
         return set_attr_mode<N, kSpecTrain>();
     }
 }

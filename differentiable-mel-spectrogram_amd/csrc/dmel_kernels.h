@@ -18,11 +18,17 @@ __device__ __forceinline__ unsigned short bf16_bits(float v) { return __builtin_
 enum Mode : int { kTrain = 0, kInfer = 1, kSpec = 2, kSpecTrain = 3,      // kSpec*: power spectrogram (B,F,T), no mel stage
                   kTrainH = 4,     // kTrain with the DENSE contraction on the bf16 matrix pipe (DMEL_FLAG_MFMA_BF16X3): the pairing pass
                                    // leaves PD as four bf16 planes (P hi, P lo, D hi, D lo), three v_mfma_f32_16x16x32_bf16 per fp32 product
-                  kTrainW = 5 };   // kTrain with the WAVE-LOCAL contraction (round 5): every wave contracts the frames it transformed itself with
+                  kTrainW = 5,     // kTrain with the WAVE-LOCAL contraction (round 5): every wave contracts the frames it transformed itself with
                                    // v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4 blocks: rows = the wave's (frame, P | D) pairs, one block per
                                    // quad of mel bands) -- no workgroup barrier between transform and contraction, no exchange of partial sums
+                  kTrainWW = 6 };  // kTrainW with workgroups of 16 waves (n_fft 1024: 32 frames, one workgroup per CU): a clip of up to 32 frames is ONE
+                                   // tile -- its mean comes from the samples the frames load anyway (no second pass over the clip), one window and
+                                   // twiddle table per CU, whole 128-byte rows in the staged epilogue
+constexpr bool mode_wlc(int mode) { return mode == kTrainW || mode == kTrainWW; }
 // sizes kTrainW is built for: whole frames inside one wave, compact layout (FftPlan::PAIRING == kPairBperm)
-constexpr bool wlc_size(int n_fft) { return n_fft == 1024; }    // (2048 / 4096: one frame per wave fills two of the four rows -- measured -1 % ... +8 % with the first schedule)
+// (n_fft 4096, one frame per wave and one workgroup per CU: 147.6 us against 138.5 for kTrain at the reference's ESC-50 shape -- with two of the
+// four MFMA rows in use a wave issues 264 steps for 64 mel bands; n_fft 2048: config 3 46.0 against 48.0 us, config 5 70.4 against 70.2)
+constexpr bool wlc_size(int n_fft) { return n_fft == 1024 || n_fft == 2048; }
 constexpr int kWlMaxPhases = 8;    // phases of 16 mel quads each: up to 512 mel bands (more: the host falls back to kTrain)
 constexpr int kHsplitMinNfft = 64, kHsplitMaxNfft = 4096;    // sizes kTrainH is built for (frames inside one wave, N/2 a multiple of 32)
 constexpr int hsplit_plane_stride(int n_fft) { return n_fft / 2 + 8; }   // bf16 entries per plane: bins 0 .. N/2, rows stay 16-byte aligned
@@ -203,6 +209,7 @@ constexpr int kRedTan = 32;
 struct FftGeom {
     int N, R, C, G, FPW, PASSES, WAVES, NLOC, THREADS, SLOTS, MT, EX_STRIDE, SLOT_STRIDE_F2, NBPRE, MINW, LDS_BYTES, AUX_OFF, RED_OFF, WIN_LDS;
     int PAIRING, SPLIT, WIN_SYM, WPF, PLANE_PAD;
+    int TW1_OFF;      // kTrainW, where it fits: byte offset of the first-stage twiddle table in LDS (rows q = 1 .. R - 1 of FwdParams::tw1), else 0
 };
 
 constexpr int ex_stride(int G, int C) { return G + (G >= 32 ? C : 1); }
@@ -225,14 +232,14 @@ constexpr int slot_stride_f2(int N, int R, int C, int pairing = 0, int split = 0
     return ((need + 127) / 128 * 128 + 48) / 8;
 }
 
-template <int N, bool PAIR = false, bool WL = false> constexpr FftGeom geom()
+template <int N, bool PAIR = false, bool WL = false, bool WIDE = false> constexpr FftGeom geom()
 {
     using P = FftPlanSel<N, PAIR>;
     FftGeom g{};
     g.N = N; g.R = P::R; g.C = P::C; g.G = N / P::R; g.PASSES = P::PASSES;
     g.WPF = g.G > kWave ? g.G / kWave : 1;                // waves per frame
     g.FPW = g.G > kWave ? 1 : kWave / g.G;                // frames per wave (1 when a frame has several waves: see SLOTS)
-    g.WAVES = P::WAVES; g.NLOC = 2; g.THREADS = kWave * P::WAVES; g.NBPRE = P::NBPRE; g.MINW = P::MINW;
+    g.WAVES = WIDE ? 16 : P::WAVES; g.NLOC = 2; g.THREADS = kWave * g.WAVES; g.NBPRE = P::NBPRE; g.MINW = P::MINW;
     g.SLOTS = g.WAVES * g.FPW * g.PASSES / g.WPF;
     // the pairing plane is indexed by k + PLANE_PAD * (k / R^2): the C lanes of a quad write to different banks
     g.PLANE_PAD = P::C > 1 ? 64 / P::C : 0;
@@ -250,13 +257,31 @@ template <int N, bool PAIR = false, bool WL = false> constexpr FftGeom geom()
     const int win = g.WIN_LDS ? (g.WIN_SYM ? (N / 2 + 1) * 8 : N * 8) : 0;
     g.AUX_OFF = g.SLOTS * g.SLOT_STRIDE_F2 * 8;
     g.RED_OFF = g.AUX_OFF + (xch > win ? xch : win);
+    g.TW1_OFF = 0;
+    if (WL) {
+        // kTrainW exchanges nothing: behind the window table there is room for the twiddles w_N^(lg q) of the first stage (n_fft 1024:
+        // 31 x 32 entries, 7 936 bytes; two workgroups per CU stay resident) -- 31 LDS reads per lane instead of 4 loads and 27 complex products
+        const int tw1 = (P::R - 1) * g.G * 8;
+        const int win16 = (win + 15) / 16 * 16;               // (the table is copied 16 bytes at a time)
+        const int with_tw1 = g.AUX_OFF + win16 + tw1 + kRedBytes + ((P::C > 1 && N <= 2048) ? P::R * P::C * 8 : 0);
+        const int per_cu_now = 163840 / (g.RED_OFF + kRedBytes + ((P::C > 1 && N <= 2048) ? P::R * P::C * 8 : 0));
+#ifndef DMEL_WL_TW1LDS
+#define DMEL_WL_TW1LDS 1
+#endif
+        if (DMEL_WL_TW1LDS && 163840 / with_tw1 >= per_cu_now) { g.TW1_OFF = g.AUX_OFF + win16; g.RED_OFF = g.TW1_OFF + tw1; }
+        else g.RED_OFF = g.AUX_OFF + win16;
+    }
     // [16 sums + tangent scale (kRedBytes)][tw2 table: R x C complex, the radix-C twiddles: every lane of a wave reads one of C values per p1]
     g.LDS_BYTES = g.RED_OFF + kRedBytes + ((P::C > 1 && N <= 2048) ? P::R * P::C * 8 : 0);
     return g;
 }
 
 // the geometry of a kernel instantiation (kTrainW has its own slot stride)
-template <int N, int MODE> constexpr FftGeom geom_mode() { return geom<N, mode_pairs(MODE), MODE == kTrainW>(); }
+template <int N, int MODE> constexpr FftGeom geom_mode() { return geom<N, mode_pairs(MODE), mode_wlc(MODE), MODE == kTrainWW>(); }
+// sizes kTrainWW is built for: none.  Measured at n_fft 1024 (round 5): config 2 18.3 us against 18.1 for the 8-wave workgroups -- the
+// second pass over the clip it saves is not what a one-round launch waits for --, config 4's batch on one GPU 131 us against 110: a
+// CU's next workgroup starts only when all 16 waves of the previous one have finished.  (wlc_wide_size(1024) = true builds it; DMEL_WLC=2.)
+constexpr bool wlc_wide_size(int n_fft) { return false; }
 
 // One 4(k) x 16(mel) block of the filterbank, pre-arranged as the B operand of
 // v_mfma_f32_16x16x4_f32: lane l holds fb[4*ks + (l >> 4)][16*tile + (l & 15)].
@@ -317,6 +342,7 @@ int forward_nbpre(int n_fft);              // k-steps per run kept in registers 
 bool forward_plan_rc(int n_fft, bool pair, int* R, int* C);   // pair: the plan of the modes that pack two frames per FFT
 bool forward_has_hsplit(int n_fft);        // kTrainH is built for this size
 bool forward_has_wlc(int n_fft);           // kTrainW is built for this size
+bool forward_has_wlc_wide(int n_fft);      // ... and kTrainWW
 bool forward_window_in_lds(int n_fft);     // the kernel builds its own window table (otherwise dmel_prep_kernel writes FwdParams::win2)   // radix per lane and cross-lane radix of the plan (layout of tw1 / tw2)
 hipError_t forward_prepare_attributes();   // raises the dynamic-LDS limit of every instantiation once
 

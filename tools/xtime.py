@@ -15,7 +15,8 @@ flags = [int(f, 16) for f in sys.argv[2].split(",")]
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 300
 rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 train = os.environ.get("XTIME_MODE", "train") == "train"
-B, L, sr, lam, hop, M = CONFIGS[name]
+EXTRA = {"c4": (2048, 16000, 16000, 128.0, 512, 128), "esc_n4096": (32, 40000, 8000, 400.0, 80, 64)}
+B, L, sr, lam, hop, M = CONFIGS[name] if name in CONFIGS else EXTRA[name]
 T = L // hop + 1
 x = torch.from_numpy(synth.waveforms(B, L, seed=0)).cuda()
 out = torch.empty((B, 1, M, T), device="cuda"); tan = torch.empty_like(out)
