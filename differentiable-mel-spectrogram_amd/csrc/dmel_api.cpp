@@ -1783,7 +1783,21 @@ dmel_status backward_x_impl(dmel_plan* plan, const float* x, int32_t batch, floa
     if (span > 0x3fffffffLL) return fail(DMEL_ERR_UNSUPPORTED, "gradient w.r.t. the waveform: hop_length too large");
     const size_t rows = wave_path ? (size_t)tiles : (size_t)plan->T, row_len = wave_path ? (size_t)span : (size_t)N;
     const size_t frame_floats = ((size_t)batch * rows * row_len + 63) / 64 * 64;
-    const size_t need = frame_floats + 2 * (size_t)batch * rows + 16;    // + one fp64 sum per frame / tile
+    size_t need = frame_floats + 2 * (size_t)batch * rows + 16;    // + one fp64 sum per frame / tile
+    if (check_nfft && !is_capturing(s)) {
+        // One call per candidate n_fft of a tracked forward (DMEL_FLAG_CHECK_NFFT): a step captured later may hold a neighbour -- 2 n_fft
+        // or n_fft / 2 -- that no eager call has run yet (GraphedStep captures with the launches lambd can reach, not the ones the warm-up
+        // happened to issue), and a workspace cannot grow under capture.  Size it here for the neighbours too (a re-capture
+        // near an n_fft boundary raised in the middle of training).
+        for (int nn : {N / 2, 2 * N}) {
+            if (nn < 2 || nn > dmel::kMaxNfft || (nn & (nn - 1))) continue;
+            int fq = 0;
+            const bool wp = dmel::xgrad_wave_shape(nn, spec_mode ? 0 : plan->cfg.n_mels, win_half ? nn : nn / 2 + 1, &fq) && std::getenv("DMEL_XGRAD_LDS") == nullptr;
+            const size_t r2 = wp ? (size_t)((plan->T + fq - 1) / fq) : (size_t)plan->T;
+            const size_t l2 = wp ? (size_t)(fq - 1) * plan->cfg.hop_length + nn : (size_t)nn;
+            need = std::max(need, ((size_t)batch * r2 * l2 + 63) / 64 * 64 + 2 * (size_t)batch * r2 + 16);
+        }
+    }
     if (need > plan->fbw_floats) {
         if (is_capturing(s)) return fail(DMEL_ERR_INVALID_ARGUMENT, "workspace must grow but the stream is capturing: run one call eagerly first");
         DMEL_HIP(hipStreamSynchronize(s));

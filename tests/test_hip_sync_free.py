@@ -269,3 +269,42 @@ def test_dense_bank_forward_on_the_bf16_matrix_pipe(name):
             assert float(((oh - oe).abs() / oe.abs()).max()) <= 1e-4               # a dense positive bank: no element near zero
         tscale = float(te.abs().max())
         assert float((th - te).abs().max()) <= 1e-4 * tscale
+
+
+def test_a_captured_step_may_hold_a_neighbour_n_fft_that_no_eager_step_has_run():
+    """GraphedStep captures with the launches lambd can REACH (dmel_plan_force_launch), which near a boundary adds the
+    2 n_fft candidate although the eager warm-up issued the primary only -- and the tracked waveform gradient runs
+    dmel_backward_x_dev once per candidate, whose workspace cannot grow under capture (n_fft 1024 -> 2048 at hop 512 needs more).
+    The eager calls now size it for the neighbours too."""
+    from dmel_amd import MelSpectrogramLayer
+    L, hop, M, sr, B = 16000, 512, 128, 16000, 4
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(B, L, generator=gen).to(DEV).requires_grad_(True)
+    g = torch.randn(B, 1, M, L // hop + 1, generator=gen).to(DEV)
+    layer = MelSpectrogramLayer(torch.tensor(128.0), n_mels=M, n_points=L, sample_rate=sr, hop_length=hop, device=DEV, optimized=True,
+                                log=True).to(DEV)
+    plan = layer._plan_for(torch.device(DEV))
+    plan.force_launch(1024, 0)                                  # eager: the primary launch alone
+
+    def step():
+        if x.grad is not None:
+            x.grad.zero_()
+        layer.zero_grad(set_to_none=False)
+        layer(x).backward(g)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step(); step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    ref_gx, ref_dl = x.grad.clone(), layer.lambd.grad.clone()
+    plan.force_launch(1024, 3)                                  # the graph holds both neighbours
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    plan.force_launch(0, 0)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(x.grad, ref_gx) and torch.equal(layer.lambd.grad, ref_dl)
+    assert layer.lambd_status()["error"] == 0
