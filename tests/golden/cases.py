@@ -136,3 +136,10 @@ def fill_state(net, seed=0):
             v = 0.1 * v
         t.copy_(v.to(t.device))
     return net
+
+
+def traj_inputs(cfg):
+    """inputs of the G12 training trajectories (make_golden.py: TRAJ): waveforms and the fixed cotangent of the log-mel output"""
+    from dmel_amd import synth
+    B, L, hop, M = int(cfg["B"]), int(cfg["L"]), int(cfg["hop"]), int(cfg["M"])
+    return synth.waveforms(B, L, seed=121, scale=1.0), synth.cotangent((B, 1, M, L // hop + 1), seed=122)

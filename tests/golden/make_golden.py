@@ -264,6 +264,45 @@ def run_net_keys(models):
     print("net_state_keys.json:", {k: list(v) for k, v in out.items()})
 
 
+# ---- G12: a TRAINING TRAJECTORY across an n_fft boundary -------------------------------------------------------------
+# The reference re-derives n_fft from lambd at every forward (time_frequency.py:39,60-65); the layer here keeps lambd on the device and
+# follows it with guard launches / re-captured graphs.  These fixtures pin that machinery against the reference ITSELF: its
+# MelSpectrogramLayer (models.py:14-56) + log (models.py:73) under torch.optim.Adam (main.py:52 uses Adam with lr_tf) for 48 steps from a
+# lambd next to a power-of-two boundary; the loss changes sign at step 8 so that lambd turns round and crosses both ways
+# where the gradient allows.  Stored: lambd BEFORE each step, the n_fft that forward used, the gradient it produced.
+TRAJ = {"g12_traj_512_1024": dict(lam0=85.9, B=2, L=4000, hop=128, M=32, sr=8000, lr=0.1, steps=48, flip=8),
+        "g12_traj_1024_2048": dict(lam0=171.4, B=2, L=4000, hop=128, M=32, sr=8000, lr=0.2, steps=48, flip=6)}
+
+
+def run_trajectory(models, tf, cfg):
+    torch.set_num_threads(8)
+    x_np, g_np = C.traj_inputs(cfg)
+    x, g = torch.from_numpy(x_np), torch.from_numpy(g_np)
+    layer = models.MelSpectrogramLayer(init_lambd=torch.tensor(float(cfg["lam0"]), dtype=torch.float32), n_mels=cfg["M"], n_points=cfg["L"],
+                                       sample_rate=cfg["sr"], hop_length=cfg["hop"], device="cpu", optimized=True)
+    opt = torch.optim.Adam([layer.lambd], lr=cfg["lr"])
+    lam, nfft, dlam = [], [], []
+    for k in range(cfg["steps"]):
+        lam.append(float(layer.lambd.detach()))
+        nfft.append(int(tf.next_power_of_2((torch.abs(layer.lambd) * 6).detach().cpu().numpy())))
+        opt.zero_grad()
+        y = torch.log(layer(x) + 1e-10)
+        sign = 1.0 if k < cfg["flip"] else -1.0
+        (sign * (y * g).sum()).backward()
+        dlam.append(float(layer.lambd.grad))
+        opt.step()
+    lam.append(float(layer.lambd.detach()))
+    nfft = np.asarray(nfft, dtype=np.int64)
+    crossings = int((nfft[1:] != nfft[:-1]).sum())
+    # distance of 6 lambd from the integers where next_power_of_2(int(.)) changes: a port that is 1e-4 off must still take the same branch
+    edges = np.asarray([2.0 ** e + 1.0 for e in range(5, 14)])
+    margin = float(np.min(np.abs(6.0 * np.asarray(lam[:-1])[:, None] - edges[None, :]) / (6.0 * np.asarray(lam[:-1])[:, None])))
+    if crossings < 2 or margin <= 2.5e-4:
+        return None                                  # never crossed both ways, or a step too close to a boundary to pin with a 1e-4 tolerance
+    return dict(lam=np.asarray(lam, dtype=np.float64), n_fft=nfft, dlam=np.asarray(dlam, dtype=np.float64), crossings=np.int64(crossings),
+                margin=np.float64(margin), **{k: np.float64(v) for k, v in cfg.items()})
+
+
 def main(argv):
     models, tf = import_reference()
     if len(argv) == 1 or "net_keys" in argv:
@@ -271,7 +310,7 @@ def main(argv):
         argv = [a for a in argv if a != "net_keys"]
         if len(argv) == 1 and "net_keys" in sys.argv:
             return
-    names = argv[1:] or [c["name"] for c in C.CASES] + ["g7_dspec", "g7_dspec_100", "g7_dspec_xgrad", "g7_dspec_xgrad_100"] + ["g8_fbgrad_" + n for n in FBGRAD_CASES] + ["g9_panns"] + ["g10_xgrad_" + n for n in XGRAD_CASES] + ["g11_nets"]
+    names = argv[1:] or [c["name"] for c in C.CASES] + ["g7_dspec", "g7_dspec_100", "g7_dspec_xgrad", "g7_dspec_xgrad_100"] + ["g8_fbgrad_" + n for n in FBGRAD_CASES] + ["g9_panns"] + ["g10_xgrad_" + n for n in XGRAD_CASES] + ["g11_nets"] + list(TRAJ)
     for name in names:
         if name == "g7_dspec":
             out = run_dspec(models, tf)
@@ -287,6 +326,14 @@ def main(argv):
             out = run_panns(models)
         elif name == "g11_nets":
             out = run_nets(models)
+        elif name in TRAJ:
+            # the first start on a fixed grid whose trajectory crosses both ways and keeps every step 2.5e-4 (relative) clear of a boundary
+            for d in range(40):
+                cfg = dict(TRAJ[name]); cfg["lam0"] = round(cfg["lam0"] + 0.013 * d, 4)
+                out = run_trajectory(models, tf, cfg)
+                if out is not None:
+                    break
+            assert out is not None, "no start on the grid gives a pinnable trajectory"
         elif name.startswith("g8_fbgrad_"):
             out = run_fbgrad(models, tf, C.BY_NAME[name[len("g8_fbgrad_"):]])
         else:
