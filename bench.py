@@ -482,6 +482,41 @@ def main():
                                               "note": "INTEGRATION.md's training loop (train.py:25-49): a new batch every step through a device-side "
                                                       "copy into the graph's static input; side figure, never `value`"}
             del gs4
+            # loader_fed_slots (round 5): GraphedStep(inputs=[x], steps_per_replay=10) -- ten static slots per set, feed() copies the next
+            # batch on a side stream while the previous replay runs, one replay per ten batches; the same pool rotation
+            if chosen != "eager":
+                KS = 10
+                layer6 = MelSpectrogramLayer(torch.tensor(lam), n_mels=M, n_points=L, sample_rate=sr, hop_length=hop, device=str(dev),
+                                             optimized=True, log=True, out_dtype=act).to(dev)
+                opt6s = torch.optim.Adam([layer6.lambd], lr=ADAM_LR, fused=True, capturable=True)
+
+                def module_step6(xb):
+                    opt6s.zero_grad(set_to_none=True)
+                    layer6(xb).backward(g)
+                    opt6s.step()
+
+                for _ in range(3):
+                    module_step6(pool[0])
+                torch.cuda.synchronize()
+                gs6 = GraphedStep(module_step6, [layer6], max_ahead=MAX_AHEAD, steps_per_replay=KS, inputs=[pool[0]])
+                it6 = [0]
+
+                def fed_slot():
+                    gs6.feed(pool[it6[0] % POOL])
+                    it6[0] += 1
+
+                for _ in range((MAX_AHEAD + 4) * KS):
+                    fed_slot()
+                torch.cuda.synchronize()
+                nfs = 24 * KS
+                el6 = sorted(time_loop(fed_slot, KS if r == 0 else 0, nfs) for r in range(5))[2]
+                assert layer6.lambd_status()["error"] == 0
+                module_step_info["loader_fed_slots"] = {"ms_per_step": round(1e3 * el6 / nfs, 5), "frames_per_s": round(frames_per_rank * nfs / el6, 1),
+                                                        "steps_per_replay": KS, "steps": nfs, "pool_batches": POOL, "median_of": 5,
+                                                        "issued": "GraphedStep(inputs=[x], steps_per_replay=10).feed(batch): copies on a side stream under the previous replay, one replay per ten batches",
+                                                        "note": "the loop INTEGRATION.md documents since round 5 (train.py:25-49: a new batch every step); side figure, never `value`"}
+                gs6.close()
+                del gs6, layer6, opt6s
             # cold inputs, no copy: k steps per replay, step j of a replay reads pool[j]
             kc = k_chosen if chosen != "eager" else 1
             kc = max(kc, 20) if chosen != "eager" else 1

@@ -80,6 +80,32 @@ class _CudaBackend:
     def event(self):
         return self.torch.cuda.Event()
 
+    # -- input slots (GraphedStep(inputs=...)) ---------------------------------------------------------------------------------
+    def empty_like(self, t):
+        return self.torch.empty_like(t)
+
+    def copy_stream(self):
+        return self.torch.cuda.Stream(self.dev)
+
+    def copy_into(self, stream, dsts, srcs, after=None):
+        """dst.copy_(src) for every pair on `stream` (after the event `after`, if any); returns nothing: record_on() marks the end"""
+        t = self.torch
+        if after is not None:
+            stream.wait_event(after)
+        # (torch's own copy: a copy kernel of this package that fits into the registers the resident forward workgroups leave free
+        # -- 16 per lane, 512 workgroups -- measured SLOWER, 49.8 against 42.5 us per step at BASELINE config 2, round 5)
+        with t.cuda.stream(stream):
+            for d, s_ in zip(dsts, srcs):
+                d.copy_(s_, non_blocking=True)
+
+    def record_on(self, stream=None):
+        ev = self.torch.cuda.Event()
+        ev.record(stream if stream is not None else self.torch.cuda.current_stream(self.dev))
+        return ev
+
+    def wait_on_current(self, ev):
+        self.torch.cuda.current_stream(self.dev).wait_event(ev)
+
 
 class GraphedStep:
     """``gs = GraphedStep(step_fn, layers=[net.spectrogram_layer]); for batch in loader: x_static.copy_(batch); gs()``
@@ -91,17 +117,33 @@ class GraphedStep:
     whenever the graph has to be captured again -- run eagerly, after which the graph is captured for the calls that follow
     (capturing executes nothing).  ``warmup`` extra eager steps before the first capture are real steps too (default 0).
     With several ranks every rank must make the same calls in the same order (as any SPMD loop does); eager forwards through
-    the same layers between calls (a validation pass) are fine as long as every rank makes them."""
+    the same layers between calls (a validation pass) are fine as long as every rank makes them.
 
-    def __init__(self, step_fn, layers, max_ahead: int = 8, steps_per_replay: int = 1, warmup: int = 0, backend=None, decide=None):
+    **Input slots** (round 5; the loop of train.py:25-49 gets a NEW batch every step): ``GraphedStep(step_fn, layers,
+    steps_per_replay=K, inputs=[x_like, y_like])`` makes ``step_fn(x, y)`` take its batch as arguments and keeps two sets of K
+    static slots per input.  ``gs.feed(x, y)`` copies one batch into the next slot ON A SIDE STREAM -- while the replay of the
+    previous K batches runs -- and after every K-th batch joins that stream (an event) and replays the graph that reads the filled
+    set, so one graph launch serves K batches and the copies cost the step nothing (one replay per step plus a serial
+    ``x_static.copy_`` measured 52.5 us per step at BASELINE config 2, the slots 42.2, against 33 for a resident batch: the copies overlap the replay only in part -- the forward fills the register file of every CU, so a copy kernel runs between the forward launches).  The batches handed to
+    ``feed`` must be ready when it is called (tensors already resident, pinned host memory, or produced on ``gs.copy_stream``):
+    nothing on the current stream is waited for, or the copy would queue behind the running replay.  ``feed`` returns True when
+    it issued the K steps.  ``flush()`` runs a partly filled set eagerly (the end of an epoch)."""
+
+    def __init__(self, step_fn, layers, max_ahead: int = 8, steps_per_replay: int = 1, warmup: int = 0, backend=None, decide=None,
+                 inputs=None):
         self.step_fn, self.layers = step_fn, list(layers)
+        self.inputs = None if inputs is None else list(inputs)
+        self._slots, self._set, self._fill, self._copy_stream, self._set_free = None, 0, 0, None, [None, None]
         self.max_ahead, self.k, self.warmup = max(1, int(max_ahead)), int(steps_per_replay), int(warmup)
         self.backend = backend
         if decide is None:
             from . import capi
             decide = capi.decide_launch
         self._decide = decide
+        if self.inputs is not None and self.warmup:
+            raise ValueError("GraphedStep(inputs=...): warm-up steps would train on whatever the slots hold; run them yourself")
         self.graph = None
+        self._graphs = [None, None]                      # with input slots: one graph per slot set
         self._held_plans = []                            # raw handles retained for the life of the captured graph (include/dmel.h)
         self._ring_size = None
         self.captures, self.capture_calls, self.calls = 0, [], 0
@@ -142,15 +184,79 @@ class GraphedStep:
             self._expected_calls[id(plan)] = st["calls"]
         self._replays = 0
 
+    def _one_step(self, slot_set):
+        """a callable that runs the next step: step_fn() -- or, with input slots, step_fn(*slot j of `slot_set`), j = 0, 1, ... per call"""
+        if self.inputs is None:
+            return self.step_fn
+        ctr = [0]
+
+        def one():
+            self.step_fn(*self._slots[slot_set][ctr[0] % self.k])
+            ctr[0] += 1
+        return one
+
+    def _make_slots(self) -> None:
+        b = self.backend
+        self._slots = [[[b.empty_like(t) for t in self.inputs] for _ in range(self.k)] for _ in range(2)]
+        self._copy_stream = b.copy_stream()
+
+    @property
+    def copy_stream(self):
+        """the side stream feed() copies on (produce batches on it, or hand feed() tensors that are ready)"""
+        if self.backend is None:
+            self.backend = _CudaBackend()
+        if self.inputs is not None and self._slots is None:
+            self._make_slots()
+        return self._copy_stream
+
+    def feed(self, *batch) -> bool:
+        """one batch into the next slot (side stream); after the K-th: join, then the K steps (one replay).  True when they were issued."""
+        if self.inputs is None:
+            raise ValueError("feed() needs GraphedStep(inputs=[...])")
+        if len(batch) != len(self.inputs):
+            raise ValueError(f"feed() takes {len(self.inputs)} tensors")
+        b = self.backend
+        if b is None:
+            b = self.backend = _CudaBackend()
+        if self._slots is None:
+            self._make_slots()
+        s, j = self._set, self._fill
+        # the first copy into a set waits until the replay that last read that set has finished; the others follow it in stream order
+        b.copy_into(self._copy_stream, self._slots[s][j], batch, after=self._set_free[s] if j == 0 else None)
+        self._fill = j + 1
+        if self._fill < self.k:
+            return False
+        b.wait_on_current(b.record_on(self._copy_stream))
+        self._fill = 0
+        self()                                           # the K steps on set s (replayed, or eager + capture)
+        self._set_free[s] = b.record_on()
+        self._set = s ^ 1
+        return True
+
+    def flush(self) -> int:
+        """runs the batches of a partly filled set eagerly (no graph holds fewer than K steps); returns how many"""
+        n, self._fill = self._fill, 0
+        if n == 0 or self.inputs is None:
+            return 0
+        b = self.backend
+        b.wait_on_current(b.record_on(self._copy_stream))
+        for j in range(n):
+            self.step_fn(*self._slots[self._set][j])
+        b.synchronize()                                  # eager forwards the graph did not issue: the next call takes an exact picture
+        self._set_free[self._set] = None
+        return n
+
     def _capture(self) -> None:
         b = self.backend
         if b is None:
             b = self.backend = _CudaBackend()
+        if self.inputs is not None and self._slots is None:
+            self._make_slots()
         b.synchronize()
         first = self.graph is None
         before = {id(p): p.lambd_status() for p in self._plans()}
         n_eager = self.k + (self.warmup if first else 0)
-        b.run_eager(self.step_fn, n_eager)               # this call's steps (and what capture needs warm)
+        b.run_eager(self._one_step(self._set), n_eager)  # this call's steps (and what capture needs warm)
         b.synchronize()
         plans = self._plans()                            # plans are created by the first forward
         per = {}
@@ -188,7 +294,11 @@ class GraphedStep:
             tr.held = tr.want(self._horizon(tr))
             plan.force_launch(*tr.held)                  # the graph holds exactly these launches, on every rank
         try:
-            self.graph = b.capture(self.step_fn, self.k)
+            if self.inputs is None:
+                self.graph = b.capture(self.step_fn, self.k)
+            else:                                        # one graph per slot set: they differ in the addresses their steps read
+                self._graphs = [b.capture(self._one_step(0), self.k), b.capture(self._one_step(1), self.k)]
+                self.graph = self._graphs[0]
         finally:
             for plan in plans:
                 plan.force_launch(0, 0)
@@ -238,7 +348,7 @@ class GraphedStep:
                 self._rebase()
             if any(self._tracker(p).want(self._horizon(self._tracker(p))) != self._tracker(p).held for p in plans):
                 return self._capture()
-        self.graph.replay()
+        (self.graph if self.inputs is None else self._graphs[self._set]).replay()
         self._ring[self._replays % len(self._ring)].record()
         self._replays += 1
 
@@ -257,6 +367,7 @@ class GraphedStep:
         if self.graph is not None and self.backend is not None:
             self.backend.synchronize()
         self.graph = None
+        self._graphs = [None, None]
         self._release_held()
 
     def __del__(self):

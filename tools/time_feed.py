@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Host time against device time of GraphedStep.feed() at BASELINE config 2 (K batches per replay from a pool > 256 MiB).
+usage: python tools/time_feed.py [K]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import dmel_amd
+from dmel_amd import GraphedStep, MelSpectrogramLayer, synth
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+B, L, sr, lam, hop, M = 256, 16000, 16000, 128.0, 512, 128
+dev = "cuda:0"
+POOL = 24
+pool = [torch.from_numpy(synth.waveforms(B, L, seed=1000 + i)).to(dev) for i in range(POOL)]
+g = torch.from_numpy(synth.cotangent((B, 1, M, L // hop + 1), seed=1)).to(dev)
+layer = MelSpectrogramLayer(torch.tensor(lam), n_mels=M, n_points=L, sample_rate=sr, hop_length=hop, device=dev, optimized=True, log=True).to(dev)
+opt = torch.optim.Adam([layer.lambd], lr=1e-9, fused=True, capturable=True)
+def step(xb):
+    opt.zero_grad(set_to_none=True); layer(xb).backward(g); opt.step()
+gs = GraphedStep(step, [layer], steps_per_replay=K, inputs=[pool[0]])
+it = [0]
+def fed():
+    gs.feed(pool[it[0] % POOL]); it[0] += 1
+for _ in range(12 * K): fed()
+torch.cuda.synchronize()
+n = 24 * K
+for rep in range(3):
+    t0 = time.perf_counter()
+    for _ in range(n): fed()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f"K={K}: host {1e6*(t1-t0)/n:.1f} us per feed, wall {1e6*(t2-t0)/n:.1f} us per step")
