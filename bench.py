@@ -642,6 +642,39 @@ def main():
             del fn2, opt2, layer2
         except Exception as e:                                          # noqa: BLE001
             module_step_info["with_lambd_adam"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+        # ... and with that update applied by the workgroup that finishes the backward's dot product (LambdAdam(fused_into_backward=layer),
+        # dmel_plan_attach_adam): the step is two launches -- fused forward, dot
+        try:
+            from dmel_amd import LambdAdam
+            layer2f = MelSpectrogramLayer(torch.tensor(lam), n_mels=M, n_points=L, sample_rate=sr, hop_length=hop, device=str(dev),
+                                          optimized=True, log=True, out_dtype=act).to(dev)
+            layer2f(x)
+            opt2f = LambdAdam([layer2f.lambd], lr=ADAM_LR, fused_into_backward=layer2f)
+
+            def module_step2f():
+                opt2f.zero_grad(set_to_none=True)
+                layer2f(x).backward(g)
+                opt2f.step()
+
+            for _ in range(3):
+                module_step2f()
+            torch.cuda.synchronize()
+            fn2f = module_step2f
+            if chosen != "eager":
+                fn2f = GraphedStep(module_step2f, [layer2f], max_ahead=MAX_AHEAD, steps_per_replay=k_chosen)
+                for _ in range(MAX_AHEAD + 4):
+                    fn2f()
+                torch.cuda.synchronize()
+            n2f = max(200, 50 * k_chosen)
+            el2f = min(time_loop(fn2f, 8, n2f // k_chosen), time_loop(fn2f, 0, n2f // k_chosen))
+            assert layer2f.lambd_status()["error"] == 0 and float(opt2f.state[layer2f.lambd]["step"]) > 0
+            module_step_info["with_lambd_adam_fused"] = {"ms_per_step": round(1e3 * el2f / n2f, 5), "frames_per_s": round(frames_per_rank * n2f / el2f, 1),
+                                                         "steps": n2f, "issued": chosen, "lambd_end": round(float(layer2f.lambd.detach()), 4),
+                                                         "note": "opt-in LambdAdam(fused_into_backward=layer): Adam's update of lambd applied in the tail of the "
+                                                                 "backward's dot kernel (two launches per step); a side figure, never `value`"}
+            del fn2f, opt2f, layer2f
+        except Exception as e:                                          # noqa: BLE001
+            module_step_info["with_lambd_adam_fused"] = {"error": f"{type(e).__name__}: {e}"[:200]}
 
     # ---- side figure, never `value`: BASELINE config 2 read literally ("bf16 activations / fp32 grad"): the log-mel output stored
     # as bf16 and its gradient read as bf16 (arithmetic, tangent and d lambd stay fp32), issued the way the headline was

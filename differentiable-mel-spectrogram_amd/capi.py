@@ -39,7 +39,7 @@ SYMBOLS = (
     "dmel_plan_lambd_status", "dmel_plan_set_tracking", "dmel_plan_lambd_reset",
     "dmel_plan_retain", "dmel_plan_release", "dmel_plan_lambd_report", "dmel_decide_launch", "dmel_plan_force_launch",
     "dmel_adam_step", "dmel_mailbox_create", "dmel_mailbox_connect", "dmel_mailbox_destroy", "dmel_mailbox_allreduce", "dmel_mailbox_error",
-    "dmel_mailbox_set_spin_limit", "dmel_mailbox_set_timeout_ms", "dmel_plan_is_live", "dmel_lambd_ring_size", "dmel_spectrogram_ex_dev", "dmel_forward_dev_fixed_spec", "dmel_backward_fb_saved", "dmel_backward_fb_saved_dl", "dmel_backward_x_dev", "dmel_backward_x_spec_dev", "dmel_plan_attach_mailbox", "dmel_backward_x_spec",
+    "dmel_mailbox_set_spin_limit", "dmel_mailbox_set_timeout_ms", "dmel_plan_is_live", "dmel_lambd_ring_size", "dmel_spectrogram_ex_dev", "dmel_forward_dev_fixed_spec", "dmel_backward_fb_saved", "dmel_backward_fb_saved_dl", "dmel_backward_x_dev", "dmel_backward_x_spec_dev", "dmel_plan_attach_mailbox", "dmel_backward_x_spec", "dmel_plan_attach_adam",
 )
 TORCH_LIB_PATH = os.path.join(_PKG_DIR, "libdmel_torch.so")
 
@@ -181,6 +181,8 @@ def load():
     L.dmel_mailbox_destroy.restype = C.c_int
     L.dmel_adam_step.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, vp]
     L.dmel_adam_step.restype = C.c_int
+    L.dmel_plan_attach_adam.argtypes = [vp, vp, vp, vp, vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32]
+    L.dmel_plan_attach_adam.restype = C.c_int
     L.dmel_mailbox_allreduce.argtypes = [vp, vp, vp]
     L.dmel_mailbox_allreduce.restype = C.c_int
     L.dmel_mailbox_error.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]
@@ -428,6 +430,14 @@ class Plan:
         """dmel_plan_attach_mailbox: backward() on this plan returns the sum over the mailbox's ranks (None detaches)."""
         _check(load().dmel_plan_attach_mailbox(self._h, mailbox._h if mailbox is not None else None))
         self._mailbox = mailbox                       # keep it alive as long as the plan points at it
+
+    def attach_adam(self, param_ptr, exp_avg_ptr=0, exp_avg_sq_ptr=0, step_ptr=0, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8,
+                    weight_decay=0.0, maximize=False):
+        """dmel_plan_attach_adam: every backward() on this plan ends with Adam's update of the fp32 device scalar at ``param_ptr`` by the
+        gradient it has just written (``param_ptr`` = 0 / None detaches)."""
+        _check(load().dmel_plan_attach_adam(self._h, param_ptr or None, exp_avg_ptr or None, exp_avg_sq_ptr or None, step_ptr or None,
+                                            C.c_double(float(lr)), C.c_double(float(beta1)), C.c_double(float(beta2)), C.c_double(float(eps)),
+                                            C.c_double(float(weight_decay)), 1 if maximize else 0))
 
     def force_launch(self, n_fft_: int = 0, guards: int = 0):
         """dmel_plan_force_launch: the caller chooses the launches of dmel_forward_dev (n_fft_ = 0: automatic again)."""

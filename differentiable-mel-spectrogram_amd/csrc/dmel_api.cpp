@@ -140,6 +140,7 @@ struct dmel_plan {
     int last_guards = 0;           // bit 0: n_fft/2 launched, bit 1: 2 n_fft launched (most recent call)
     int refs = 1;                  // dmel_plan_retain / dmel_plan_release (guarded by g_plans_mu)
     dmel_mailbox* mailbox = nullptr;    // dmel_plan_attach_mailbox: the backward's result is the sum over the mailbox's ranks
+    dmel::AdamParams fused_adam{};      // dmel_plan_attach_adam: param != nullptr -> the backward's dot kernel applies this update
     std::mutex mu;
     dmel_plan_info info{};
     // optional event timing
@@ -1580,8 +1581,26 @@ dmel_status dmel_backward_scratch(dmel_plan* plan, const void* grad_out, int32_t
     if (use_mb) { dmel_status ms = mailbox_status(plan); if (ms != DMEL_OK) return ms; }
     const size_t m0 = prof_mark(plan, s);
     DMEL_HIP(dmel::launch_dot(grad_out, grad_dtype == DMEL_DTYPE_BF16, tangent, (long long)count, accumulate, sc.partials,
-                              sc.counter, kMaxPartials, dlambd, s, use_mb ? &mba : nullptr));
+                              sc.counter, kMaxPartials, dlambd, s, use_mb ? &mba : nullptr, plan->fused_adam.param ? &plan->fused_adam : nullptr));
     prof_span(plan, m0, prof_mark(plan, s), 2);
+    return DMEL_OK;
+}
+
+dmel_status dmel_plan_attach_adam(dmel_plan* plan, float* param, float* exp_avg, float* exp_avg_sq, float* step,
+                                  double lr, double beta1, double beta2, double eps, double weight_decay, int32_t maximize)
+{
+    if (!plan) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
+    std::lock_guard<std::mutex> lock(plan->mu);
+    if (!param) { plan->fused_adam = dmel::AdamParams{}; return DMEL_OK; }
+    if (!exp_avg || !exp_avg_sq || !step) return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_plan_attach_adam: NULL state pointer");
+    if (!(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0) || !std::isfinite(lr) || !(lr >= 0.0) ||
+        !std::isfinite(weight_decay) || !(weight_decay >= 0.0))
+        return fail(DMEL_ERR_INVALID_ARGUMENT, "dmel_plan_attach_adam: lr / betas / eps / weight_decay out of range");
+    dmel::AdamParams ap{};
+    ap.param = param; ap.grad = nullptr; ap.exp_avg = exp_avg; ap.exp_avg_sq = exp_avg_sq; ap.step = step; ap.ticket = nullptr;
+    ap.n = 1; ap.maximize = maximize ? 1 : 0;
+    ap.lr = lr; ap.beta1 = beta1; ap.beta2 = beta2; ap.eps = eps; ap.weight_decay = weight_decay;
+    plan->fused_adam = ap;
     return DMEL_OK;
 }
 

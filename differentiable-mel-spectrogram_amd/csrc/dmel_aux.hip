@@ -47,6 +47,33 @@ __device__ __forceinline__ double block_sum(double v, double* red4)
     return s;
 }
 
+// the constants of one update (shared by dmel_adam_kernel and the fused tail of dmel_dot_kernel: the same arithmetic, the same bits)
+struct AdamConsts { float step, step_size, bc2_sqrt, omb1, omb2, b2, wd, eps; int maximize; };
+__device__ __forceinline__ AdamConsts adam_consts(const AdamParams& p, float old_step)
+{
+    AdamConsts c;
+    c.step = old_step + 1.0f;
+    // the hyper-parameters are doubles, as torch passes them to its kernel: 1 - beta is formed in fp64 (in fp32 1 - 0.999f is off by
+    // 5e-5 of itself, which the second moment would carry), the state stays fp32
+    const float bc1 = (float)(1.0 - pow(p.beta1, (double)c.step)), bc2 = (float)(1.0 - pow(p.beta2, (double)c.step));
+    c.step_size = (float)(p.lr / (double)bc1); c.bc2_sqrt = sqrtf(bc2);
+    c.omb1 = (float)(1.0 - p.beta1); c.omb2 = (float)(1.0 - p.beta2); c.b2 = (float)p.beta2; c.wd = (float)p.weight_decay; c.eps = (float)p.eps;
+    c.maximize = p.maximize;
+    return c;
+}
+__device__ __forceinline__ void adam_update(const AdamParams& p, const AdamConsts& c, long long i, float g)
+{
+    const float w = p.param[i];
+    if (c.maximize) g = -g;
+    if (c.wd != 0.f) g = fmaf(w, c.wd, g);
+    float m = p.exp_avg[i], v = p.exp_avg_sq[i];
+    m = fmaf(c.omb1, g - m, m);                                  // lerp(m, g, 1 - beta1)
+    v = fmaf(c.b2, v, c.omb2 * g * g);
+    const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
+    p.param[i] = w - c.step_size * m / denom;
+    p.exp_avg[i] = m; p.exp_avg_sq[i] = v;
+}
+
 // four consecutive gradient elements as fp32: one 16-byte load (fp32) or one 8-byte load (bf16, exact widening)
 template <bool GBF16> __device__ __forceinline__ float4 load_g4(const void* g, long long i)
 {
@@ -107,10 +134,13 @@ hipError_t launch_mailbox_allreduce(float* buf, const MailboxArgs& mb, hipStream
     return hipGetLastError();
 }
 
+// `adam.param != nullptr` (dmel_plan_attach_adam): the workgroup that draws the last ticket also applies Adam's update of the ONE parameter
+// this gradient belongs to (lambd) -- dmel_adam_kernel's arithmetic on the value it has just written --, so a step whose only
+// trainable parameter of the layer is lambd needs no optimizer launch at all
 template <bool GBF16, bool MBOX>
 __global__ void __launch_bounds__(kDotThreads) dmel_dot_kernel(const void* __restrict__ g, const float* __restrict__ t,
                                                             long long count, double* partials, unsigned* counter,
-                                                            int accumulate, float* result, MailboxArgs mb)
+                                                            int accumulate, float* result, MailboxArgs mb, AdamParams adam)
 {
     __shared__ double red4[kDotThreads / 16], red4b[kDotThreads / 16];
     __shared__ int is_last;
@@ -157,6 +187,11 @@ __global__ void __launch_bounds__(kDotThreads) dmel_dot_kernel(const void* __res
         } else {
             result[0] = accumulate ? (float)((double)result[0] + total) : (float)total;
         }
+        if (adam.param) {
+            const AdamConsts c = adam_consts(adam, *adam.step);
+            adam_update(adam, c, 0, result[0]);
+            *adam.step = c.step;
+        }
     }
 }
 
@@ -169,17 +204,19 @@ int dot_blocks_for(long long count, int max_partials)
 }
 
 hipError_t launch_dot(const void* g, int g_bf16, const float* t, long long count, int accumulate, double* partials,
-                      unsigned* counter, int max_partials, float* result, hipStream_t s, const MailboxArgs* mb)
+                      unsigned* counter, int max_partials, float* result, hipStream_t s, const MailboxArgs* mb, const AdamParams* fused)
 {
     const int blocks = dot_blocks_for(count, max_partials);
     const MailboxArgs none{};
+    AdamParams adam{};
+    if (fused) adam = *fused;
     const dim3 gr(blocks), bl(kDotThreads);
     if (mb) {
-        if (g_bf16) hipLaunchKernelGGL((dmel_dot_kernel<true, true>), gr, bl, 0, s, g, t, count, partials, counter, accumulate, result, *mb);
-        else hipLaunchKernelGGL((dmel_dot_kernel<false, true>), gr, bl, 0, s, g, t, count, partials, counter, accumulate, result, *mb);
+        if (g_bf16) hipLaunchKernelGGL((dmel_dot_kernel<true, true>), gr, bl, 0, s, g, t, count, partials, counter, accumulate, result, *mb, adam);
+        else hipLaunchKernelGGL((dmel_dot_kernel<false, true>), gr, bl, 0, s, g, t, count, partials, counter, accumulate, result, *mb, adam);
     } else {
-        if (g_bf16) hipLaunchKernelGGL((dmel_dot_kernel<true, false>), gr, bl, 0, s, g, t, count, partials, counter, accumulate, result, none);
-        else hipLaunchKernelGGL((dmel_dot_kernel<false, false>), gr, bl, 0, s, g, t, count, partials, counter, accumulate, result, none);
+        if (g_bf16) hipLaunchKernelGGL((dmel_dot_kernel<true, false>), gr, bl, 0, s, g, t, count, partials, counter, accumulate, result, none, adam);
+        else hipLaunchKernelGGL((dmel_dot_kernel<false, false>), gr, bl, 0, s, g, t, count, partials, counter, accumulate, result, none, adam);
     }
     return hipGetLastError();
 }
@@ -387,25 +424,10 @@ hipError_t launch_naive(const NaiveParams& p, hipStream_t s)
 constexpr int kAdamPerThread = 4;
 __global__ void __launch_bounds__(256) dmel_adam_kernel(AdamParams p)
 {
-    const float step = __hip_atomic_load(p.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1.0f;
-    // the hyper-parameters are doubles, as torch passes them to its kernel: 1 - beta is formed in fp64 (in fp32 1 - 0.999f is off by
-    // 5e-5 of itself, which the second moment would carry), the state stays fp32
-    const float bc1 = (float)(1.0 - pow(p.beta1, (double)step)), bc2 = (float)(1.0 - pow(p.beta2, (double)step));
-    const float step_size = (float)(p.lr / (double)bc1), bc2_sqrt = sqrtf(bc2);
-    const float omb1 = (float)(1.0 - p.beta1), omb2 = (float)(1.0 - p.beta2), b2 = (float)p.beta2, wd = (float)p.weight_decay, eps = (float)p.eps;
+    const AdamConsts c = adam_consts(p, __hip_atomic_load(p.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const float step = c.step;
     const long long stride = 256LL * gridDim.x;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.n; i += stride) {
-        float g = p.grad[i];
-        const float w = p.param[i];
-        if (p.maximize) g = -g;
-        if (wd != 0.f) g = fmaf(w, wd, g);
-        float m = p.exp_avg[i], v = p.exp_avg_sq[i];
-        m = fmaf(omb1, g - m, m);                                  // lerp(m, g, 1 - beta1)
-        v = fmaf(b2, v, omb2 * g * g);
-        const float denom = sqrtf(v) / bc2_sqrt + eps;
-        p.param[i] = w - step_size * m / denom;
-        p.exp_avg[i] = m; p.exp_avg_sq[i] = v;
-    }
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.n; i += stride) adam_update(p, c, i, p.grad[i]);
     __syncthreads();                                               // every thread of this workgroup holds the old count
     if (threadIdx.x == 0) {
         // (relaxed: the ticket orders nothing but itself -- every workgroup's read of the count is complete before its ticket is

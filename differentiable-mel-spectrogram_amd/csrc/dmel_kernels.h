@@ -490,8 +490,10 @@ struct MailboxArgs {
 
 // g: fp32, or bf16 when g_bf16 != 0 (the gradient of a bf16 output); t (the tangent) is always fp32
 // mb != nullptr: the result is the SUM over all ranks of the mailbox (dmel_comm.cpp)
+// fused != nullptr: the last workgroup applies that Adam update (n = 1) with the gradient it has just written (dmel_plan_attach_adam)
 hipError_t launch_dot(const void* g, int g_bf16, const float* t, long long count, int accumulate, double* partials,
-                      unsigned* counter, int max_partials, float* result, hipStream_t s, const MailboxArgs* mb = nullptr);
+                      unsigned* counter, int max_partials, float* result, hipStream_t s, const MailboxArgs* mb = nullptr,
+                      const AdamParams* fused = nullptr);
 // the same exchange for a value that is already in memory (one wave): buf[0] = sum over ranks of buf[0]
 hipError_t launch_mailbox_allreduce(float* buf, const MailboxArgs& mb, hipStream_t s);
 

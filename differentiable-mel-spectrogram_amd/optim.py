@@ -9,6 +9,12 @@ keeps its own optimizer; ``torch.optim.Adam`` on ``lambd`` keeps working and is 
     opt_model = torch.optim.Adam(net.model_parameters(), lr=lr_model)
     opt_tf = dmel_amd.LambdAdam([net.spectrogram_layer.lambd], lr=lr_tf)
 
+``LambdAdam([layer.lambd], lr=lr_tf, fused_into_backward=layer)`` (round 5) goes one step further: the update of ``lambd`` is applied by
+the workgroup that finishes the backward's dot product (``dmel_plan_attach_adam``: the same arithmetic on the gradient it has just
+written), and ``step()`` launches nothing for that parameter -- the step of train.py:47-49 is then forward kernel + dot kernel.  For
+steps with ONE backward per update whose only gradient of the layer is ``lambd.grad`` (no trainable filterbank, no waveform gradient,
+no gradient accumulation, no all-reduce of ``lambd.grad`` outside the layer's mailbox).
+
 ``lr`` is passed by value at every ``step()``: a HIP graph captured around the step holds the value of the capture (as with
 torch's capturable Adam and a Python-float lr), so re-capture when a scheduler changes it.
 """
@@ -22,9 +28,12 @@ from . import capi
 class LambdAdam(torch.optim.Optimizer):
     """torch.optim.Adam (no amsgrad) for the layer's fp32 CUDA parameters (lambd, the trainable filterbank), one launch per parameter."""
 
-    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0, maximize: bool = False):
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0, maximize: bool = False,
+                 fused_into_backward=None):
         if lr < 0.0 or eps < 0.0 or not (0.0 <= betas[0] < 1.0) or not (0.0 <= betas[1] < 1.0) or weight_decay < 0.0:
             raise ValueError("LambdAdam: lr / betas / eps / weight_decay out of range")
+        self._fused_layer = fused_into_backward
+        self._fused_plans = []
         # capturable=True: torch's Optimizer.load_state_dict then moves state["step"] to the parameter's device as fp32 (its
         # _process_value_according_to_param_policy); without the key a checkpoint loaded with map_location="cpu" left the step count
         # on the host and step() handed a host pointer to the kernel (ADVICE r03)
@@ -34,6 +43,38 @@ class LambdAdam(torch.optim.Optimizer):
             for p in group["params"]:
                 if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous():
                     raise ValueError("LambdAdam takes contiguous fp32 CUDA parameters (the layer's lambd and mel_fb); use torch.optim for the rest")
+
+        if self._fused_layer is not None:
+            lay = self._fused_layer
+            if getattr(lay, "learnable_fb", False) or getattr(lay, "lambd_sync", False):
+                raise ValueError("LambdAdam(fused_into_backward=layer): the layer's only parameter must be lambd, kept on the device (lambd_sync=False)")
+            ps = [p for g in self.param_groups for p in g["params"]]
+            if len(ps) != 1 or ps[0] is not lay.lambd or ps[0].numel() != 1:
+                raise ValueError("LambdAdam(fused_into_backward=layer) takes exactly [layer.lambd]")
+
+    def _attach(self):
+        """(re-)attaches the update to the layer's plans with the current hyper-parameters: plans appear with the first forward on a device"""
+        lay, group = self._fused_layer, self.param_groups[0]
+        p = group["params"][0]
+        st = self._checked_state(p)
+        plans = list(lay._plans.values())
+        b1, b2 = group["betas"]
+        for plan in plans:
+            plan.attach_adam(p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr(), group["lr"], b1, b2,
+                             group["eps"], group["weight_decay"], group["maximize"])
+        self._fused_plans = plans
+
+    def detach(self):
+        """stops the fused update (the plans go back to writing the gradient only)"""
+        for plan in self._fused_plans:
+            plan.attach_adam(0)
+        self._fused_plans, self._fused_layer = [], None
+
+    def zero_grad(self, set_to_none: bool = True):
+        # the natural place before every backward: hyper-parameters changed by a scheduler, plans created since, state loaded from a checkpoint
+        if self._fused_layer is not None:
+            self._attach()
+        return super().zero_grad(set_to_none=set_to_none)
 
     def _ticket(self, p):
         t = self._tickets.get(id(p))
@@ -70,6 +111,10 @@ class LambdAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if self._fused_layer is not None:
+            if not self._fused_plans:
+                raise RuntimeError("LambdAdam(fused_into_backward=layer): call zero_grad() before the backward (it attaches the update to the layer's plans)")
+            return loss                                  # the backward's dot kernel has applied the update
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:

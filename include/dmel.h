@@ -410,6 +410,16 @@ dmel_status dmel_plan_attach_mailbox(dmel_plan* plan, dmel_mailbox* mb);
 dmel_status dmel_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* step, uint32_t* ticket, int64_t n,
                            double lr, double beta1, double beta2, double eps, double weight_decay, int32_t maximize, void* stream);
 
+/* Adam fused into the backward (round 5; opt-in).  While attached, every dmel_backward / dmel_backward_ex / dmel_backward_scratch on
+ * the plan ends with dmel_adam_step's update of ONE fp32 device scalar -- `param`, i.e. lambd -- by the gradient the call has just
+ * written to `dlambd` (after the mailbox all-reduce, if one is attached): the workgroup that finishes the dot product applies it, so
+ * the step of train.py:47-49 needs no optimizer launch for lambd.  Same arithmetic and state (exp_avg, exp_avg_sq, step: device
+ * floats, as dmel_adam_step) bit for bit.  Meant for steps with one backward per update and no other gradient of the layer read
+ * after it (no trainable filterbank, no waveform gradient: their kernels read lambd).  param == NULL detaches.  The pointers must
+ * stay valid while attached; the hyper-parameters are taken by value at every call (a captured graph holds those of its capture). */
+dmel_status dmel_plan_attach_adam(dmel_plan* plan, float* param, float* exp_avg, float* exp_avg_sq, float* step,
+                                  double lr, double beta1, double beta2, double eps, double weight_decay, int32_t maximize);
+
 /* Introspection for tests / benchmarks */
 typedef struct dmel_plan_info {
     int32_t n_fft;             /* of the most recent forward                                */

@@ -126,3 +126,55 @@ def test_lambd_adam_state_dict_round_trip_through_the_cpu():
     c.grad = torch.tensor(1.0, device=DEV); oc.step()
     torch.cuda.synchronize()
     assert float(oc.state[c]["step"]) == 2.0 and oc.state[c]["step"].is_cuda and "ticket" not in oc.state[c]
+
+
+def test_adam_fused_into_the_backward_is_lambd_adam_bit_for_bit():
+    """LambdAdam(fused_into_backward=layer): the workgroup that finishes the backward's dot product applies the update itself
+    (dmel_plan_attach_adam) -- the same arithmetic as dmel_adam_step on the gradient it has just written, so lambd, both moments and
+    the step count follow the one-launch optimizer bit for bit, eagerly and replayed from a HIP graph; step() launches nothing."""
+    from dmel_amd import LambdAdam, MelSpectrogramLayer
+    case = C.BY_NAME["g1_c1"]
+    x = torch.from_numpy(C.make_input(case)).to(DEV)
+    g = torch.from_numpy(C.make_cotangent(case)).to(DEV)
+
+    def mk():
+        return MelSpectrogramLayer(torch.tensor(float(case["lambd"])), n_mels=case["n_mels"], n_points=case["L"], sample_rate=case["sr"],
+                                   hop_length=case["hop"], device=DEV, optimized=True, log=True).to(DEV)
+
+    la, lb = mk(), mk()
+    la(x); lb(x)                                               # the plans exist from the first forward on
+    oa = LambdAdam([la.lambd], lr=0.05, weight_decay=0.01, fused_into_backward=la)
+    ob = LambdAdam([lb.lambd], lr=0.05, weight_decay=0.01)
+
+    def step(lay, o):
+        o.zero_grad(set_to_none=True)
+        (lay(x) * g).sum().backward()
+        o.step()
+
+    hist = []
+    for _ in range(3):
+        step(la, oa); step(lb, ob)
+        hist.append((la.lambd.detach().clone(), lb.lambd.detach().clone()))
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        step(la, oa)
+    for _ in range(10):
+        gr.replay()
+        step(lb, ob)
+        hist.append((la.lambd.detach().clone(), lb.lambd.detach().clone()))
+    torch.cuda.synchronize()
+    for a, b in hist:
+        assert torch.equal(a, b), (float(a), float(b))
+    assert float(la.lambd.detach()) != float(case["lambd"])
+    for key in ("exp_avg", "exp_avg_sq", "step"):
+        assert torch.equal(oa.state[la.lambd][key], ob.state[lb.lambd][key]), key
+    # the gradient is still delivered (AccumulateGrad runs behind the op), and detaching gives the plain backward back
+    assert la.lambd.grad is not None and torch.isfinite(la.lambd.grad).all()
+    oa.detach()
+    before = la.lambd.detach().clone()
+    (la(x) * g).sum().backward()
+    torch.cuda.synchronize()
+    assert torch.equal(la.lambd.detach(), before)
+    with pytest.raises(ValueError):
+        LambdAdam([lb.lambd], lr=0.05, fused_into_backward=la)           # not that layer's parameter
