@@ -308,6 +308,18 @@ def main():
         else:
             sar = ddist.ScalarAllReduce()
             reducer = "RCCL ncclAllReduce in the step's stream (" + ("native dmel_comm" if sar.native else "torch.distributed: " + sar.why) + ")"
+    # proof that `world` ranks joined the reducer the step uses: a vector of ones summed through THAT path (the native RCCL
+    # communicator in the step's stream, or the mailbox) -- a rank that fell back, or a group of fewer ranks, shows here
+    ranks_seen = 1
+    if dist is not None:
+        probe = torch.ones(1, device=dev)
+        if sar is not None:
+            sar.reduce(probe, torch.cuda.current_stream(dev).cuda_stream)
+        else:
+            mar.reduce(probe, torch.cuda.current_stream(dev).cuda_stream)
+        torch.cuda.synchronize()
+        ranks_seen = int(round(float(probe)))
+        assert ranks_seen == world, f"the reducer summed {ranks_seen} ranks, the job has {world}"
     lam_param = layer.lambd
 
     def module_step():
@@ -816,6 +828,7 @@ def main():
                                f"(lambd {lam}), hop {hop}, n_mels {M}, log fused; step = nn.Module forward + backward to lambd.grad + Adam update of lambd"
                    if args.config == "c2" else f"{args.config}: batch {B} x {L} @ {sr}, lambd {lam}, hop {hop}, n_mels {M}",
                    "global_batch": B * world, "frames_per_step": frames_per_rank * world, "parallelism": par, "reducer": reducer,
+                   "rccl_ranks_seen": ranks_seen,
                    "launch": ("eager from Python: torch.ops.dmel.mel_spectrogram + autograd + optimizer.step()" if chosen == "eager" else
                               f"HIP graph captured from the nn.Module step (dmel_amd.GraphedStep), {modes[chosen][1]} step(s) per replay") +
                              "; lambd stays on the device, no host synchronisation inside the timed region"},
@@ -945,6 +958,11 @@ def other_configs(torch, capi, synth, dev, kernel_times):
         res["c5"]["train_step"] = c5_train_step(torch, synth, dev)
     except Exception as e:                                              # noqa: BLE001
         res["c5"]["train_step"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    # the paper's own model: MelPANNsNet / Cnn6 (models.py:138-166, panns.py:135-202) at the ESC-50 shape of search_spaces.py:4-33
+    try:
+        res["c5_panns"] = {"train_step": panns_train_step(torch, synth, dev)}
+    except Exception as e:                                              # noqa: BLE001
+        res["c5_panns"] = {"train_step": {"error": f"{type(e).__name__}: {e}"[:300]}}
     return res
 
 
@@ -1079,6 +1097,48 @@ def c5_train_step(torch, synth, dev, steps=8):
             "launches_per_step": {"prep": pr["prep_launches"] / steps, "forward": pr["fwd_launches"] / steps, "backward": pr["bwd_launches"] / steps},
             "note": "MelConvNet + CrossEntropy + Adam (lr_model 1e-4, lr_tf 1.0), batch 32; front end = HIP-event time of its kernels "
                     "(each event pair also brackets the launch packets)"}
+
+
+def panns_train_step(torch, synth, dev, steps=8):
+    """The model the paper trains on ESC-50 (search_spaces.py:7: MelPANNsNet = DMEL layer -> log -> Cnn6, models.py:138-166,
+    panns.py:135-202) at its own shape: 32 clips of 40 000 samples at 8 kHz, hop 80, 64 mel bands, init_lambd = 8000 x 0.3 / 6 = 400
+    (n_fft 4096), CrossEntropy, Adam with the two learning-rate groups of main.py:36-53; the front end's kernels isolated with the
+    library's HIP-event profiling, as in c5.train_step."""
+    from dmel_amd import nets, panns
+    B, L, sr, lam, hop, M, ncls = 32, 40000, 8000, 400.0, 80, 64, 50
+    torch.manual_seed(0)
+    net = panns.MelPANNsNet(ncls, torch.tensor(lam), str(dev), M, sr, L, hop_length=hop, optimized=True, energy_normalize=True).to(dev)
+    opt = nets.make_optimizer(net, lr_model=1e-4, lr_tf=1.0)
+    loss_fn = torch.nn.CrossEntropyLoss()
+    x = torch.from_numpy(synth.waveforms(B, L, seed=0)).to(dev)
+    y = (torch.arange(B, device=dev) * 7) % ncls
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        logits, _ = net(x)
+        loss_fn(logits, y).backward()
+        opt.step()
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    plan = net.spectrogram_layer._plan_for(torch.device(dev))
+    plan.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    pr = plan.get_profile()
+    plan.set_profiling(False)
+    front_ms = (pr["prep_ms"] + pr["fwd_ms"] + pr["bwd_ms"]) / steps
+    T = L // hop + 1
+    return {"step_ms": round(1e3 * dt, 3), "frontend_ms": round(front_ms, 4), "frontend_share": round(front_ms / (1e3 * dt), 4),
+            "frontend_frames_per_s": round(B * T / (front_ms * 1e-3), 1), "n_fft": int(plan.info()["n_fft"]),
+            "parameters": int(sum(p.numel() for p in net.parameters())),
+            "launches_per_step": {"prep": pr["prep_launches"] / steps, "forward": pr["fwd_launches"] / steps, "backward": pr["bwd_launches"] / steps},
+            "note": "MelPANNsNet (DMEL layer + log + Cnn6, 4.6 M parameters) + CrossEntropy + Adam (lr_model 1e-4, lr_tf 1.0), batch 32 x 40000 @ 8 kHz, "
+                    "hop 80, 64 mels, lambd 400 (n_fft 4096); eager steps; front end = HIP-event time of its kernels"}
 
 
 if __name__ == "__main__":

@@ -148,9 +148,9 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_ranks_exchange_through_ipc_mapped_inboxes(tmp_path, world):
-    """two and four ranks sharing the one GPU: both parity slots, a late rank (waited for), a dead rank (NaN + DMEL_ERR_MAILBOX_TIMEOUT
+    """two, four and eight ranks (config 4's world size) sharing the one GPU: both parity slots, a late rank (waited for), a dead rank (NaN + DMEL_ERR_MAILBOX_TIMEOUT
     at the next call), close() with a plan still attached"""
     port = _free_port()
     script = tmp_path / "worker.py"
