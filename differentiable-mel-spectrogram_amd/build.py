@@ -50,6 +50,15 @@ def _units():
             yield sp, os.path.join(OBJ_DIR, stem + ".o"), []
 
 
+def _reap(procs) -> None:
+    """ends the compiler processes this build started and still has running (their exact handles: nothing is matched by name)"""
+    for pr in procs:
+        if pr.poll() is None:
+            pr.kill()
+    for pr in procs:
+        pr.wait()
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = _hipcc()
@@ -63,10 +72,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 print(" ".join(cmd), flush=True)
             while len(running) >= jobs:
                 if running.pop(0).wait() != 0:
+                    _reap(running)
                     raise RuntimeError("hipcc failed")
             running.append(subprocess.Popen(cmd))
-    for pr in running:
-        if pr.wait() != 0:
+    while running:
+        if running.pop(0).wait() != 0:
+            _reap(running)                               # (the other compilers would run on, detached, for minutes: ADVICE r04)
             raise RuntimeError("hipcc failed")
     if force or _stale(LIB_PATH, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-ldl"]

@@ -355,7 +355,7 @@ dmel_status build_tables(dmel_plan* pl, int N, NfftTables** out)
                 first = first / 4 * 4;                       // groups of 4 k-steps start at multiples of 16 bins
                 first_of[tl] = first; units[tl] = (last - first + 1 + 3) / 4;
             }
-            if (waves == 8 || ntg <= waves) {
+            if (waves == 8 || (ntg <= waves && g < 32)) {         // (FwdParams::xch_groups is a 32-bit mask: groups beyond it keep whole tiles -- ADVICE r04)
                 // (4-wave plans, n_fft <= 512: only when every tile has a wave of its own -- up to 64 mels, the reference's experiments --
                 // since run 1 is then free to carry a piece; with more tiles wave w owns tiles w and 7 - w whole, as before)
                 // Wave tl owns tile tl (run 0: it writes the tile's outputs).  The HTK bands widen with frequency -- at 128 mels the last
@@ -381,7 +381,7 @@ dmel_status build_tables(dmel_plan* pl, int N, NfftTables** out)
                     tr.w |= 1 << 30;                                   // a piece: summed into its owner's tile, not written by this wave
                     ranges[(size_t)(g * W + pc.wave) * 2 + 1] = tr;
                 }
-                if (W != 8 && !pieces.empty() && g < 32) tb.xch_groups |= 1u << g;
+                if (W != 8 && !pieces.empty()) tb.xch_groups |= 1u << g;       // g < 32 here
             } else {
                 // 4 waves: wave w owns tiles w and 7-w whole
                 for (int tl = 0; tl < ntg; ++tl) {

@@ -442,6 +442,16 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
                     if (p.flags & 4u) reinterpret_cast<unsigned short*>(p.out)[o] = 0x7fc0u; else p.out[o] = qn;
                     if (p.tangent) p.tangent[o] = qn;
                 }
+                // ... and the saved spectrogram (B, F, T): the filterbank gradient contracts it before the next forward raises (ADVICE r04:
+                // with a linear output and a finite upstream gradient, uninitialised memory reached the optimizer)
+                if constexpr (TRAINLIKE) {
+                    if (p.spec_out) {
+                        for (int idx = tid; idx < F * FPT * TPW; idx += THREADS) {
+                            const int kk = idx / (FPT * TPW), t = tile0 * FPT + idx % (FPT * TPW);
+                            if (t < p.T) p.spec_out[((size_t)b * F + kk) * p.T + t] = qn;
+                        }
+                    }
+                }
             }
             return;
         }

@@ -1,4 +1,4 @@
-"""GPU soak tests: run-to-run determinism under load (tools/determinism_stress.py as a test) and the hand-off of the dot kernel.
+"""GPU soak tests: run-to-run determinism under load (round 3's tools/determinism_stress.py, now this test) and the hand-off of the dot kernel.
 
 The dot kernel's last-ticket hand-off (csrc/dmel_aux.hip: relaxed agent-scope store of the partial, `s_waitcnt vmcnt(0)`, relaxed
 ticket) follows the guide's recipe but sits outside HIP's formal memory model: it is covered here by
