@@ -795,21 +795,8 @@ def main():
     achieved = alg_bytes / (fwd_us * 1e-6) / 1e9
     # HBM-side bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read from inside the
     # process); the committed measurement is quoted only if it was taken on THIS kernel source, otherwise traffic is null
-    traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            import hashlib
-            tj = json.load(open(tpath))
-            src = open(os.path.join(ROOT, "differentiable-mel-spectrogram_amd", "csrc", "dmel_fwd.hip"), "rb").read()
-            sha = hashlib.sha256(src).hexdigest()[:16]
-            if tj.get("kernel_source_sha16") == sha:
-                traffic = tj.get(args.config, {}).get("dmel_fwd_kernel_bytes_per_launch")
-                traffic_src = f"profiles/hbm_traffic.json (rocprofv3 --pmc, dmel_fwd.hip sha16 {sha})"
-            else:
-                traffic_src = f"profiles/hbm_traffic.json was measured on another build of dmel_fwd.hip (have {sha}): not quoted"
-        except Exception:                                               # noqa: BLE001
-            traffic = None
+    quoted, traffic_src = profile_quotes()
+    traffic = quoted.get(args.config, {}).get("dmel_fwd_kernel_bytes_per_launch")
     # the contraction stage on the matrix cores: executed fp32 MFMA flops of one launch = non-zero 4x16 filterbank blocks
     # x 16-row tiles x 2048 flop per v_mfma_f32_16x16x4_f32, against the dense fp32 matrix peak
     mfma_flops = 2048.0 * info["fb_blocks"] * mfma_row_tiles(info, B, T) if info["kernel_path"] == 0 else 0.0
@@ -817,6 +804,9 @@ def main():
             "frac": round(mfma_flops / (fwd_us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
             "note": "banded filterbank: only the non-zero blocks are multiplied (dense would be fb_blocks_dense); the kernel is not MFMA-bound"}
     roofline = roofline_of(info, B, T, alg_bytes, fwd_us, mfma_flops)
+    # what binds: the vector pipe's instruction stream -- SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel cycles) and the
+    # vector instructions per wave, from the same PMC session as `traffic` (same source-sha rule)
+    roofline.update({"valu_busy": quoted.get(args.config, {}).get("valu_busy"), "valu_insts_per_wave": quoted.get(args.config, {}).get("valu_insts_per_wave")})
     roofline.update({"traffic": traffic, "traffic_source": traffic_src, "avg_launch_us_single_event_pair": round(fwd_pair_us, 2),
                      "other_kernels_us": {"prep": round(prep_us, 2), "backward_dot": round(bwd_us, 2)}, "mfma_stage": mfma})
 
@@ -847,6 +837,12 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_other_configs and args.config == "c2":
         result["other_configs"] = other_configs(torch, capi, synth, dev, kernel_times)
+        # `frac` prices the forward with its input resident in cache (the timed loop re-reads one batch); the same kernel on a batch no
+        # cache holds (other_configs.c2_cold: a pool > 256 MiB) beside it
+        cold = result["other_configs"].get("c2_cold", {}).get("fused_forward_us_cold")
+        if cold:
+            roofline["hbm_frac_cold"] = round(roofline["algorithmic_bytes_per_launch"] / (cold * 1e-6) / (HBM_PEAK_GBS * 1e9), 4)
+            roofline["avg_launch_us_cold"] = cold
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg)
     if dist is not None:
@@ -898,11 +894,31 @@ def roofline_of(info, B, T, alg_bytes, fwd_us, mfma_flops):
     return r
 
 
+def profile_quotes():
+    """({config: {dmel_fwd_kernel_bytes_per_launch, valu_busy, valu_insts_per_wave, ...}}, source note) from profiles/hbm_traffic.json -- HBM-side bytes
+    and SQ counters come from rocprofv3 PMC passes (they cannot be read from inside the process); the committed measurement is quoted
+    only if it was taken on THIS kernel source, otherwise nothing is"""
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if not os.path.exists(tpath):
+        return {}, None
+    try:
+        import hashlib
+        tj = json.load(open(tpath))
+        src = open(os.path.join(ROOT, "differentiable-mel-spectrogram_amd", "csrc", "dmel_fwd.hip"), "rb").read()
+        sha = hashlib.sha256(src).hexdigest()[:16]
+        if tj.get("kernel_source_sha16") == sha:
+            return {k: v for k, v in tj.items() if isinstance(v, dict)}, f"profiles/hbm_traffic.json (rocprofv3 --pmc, dmel_fwd.hip sha16 {sha})"
+        return {}, f"profiles/hbm_traffic.json was measured on another build of dmel_fwd.hip (have {sha}): not quoted"
+    except Exception:                                                   # noqa: BLE001
+        return {}, None
+
+
 def other_configs(torch, capi, synth, dev, kernel_times):
     """BASELINE configs 3 and 5 (both n_fft 2048) and the shapes of the reference's own experiments, not bench lines of their own:
     kernel times of the forward + dot through the C ABI and the same roofline accounting, plus config 5's front end isolated
     inside a real MelConvNet training step."""
     res = {}
+    quoted, _ = profile_quotes()
 
     def one(name, B, L, sr, lam, hop, M):
         T = L // hop + 1
@@ -917,7 +933,9 @@ def other_configs(torch, capi, synth, dev, kernel_times):
         alg = 4 * (B * L + 2 * B * M * T)
         mflops = 2048.0 * info["fb_blocks"] * mfma_row_tiles(info, B, T) if info["kernel_path"] == 0 else 0.0
         rl = roofline_of(info, B, T, alg, fwd_us, mflops)
-        rl["traffic"] = None
+        q = quoted.get({"c4_on_one_gpu": "c4", "esc50_x0.3": "esc_n4096", "esc50_lambd700": "esc_n8192"}.get(name, name), {})
+        rl["traffic"] = q.get("dmel_fwd_kernel_bytes_per_launch")
+        rl["valu_busy"], rl["valu_insts_per_wave"] = q.get("valu_busy"), q.get("valu_insts_per_wave")
         return {"workload": f"batch {B} x {L} @ {sr} Hz, n_fft {info['n_fft']} (lambd {round(lam, 1)}), hop {hop}, n_mels {M}",
                 "frames_per_step": B * T, "step_us": round(step_us, 2), "frames_per_s": round(B * T / (step_us * 1e-6), 1),
                 "kernels_us": {"prep_partial_sums": round(prep_us, 2), "fused_forward": round(fwd_us, 2), "backward_dot": round(bwd_us, 2)},

@@ -613,8 +613,10 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
                     });
                     static_for<0, KB>([&](auto jj) {
                         constexpr int jv = decltype(jj)::value;
-                        const bool ok = base + tid + THREADS * jv < n4;
-                        a0 += ok ? v[jv].x : 0.f; a1 += ok ? v[jv].y : 0.f; a2 += ok ? v[jv].z : 0.f; a3 += ok ? v[jv].w : 0.f;
+                        // (one select per 16-byte load instead of four: a + 1 v is a + v to the bit, a + 0 v is a -- the clamped load read a
+                        // sample of this very clip, so a non-finite one is in the true sum too)
+                        const float okf = (base + tid + THREADS * jv < n4) ? 1.f : 0.f;
+                        a0 = fmaf(v[jv].x, okf, a0); a1 = fmaf(v[jv].y, okf, a1); a2 = fmaf(v[jv].z, okf, a2); a3 = fmaf(v[jv].w, okf, a3);
                     });
                 }
                 i = n4 * 4;

@@ -5,7 +5,7 @@
 # two and four ranks sharing this GPU, the two-rank run five times), the optional gradients and the trainable-filterbank step.
 # Raw output under gpurun_out/prof_$TAG; tools/summarize_profile.py turns it into the files committed under profiles/.
 #   usage: tools/profile_session.sh <tag> [parts]      parts: any of  bench trace pmc shapes reducers extras stamps  (default: all)
-TAG=${1:-r04}
+TAG=${1:-r05}
 PARTS=${2:-"bench trace pmc shapes reducers extras stamps"}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -32,6 +32,7 @@ if has shapes; then
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$cfg -- python3 tools/ktime.py $cfg train 10 > $OUT/fetch_$cfg.log 2>&1
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_$cfg -- python3 tools/ktime.py $cfg train 10 > $OUT/write_$cfg.log 2>&1
     rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_MFMA --output-format csv -d $OUT/sq_$cfg -- python3 tools/ktime.py $cfg train 10 > $OUT/sq_$cfg.log 2>&1
+    rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $OUT/sq2_$cfg -- python3 tools/ktime.py $cfg train 10 > $OUT/sq2_$cfg.log 2>&1
     python3 tools/ktime.py $cfg train 2>&1 | tail -1 >> $OUT/ktime.txt
   done
   python3 tools/ktime.py c2 train 2>&1 | tail -1 >> $OUT/ktime.txt
@@ -48,6 +49,7 @@ if has reducers; then
     DMEL_BENCH_SHARE_GPU=1 python3 bench.py $A --gpus 2 --reducer mailbox 2> /dev/null | grep "^{" > $OUT/bench_2ranks_one_gpu_mailbox_$i.json
   done
   DMEL_BENCH_SHARE_GPU=1 python3 bench.py $A --gpus 4 --reducer mailbox 2> /dev/null | grep "^{" > $OUT/bench_4ranks_one_gpu_mailbox.json
+  DMEL_BENCH_SHARE_GPU=1 python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-other-configs --gpus 8 --reducer mailbox 2> /dev/null | grep "^{" > $OUT/bench_8ranks_one_gpu_mailbox.json
 fi
 if has extras; then
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_f2 -- python3 tools/time_backward_extras.py > $OUT/kt_f2.log 2>&1

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "prof_r04")
 tag = sys.argv[2] if len(sys.argv) > 2 else "r04"
 out = os.path.join(ROOT, "profiles")
-FWD_C2 = "dmel_fwd_kernel<1024, 0"          # the training-mode forward at n_fft 1024
+FWD_C2 = "dmel_fwd_kernel<1024, 5"          # the training-mode forward at n_fft 1024 (kTrainW since round 5; "<1024, 0" before)
 
 
 def hits(pattern):
@@ -87,6 +87,17 @@ def sq_digest(med):
     return d
 
 
+def valu_figures(med, avg_kernel_us):
+    """roofline.valu_busy / valu_insts_per_wave of bench.py: SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip's 1024 SIMDs"""
+    out_ = {}
+    if med.get("SQ_WAVES") and "SQ_INSTS_VALU" in med:
+        out_["valu_insts_per_wave"] = round(med["SQ_INSTS_VALU"] / med["SQ_WAVES"], 1)
+    if "SQ_ACTIVE_INST_VALU" in med and avg_kernel_us:
+        out_["valu_busy"] = round(med["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (avg_kernel_us * 2400.0), 4)
+        out_["valu_busy_note"] = "SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel cycles at 2.4 GHz, kernel-trace average of the same session)"
+    return out_
+
+
 sha = hashlib.sha256(open(os.path.join(ROOT, "differentiable-mel-spectrogram_amd", "csrc", "dmel_fwd.hip"), "rb").read()).hexdigest()[:16]
 hbm = {"_how": "rocprofv3 --pmc FETCH_SIZE and, separately, --pmc WRITE_SIZE (tools/profile_session.sh); medians over the dispatches.  gfx950 correction "
                "(MI355X_MICROARCH.md, HBM): FETCH_SIZE reads 1/2 of streamed bytes -> doubled, calibrated in the config-2 run on dmel_dot_kernel, which "
@@ -141,6 +152,11 @@ for sub in ("sq1", "sq2"):
     for k, v in counters(sub, FWD_C2).items():
         sq[k] = statistics.median(v)
 if sq:
+    avg_c2 = None
+    if rows:
+        ks = [k for k in kernel_summary(rows, only_dmel=False, min_calls=20) if FWD_C2 in k["kernel"]]
+        avg_c2 = ks[0]["avg_ns"] / 1e3 if ks else None
+    hbm.setdefault("c2", {}).update(valu_figures(sq, avg_c2))
     d = sq_digest(sq)
     d["_how"] = ("rocprofv3 --pmc, two separate passes (tools/profile_session.sh: sq1, sq2) around `bench.py --steps 30 --warmup 5 --mode eager`; medians over the "
                  "dispatches of dmel_fwd_kernel<1024, train>; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles")
@@ -175,8 +191,14 @@ for cfg in ("c3", "c5", "c4", "esc_n4096", "esc_n8192"):
             ent["traffic"]["dmel_prep_kernel_bytes_per_launch"] = int(round(statistics.median(pf["FETCH_SIZE"]) * 2048 + statistics.median(pw["WRITE_SIZE"]) * 1024))
         hbm[cfg] = ent["traffic"]
     s_ = {k: statistics.median(v) for k, v in counters(f"sq_{cfg}", "dmel_fwd_kernel").items()}
+    s2_ = {k: statistics.median(v) for k, v in counters(f"sq2_{cfg}", "dmel_fwd_kernel").items()}
+    s_.update(s2_)
     if s_:
         ent["sq"] = sq_digest(s_)
+        fk = [k for k in ent["kernels"] if "dmel_fwd_kernel" in k["kernel"]]
+        hbm.setdefault(cfg, {}).update(valu_figures(s_, fk[0]["avg_ns"] / 1e3 if fk else None))
+        if "traffic" in ent:
+            ent["traffic"] = hbm[cfg]
     shapes[cfg] = ent
 if shapes:
     shapes["_how"] = ("tools/profile_session.sh `shapes`: per shape a kernel trace of a train of forward launches (tools/ktime.py <cfg> train) and three counter passes "
@@ -194,8 +216,9 @@ for nm, fn in (("reference_shapes", "reference_shapes.json"), ("batch_sweep", "b
 red = {}
 def red_entry(d):
     return {"value_frames_per_s": d["value"], "ms_per_step": d["ms_per_step"], "n_ranks": d["n_gpus"], "reducer": d["config"].get("reducer"),
+            "rccl_ranks_seen": d["config"].get("rccl_ranks_seen"),
             "issued": d["module_step"]["issued"], "regions": d["module_step"].get("timed_regions")}
-for nm in ("bench_1rank_plain", "bench_1rank_rccl", "bench_1rank_mailbox", "bench_4ranks_one_gpu_mailbox"):
+for nm in ("bench_1rank_plain", "bench_1rank_rccl", "bench_1rank_mailbox", "bench_4ranks_one_gpu_mailbox", "bench_8ranks_one_gpu_mailbox"):
     d = last_json(os.path.join(src, nm + ".json"))
     if d:
         red[nm] = red_entry(d)
@@ -229,7 +252,7 @@ if d:
 rws = trace_rows("kt_lfb")
 if rws:
     tf["kernels_profiled"] = kernel_summary(rws, only_dmel=False, min_calls=50, by_grid=True)
-for kern, key in (("dmel_fwd_kernel<1024, 4", "dmel_fwd_kernel<1024,kTrainH>"), ("dmel_fwd_kernel<1024, 0", "dmel_fwd_kernel<1024,kTrain>"),
+for kern, key in (("dmel_fwd_kernel<1024, 4", "dmel_fwd_kernel<1024,kTrainH>"), ("dmel_fwd_kernel<1024, 0", "dmel_fwd_kernel<1024,kTrain>"), ("dmel_fwd_kernel<1024, 5", "dmel_fwd_kernel<1024,kTrainW>"),
                   ("dmel_fbgrad_lds_kernel<true, false, true>", "dmel_fbgrad_lds_kernel<bf16x3>"), ("dmel_fbgrad_lds_kernel<true, false, false>", "dmel_fbgrad_lds_kernel<fp32>")):
     c = {k: statistics.median(v) for k, v in counters("sq_lfb", kern).items()}
     if c:
