@@ -821,7 +821,10 @@ dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dm
     // the wave-local contraction where it is built (n_fft 1024, up to 512 mel bands): DMEL_WLC=0 keeps the round-4 kernel, DMEL_WLC=1
     // the 8-wave workgroups, DMEL_WLC=2 the 16-wave ones where they are built (diagnostics).
     static const int wlc_env = std::getenv("DMEL_WLC") ? std::atoi(std::getenv("DMEL_WLC")) : -1;
-    if (mode == dmel::kTrain && tb->wl_b4 != nullptr && wlc_env != 0) {
+    // (a dense bank -- a caller-supplied or trainable matrix -- makes every quad's band the whole spectrum: 1 032 steps per wave at n_fft 1024
+    // against 68 for the HTK bank; the 16 x 16 x 4 tiles of kTrain then win -- trainable-filterbank step 128.9 against 114.4 us, round 5)
+    const bool wl_compact = tb->wl_total4 * 4 <= 320;
+    if (mode == dmel::kTrain && tb->wl_b4 != nullptr && wlc_env != 0 && (wl_compact || wlc_env > 0)) {
         const int wide_fpt = dmel::forward_has_wlc_wide(N) ? dmel::forward_frames_per_tile(N, dmel::kTrainWW) : 0;
         const bool wide = wide_fpt > 0 && wlc_env == 2;      // (16-wave workgroups: measured slower, dmel_kernels.h; built only on request)
         mode = wide ? dmel::kTrainWW : dmel::kTrainW;

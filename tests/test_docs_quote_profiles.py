@@ -1,7 +1,7 @@
 """The figures DESIGN.md and profiles/README.md quote from the committed profiles must BE the figures in those files (VERDICT r03 weak #7:
 the documents said 20.77 us where the file said 20.28, and 325 M frames/s where the file said 178.8 M).
 
-`profiles/r04_quoted.json` lists every such figure: the document, the exact text around it (must occur in the document), the file
+`profiles/r05_quoted.json` (round 4: `r04_quoted.json`) lists every such figure: the document, the exact text around it (must occur in the document), the file
 and the path inside it, a scale (file units -> quoted units) and a relative tolerance (rounding of the quoted text).  A figure that
 is re-measured changes the file; this test then fails until the document follows."""
 import json
@@ -11,7 +11,7 @@ import re
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-QUOTED = json.load(open(os.path.join(ROOT, "profiles", "r04_quoted.json")))
+QUOTED = json.load(open(os.path.join(ROOT, "profiles", "r05_quoted.json")))
 
 
 def resolve(obj, path):
@@ -47,3 +47,37 @@ def test_design_is_short_and_the_notebook_exists():
     n = len(open(os.path.join(ROOT, "DESIGN.md")).read().splitlines())
     assert n <= 300, f"DESIGN.md has {n} lines: the current state fits 300, history goes to NOTEBOOK.md"
     assert os.path.exists(os.path.join(ROOT, "NOTEBOOK.md"))
+
+
+# ---- the documents also drifted where no profile file is involved -- the test counts ("328 GPU
+# tests" when there were 352) and a claim about bench.py's output ("traffic is no longer null for any of them" when it was).  Both
+# kinds are listed in r05_quoted.json and checked against the test collection / the committed bench line.
+def _collected(marker):
+    import subprocess, sys
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests"), "--collect-only", "-q", "-m", marker, "-p", "no:cacheprovider"],
+                         capture_output=True, text=True, cwd=ROOT).stdout
+    m = re.search(r"(\d+)/(\d+) tests collected", out) or re.search(r"(\d+) tests collected", out)
+    assert m, out[-400:]
+    return int(m.group(1))
+
+
+@pytest.mark.parametrize("c", QUOTED.get("test_counts", []), ids=["count_" + c["marker"].replace(" ", "_").replace("gpu", "device") for c in QUOTED.get("test_counts", [])])
+def test_quoted_test_count_is_the_collected_one(c):
+    text = open(os.path.join(ROOT, c["doc"])).read()
+    assert c["quote"] in text, f'{c["doc"]} no longer contains {c["quote"]!r}'
+    said = int(re.findall(r"\d+", c["quote"].replace(" ", ""))[c.get("which", 0)])
+    have = _collected(c["marker"])
+    assert said == have, f'{c["doc"]} says {said} ({c["quote"]!r}) but pytest collects {have} tests for -m "{c["marker"]}"'
+
+
+@pytest.mark.parametrize("c", QUOTED.get("bench_claims", []), ids=[c["quote"][:40] for c in QUOTED.get("bench_claims", [])])
+def test_claim_about_the_bench_line_holds_in_the_committed_one(c):
+    text = open(os.path.join(ROOT, c["doc"])).read()
+    assert c["quote"] in text, f'{c["doc"]} no longer contains {c["quote"]!r}'
+    data = json.load(open(os.path.join(ROOT, c["file"])))
+    for path in c["paths"]:
+        try:
+            v = resolve(data, path)
+        except (KeyError, IndexError, StopIteration, TypeError):
+            v = None
+        assert v is not None, f'{c["doc"]} claims {c["quote"]!r} but {c["file"]} holds nothing at {path}'
