@@ -502,7 +502,7 @@ def main():
             del gs4
             # loader_fed_slots (round 5): GraphedStep(inputs=[x], steps_per_replay=10) -- ten static slots per set, feed() copies the next
             # batch on a side stream while the previous replay runs, one replay per ten batches; the same pool rotation
-            if chosen != "eager":
+            for by_address in ((False, True) if chosen != "eager" else ()):
                 KS = 10
                 layer6 = MelSpectrogramLayer(torch.tensor(lam), n_mels=M, n_points=L, sample_rate=sr, hop_length=hop, device=str(dev),
                                              optimized=True, log=True, out_dtype=act).to(dev)
@@ -516,7 +516,7 @@ def main():
                 for _ in range(3):
                     module_step6(pool[0])
                 torch.cuda.synchronize()
-                gs6 = GraphedStep(module_step6, [layer6], max_ahead=MAX_AHEAD, steps_per_replay=KS, inputs=[pool[0]])
+                gs6 = GraphedStep(module_step6, [layer6], max_ahead=MAX_AHEAD, steps_per_replay=KS, inputs=[pool[0]], zero_copy=[True] if by_address else None)
                 it6 = [0]
 
                 def fed_slot():
@@ -529,10 +529,19 @@ def main():
                 nfs = 24 * KS
                 el6 = sorted(time_loop(fed_slot, KS if r == 0 else 0, nfs) for r in range(5))[2]
                 assert layer6.lambd_status()["error"] == 0
-                module_step_info["loader_fed_slots"] = {"ms_per_step": round(1e3 * el6 / nfs, 5), "frames_per_s": round(frames_per_rank * nfs / el6, 1),
-                                                        "steps_per_replay": KS, "steps": nfs, "pool_batches": POOL, "median_of": 5,
-                                                        "issued": "GraphedStep(inputs=[x], steps_per_replay=10).feed(batch): copies on a side stream under the previous replay, one replay per ten batches",
-                                                        "note": "the loop INTEGRATION.md documents since round 5 (train.py:25-49: a new batch every step); side figure, never `value`"}
+                if by_address:
+                    module_step_info["loader_fed_by_address"] = {
+                        "ms_per_step": round(1e3 * el6 / nfs, 5), "frames_per_s": round(frames_per_rank * nfs / el6, 1),
+                        "steps_per_replay": KS, "steps": nfs, "pool_batches": POOL, "median_of": 5,
+                        "issued": "GraphedStep(inputs=[x], zero_copy=[True], steps_per_replay=10).feed(batch): no copy of the batch -- its address goes into a "
+                                  "pointer cell the fused forward reads (DMEL_FLAG_X_INDIRECT), ten addresses per replay in one 80-byte copy inside the graph",
+                        "note": "for batches that are already device tensors (train.py:33 `inputs.to(device)` makes one per step); side figure, never `value`"}
+                else:
+                    module_step_info["loader_fed_slots"] = {
+                        "ms_per_step": round(1e3 * el6 / nfs, 5), "frames_per_s": round(frames_per_rank * nfs / el6, 1),
+                        "steps_per_replay": KS, "steps": nfs, "pool_batches": POOL, "median_of": 5,
+                        "issued": "GraphedStep(inputs=[x], steps_per_replay=10).feed(batch): copies on a side stream under the previous replay, one replay per ten batches",
+                        "note": "the loop INTEGRATION.md documents since round 5 (train.py:25-49: a new batch every step); side figure, never `value`"}
                 gs6.close()
                 del gs6, layer6, opt6s
             # cold inputs, no copy: k steps per replay, step j of a replay reads pool[j]

@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import importlib
 
-__all__ = ["MelSpectrogramLayer", "DifferentiableMelSpectrogram", "SpectrogramLayer", "dmel_log_mel", "GraphedStep", "LambdAdam", "capi", "synth", "dist",
+__all__ = ["MelSpectrogramLayer", "DifferentiableMelSpectrogram", "SpectrogramLayer", "SlotInput", "dmel_log_mel", "GraphedStep", "LambdAdam", "capi", "synth", "dist",
            "nets", "panns", "graph", "optim"]
 
 _LAZY = {
@@ -19,6 +19,7 @@ _LAZY = {
     "DifferentiableMelSpectrogram": ("layer", "DifferentiableMelSpectrogram"),
     "dmel_log_mel": ("layer", "dmel_log_mel"),
     "SpectrogramLayer": ("layer", "SpectrogramLayer"),
+    "SlotInput": ("layer", "SlotInput"),
     "GraphedStep": ("graph", "GraphedStep"),
     "LambdAdam": ("optim", "LambdAdam"),
 }

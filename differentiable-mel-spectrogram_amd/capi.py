@@ -22,6 +22,7 @@ DMEL_ERR_LAMBD_TRACKING = 6
 DMEL_ERR_MAILBOX_TIMEOUT = 7
 DMEL_FLAG_MFMA_BF16X3 = 8
 DMEL_FLAG_CHECK_NFFT = 16
+DMEL_FLAG_X_INDIRECT = 32
 DMEL_FLAG_LOG = 1
 DMEL_FLAG_FULL_WINDOW = 2
 DMEL_FLAG_OUT_BF16 = 4

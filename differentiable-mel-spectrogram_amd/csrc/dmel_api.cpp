@@ -692,6 +692,11 @@ dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dm
     if (spec_out && (big || N < dmel::kMinFastNfft || mode != dmel::kTrain))
         return fail(DMEL_ERR_UNSUPPORTED, "the spectrogram is saved by the fused training kernel only (power-of-two n_fft from 32 to 16384, tangent requested)");
     if (big && (N & 1)) return fail(DMEL_ERR_UNSUPPORTED, "n_fft = " + std::to_string(N) + " is odd");
+    // DMEL_FLAG_X_INDIRECT: the kernel reads the batch's address from a pointer cell -- only where ONE fused launch touches x (no prep
+    // kernel: no partial sums of long clips, no window table in memory, no direct-DFT / global-memory path)
+    if ((flags & DMEL_FLAG_X_INDIRECT) && (big || N < dmel::kMinFastNfft || N > dmel::kWinLdsMaxNfft || pl->cfg.n_points > 32768))
+        return fail(DMEL_ERR_UNSUPPORTED, "DMEL_FLAG_X_INDIRECT: clips up to 32768 samples at a power-of-two n_fft from 32 to 4096 (n_fft " +
+                    std::to_string(N) + ", " + std::to_string(pl->cfg.n_points) + " samples here)");
     NfftTables* tb = nullptr;
     dmel_status st = build_tables(pl, N, &tb);
     if (st != DMEL_OK) return st;
@@ -810,6 +815,11 @@ dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dm
         return DMEL_OK;
     }
     dmel::FwdParams fp{};
+    if (flags & DMEL_FLAG_X_INDIRECT) {
+        fp.x_ind = reinterpret_cast<const float* const*>(x);      // (the shapes this is for were checked at the top of this function)
+        x = nullptr;
+        flags &= ~DMEL_FLAG_X_INDIRECT;
+    }
     fp.x = x; fp.out = out; fp.tangent = tangent; fp.psum = (remove_dc && !kernel_mean) ? sc.psum : nullptr; fp.win2 = sc.win;
     fp.tw1 = dmel::mode_pairs(mode) ? tb->tw1p : tb->tw1; fp.tw2 = dmel::mode_pairs(mode) ? tb->tw2p : tb->tw2; fp.ent_b = tb->ent_b; fp.tile_ranges = tb->tile_ranges; fp.ent_b_floats = tb->ent_b_floats; fp.ent_pre = tb->ent_pre;
     for (int i = 0; i < 16; ++i) fp.pre_groups[i] = tb->pre_groups[i];
@@ -1253,6 +1263,7 @@ dmel_status dmel_plan_set_filterbank_dev(dmel_plan* plan, int32_t n_fft, const f
 dmel_status dmel_forward_scratch(dmel_plan* plan, const float* x, int32_t batch, float lambd, uint32_t flags,
                                  double eps, void* out, float* tangent, void* scratch, void* stream)
 {
+    if (flags & DMEL_FLAG_X_INDIRECT) return fail(DMEL_ERR_INVALID_ARGUMENT, "DMEL_FLAG_X_INDIRECT belongs to dmel_forward_dev");
     if (flags & DMEL_FLAG_FULL_WINDOW) {
         if (!plan) return fail(DMEL_ERR_INVALID_ARGUMENT, "plan is NULL");
         const int L = plan->cfg.n_points;
@@ -1339,6 +1350,12 @@ dmel_status dmel_forward_dev(dmel_plan* plan, const float* x, int32_t batch, con
         for (int n : {N, 2 * N, N / 2})
             if (n >= 1 && n <= dmel::kMaxBigFft && (st = build_tables(plan, n, &tb)) != DMEL_OK) return st;
     }
+    if (flags & DMEL_FLAG_X_INDIRECT) {
+        // a batch handed over by address is served at n_fft 32 ... 4096: a guard beyond that range is left out -- should lambd get there the
+        // launches that ran do not cover it, the output is NaN and the plan reports the error (the same loud end as any uncovered value)
+        if (2 * N > dmel::kWinLdsMaxNfft) guards &= ~2;
+        if (N / 2 < dmel::kMinFastNfft) guards &= ~1;
+    }
     int cand[3], nc = 0;
     cand[nc++] = N;
     if (guards & 2) cand[nc++] = 2 * N;
@@ -1377,6 +1394,7 @@ dmel_status dmel_forward_dev_fixed(dmel_plan* plan, const float* x, int32_t batc
     dmel_status st = check_forward_args(plan, x, batch, out);
     if (st != DMEL_OK) return st;
     if (!lambd_dev) return fail(DMEL_ERR_INVALID_ARGUMENT, "lambd_dev is NULL");
+    if (flags & DMEL_FLAG_X_INDIRECT) return fail(DMEL_ERR_INVALID_ARGUMENT, "DMEL_FLAG_X_INDIRECT belongs to dmel_forward_dev");
     if (flags & DMEL_FLAG_FULL_WINDOW) {
         // optimized=False (time_frequency.py:41,51): window = the clip, n_fft = 2 n_points whatever lambd is -- nothing to check on
         // the device, nothing for the host to read: lambd only shapes the window, which the kernels build from the device value

@@ -256,7 +256,11 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
         if ((hw >> 16) & 1u) for (unsigned i = 0; i < (p.flags >> 24) * 16u; ++i) __builtin_amdgcn_s_sleep(1);
     }
 #endif
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (size_t)b * p.L, (unsigned)p.L * 4u);
+    // the batch: by address, or (DMEL_FLAG_X_INDIRECT) through a pointer cell read with a scalar load -- a captured step is handed a
+    // new batch by rewriting 8 bytes
+    const float* xbase = p.x;
+    if (p.x_ind) { typedef const float* cfp; xbase = *(const __attribute__((address_space(4))) cfp*)p.x_ind; }
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(xbase + (size_t)b * p.L, (unsigned)p.L * 4u);
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.ent_b, (unsigned)p.ent_b_floats * 4u);
 
     // ---- what phase 2 needs from global memory: (ks0, nks, boff, tile) of this wave's mel runs in group 0 and their
@@ -593,7 +597,7 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
             // fixed order, instead of a separate pass over x
             // Loads go out in batches of 8 per thread before anything is added: one memory round trip per batch
             // instead of one per load (a plain loop waits for every load before issuing the next).
-            const float* xc = p.x + (size_t)b * p.L;
+            const float* xc = xbase + (size_t)b * p.L;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
             int i = 0;
             constexpr int KB = 8;

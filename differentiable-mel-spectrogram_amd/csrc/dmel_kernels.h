@@ -287,6 +287,7 @@ constexpr bool wlc_wide_size(int n_fft) { return false; }
 // v_mfma_f32_16x16x4_f32: lane l holds fb[4*ks + (l >> 4)][16*tile + (l & 15)].
 struct FwdParams {
     const float* x;            // (B, L)
+    const float* const* x_ind; // DMEL_FLAG_X_INDIRECT: the address of x is read from here when the kernel runs (then x is nullptr)
     float* out;                // (B, 1, M, T) or spec (B, F, T) in kSpec mode
     float* tangent;            // same shape as out or nullptr
     const float* psum;         // (B, nchunks) partial sums of x, or nullptr: the kernel sums the clip itself (short clips)

@@ -52,7 +52,11 @@ std::tuple<at::Tensor, at::Tensor> dmel_forward_op(const at::Tensor& x, const at
                                                    double eps, bool want_tangent, bool lambd_sync, bool out_bf16)
 {
     TORCH_CHECK(x.is_cuda(), "dmel::forward: x must be on the GPU (no CPU fallback)");
-    TORCH_CHECK(x.dim() == 2 && x.scalar_type() == at::kFloat && x.is_contiguous(), "dmel::forward: x must be a contiguous (batch, n_points) float32 tensor");
+    // DMEL_FLAG_X_INDIRECT (dmel_amd.SlotInput): x is a (batch, n_points) VIEW with zero strides over a pointer cell -- its shape is the
+    // batch's, its data pointer the cell's; the kernel reads the batch's address from the cell when it runs
+    const bool indirect = (flags & DMEL_FLAG_X_INDIRECT) != 0;
+    TORCH_CHECK(x.dim() == 2 && x.scalar_type() == at::kFloat && (x.is_contiguous() || indirect), "dmel::forward: x must be a contiguous (batch, n_points) float32 tensor");
+    TORCH_CHECK(!indirect || (!lambd_sync && !(flags & DMEL_FLAG_FULL_WINDOW)), "dmel::forward: a pointer-slot input needs lambd on the device and optimized=True");
     TORCH_CHECK(lambd.numel() == 1 && lambd.scalar_type() == at::kFloat, "dmel::forward: lambd must hold one float32");
     dmel_plan* plan = as_plan(plan_h);
     dmel_plan_info info{};

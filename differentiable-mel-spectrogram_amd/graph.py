@@ -98,6 +98,29 @@ class _CudaBackend:
             for d, s_ in zip(dsts, srcs):
                 d.copy_(s_, non_blocking=True)
 
+    def pointer_cells(self, n):
+        """(n int64 cells on the device, their pinned host staging): GraphedStep(zero_copy=...) publishes batch ADDRESSES through them"""
+        t = self.torch
+        host = t.zeros(n, dtype=t.int64).pin_memory()
+        return t.zeros(n, dtype=t.int64, device=f"cuda:{self.dev}"), host, host.numpy()      # (numpy: an item write costs 0.1 us, not 10)
+
+    def slot_input(self, cell, like):
+        from .layer import SlotInput
+        t = self.torch
+        if like.dtype != t.float32 or like.dim() != 2 or not like.is_cuda:
+            raise ValueError("GraphedStep(zero_copy=...): only the (batch, n_points) float32 device input of the layer can be passed by address")
+        return SlotInput(cell, like.shape)
+
+    def publish_cells(self, dev, host):
+        """pinned host -> device copy of the address cells on the CURRENT stream: run eagerly, or captured as the first node of a set's graph
+        (a replay then reads the staging when it executes: feed() does not touch a set's staging until the replay that read it is over)"""
+        dev.copy_(host, non_blocking=True)
+
+    def check_by_address(self, t_, like):
+        if t_.dtype is not like.dtype or t_.shape != like.shape or t_.device != like.device or not t_.is_contiguous():
+            raise ValueError(f"feed(): a zero-copy input must be a contiguous float32 tensor of shape {tuple(like.shape)} on {like.device}")
+        return t_.data_ptr()
+
     def record_on(self, stream=None):
         ev = self.torch.cuda.Event()
         ev.record(stream if stream is not None else self.torch.cuda.current_stream(self.dev))
@@ -127,12 +150,25 @@ class GraphedStep:
     ``x_static.copy_`` measured 52.5 us per step at BASELINE config 2, the slots 42.2, against 33 for a resident batch: the copies overlap the replay only in part -- the forward fills the register file of every CU, so a copy kernel runs between the forward launches).  The batches handed to
     ``feed`` must be ready when it is called (tensors already resident, pinned host memory, or produced on ``gs.copy_stream``):
     nothing on the current stream is waited for, or the copy would queue behind the running replay.  ``feed`` returns True when
-    it issued the K steps.  ``flush()`` runs a partly filled set eagerly (the end of an epoch)."""
+    it issued the K steps.  ``flush()`` runs a partly filled set eagerly (the end of an epoch).
+
+    **By address** (``zero_copy=[True, False]``, one flag per input): a flagged input -- the layer's ``(batch, n_points)`` float32
+    waveforms, already on the device -- is not copied at all: its slot is a ``dmel_amd.SlotInput`` (an 8-byte cell holding the
+    batch's address, which the fused forward reads when it runs: ``DMEL_FLAG_X_INDIRECT``), ``feed`` notes the tensor's address and
+    the K addresses travel in ONE 8K-byte copy that is the first node of the set's graph.  ``step_fn`` receives the ``SlotInput`` where it received
+    the slot tensor and must hand it to the layer (``net(x)`` of the reference's nets does, models.py:70) and to nothing else.
+    ``feed`` keeps the K tensors alive until the replay that reads them has finished; they must not be written meanwhile."""
 
     def __init__(self, step_fn, layers, max_ahead: int = 8, steps_per_replay: int = 1, warmup: int = 0, backend=None, decide=None,
-                 inputs=None):
+                 inputs=None, zero_copy=None):
         self.step_fn, self.layers = step_fn, list(layers)
         self.inputs = None if inputs is None else list(inputs)
+        if zero_copy is not None and self.inputs is None:
+            raise ValueError("GraphedStep(zero_copy=...) needs inputs=[...]")
+        self._by_addr = [False] * len(self.inputs or []) if zero_copy is None else [bool(z) for z in zero_copy]
+        if len(self._by_addr) != len(self.inputs or []):
+            raise ValueError("GraphedStep: zero_copy takes one flag per input")
+        self._cells, self._staging, self._alive, self._last_event = None, None, [[], []], None
         self._slots, self._set, self._fill, self._copy_stream, self._set_free = None, 0, 0, None, [None, None]
         self.max_ahead, self.k, self.warmup = max(1, int(max_ahead)), int(steps_per_replay), int(warmup)
         self.backend = backend
@@ -191,14 +227,49 @@ class GraphedStep:
         ctr = [0]
 
         def one():
+            if self._cells is not None and ctr[0] % self.k == 0:
+                self.backend.publish_cells(self._cells[slot_set], self._staging[slot_set])      # the K addresses of this set's by-address inputs
             self.step_fn(*self._slots[slot_set][ctr[0] % self.k])
             ctr[0] += 1
         return one
 
     def _make_slots(self) -> None:
         b = self.backend
-        self._slots = [[[b.empty_like(t) for t in self.inputs] for _ in range(self.k)] for _ in range(2)]
+        n_addr = sum(self._by_addr)
+        if n_addr:
+            pairs = [b.pointer_cells(self.k * n_addr) for _ in range(2)]
+            self._cells, self._staging, self._staging_np = [p[0] for p in pairs], [p[1] for p in pairs], [p[2] for p in pairs]
+        self._n_addr = n_addr
+        self._addr_idx = [i for i, z in enumerate(self._by_addr) if z]
+        self._copy_idx = [i for i, z in enumerate(self._by_addr) if not z]
+        self._slots = []
+        for s in range(2):
+            rows = []
+            for j in range(self.k):
+                row, a = [], 0
+                for t, by_addr in zip(self.inputs, self._by_addr):
+                    if by_addr:
+                        row.append(b.slot_input(self._cells[s][j * n_addr + a:j * n_addr + a + 1], t))
+                        a += 1
+                    else:
+                        row.append(b.empty_like(t))
+                rows.append(row)
+            self._slots.append(rows)
         self._copy_stream = b.copy_stream()
+
+    def _note_addresses(self, s, j, batch) -> None:
+        """slot j of set s: the addresses of the by-address inputs into the host staging; the tensors stay referenced"""
+        b = self.backend
+        if j == 0:
+            # the replay that last read this set (two replays ago) reads its staging when it EXECUTES and its batches until it ends: wait
+            # for it (the other set's replay is what the device is busy with meanwhile), then the tensors it read may go
+            if self._set_free[s] is not None:
+                self._set_free[s].synchronize()
+            self._alive[s] = []
+        base, stage, alive = j * self._n_addr, self._staging_np[s], self._alive[s]
+        for a, i in enumerate(self._addr_idx):
+            stage[base + a] = b.check_by_address(batch[i], self.inputs[i])
+            alive.append(batch[i])
 
     @property
     def copy_stream(self):
@@ -222,14 +293,22 @@ class GraphedStep:
             self._make_slots()
         s, j = self._set, self._fill
         # the first copy into a set waits until the replay that last read that set has finished; the others follow it in stream order
-        b.copy_into(self._copy_stream, self._slots[s][j], batch, after=self._set_free[s] if j == 0 else None)
+        if self._cells is not None:
+            self._note_addresses(s, j, batch)
+        after = self._set_free[s] if j == 0 else None
+        if self._copy_idx:
+            row = self._slots[s][j]
+            b.copy_into(self._copy_stream, [row[i] for i in self._copy_idx], [batch[i] for i in self._copy_idx], after=after)
         self._fill = j + 1
         if self._fill < self.k:
             return False
-        b.wait_on_current(b.record_on(self._copy_stream))
+        if self._copy_idx:
+            b.wait_on_current(b.record_on(self._copy_stream))
         self._fill = 0
+        self._last_event = None
         self()                                           # the K steps on set s (replayed, or eager + capture)
-        self._set_free[s] = b.record_on()
+        # (a replay leaves the event it recorded for the run-ahead bound; a capture ran its steps eagerly and synchronised)
+        self._set_free[s] = self._last_event
         self._set = s ^ 1
         return True
 
@@ -239,11 +318,15 @@ class GraphedStep:
         if n == 0 or self.inputs is None:
             return 0
         b = self.backend
-        b.wait_on_current(b.record_on(self._copy_stream))
+        if self._copy_idx:
+            b.wait_on_current(b.record_on(self._copy_stream))
+        if self._cells is not None:
+            b.publish_cells(self._cells[self._set], self._staging[self._set])
         for j in range(n):
             self.step_fn(*self._slots[self._set][j])
         b.synchronize()                                  # eager forwards the graph did not issue: the next call takes an exact picture
         self._set_free[self._set] = None
+        self._alive[self._set] = []
         return n
 
     def _capture(self) -> None:
@@ -349,7 +432,8 @@ class GraphedStep:
             if any(self._tracker(p).want(self._horizon(self._tracker(p))) != self._tracker(p).held for p in plans):
                 return self._capture()
         (self.graph if self.inputs is None else self._graphs[self._set]).replay()
-        self._ring[self._replays % len(self._ring)].record()
+        self._last_event = self._ring[self._replays % len(self._ring)]
+        self._last_event.record()
         self._replays += 1
 
     def steps_done_per_call(self) -> int:

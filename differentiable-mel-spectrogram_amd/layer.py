@@ -244,6 +244,29 @@ class _DmelFbDevFunction(torch.autograd.Function):
         return gx, dl, None, None, None, None, gfb, None, None, None, None
 
 
+class SlotInput:
+    """A batch handed to the layer BY ADDRESS (round 5): ``cell`` is a one-element int64 device tensor holding the address of a contiguous
+    fp32 ``(batch, n_points)`` tensor on the same device; the fused forward reads that address when it RUNS (``DMEL_FLAG_X_INDIRECT``).
+    A step captured into a HIP graph reads static addresses -- with a ``SlotInput`` the static address is the cell's, and giving the
+    replayed step a new batch is an 8-byte write instead of a copy of the batch (``GraphedStep(..., zero_copy=[True, ...]).feed``).
+    Only the layer understands it: pass it where the step passes ``x`` to ``net(x)`` / ``layer(x)`` (the reference's nets hand ``x``
+    to the layer and to nothing else, models.py:70,93,122,154)."""
+
+    __slots__ = ("cell", "shape", "device")
+
+    def __init__(self, cell, shape):
+        if cell.dtype != torch.int64 or cell.numel() != 1 or not cell.is_cuda:
+            raise ValueError("SlotInput: cell must be a one-element int64 device tensor")
+        self.cell, self.shape, self.device = cell, tuple(int(v) for v in shape), cell.device
+
+    def dim(self):
+        return len(self.shape)
+
+    def view(self):
+        """the (batch, n_points) fp32 view with zero strides whose data pointer is the cell's (what torch.ops.dmel.* is handed)"""
+        return torch.as_strided(self.cell.view(torch.float32), self.shape, (0,) * len(self.shape))
+
+
 _MEL_OP = None
 
 
@@ -384,6 +407,15 @@ class MelSpectrogramLayer(nn.Module):
         if n_points != self.n_points:
             # the reference fails here too (RuntimeError from the slice-assign at models.py:54)
             raise RuntimeError(f"input has {n_points} points, the layer was built for n_points={self.n_points}")
+        if isinstance(x, SlotInput):
+            # the batch by address: the hot path only (HTK bank, optimized=True, lambd on the device)
+            if self.mel_fb is not None or not self.optimized or self.lambd_sync:
+                raise RuntimeError("a SlotInput needs the default layer: HTK bank, optimized=True, lambd_sync=False")
+            if self.lambd.device != x.device:
+                raise RuntimeError(f"lambd is on {self.lambd.device} but the slot is on {x.device}; call layer.to(device)")
+            lam = self.lambd if self.lambd.dtype == torch.float32 else self.lambd.to(torch.float32)
+            flags = (capi.DMEL_FLAG_LOG if self.log else 0) | capi.DMEL_FLAG_X_INDIRECT
+            return _mel_op()(x.view(), lam, self._plan_for(x.device).handle, flags, self.eps, False, self.out_dtype == torch.bfloat16)
         if not x.is_cuda:
             raise RuntimeError("dmel_amd runs on MI355X only: x must be a CUDA/HIP tensor (no CPU fallback)")
         if self.lambd.device != x.device:

@@ -21,8 +21,9 @@ def _layer_opt(lam0, B, L, hop, M, sr):
     return layer, torch.optim.Adam([layer.lambd], lr=0.05, capturable=True)
 
 
+@pytest.mark.parametrize("by_address", [False, True], ids=["copied", "by_address"])
 @pytest.mark.parametrize("K,n", [(4, 14), (1, 5), (10, 30)])
-def test_fed_replays_equal_eager_steps_on_the_same_batches(K, n):
+def test_fed_replays_equal_eager_steps_on_the_same_batches(K, n, by_address):
     from dmel_amd import GraphedStep
     B, L, hop, M, sr, lam0 = 3, 4000, 128, 32, 8000, 40.0
     T = L // hop + 1
@@ -49,7 +50,7 @@ def test_fed_replays_equal_eager_steps_on_the_same_batches(K, n):
         hist.index_copy_(0, k, layer2.lambd.detach().view(1))
         k.add_(1)
 
-    gs = GraphedStep(step, [layer2], steps_per_replay=K, inputs=[data[0][0], data[0][1]])
+    gs = GraphedStep(step, [layer2], steps_per_replay=K, inputs=[data[0][0], data[0][1]], zero_copy=[True, False] if by_address else None)
     issued = 0
     for x, g in data:
         issued += K if gs.feed(x, g) else 0
@@ -63,3 +64,51 @@ def test_fed_replays_equal_eager_steps_on_the_same_batches(K, n):
         gs.feed(x, g)
     torch.cuda.synchronize()
     assert layer2.lambd_status()["error"] == 0
+
+
+@pytest.mark.parametrize("lam0,n_fft", [(4.0, 32), (20.0, 128), (40.0, 256), (80.0, 512), (150.0, 1024), (300.0, 2048), (600.0, 4096)])
+@pytest.mark.parametrize("grad", [False, True], ids=["infer", "train"])
+def test_a_batch_passed_by_address_gives_the_bits_of_the_batch_passed_directly(lam0, n_fft, grad):
+    """DMEL_FLAG_X_INDIRECT: the kernel reads the batch's address from a cell -- every fused transform size, with and without the tangent"""
+    from dmel_amd import MelSpectrogramLayer, SlotInput
+    B, L, hop, M, sr = 5, 16000, 512, 64, 16000
+    gen = torch.Generator().manual_seed(7)
+    xs = [torch.randn(B, L, generator=gen).to(DEV) for _ in range(2)]
+    layer = MelSpectrogramLayer(torch.tensor(lam0), n_mels=M, n_points=L, sample_rate=sr, hop_length=hop, device=DEV, optimized=True, log=True).to(DEV)
+    layer.lambd.requires_grad_(grad)
+    cell = torch.zeros(1, dtype=torch.int64, device=DEV)
+    slot = SlotInput(cell, (B, L))
+    g = torch.randn(B, 1, M, L // hop + 1, generator=gen).to(DEV)
+    for x in xs:                                       # the same cell, two batches: only the 8 bytes change
+        cell.fill_(x.data_ptr())
+        want = layer(x)
+        got = layer(slot)
+        assert layer.plan_info()["n_fft"] == n_fft
+        assert torch.equal(got, want)
+        if grad:
+            layer.lambd.grad = None
+            want.backward(g)
+            d0 = layer.lambd.grad.clone()
+            layer.lambd.grad = None
+            got.backward(g)
+            assert torch.equal(layer.lambd.grad, d0)
+
+
+def test_by_address_is_refused_where_more_than_one_launch_reads_the_batch():
+    from dmel_amd import MelSpectrogramLayer, SlotInput
+    B, L, hop, M, sr = 2, 16000, 512, 64, 16000
+    cell = torch.zeros(1, dtype=torch.int64, device=DEV)
+    x = torch.randn(B, L, device=DEV)
+    cell.fill_(x.data_ptr())
+    # n_fft 8192: the window table lives in memory, a prep launch reads x
+    big = MelSpectrogramLayer(torch.tensor(1200.0), n_mels=M, n_points=L, sample_rate=sr, hop_length=hop, device=DEV, optimized=True, log=True).to(DEV)
+    with pytest.raises(RuntimeError, match="X_INDIRECT"):
+        big(SlotInput(cell, (B, L)))
+    # optimized=False / a host-read lambd / a trainable filterbank: not the hot path
+    for kw in (dict(optimized=False), dict(lambd_sync=True)):
+        lay = MelSpectrogramLayer(torch.tensor(100.0), n_mels=M, n_points=L, sample_rate=sr, hop_length=hop, device=DEV, log=True,
+                                  **{"optimized": True, **kw}).to(DEV)
+        with pytest.raises(RuntimeError, match="SlotInput"):
+            lay(SlotInput(cell, (B, L)))
+    with pytest.raises(ValueError):
+        SlotInput(torch.zeros(2, dtype=torch.int64, device=DEV), (B, L))
