@@ -692,11 +692,10 @@ dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dm
     if (spec_out && (big || N < dmel::kMinFastNfft || mode != dmel::kTrain))
         return fail(DMEL_ERR_UNSUPPORTED, "the spectrogram is saved by the fused training kernel only (power-of-two n_fft from 32 to 16384, tangent requested)");
     if (big && (N & 1)) return fail(DMEL_ERR_UNSUPPORTED, "n_fft = " + std::to_string(N) + " is odd");
-    // DMEL_FLAG_X_INDIRECT: the kernel reads the batch's address from a pointer cell -- only where ONE fused launch touches x (no prep
-    // kernel: no partial sums of long clips, no window table in memory, no direct-DFT / global-memory path)
-    if ((flags & DMEL_FLAG_X_INDIRECT) && (big || N < dmel::kMinFastNfft || N > dmel::kWinLdsMaxNfft || pl->cfg.n_points > 32768))
-        return fail(DMEL_ERR_UNSUPPORTED, "DMEL_FLAG_X_INDIRECT: clips up to 32768 samples at a power-of-two n_fft from 32 to 4096 (n_fft " +
-                    std::to_string(N) + ", " + std::to_string(pl->cfg.n_points) + " samples here)");
+    // DMEL_FLAG_X_INDIRECT: the kernels read the batch's address from a pointer cell -- the fused kernel and the partial sums of long clips
+    // (dmel_prep_kernel) do; the direct-DFT and the global-memory / chirp-z paths do not
+    if ((flags & DMEL_FLAG_X_INDIRECT) && (big || N < dmel::kMinFastNfft || N > dmel::kMaxFastNfft))
+        return fail(DMEL_ERR_UNSUPPORTED, "DMEL_FLAG_X_INDIRECT: a power-of-two n_fft from 32 to 16384 (n_fft " + std::to_string(N) + " here)");
     NfftTables* tb = nullptr;
     dmel_status st = build_tables(pl, N, &tb);
     if (st != DMEL_OK) return st;
@@ -791,6 +790,7 @@ dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dm
     if (need_sums || need_window) {
         dmel::PrepParams pp{};
         pp.x = x; pp.psum = sc.psum; pp.win2 = sc.win;
+        if (flags & DMEL_FLAG_X_INDIRECT) { pp.x_ind = reinterpret_cast<const float* const*>(x); pp.x = nullptr; }
         pp.B = need_sums ? batch : 0; pp.L = pl->cfg.n_points; pp.nchunks = pl->nchunks; pp.chunk = pl->chunk;
         pp.N = need_window ? N : 0; pp.normalize = pl->cfg.normalize_window; pp.win_half = win_half; pp.center = center;
         pp.lam = lam; pp.lam.role = dmel::kLamQuiet;
@@ -1351,9 +1351,9 @@ dmel_status dmel_forward_dev(dmel_plan* plan, const float* x, int32_t batch, con
             if (n >= 1 && n <= dmel::kMaxBigFft && (st = build_tables(plan, n, &tb)) != DMEL_OK) return st;
     }
     if (flags & DMEL_FLAG_X_INDIRECT) {
-        // a batch handed over by address is served at n_fft 32 ... 4096: a guard beyond that range is left out -- should lambd get there the
+        // a batch handed over by address is served at n_fft 32 ... 16384: a guard beyond that range is left out -- should lambd get there the
         // launches that ran do not cover it, the output is NaN and the plan reports the error (the same loud end as any uncovered value)
-        if (2 * N > dmel::kWinLdsMaxNfft) guards &= ~2;
+        if (2 * N > dmel::kMaxFastNfft) guards &= ~2;
         if (N / 2 < dmel::kMinFastNfft) guards &= ~1;
     }
     int cand[3], nc = 0;

@@ -80,7 +80,9 @@ __global__ void __launch_bounds__(kThreads) dmel_prep_kernel(PrepParams p)
     const int b = blockIdx.y, c = blockIdx.x;
     const long long lo = (long long)c * p.chunk;
     long long hi = lo + p.chunk; if (hi > p.L) hi = p.L;
-    const float* xb = p.x + (size_t)b * p.L;
+    const float* xbase = p.x;
+    if (p.x_ind) { typedef const float* cfp; xbase = *(const __attribute__((address_space(4))) cfp*)p.x_ind; }      // the batch by address
+    const float* xb = xbase + (size_t)b * p.L;
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
     long long i = lo + tid;
     if (((reinterpret_cast<uintptr_t>(xb + lo)) & 15) == 0) {

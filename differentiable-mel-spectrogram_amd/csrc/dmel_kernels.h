@@ -325,6 +325,7 @@ struct FwdParams {
 
 struct PrepParams {
     const float* x; float* psum; float2* win2;
+    const float* const* x_ind;      // DMEL_FLAG_X_INDIRECT: the address of x is read from here (then x is nullptr), as in FwdParams
     int B, L, nchunks, chunk, N, normalize;
     LamArgs lam;      // the window block reads lambd itself (role 0: it neither reports nor poisons)
     int win_half;

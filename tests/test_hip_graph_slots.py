@@ -66,12 +66,15 @@ def test_fed_replays_equal_eager_steps_on_the_same_batches(K, n, by_address):
     assert layer2.lambd_status()["error"] == 0
 
 
-@pytest.mark.parametrize("lam0,n_fft", [(4.0, 32), (20.0, 128), (40.0, 256), (80.0, 512), (150.0, 1024), (300.0, 2048), (600.0, 4096)])
+@pytest.mark.parametrize("lam0,n_fft,L", [(4.0, 32, 16000), (20.0, 128, 16000), (40.0, 256, 16000), (80.0, 512, 16000), (150.0, 1024, 16000),
+                                         (300.0, 2048, 16000), (600.0, 4096, 16000), (1200.0, 8192, 16000), (2500.0, 16384, 16000),
+                                         (46.7, 512, 40000), (400.0, 4096, 40000), (300.0, 2048, 160000)])
 @pytest.mark.parametrize("grad", [False, True], ids=["infer", "train"])
-def test_a_batch_passed_by_address_gives_the_bits_of_the_batch_passed_directly(lam0, n_fft, grad):
-    """DMEL_FLAG_X_INDIRECT: the kernel reads the batch's address from a cell -- every fused transform size, with and without the tangent"""
+def test_a_batch_passed_by_address_gives_the_bits_of_the_batch_passed_directly(lam0, n_fft, L, grad):
+    """DMEL_FLAG_X_INDIRECT: the kernels read the batch's address from a cell -- every fused transform size, with and without the tangent, short
+    clips (the fused kernel adds the clip up itself) and long ones (dmel_prep_kernel's partial sums: the ESC-50 clip, BASELINE config 3's)"""
     from dmel_amd import MelSpectrogramLayer, SlotInput
-    B, L, hop, M, sr = 5, 16000, 512, 64, 16000
+    B, hop, M, sr = 5, 512, 64, 16000
     gen = torch.Generator().manual_seed(7)
     xs = [torch.randn(B, L, generator=gen).to(DEV) for _ in range(2)]
     layer = MelSpectrogramLayer(torch.tensor(lam0), n_mels=M, n_points=L, sample_rate=sr, hop_length=hop, device=DEV, optimized=True, log=True).to(DEV)
@@ -94,14 +97,14 @@ def test_a_batch_passed_by_address_gives_the_bits_of_the_batch_passed_directly(l
             assert torch.equal(layer.lambd.grad, d0)
 
 
-def test_by_address_is_refused_where_more_than_one_launch_reads_the_batch():
+def test_by_address_is_refused_outside_the_fused_kernel():
     from dmel_amd import MelSpectrogramLayer, SlotInput
     B, L, hop, M, sr = 2, 16000, 512, 64, 16000
     cell = torch.zeros(1, dtype=torch.int64, device=DEV)
     x = torch.randn(B, L, device=DEV)
     cell.fill_(x.data_ptr())
-    # n_fft 8192: the window table lives in memory, a prep launch reads x
-    big = MelSpectrogramLayer(torch.tensor(1200.0), n_mels=M, n_points=L, sample_rate=sr, hop_length=hop, device=DEV, optimized=True, log=True).to(DEV)
+    # n_fft 32768: the global-memory transform, several launches read x
+    big = MelSpectrogramLayer(torch.tensor(5000.0), n_mels=M, n_points=L, sample_rate=sr, hop_length=hop, device=DEV, optimized=True, log=True).to(DEV)
     with pytest.raises(RuntimeError, match="X_INDIRECT"):
         big(SlotInput(cell, (B, L)))
     # optimized=False / a host-read lambd / a trainable filterbank: not the hot path
@@ -112,3 +115,46 @@ def test_by_address_is_refused_where_more_than_one_launch_reads_the_batch():
             lay(SlotInput(cell, (B, L)))
     with pytest.raises(ValueError):
         SlotInput(torch.zeros(2, dtype=torch.int64, device=DEV), (B, L))
+
+
+def test_the_reference_loop_on_a_net_fed_by_address():
+    """train.py:25-49 on MelConvNet (models.py:105-136; no dropout): waveforms by address, labels copied, the two learning rates of
+    main.py:36-53 -- against eager steps on the same batches.  (The heads run on MIOpen / rocBLAS whose backward is not promised to be
+    bit-stable between an eager and a captured call: lambd and the weights are compared to 1e-5.)"""
+    from dmel_amd import GraphedStep
+    from dmel_amd.nets import MelConvNet
+    B, L, hop, M, sr, K, n = 4, 4000, 200, 16, 8000, 3, 9
+    gen = torch.Generator().manual_seed(5)
+    data = [(torch.randn(B, L, generator=gen).to(DEV), torch.randint(0, 5, (B,), generator=gen).to(DEV)) for _ in range(n)]
+
+    def make():
+        torch.manual_seed(3)
+        net = MelConvNet(5, 30.0, DEV, M, sr, L, hop_length=hop, optimized=True, energy_normalize=True).to(DEV)
+        groups = [{"params": [p], "lr": (0.05 if name == "spectrogram_layer.lambd" else 1e-3)} for name, p in net.named_parameters()]
+        return net, torch.optim.Adam(groups, capturable=True)
+
+    crit = torch.nn.CrossEntropyLoss()
+    net, opt = make()
+    for x, y in data:
+        opt.zero_grad(set_to_none=False)
+        crit(net(x)[0], y).backward()
+        opt.step()
+    torch.cuda.synchronize()
+
+    net2, opt2 = make()
+
+    def step(x, y):
+        opt2.zero_grad(set_to_none=False)
+        crit(net2(x)[0], y).backward()
+        opt2.step()
+
+    gs = GraphedStep(step, [net2.spectrogram_layer], steps_per_replay=K, inputs=[data[0][0], data[0][1]], zero_copy=[True, False])
+    for x, y in data:
+        gs.feed(x, y)
+    assert gs.flush() == 0
+    torch.cuda.synchronize()
+    assert net2.spectrogram_layer.lambd_status()["error"] == 0 and gs.captures >= 1
+    lam, lam2 = float(net.spectrogram_layer.lambd), float(net2.spectrogram_layer.lambd)
+    assert abs(lam - 30.0) > 1e-3 and abs(lam - lam2) <= 1e-5 * abs(lam), (lam, lam2)
+    for (k1, p1), (k2, p2) in zip(net.state_dict().items(), net2.state_dict().items()):
+        assert k1 == k2 and torch.allclose(p1, p2, rtol=1e-4, atol=1e-6), k1
