@@ -32,17 +32,24 @@ def _run(gold, graphed):
     k = torch.zeros(1, dtype=torch.long, device=DEV)
     sign = torch.ones(1, device=DEV)
 
-    def step():
+    def step(xb=x):
         opt.zero_grad(set_to_none=False)
-        (layer(x) * (g * sign)).sum().backward()
+        (layer(xb) * (g * sign)).sum().backward()
         hist.index_copy_(0, k, torch.stack([layer.lambd.detach().double(), layer.lambd.grad.double()]).view(1, 2))
         opt.step()
         k.add_(1)
         sign.copy_(torch.where(k < flip, 1.0, -1.0).float())
 
-    run = GraphedStep(step, [layer], steps_per_replay=1) if graphed else step
-    for _ in range(steps):
-        run()
+    if graphed == "by_address":
+        # the batch handed to the captured step by address (DMEL_FLAG_X_INDIRECT): re-captures keep the pointer cells
+        run = GraphedStep(step, [layer], steps_per_replay=2, inputs=[x], zero_copy=[True])
+        for _ in range(steps):
+            run.feed(x)
+        run.flush()
+    else:
+        run = GraphedStep(step, [layer], steps_per_replay=1) if graphed else step
+        for _ in range(steps):
+            run()
     torch.cuda.synchronize()
     assert layer.lambd_status()["error"] == 0
     h = hist.cpu().numpy()
@@ -51,7 +58,7 @@ def _run(gold, graphed):
 
 
 @pytest.mark.parametrize("name", NAMES)
-@pytest.mark.parametrize("graphed", [True, False], ids=["graphed_device_lambd", "lambd_sync"])
+@pytest.mark.parametrize("graphed", [True, False, "by_address"], ids=["graphed_device_lambd", "lambd_sync", "graphed_batch_by_address"])
 def test_training_trajectory_across_an_n_fft_boundary_matches_the_reference(name, graphed):
     gold = np.load(os.path.join(GOLD, name + ".npz"))
     lam, dlam, nfft, captures = _run(gold, graphed)
