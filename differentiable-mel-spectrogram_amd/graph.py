@@ -157,7 +157,9 @@ class GraphedStep:
     batch's address, which the fused forward reads when it runs: ``DMEL_FLAG_X_INDIRECT``), ``feed`` notes the tensor's address and
     the K addresses travel in ONE 8K-byte copy that is the first node of the set's graph.  ``step_fn`` receives the ``SlotInput`` where it received
     the slot tensor and must hand it to the layer (``net(x)`` of the reference's nets does, models.py:70) and to nothing else.
-    ``feed`` keeps the K tensors alive until the replay that reads them has finished; they must not be written meanwhile."""
+    ``feed`` keeps the K tensors alive until the replay that reads them has finished; they must not be written meanwhile.  (A by-address
+    batch is read by the replay itself, on the current stream: work queued on that stream before ``feed`` -- the ``x.to(device)`` that made
+    the tensor -- is ordered before it as usual; only copied inputs go through the side stream.)"""
 
     def __init__(self, step_fn, layers, max_ahead: int = 8, steps_per_replay: int = 1, warmup: int = 0, backend=None, decide=None,
                  inputs=None, zero_copy=None):
@@ -452,6 +454,7 @@ class GraphedStep:
             self.backend.synchronize()
         self.graph = None
         self._graphs = [None, None]
+        self._alive = [[], []]                           # (the device is idle: nothing reads the fed batches any more)
         self._release_held()
 
     def __del__(self):
