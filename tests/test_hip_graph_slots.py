@@ -158,3 +158,52 @@ def test_the_reference_loop_on_a_net_fed_by_address():
     assert abs(lam - 30.0) > 1e-3 and abs(lam - lam2) <= 1e-5 * abs(lam), (lam, lam2)
     for (k1, p1), (k2, p2) in zip(net.state_dict().items(), net2.state_dict().items()):
         assert k1 == k2 and torch.allclose(p1, p2, rtol=1e-4, atol=1e-6), k1
+
+
+def test_by_address_batches_may_be_dropped_by_the_caller_right_after_feed():
+    """feed() keeps a by-address batch alive until the replay that reads it is over: the loop of train.py:25-49 rebinds `inputs` every iteration,
+    and the caching allocator hands the freed block to the next batch at once -- without the reference the replay would read the NEXT batch."""
+    from dmel_amd import GraphedStep
+    B, L, hop, M, sr, lam0, K, n = 8, 16000, 512, 64, 16000, 128.0, 4, 22
+    T = L // hop + 1
+    g = torch.randn(B, 1, M, T, generator=torch.Generator().manual_seed(2)).to(DEV)
+
+    def batches():
+        gen = torch.Generator(device=DEV).manual_seed(77)
+        for _ in range(n):
+            yield torch.randn(B, L, generator=gen, device=DEV)        # a fresh tensor; nobody else holds it
+
+    layer, opt = _layer_opt(lam0, B, L, hop, M, sr)
+    ref = []
+    for x in batches():
+        opt.zero_grad(set_to_none=False)
+        layer(x).backward(g)
+        opt.step()
+        ref.append(layer.lambd.detach().clone())
+        del x
+    torch.cuda.synchronize()
+
+    layer2, opt2 = _layer_opt(lam0, B, L, hop, M, sr)
+    hist = torch.zeros(n + K, device=DEV)
+    k = torch.zeros(1, dtype=torch.long, device=DEV)
+
+    def step(x):
+        opt2.zero_grad(set_to_none=False)
+        layer2(x).backward(g)
+        opt2.step()
+        hist.index_copy_(0, k, layer2.lambd.detach().view(1))
+        k.add_(1)
+
+    gs = GraphedStep(step, [layer2], steps_per_replay=K, inputs=[torch.empty(B, L, device=DEV)], zero_copy=[True])
+    ptrs = set()
+    for x in batches():
+        ptrs.add(x.data_ptr())
+        gs.feed(x)
+        del x
+        junk = torch.full((B, L), float("nan"), device=DEV)          # what the allocator would hand out next if the batch had been freed
+        del junk
+    gs.flush()
+    torch.cuda.synchronize()
+    assert layer2.lambd_status()["error"] == 0
+    assert len(ptrs) > 1                                              # the batches really lived at different addresses
+    assert torch.equal(hist[:n], torch.stack(ref)), (hist[:n] - torch.stack(ref)).abs().max().item()
