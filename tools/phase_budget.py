@@ -3,7 +3,7 @@
 its phase-skipping debug flags, rocprofv3 --pmc counts the instructions of every dispatch, the differences are the phases.
   on the box:  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA --output-format csv \\
                    -d <dir> -- python3 tools/phase_budget.py run          (DMEL_LIB = the ablate build)
-  then:        python3 tools/phase_budget.py parse <dir> > profiles/r04_phase_budget_c2.json"""
+  then:        python3 tools/phase_budget.py parse <dir> > profiles/r05_phase_budget_c2.json"""
 import csv, glob, json, os, statistics, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # (label, flags): 0x100 skip the contraction + epilogue, 0x200 skip the transforms (prologue, FFT, pairing), 0x400 skip the epilogue,
@@ -34,7 +34,7 @@ d = sys.argv[2]
 f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
 per = {}
 for r in csv.DictReader(open(f)):
-    if "dmel_fwd_kernel<1024, 0" in r["Kernel_Name"]:
+    if "dmel_fwd_kernel<1024, 5" in r["Kernel_Name"] or "dmel_fwd_kernel<1024, 0" in r["Kernel_Name"]:
         per.setdefault(int(r["Dispatch_Id"]), {})[r["Counter_Name"]] = float(r["Counter_Value"])
 ids = sorted(per)
 assert len(ids) == len(VARIANTS) * REPS, (len(ids), len(VARIANTS) * REPS)
@@ -49,8 +49,9 @@ def diff(a, b):
 phases = {"launch, indices, lambd, exit (the kernel with both halves skipped)": res["neither"]["per_wave"],
           "clip sum (models.py:38)": diff("full", "no_clip_sum"),
           "prologue without the clip sum + window multiply + both radix-32 stages + twiddles + transposition + pairing pass + PD store": diff("transforms_only_no_clip_sum", "neither"),
-          "filterbank fragments + MFMA loops + half-tile exchange": diff("contraction_only", "neither"),
-          "epilogue (scale, log, tangent, stores)": diff("epilogue_only", "neither"),
+          "contraction: lane tables, B ring, A reads, MFMA loops (round 5: wave-local; the MFMAs count as vector instructions)": diff("contraction_only", "neither"),
+          # (round 5: the no-MFMA variant of the wave-local loop puts adds in their place, so the epilogue is taken from the two variants that keep them)
+          "epilogue (scale, log, tangent, staging, stores)": diff("contraction_and_epilogue_only", "contraction_only"),
           "whole kernel": res["full"]["per_wave"]}
 print(json.dumps({"_how": "tools/phase_budget.py: SQ instruction counters (rocprofv3 --pmc) of the -DDMEL_ABLATE build launched with its phase-skipping flags at BASELINE "
                           "config 2; medians of 6 dispatches per variant, per wave (a wave = two frames); phases are differences of variants",
