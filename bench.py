@@ -341,14 +341,20 @@ def main():
         torch.cuda.synchronize()
 
     def time_loop(fn, warm, steps):
+        import gc
         for _ in range(warm):
             fn()
+        # (the driver's region is well under a millisecond: a pass of Python's cycle collector inside it would be a tenth of the figure)
+        gc_was = gc.isenabled()
+        gc.disable()
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             fn()
         barrier()
         el = time.perf_counter() - t0
+        if gc_was:
+            gc.enable()
         if dist is not None:
             t = torch.tensor([el], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

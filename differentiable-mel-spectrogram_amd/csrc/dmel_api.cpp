@@ -81,13 +81,15 @@ struct NfftTables {
     float* fb_nyq = nullptr;     // ... and the row of bin n_fft/2 (n_mels)
     float4* wl_b4 = nullptr;     // kTrainW (wave-local contraction, FwdParams::wl_*): B operands, lane table, phase lengths
     int2* wl_lane = nullptr;
+    int* wl_merge = nullptr;      // [phase * 64 + lane]: partner lane of merge round 1 | round 2 << 8 | receives in round 1 << 16 | in round 2 << 17
     int wl_phases = 0, wl_total4 = 0;
     int wl_len4[dmel::kWlMaxPhases] = {};
+    int wl_mg[dmel::kWlMaxPhases] = {};   // per phase: bit 0 / 1 = merge round 1 / 2 is needed
     void release()
     {
         if (tw1p == tw1) tw1p = nullptr;
         if (tw2p == tw2) tw2p = nullptr;
-        void* ptrs[] = {tw1, tw2, tw1p, tw2p, ent_b, ent_pre, tile_ranges, fb_dense, tw_long, fbT, band, rowband, rowpk, ent_h, fb_nyq, wl_b4, wl_lane};
+        void* ptrs[] = {tw1, tw2, tw1p, tw2p, ent_b, ent_pre, tile_ranges, fb_dense, tw_long, fbT, band, rowband, rowpk, ent_h, fb_nyq, wl_b4, wl_lane, wl_merge};
         for (void* q : ptrs) (void)hipFree(q);
         *this = NfftTables();
     }
@@ -421,39 +423,91 @@ dmel_status build_tables(dmel_plan* pl, int N, NfftTables** out)
         }
         if (dmel::forward_has_wlc(N) && (M + 3) / 4 <= 16 * dmel::kWlMaxPhases) {
             // kTrainW: the schedule of the wave-local contraction (FwdParams::wl_*).  A quad = 4 consecutive mel bands; its band =
-            // the bins where any of them is non-zero.  Quads sorted by band width, 16 per phase (block b of the 4x4x1 MFMA takes the
-            // b-th of them); a phase is as long as its widest band, rounded up to 4 steps; block b starts at k0 = the band's first
-            // bin, moved down where the padded run would pass bin F - 1 (the coefficients outside the band are zero).
+            // the bins where any of them is non-zero.  A block of the 4x4x1 MFMA walks one PIECE of a band, one bin per step; a phase
+            // holds 16 pieces and is as long as its longest, rounded up to 4 steps.  Whole quads are one piece.  Where a wave holds ONE
+            // frame (n_fft >= 2048: two of the four rows idle, phases 100-330 steps long) a wide quad is split over 2 or 4 blocks of one
+            // phase -- pieces of its band, B operands restricted to the piece -- and the partial sums are merged across lanes after the
+            // phase's loop (wl_merge: one or two rounds of ds_bpermute + add; the final piece's lanes carry the mel band).
             const int Q = (M + 3) / 4;
-            std::vector<int> first(Q, 0), width(Q, 0), order(Q);
+            struct Piece { int quad, lo, w, group, idx, s; };
+            std::vector<int> first(Q, 0), width(Q, 0);
             for (int q = 0; q < Q; ++q) {
                 int lo = tb.F, hi = -1;
                 for (int f = 0; f < tb.F; ++f)
                     for (int j = 0; j < 4 && 4 * q + j < M; ++j)
                         if (fb[(size_t)f * M + 4 * q + j] != 0.f) { lo = std::min(lo, f); hi = std::max(hi, f); }
                 first[q] = hi >= lo ? lo : 0; width[q] = hi >= lo ? hi - lo + 1 : 0;
-                order[q] = q;
             }
-            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return width[a] < width[b]; });
-            tb.wl_phases = (Q + 15) / 16;
+            const bool may_split = dmel::forward_wlc_one_frame(N) && !pl->dense_dev.count(N) && std::getenv("DMEL_WLC_NOSPLIT") == nullptr;
+            // split factors: pieces no longer than w*, s in {1, 2, 4}; w* by exhaustive search over the step count of the resulting phases
+            auto make_groups = [&](int wstar, std::vector<std::vector<Piece>>& phases) -> int {
+                struct Grp { int quad, s, len; };
+                std::vector<Grp> gs;
+                for (int q = 0; q < Q; ++q) {
+                    int sp = 1;
+                    while (may_split && (width[q] + sp - 1) / sp > wstar && sp < 4) sp *= 2;
+                    gs.push_back({q, sp, (width[q] + sp - 1) / sp});
+                }
+                std::stable_sort(gs.begin(), gs.end(), [](const Grp& a, const Grp& b) { return a.len > b.len; });
+                phases.clear();
+                std::vector<int> used;
+                int gid = 0;
+                for (const Grp& g : gs) {
+                    size_t ph = 0;
+                    while (ph < phases.size() && used[ph] + g.s > 16) ++ph;
+                    if (ph == phases.size()) { phases.emplace_back(); used.push_back(0); }
+                    for (int i = 0; i < g.s; ++i) {
+                        const int lo = first[g.quad] + i * g.len;
+                        const int w = std::max(0, std::min(g.len, first[g.quad] + width[g.quad] - lo));
+                        phases[ph].push_back({g.quad, lo, w, gid, i, g.s});
+                    }
+                    used[ph] += g.s; ++gid;
+                }
+                if ((int)phases.size() > dmel::kWlMaxPhases) return 1 << 30;
+                // cost in steps: the phases' lengths plus 40 per phase -- measured, not derived: config 3's three phases of 100 steps in all
+                // run as long as its two phases of 136 (45.9-46.2 against 45.5-46.1 us, 40 more vector instructions per wave: kept whole),
+                // config 5's three of 104 beat its two of 160 by 4 % (66.1-67.9 against 68.9-71.0 us); and -- decisively -- the staged epilogue
+                // is lost beyond four phases (config 3 in five phases: 53.0 us)
+                int total = 0;
+                for (auto& ph : phases) { int wm = 0; for (auto& pc : ph) wm = std::max(wm, pc.w); total += std::max(4, (wm + 3) / 4 * 4) + 40 + (ph.size() && ph[0].s > 1 ? 2 : 0); }
+                if ((int)phases.size() > 4) total += 1000;
+                return total;
+            };
+            std::vector<std::vector<Piece>> phases;
+            {
+                int wmaxq = 4;
+                for (int q = 0; q < Q; ++q) wmaxq = std::max(wmaxq, width[q]);
+                int best = 1 << 30, best_w = wmaxq;
+                if (may_split)
+                    for (int wstar = 4; wstar <= wmaxq; ++wstar) {
+                        std::vector<std::vector<Piece>> trial;
+                        const int t = make_groups(wstar, trial);
+                        if (t < best) { best = t; best_w = wstar; }
+                    }
+                make_groups(best_w, phases);
+                // (narrowest phase first, as before: the lane table and the first B groups of phase 0 are the ones requested early)
+                std::reverse(phases.begin(), phases.end());
+            }
+            tb.wl_phases = (int)phases.size();
             std::vector<int2> lanes((size_t)tb.wl_phases * 64);
+            std::vector<int> merge((size_t)tb.wl_phases * 64, 0);
             std::vector<float4> b4;
             tb.wl_total4 = 0;
             for (int ph = 0; ph < tb.wl_phases; ++ph) {
-                const int nq = std::min(16, Q - 16 * ph);
+                const std::vector<Piece>& pcs = phases[ph];
+                const int nq = (int)pcs.size();
                 int wmax = 0;
-                for (int i = 0; i < nq; ++i) wmax = std::max(wmax, width[order[16 * ph + i]]);
+                for (int i = 0; i < nq; ++i) wmax = std::max(wmax, pcs[i].w);
                 // Bank conflicts of the A operand reads (dmel_kernels.h, slot_stride_f2): the 8 blocks of each 32-lane group must sit
-                // at bins that differ modulo 8.  A block may start anywhere in [lo, hi] -- the band must fit into the phase's L steps
-                // and the run must not pass bin F - 1 -- so each quad is matched to one of the 16 (group, residue) places it can
+                // at bins that differ modulo 8.  A block may start anywhere in [lo, hi] -- the piece must fit into the phase's L steps
+                // and the run must not pass bin F - 1 -- so each piece is matched to one of the 16 (group, residue) places it can
                 // reach (augmenting paths; 16 x 16); if that fails the phase gets four more steps.
                 int L = std::max(4, (wmax + 3) / 4 * 4), slot_of[16], k0_of[16];
                 for (;; L += 4) {
                     int lo[16], hi[16], owner[16];
                     for (int i = 0; i < nq; ++i) {
-                        const int q = order[16 * ph + i];
-                        hi[i] = std::max(0, std::min(first[q], tb.F - L));
-                        lo[i] = std::min(hi[i], std::max(0, first[q] + width[q] - L));
+                        hi[i] = std::max(0, std::min(pcs[i].lo, tb.F - L));
+                        lo[i] = std::min(hi[i], std::max(0, pcs[i].lo + pcs[i].w - L));
                     }
                     auto can = [&](int i, int r) { for (int k = hi[i]; k >= lo[i] && k > hi[i] - 8; --k) if ((k & 7) == r) return true; return false; };
                     std::fill(owner, owner + 16, -1);
@@ -467,14 +521,14 @@ dmel_status build_tables(dmel_plan* pl, int N, NfftTables** out)
                         return false;
                     };
                     bool ok = true;
-                    for (int i = nq - 1; i >= 0 && ok; --i) {          // widest (least freedom) first
+                    for (int i = 0; i < nq && ok; ++i) {               // longest (least freedom) first
                         std::fill(seen, seen + 16, false);
                         ok = place(i);
                     }
                     if (!ok && L < wmax + 64) continue;
                     std::fill(slot_of, slot_of + 16, -1);
                     if (ok) { for (int sl = 0; sl < 16; ++sl) if (owner[sl] >= 0) slot_of[owner[sl]] = sl; }
-                    else {                                        // (not reached with 16 places for 16 quads: any residue has two)
+                    else {                                        // (not reached with 16 places for 16 pieces: any residue has two)
                         bool used[16] = {};
                         for (int i = 0; i < nq; ++i) for (int sl = 0; sl < 16; ++sl) if (!used[sl]) { used[sl] = true; slot_of[i] = sl; break; }
                     }
@@ -489,25 +543,42 @@ dmel_status build_tables(dmel_plan* pl, int N, NfftTables** out)
                 const size_t base = b4.size();
                 b4.resize(base + (size_t)n4 * 64, make_float4(0.f, 0.f, 0.f, 0.f));
                 for (int sl = 0; sl < 16; ++sl)                  // places nobody took: no mel band, a bin of their residue
-                    for (int j = 0; j < 4; ++j) lanes[(size_t)ph * 64 + 4 * sl + j] = make_int2(8 * (sl & 7), -1);
+                    for (int j = 0; j < 4; ++j) { lanes[(size_t)ph * 64 + 4 * sl + j] = make_int2(8 * (sl & 7), -1); merge[(size_t)ph * 64 + 4 * sl + j] = (4 * sl + j) | ((4 * sl + j) << 8); }
+                int mg = 0;
                 for (int i = 0; i < nq; ++i) {
-                    const int q = order[16 * ph + i], b = slot_of[i], k0 = k0_of[i];
+                    const Piece& pc = pcs[i];
+                    const int b = slot_of[i], k0 = k0_of[i];
+                    // the pieces of this piece's group in this phase (they were placed together), in the order of their index
+                    int blk[4] = {b, b, b, b};
+                    for (int i2 = 0; i2 < nq; ++i2) if (pcs[i2].group == pc.group) blk[pcs[i2].idx] = slot_of[i2];
+                    // merge tree: round 1: piece 0 += piece 1, piece 2 += piece 3; round 2: piece 0 += piece 2; the result sits with piece 0
+                    int p1 = b, p2 = b, f1 = 0, f2 = 0;
+                    if (pc.s >= 2 && pc.idx == 0) { p1 = blk[1]; f1 = 1; }
+                    if (pc.s == 4 && pc.idx == 2) { p1 = blk[3]; f1 = 1; }
+                    if (pc.s == 4 && pc.idx == 0) { p2 = blk[2]; f2 = 1; }
+                    if (pc.s >= 2) mg |= 1;
+                    if (pc.s == 4) mg |= 2;
+                    const bool fin = pc.idx == 0;
                     for (int j = 0; j < 4; ++j) {
-                        const int m = 4 * q + j;
-                        lanes[(size_t)ph * 64 + 4 * b + j] = make_int2(8 * k0, m < M ? m : -1);
+                        const int m = 4 * pc.quad + j;
+                        lanes[(size_t)ph * 64 + 4 * b + j] = make_int2(8 * k0, (fin && m < M) ? m : -1);
+                        merge[(size_t)ph * 64 + 4 * b + j] = (4 * p1 + j) | ((4 * p2 + j) << 8) | (f1 << 16) | (f2 << 17);
                         if (m >= M) continue;
                         for (int st = 0; st < 4 * n4; ++st) {
                             const int f = k0 + st;
-                            const float v = f < tb.F ? fb[(size_t)f * M + m] : 0.f;
+                            const float v = (f < tb.F && f >= pc.lo && f < pc.lo + pc.w) ? fb[(size_t)f * M + m] : 0.f;
                             float4& e = b4[base + (size_t)(st / 4) * 64 + 4 * b + j];
                             (st % 4 == 0 ? e.x : st % 4 == 1 ? e.y : st % 4 == 2 ? e.z : e.w) = v;
                         }
                     }
                 }
+                tb.wl_mg[ph] = mg;
                 tb.wl_total4 += n4;
             }
             DMEL_HIP(hipMalloc(&tb.wl_lane, lanes.size() * sizeof(int2)));
             DMEL_HIP(hipMemcpy(tb.wl_lane, lanes.data(), lanes.size() * sizeof(int2), hipMemcpyHostToDevice));
+            DMEL_HIP(hipMalloc(&tb.wl_merge, merge.size() * sizeof(int)));
+            DMEL_HIP(hipMemcpy(tb.wl_merge, merge.data(), merge.size() * sizeof(int), hipMemcpyHostToDevice));
             DMEL_HIP(hipMalloc(&tb.wl_b4, std::max<size_t>(b4.size(), 64) * sizeof(float4)));
             if (!b4.empty()) DMEL_HIP(hipMemcpy(tb.wl_b4, b4.data(), b4.size() * sizeof(float4), hipMemcpyHostToDevice));
         }
@@ -839,7 +910,8 @@ dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dm
         const bool wide = wide_fpt > 0 && wlc_env == 2;      // (16-wave workgroups: measured slower, dmel_kernels.h; built only on request)
         mode = wide ? dmel::kTrainWW : dmel::kTrainW;
         fp.wl_b4 = tb->wl_b4; fp.wl_lane = tb->wl_lane; fp.wl_phases = tb->wl_phases; fp.wl_total4 = tb->wl_total4;
-        for (int i = 0; i < dmel::kWlMaxPhases; ++i) fp.wl_len4[i] = tb->wl_len4[i];
+        for (int i = 0; i < dmel::kWlMaxPhases; ++i) { fp.wl_len4[i] = tb->wl_len4[i]; fp.wl_mg[i] = tb->wl_mg[i]; }
+        fp.wl_merge = tb->wl_merge;
     }
     const int fpt = dmel::forward_frames_per_tile(N, mode);
     fp.tiles_per_clip = (pl->T + fpt - 1) / fpt;

@@ -1101,13 +1101,24 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
 #ifndef DMEL_WL_STAGE
 #define DMEL_WL_STAGE 1
 #endif
-            const bool staged = DMEL_WL_STAGE && p.wl_phases <= 2 && p.M <= SS && !out_bf16 && (p.T & 3) == 0 && p.tangent != nullptr && SLOTS % 4 == 0;
-            float sv[2][2 * FPW];
-            int sm[2] = {-1, -1};
+            constexpr int NST = (FPW == 1) ? 4 : 2;                              // phases whose results a lane can keep (2 FPW values each)
+            const bool staged = DMEL_WL_STAGE && p.wl_phases <= NST && p.M <= SS && !out_bf16 && (p.T & 3) == 0 && p.tangent != nullptr && SLOTS % 4 == 0;
+            float sv[NST][2 * FPW];
+            int sm[NST];
+            static_for<0, NST>([&](auto pp) { sm[decltype(pp)::value] = -1; });
+            // the lane table (and merge table) of phase ph + 1 is requested at the top of phase ph: asked for where it is used, every phase
+            // began with a global round trip (~700 cycles: a phase cost as much as ~36 of its steps, which is what kept config 3's split
+            // schedule -- three phases of 100 steps against two of 136 -- from paying)
+            int2 li_pref = (WL_EARLY >= 1) ? wl_li[0] : p.wl_lane[lane];
+            int mi_pref = (FPW == 1 && p.wl_mg[0] != 0) ? p.wl_merge[lane] : 0;
             for (int ph = 0; ph < p.wl_phases; ++ph) {
                 const int n4 = p.wl_len4[ph];
-                int2 li = wl_li[ph & 1];
-                if (ph >= 2 || WL_EARLY < 1) li = p.wl_lane[ph * 64 + lane];
+                const int2 li = li_pref;
+                const int mi = mi_pref;
+                if (ph + 1 < p.wl_phases) {
+                    li_pref = p.wl_lane[(ph + 1) * 64 + lane];
+                    if constexpr (FPW == 1) mi_pref = (p.wl_mg[ph + 1] != 0) ? p.wl_merge[(ph + 1) * 64 + lane] : 0;
+                }
                 if ((WL_EARLY < 2 && ph == 0) || (!DMEL_WL_NEXT && ph > 0)) wl_ring_init(n4, off4);      // (off4: still this phase's first group)
                 off4 += n4;
                 int aaddr = a_lane + li.x;
@@ -1142,7 +1153,30 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
                 static_for<0, WL_DEPTH - 1>([&](auto dd) { if (s4 + decltype(dd)::value < n4) group(dd); });
                 // the next phase's first groups: in flight under this phase's epilogue
                 if (DMEL_WL_NEXT && ph + 1 < p.wl_phases) wl_ring_init(p.wl_len4[ph + 1], off4);
-                const floatx4 tot = acc0 + acc1;
+                floatx4 tot = acc0 + acc1;
+                if constexpr (FPW == 1) {
+                    // quads split over several blocks of this phase (the host's schedule, dmel_api.cpp): the pieces' partial sums -- rows P
+                    // and D of this wave's one frame -- are added across lanes, the piece that carries the mel band receives last
+                    const int mg = p.wl_mg[ph];
+                    if (mg != 0) {
+                        // (the rows are copied out of the vector first: __builtin_bit_cast on the vector's ELEMENTS read element 0 both times --
+                        // hipcc 7.2 emitted one ds_bpermute for the two -- and d lambd of g3_c3 came out wrong)
+                        float r0 = tot[0], r1 = tot[1];
+                        {
+                            const int pa = (mi & 63) << 2;
+                            const float t0 = __int_as_float(__builtin_amdgcn_ds_bpermute(pa, __float_as_int(r0)));
+                            const float t1 = __int_as_float(__builtin_amdgcn_ds_bpermute(pa, __float_as_int(r1)));
+                            if (mi & 0x10000) { r0 += t0; r1 += t1; }
+                        }
+                        if (mg & 2) {
+                            const int pb = ((mi >> 8) & 63) << 2;
+                            const float t0 = __int_as_float(__builtin_amdgcn_ds_bpermute(pb, __float_as_int(r0)));
+                            const float t1 = __int_as_float(__builtin_amdgcn_ds_bpermute(pb, __float_as_int(r1)));
+                            if (mi & 0x20000) { r0 += t0; r1 += t1; }
+                        }
+                        tot[0] = r0; tot[1] = r1;
+                    }
+                }
                 // ---- epilogue: column j of block b = mel band li.y, rows = (frame, P | D) ----------------
                 const int m = li.y;
                 if (m < 0) continue;
@@ -1171,7 +1205,7 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
                     tv[f] = do_log ? dmel * __builtin_amdgcn_rcpf(me) : dmel;
                 });
                 if (staged) {
-                    static_for<0, 2>([&](auto pp) {
+                    static_for<0, NST>([&](auto pp) {
                         if (decltype(pp)::value == ph) {
                             sm[decltype(pp)::value] = m;
                             static_for<0, FPW>([&](auto ff) { constexpr int f = decltype(ff)::value; sv[decltype(pp)::value][f] = ov[f]; sv[decltype(pp)::value][FPW + f] = tv[f]; });
@@ -1205,7 +1239,7 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
             STAMP(16 * ti + 9);   // contraction and epilogue arithmetic of all phases
             if (staged) {
                 float* const stg = reinterpret_cast<float*>(smem_raw + wave * FPW * (SS * 8));          // [tensor][mel band][frame of this wave]
-                static_for<0, 2>([&](auto pp) {
+                static_for<0, NST>([&](auto pp) {
                     constexpr int q = decltype(pp)::value;
                     if (sm[q] >= 0) {
                         static_for<0, 2>([&](auto tt2) {
@@ -1628,6 +1662,7 @@ hipError_t launch_forward(int n_fft, int mode, int tpw, const FwdParams& p, int 
 
 bool forward_has_hsplit(int n_fft) { return n_fft >= kHsplitMinNfft && n_fft <= kHsplitMaxNfft && (n_fft & (n_fft - 1)) == 0; }
 bool forward_has_wlc(int n_fft) { return wlc_size(n_fft); }
+bool forward_wlc_one_frame(int n_fft) { return wlc_size(n_fft) && n_fft >= 2048; }      // (G = 64: the frame fills the wave)
 bool forward_has_wlc_wide(int n_fft) { return wlc_wide_size(n_fft); }
 bool forward_window_in_lds(int n_fft) { return n_fft >= kMinFastNfft && n_fft <= kWinLdsMaxNfft; }
 

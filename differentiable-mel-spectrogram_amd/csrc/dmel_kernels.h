@@ -28,7 +28,12 @@ constexpr bool mode_wlc(int mode) { return mode == kTrainW || mode == kTrainWW; 
 // sizes kTrainW is built for: whole frames inside one wave, compact layout (FftPlan::PAIRING == kPairBperm)
 // (n_fft 4096, one frame per wave and one workgroup per CU: 147.6 us against 138.5 for kTrain at the reference's ESC-50 shape -- with two of the
 // four MFMA rows in use a wave issues 264 steps for 64 mel bands; n_fft 2048: config 3 46.0 against 48.0 us, config 5 70.4 against 70.2)
-constexpr bool wlc_size(int n_fft) { return n_fft == 1024 || n_fft == 2048; }
+// (n_fft 4096 in this scheme -- one frame per wave, quads split over blocks: 192 steps for 64 mel bands instead of 328 -- measured 140.6 us
+// against 139.7 for the 16 x 16 x 4 path at the reference's ESC-50 shape: not built by default)
+#ifndef DMEL_WLC_4096
+#define DMEL_WLC_4096 0
+#endif
+constexpr bool wlc_size(int n_fft) { return n_fft == 1024 || n_fft == 2048 || (DMEL_WLC_4096 && n_fft == 4096); }
 constexpr int kWlMaxPhases = 8;    // phases of 16 mel quads each: up to 512 mel bands (more: the host falls back to kTrain)
 constexpr int kHsplitMinNfft = 64, kHsplitMaxNfft = 4096;    // sizes kTrainH is built for (frames inside one wave, N/2 a multiple of 32)
 constexpr int hsplit_plane_stride(int n_fft) { return n_fft / 2 + 8; }   // bf16 entries per plane: bins 0 .. N/2, rows stay 16-byte aligned
@@ -321,6 +326,9 @@ struct FwdParams {
     const int2* wl_lane;        // [phase * 64 + lane]: (8 k0(p, b): byte offset of PD[k0] inside a frame slot, mel band 4 quad + j or -1)
     int wl_phases, wl_total4;   // phases; sum of wl_len4 (size of wl_b4 in 1 KB entries)
     int wl_len4[kWlMaxPhases];
+    // quads split over 2 or 4 blocks of a phase (one-frame waves): after the phase's loop the pieces' partial sums are added across lanes
+    const int* wl_merge;        // [phase * 64 + lane]: partner lane of round 1 | of round 2 << 8 | this lane receives in round 1 << 16 | in round 2 << 17
+    int wl_mg[kWlMaxPhases];    // per phase: bit 0 / 1 = round 1 / 2 has anything to do
 };
 
 struct PrepParams {
@@ -344,6 +352,7 @@ int forward_nbpre(int n_fft);              // k-steps per run kept in registers 
 bool forward_plan_rc(int n_fft, bool pair, int* R, int* C);   // pair: the plan of the modes that pack two frames per FFT
 bool forward_has_hsplit(int n_fft);        // kTrainH is built for this size
 bool forward_has_wlc(int n_fft);           // kTrainW is built for this size
+bool forward_wlc_one_frame(int n_fft);     // ... with one frame per wave (two of the four MFMA rows idle: wide quads are split over blocks)
 bool forward_has_wlc_wide(int n_fft);      // ... and kTrainWW
 bool forward_window_in_lds(int n_fft);     // the kernel builds its own window table (otherwise dmel_prep_kernel writes FwdParams::win2)   // radix per lane and cross-lane radix of the plan (layout of tw1 / tw2)
 hipError_t forward_prepare_attributes();   // raises the dynamic-LDS limit of every instantiation once

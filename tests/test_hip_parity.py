@@ -1315,3 +1315,34 @@ def test_dspec_xgrad_matches_reference_golden():
     g100 = torch.from_numpy(synth.cotangent(tuple(s100.shape), seed=78)).to("cuda:0")
     (s100 * g100).sum().backward()
     assert _gx_err(x100.grad.cpu().numpy(), gold100["gx"].astype(np.float64)) <= TOL
+
+
+@pytest.mark.parametrize("sr,L,hop,lam,M", [(44100, 44100, 441, 256.0, 128), (16000, 40000, 512, 300.0, 128), (8000, 40000, 80, 300.0, 64)])
+def test_quads_split_over_blocks_give_what_whole_quads_give(sr, L, hop, lam, M, monkeypatch):
+    """Wave-local contraction at n_fft 2048 (one frame per wave): wide quads of mel bands are split over 2 or 4 blocks of the 4x4x1 MFMA and the
+    partial sums merged across lanes (host schedule in build_tables; DMEL_WLC_NOSPLIT=1 keeps every quad whole).  Same products, another order
+    of additions: equal to 1e-5 of each row's largest entry, outputs and tangent; and both within the parity bar of the fp64 oracle."""
+    import torch
+    from dmel_amd import capi, synth
+    B = 3
+    T = L // hop + 1
+    x = torch.from_numpy(synth.waveforms(B, L, seed=5)).cuda()
+    res = []
+    for nosplit in (False, True):
+        if nosplit:
+            monkeypatch.setenv("DMEL_WLC_NOSPLIT", "1")
+        else:
+            monkeypatch.delenv("DMEL_WLC_NOSPLIT", raising=False)
+        plan = capi.Plan(L, hop, M, sr, max_batch=B)          # the tables are built by the first forward of this plan
+        out = torch.zeros((B, 1, M, T), device="cuda")
+        tan = torch.zeros_like(out)
+        plan.forward(x.data_ptr(), B, lam, out.data_ptr(), tan.data_ptr(), False, 1e-10, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert plan.info()["n_fft"] == 2048
+        res.append((out.cpu().numpy().astype(np.float64), tan.cpu().numpy().astype(np.float64)))
+        plan.close()
+    for a, b in zip(res[0], res[1]):
+        scale = np.abs(b).max(axis=(0, 1, 3), keepdims=True) + 1e-30
+        assert (np.abs(a - b) / scale).max() <= 1e-5, float((np.abs(a - b) / scale).max())
+    y_ref, _ = O.forward(x.cpu().numpy(), lam, hop, M, sr, want_tangent=False)
+    assert _rel_err(res[0][0].reshape(-1), y_ref.reshape(-1)) <= TOL

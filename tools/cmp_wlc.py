@@ -3,7 +3,7 @@ ROOT="/root/repo"; sys.path.insert(0, ROOT)
 if len(sys.argv) > 1:
     import torch, dmel_amd
     from dmel_amd import capi, synth
-    B,L,sr,lam,hop,M = 8,16000,16000,128.0,512,128
+    B,L,sr,lam,hop,M = (8,16000,16000,128.0,512,128) if os.environ.get("CMP_CFG","c2")=="c2" else ((2,160000,16000,256.0,512,128) if os.environ["CMP_CFG"]=="c3" else (2,40000,8000,400.0,80,64))
     T = L//hop+1
     x = torch.from_numpy(synth.waveforms(B, L, seed=0)).cuda()
     out = torch.zeros((B,1,M,T), device="cuda"); tan = torch.zeros_like(out)
