@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Paper exercise for the wave-local contraction (csrc/dmel_fwd.hip, mode kTrainW): how many MFMA steps per wave would a schedule need in which a
-wide quad of mel bands is split over s = 2 or 4 neighbouring blocks of the 4x4x1 instruction (partial sums merged across lanes afterwards)?
-Today a phase holds 16 whole quads and is as long as its widest one.  HTK bank, f_min 0, f_max sr/2 (dmel_mel_fbanks_host).  No GPU needed.
+"""The arithmetic behind the split schedule of the wave-local contraction (csrc/dmel_fwd.hip, mode kTrainW; built in csrc/dmel_api.cpp build_tables,
+NOTEBOOK R5.15 / R5.16): how many MFMA steps per wave does a schedule need in which a wide quad of mel bands is split over s = 2 or 4 blocks of
+the 4x4x1 instruction (partial sums merged across lanes afterwards), against phases of 16 whole quads as long as their widest one?  An
+approximation of the host code (continuous HTK band edges, no start-bin matching, no per-phase cost).  No GPU needed.
 usage: python tools/wlc_packing_plan.py"""
 import math
 import numpy as np
