@@ -329,7 +329,9 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
         if (grp < n4) dst = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rbw, lane * 16, (boff4 + __builtin_amdgcn_readfirstlane(grp)) * 1024, 0));
     };
     auto wl_ring_init = [&](int n4, int boff4) {
-        if constexpr (WLC) static_for<0, WL_DEPTH>([&](auto dd) { constexpr int d = decltype(dd)::value; wl_ring[d] = floatx4{0.f, 0.f, 0.f, 0.f}; wl_bload(wl_ring[d], d, n4, boff4); });
+        // (a slot whose group does not exist in this phase is never used -- the tail groups are guarded -- so it is "defined" by an empty asm
+        // statement instead of four zeros: 24 moves less per ring start, 48-72 vector instructions per wave)
+        if constexpr (WLC) static_for<0, WL_DEPTH>([&](auto dd) { constexpr int d = decltype(dd)::value; asm volatile("" : "=v"(wl_ring[d])); wl_bload(wl_ring[d], d, n4, boff4); });
     };
     auto wl_prefetch = [&]() {
         if constexpr (WLC && WL_EARLY >= 1) {
