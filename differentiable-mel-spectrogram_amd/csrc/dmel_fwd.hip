@@ -804,9 +804,38 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
                     // one plane of N floats: real parts through, then imaginary parts (LDS executes a wave's accesses in order, so
                     // the second set of writes cannot overtake the first set of reads)
                     float* slf = reinterpret_cast<float*>(sl);
+#ifndef DMEL_TW1_CHUNK
+#define DMEL_TW1_CHUNK 4
+#endif
+                    // first-stage twiddles from the LDS table in chunks, the next chunk requested while one is used (as the radix-C twiddles
+                    // below): read one by one, every element waited for its own LDS round trip behind the plane write of the one before
+                    // (`ds_read_b64; s_waitcnt lgkmcnt(0)` 31 times per wave in the assembly).  Chunks of 4 or 8: config 4's batch 106.9-107.0 -> 105.9-106.2 us, config 2
+                    // within the noise; chunks of 16 spill (+4.5 %)
+                    constexpr int TW1C = (TW1_LDS && DMEL_TW1_CHUNK > 0) ? DMEL_TW1_CHUNK : R;
+                    float2 tw1r[(TW1_LDS && DMEL_TW1_CHUNK > 0) ? R : 1];
+                    auto tw1_fetch = [&](auto cc) {
+                        constexpr int c0 = decltype(cc)::value;
+                        static_for<(c0 == 0 ? 1 : c0), (c0 + TW1C < R ? c0 + TW1C : R)>([&](auto q1) {
+                            constexpr int q = decltype(q1)::value;
+                            tw1r[q] = *reinterpret_cast<const float2*>(smem_raw + tw1b + (q - 1) * (G * 8));
+                        });
+                    };
+                    if constexpr (TW1_LDS && DMEL_TW1_CHUNK > 0) {
+                        tw1_fetch(IC<0>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     static_for<0, R>([&](auto qq) {
                         constexpr int q = decltype(qq)::value;
-                        v2f v = twiddled(qq, z[bitrev(q, LB)]);
+                        v2f v;
+                        if constexpr (TW1_LDS && DMEL_TW1_CHUNK > 0) {
+                            if constexpr (q % TW1C == 0 && q + TW1C < R) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                tw1_fetch(IC<q + TW1C>{});
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                            v = z[bitrev(q, LB)];
+                            if constexpr (q != 0) v = cmul(v, tw1r[q]);
+                        } else v = twiddled(qq, z[bitrev(q, LB)]);
                         z[bitrev(q, LB)] = v;
                         slf[q * EXS + lg] = v.x;
                     });
