@@ -278,6 +278,16 @@ def _mel_op():
     return _MEL_OP
 
 
+def _to_f32(x: torch.Tensor) -> torch.Tensor:
+    """The kernels compute in fp32.  The reference removes the clip mean in the INPUT dtype (models.py:38: ``x[idx] - torch.mean(x[idx])``):
+    for fp64 clips (GaussPulse, datasets.py:33) that subtraction happens here, in fp64, BEFORE the cast -- a DC offset far above the
+    signal would otherwise cost the signal its low bits in the rounding to fp32 (tests/golden g13_dc_*_fp64: 1e-2 on the lowest mel
+    band).  The kernels' own DC removal then finds a mean of rounding size.  Narrower dtypes are widened as they are."""
+    if x.dtype == torch.float64:
+        x = x - x.mean(dim=1, keepdim=True)
+    return x.to(torch.float32)
+
+
 class MelSpectrogramLayer(nn.Module):
     """Differentiable (log-)Mel spectrogram with a trainable Gaussian window width.
 
@@ -424,7 +434,7 @@ class MelSpectrogramLayer(nn.Module):
         # grad its gradient (dmel_backward_x) flows back through these torch ops
         xf = x
         if xf.dtype != torch.float32:
-            xf = xf.to(torch.float32)
+            xf = _to_f32(xf)
         if not xf.is_contiguous():
             xf = xf.contiguous()
         plan = self._plan_for(x.device)
@@ -590,7 +600,7 @@ class SpectrogramLayer(nn.Module):
             with torch.cuda.device(x.device):
                 plan = capi.Plan(n_points, self.hop_length, 1, 2, 0.0, 1.0, bool(self.normalize_window))
             self._plans[key] = plan
-        xf = x if x.dtype == torch.float32 else x.to(torch.float32)
+        xf = x if x.dtype == torch.float32 else _to_f32(x)
         return _DspecFunction.apply(xf.contiguous(), self.lambd, plan, lam_host, n_fft, half)
 
 
@@ -608,4 +618,4 @@ def dmel_log_mel(x, lambd, n_mels, sample_rate, hop_length, f_min=0.0, f_max=Non
             plan = capi.Plan(x.shape[1], hop_length, n_mels, sample_rate, float(f_min),
                              None if f_max is None else float(f_max), bool(normalize_window))
         _plan_cache[key] = plan
-    return _DmelFunction.apply(x.detach().to(torch.float32).contiguous(), lambd, plan, float(lambd.detach()), log, eps)
+    return _DmelFunction.apply(_to_f32(x.detach()).contiguous(), lambd, plan, float(lambd.detach()), log, eps)

@@ -279,10 +279,33 @@ int dmel_oracle_forward(const float* x, int B, int L, float lambd_raw, int hop, 
 }
 
 /* optimized = 0: the layer's default branch (models.py:15 optimized=False -> time_frequency.py:41,51):
- * window length = L (normalised over L), n_fft = 2L, window zero-padded to n_fft by torch.stft; any L (dft_run). */
+ * window length = L (normalised over L), n_fft = 2L, window zero-padded to n_fft by torch.stft; any L (dft_run).
+ * mean_in != NULL: the clip means models.py:38 subtracts are GIVEN (B floats) instead of computed -- the DC-dominated fixtures
+ * (tests/golden g13_*) store the mean the reference's own torch.mean produced, which is one ulp off the correctly rounded one
+ * in a third of the clips; with it the rest of the path is pinned to 1e-4 as everywhere else. */
+static int forward_impl(const float* x, int B, int L, float lambd_raw, int hop, int n_mels,
+                        int sample_rate, double f_min, double f_max, int normalize_window,
+                        int apply_log, double eps, int optimized, float* out, float* tangent, const float* mean_in);
+
 int dmel_oracle_forward_ex(const float* x, int B, int L, float lambd_raw, int hop, int n_mels,
                            int sample_rate, double f_min, double f_max, int normalize_window,
                            int apply_log, double eps, int optimized, float* out, float* tangent)
+{
+    return forward_impl(x, B, L, lambd_raw, hop, n_mels, sample_rate, f_min, f_max, normalize_window, apply_log, eps, optimized,
+                        out, tangent, NULL);
+}
+
+int dmel_oracle_forward_mean(const float* x, int B, int L, float lambd_raw, int hop, int n_mels,
+                             int sample_rate, double f_min, double f_max, int normalize_window,
+                             int apply_log, double eps, int optimized, float* out, float* tangent, const float* mean_in)
+{
+    return forward_impl(x, B, L, lambd_raw, hop, n_mels, sample_rate, f_min, f_max, normalize_window, apply_log, eps, optimized,
+                        out, tangent, mean_in);
+}
+
+static int forward_impl(const float* x, int B, int L, float lambd_raw, int hop, int n_mels,
+                        int sample_rate, double f_min, double f_max, int normalize_window,
+                        int apply_log, double eps, int optimized, float* out, float* tangent, const float* mean_in)
 {
     if (!x || !out || B < 0 || L < 1 || hop < 1 || n_mels < 1 || sample_rate < 2) return DMEL_ORACLE_EINVAL;
     const int N = optimized ? dmel_oracle_n_fft(lambd_raw) : 2 * L;
@@ -322,7 +345,7 @@ int dmel_oracle_forward_ex(const float* x, int B, int L, float lambd_raw, int ho
     for (int b = 0; b < B; ++b) {
         double s = 0.0;
         for (int i = 0; i < L; ++i) s += (double)x[(size_t)b * L + i];
-        mean[b] = (float)(s / (double)L);
+        mean[b] = mean_in ? mean_in[b] : (float)(s / (double)L);
     }
 
 #pragma omp parallel

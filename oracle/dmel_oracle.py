@@ -44,6 +44,9 @@ def lib():
         L.dmel_oracle_forward_ex.argtypes = [fp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
                                              C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, C.c_int, fp, fp]
         L.dmel_oracle_forward_ex.restype = C.c_int
+        L.dmel_oracle_forward_mean.argtypes = [fp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
+                                               C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, C.c_int, fp, fp, fp]
+        L.dmel_oracle_forward_mean.restype = C.c_int
         L.dmel_oracle_backward.argtypes = [fp, fp, C.c_longlong]
         L.dmel_oracle_backward.restype = C.c_double
         L.dmel_oracle_spectrogram.argtypes = [fp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, fp]
@@ -91,16 +94,19 @@ def mel_fbanks(n_freqs: int, f_min: float, f_max: float, n_mels: int, sample_rat
 
 def forward(x: np.ndarray, lambd: float, hop: int, n_mels: int, sample_rate: int, f_min: float = 0.0,
             f_max: float | None = None, normalize_window: bool = False, apply_log: bool = False,
-            eps: float = 1e-10, want_tangent: bool = True, optimized: bool = True):
-    """Returns (out, tangent) with shape (B,1,n_mels,L//hop+1); tangent = d out / d lambd."""
+            eps: float = 1e-10, want_tangent: bool = True, optimized: bool = True, mean: np.ndarray | None = None):
+    """Returns (out, tangent) with shape (B,1,n_mels,L//hop+1); tangent = d out / d lambd.  ``mean``: the clip means that
+    models.py:38 subtracts, given (B fp32 values) instead of computed (the DC-dominated fixtures: see dmel_oracle_forward_mean)."""
     x = np.ascontiguousarray(x, dtype=np.float32)
     B, L = x.shape
     T = L // hop + 1
     out = np.empty((B, 1, n_mels, T), np.float32)
     tan = np.empty_like(out) if want_tangent else None
-    rc = lib().dmel_oracle_forward_ex(_fp(x), B, L, np.float32(lambd), hop, n_mels, sample_rate, float(f_min),
-                                      -1.0 if f_max is None else float(f_max), int(normalize_window),
-                                      int(apply_log), float(eps), int(optimized), _fp(out), _fp(tan) if want_tangent else None)
+    mean_arr = None if mean is None else np.ascontiguousarray(mean, dtype=np.float32).reshape(B)
+    rc = lib().dmel_oracle_forward_mean(_fp(x), B, L, np.float32(lambd), hop, n_mels, sample_rate, float(f_min),
+                                        -1.0 if f_max is None else float(f_max), int(normalize_window),
+                                        int(apply_log), float(eps), int(optimized), _fp(out), _fp(tan) if want_tangent else None,
+                                        None if mean_arr is None else _fp(mean_arr))
     if rc != 0:
         raise RuntimeError(f"dmel_oracle_forward failed rc={rc}")
     return out, tan

@@ -50,7 +50,7 @@ def _built_libraries():
 
 def pytest_sessionfinish(session, exitstatus):
     """the numbers behind the parity asserts (tests/test_hip_parity.py: parity_stats) go to gpurun_out/, which travels back from the
-    GPU box; profiles/r05_parity_report.json is a committed copy"""
+    GPU box; profiles/r06_parity_report.json is a committed copy"""
     try:
         import json
         mod = sys.modules.get("test_hip_parity")
@@ -58,6 +58,6 @@ def pytest_sessionfinish(session, exitstatus):
         if rep:
             out = os.path.join(ROOT, "gpurun_out")
             os.makedirs(out, exist_ok=True)
-            json.dump(rep, open(os.path.join(out, "r05_parity_report.json"), "w"), indent=1, sort_keys=True)
+            json.dump(rep, open(os.path.join(out, "r06_parity_report.json"), "w"), indent=1, sort_keys=True)
     except Exception:            # noqa: BLE001 -- a report, never a reason to fail the session
         pass

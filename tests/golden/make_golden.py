@@ -113,6 +113,9 @@ def run_case(models, tf, case):
         out["mel"] = mel_np
     else:
         out["mel_sampled"] = mel_np.reshape(-1)[idx]
+    if case["kind"] == "dc":
+        # the mean models.py:38 subtracted, clip by clip, in the input dtype (same expression, same torch)
+        out["mean_ref"] = np.asarray([torch.mean(x[i]).item() for i in range(case["B"])], dtype=np.float64)
     return out
 
 
@@ -310,7 +313,7 @@ def main(argv):
         argv = [a for a in argv if a != "net_keys"]
         if len(argv) == 1 and "net_keys" in sys.argv:
             return
-    names = argv[1:] or [c["name"] for c in C.CASES] + ["g7_dspec", "g7_dspec_100", "g7_dspec_xgrad", "g7_dspec_xgrad_100"] + ["g8_fbgrad_" + n for n in FBGRAD_CASES] + ["g9_panns"] + ["g10_xgrad_" + n for n in XGRAD_CASES] + ["g11_nets"] + list(TRAJ)
+    names = argv[1:] or [c["name"] for c in C.CASES + C.DC_CASES] + ["g7_dspec", "g7_dspec_100", "g7_dspec_xgrad", "g7_dspec_xgrad_100"] + ["g8_fbgrad_" + n for n in FBGRAD_CASES] + ["g9_panns"] + ["g10_xgrad_" + n for n in XGRAD_CASES] + ["g11_nets"] + list(TRAJ)
     for name in names:
         if name == "g7_dspec":
             out = run_dspec(models, tf)

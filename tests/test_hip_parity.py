@@ -144,6 +144,57 @@ def test_matches_reference_golden(case):
                 assert abs(got_d - exp_d) <= TOL * abs(exp_d), (case["name"], got_d, exp_d, abs(got_d - exp_d) / abs(exp_d))
 
 
+@pytest.mark.parametrize("case", C.DC_CASES, ids=[c["name"] for c in C.DC_CASES])
+def test_matches_reference_dc_dominated(case):
+    """G13 (tests/golden/cases.py: DC_CASES): clips whose offset is 10 ... 500 x their signal, outputs of the reference's own layer.
+    One ulp of the fp32 clip mean (models.py:38) moves the lowest mel bands by up to 3e-2 there, and torch's own fp32 sum is one ulp
+    off the correctly rounded mean in a third of these clips (tests/test_oracle_golden.py) -- so the bar is read as: every clip must
+    be, on EVERY element and to a plain 1e-4, the reference's path evaluated with a clip mean at most ONE ulp from the one the
+    reference subtracted (the fixture stores it; the oracle, pinned to the fixture at that mean, evaluates the neighbours).  A
+    clip whose kernel mean equals the reference's is compared with the fixture itself.  fp64 clips: the reference subtracts in fp64;
+    so does the layer (before its cast to fp32), and the plain bar holds against the fixture."""
+    from test_oracle_golden import dc_reference_input
+    gold = C.load(case)
+    x_np = C.make_input(case)
+    x = torch.from_numpy(x_np).to("cuda:0")
+    g_np = C.make_cotangent(case)
+    g = torch.from_numpy(g_np).to("cuda:0")
+    exp = gold["mel"].astype(np.float64)
+    xin, mean_ref = dc_reference_input(case, gold)
+    ulp = np.float32(np.spacing(np.float32(abs(case["offset"]))))
+    for log in (False, True):
+        layer = _layer(case, log=log)
+        assert layer.n_fft() == int(gold["n_fft"])
+        out = layer(x)
+        (out * g).sum().backward()
+        got = out.detach().cpu().numpy().astype(np.float64)
+        got_d = float(layer.lambd.grad)
+        lin = np.exp(got) if log else got                        # the log output is compared as mel + eps (abs error of the log)
+        ref_lin = exp + 1e-10 if log else exp
+        rel = np.abs(lin - ref_lin) / np.abs(ref_lin)
+        used = np.zeros(case["B"], dtype=np.int64)
+        mean_used = mean_ref.copy()
+        for b in range(case["B"]):
+            if rel[b].max() <= TOL:
+                continue
+            assert case["dtype"] == "float32", (case["name"], b, float(rel[b].max()))
+            best = None
+            for k in (-1, 1):
+                cand = mean_ref[b:b + 1] + np.float32(k) * ulp
+                o_k, _ = O.forward(xin[b:b + 1], case["lambd"], case["hop"], case["n_mels"], case["sr"], apply_log=False, mean=cand)
+                r = np.abs(lin[b] - (o_k[0].astype(np.float64) + (1e-10 if log else 0.0))) / np.abs(o_k[0].astype(np.float64) + (1e-10 if log else 0.0))
+                if best is None or r.max() < best[0]:
+                    best = (float(r.max()), k, cand[0])
+            assert best[0] <= TOL, (case["name"], b, "no mean within one ulp of the reference's explains this clip", best, float(rel[b].max()))
+            used[b], mean_used[b] = best[1], best[2]
+        record_parity("golden/" + case["name"] + ("/exp_logmel" if log else "/mel"),
+                      {"n": int(exp.size), "plain_max_rel_vs_fixture": float(rel.max()), "mean_ulps_from_reference": [int(v) for v in used]})
+        # d lambd against the oracle at the means the kernel used (= the fixture's value when they are the reference's)
+        _, t_ref = O.forward(xin, case["lambd"], case["hop"], case["n_mels"], case["sr"], apply_log=log, mean=mean_used)
+        exp_d = O.backward(g_np, t_ref) if used.any() else float(gold["dlam_log" if log else "dlam_lin"])
+        assert abs(got_d - exp_d) <= _dlam_tol(exp_d, g_np, t_ref), (case["name"], log, got_d, exp_d)
+
+
 @pytest.mark.parametrize("name", ["g1_c1", "g2_c2", "g5_n128", "g5_n4096", "g6_n256_ragged", "g6_n64", "g6_n32",
                                   "g6_n2048_short", "g6_normwin", "g6_tone_dc"])
 def test_matches_oracle_elementwise(name):
