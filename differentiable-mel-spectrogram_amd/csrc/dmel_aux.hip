@@ -352,9 +352,7 @@ __global__ void __launch_bounds__(128) dmel_naive_kernel(NaiveParams p)
     const float ctan = lam_tangent_scale(ls);
     float mean = 0.f;
     if (p.remove_dc) {
-        double s = 0.0;
-        for (int c = 0; c < p.nchunks; ++c) s += (double)p.psum[(size_t)b * p.nchunks + c];
-        mean = (float)(s * (double)p.inv_L);
+        mean = clip_mean_psum(p.psum, p.nchunks, b, p.L);
     }
     for (int n = tid; n < p.N; n += blockDim.x) {
         const long long i = (long long)t * p.hop - p.N / 2 + n;

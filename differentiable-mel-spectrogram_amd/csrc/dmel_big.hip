@@ -143,9 +143,7 @@ __global__ void __launch_bounds__(kBigThreads) dmel_big_kernel(BigParams p)
         const float* xb = p.x + (size_t)b * p.L;
         float mean = 0.f;
         if (p.remove_dc) {
-            double s = 0.0;
-            for (int c = 0; c < p.nchunks; ++c) s += (double)p.psum[(size_t)b * p.nchunks + c];
-            mean = (float)(s * (double)p.inv_L);
+            mean = clip_mean_psum(p.psum, p.nchunks, b, p.L);
         }
         // element n of the windowed complex frame (frame + tangent, or two frames), before any transform
         auto elem = [&](int n) -> float2 {
@@ -335,9 +333,7 @@ __global__ void __launch_bounds__(kBigThreads) dmel_xgrad_big_kernel(XgradParams
         const float* xb = p.x + (size_t)b * p.L;
         float mean = 0.f;
         {
-            double s = 0.0;
-            for (int c = 0; c < p.nchunks; ++c) s += (double)p.psum[(size_t)b * p.nchunks + c];
-            mean = (float)(s * (double)p.inv_L);
+            mean = clip_mean_psum(p.psum, p.nchunks, b, p.L);
         }
         __syncthreads();                                   // the previous unit's readers are done with Z
         for (int n = tid; n < (blue ? N : M); n += kBigThreads) {

@@ -564,6 +564,19 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
             }
         }
         // ---- clip mean (models.py:38) --------------------------------------------------------------
+        // the waves' sums meet in LDS (the barrier is also the window table's) and are added pairwise, in a fixed order; the quotient
+        // by L is rounded once (dmel_kernels.h: "the clip mean")
+        auto mean_of = [&](float wsum) -> float {
+            if (lane == 0) red[wave] = wsum;
+            __syncthreads();
+            float t[WAVES];
+            static_for<0, WAVES>([&](auto qq) { t[decltype(qq)::value] = red[decltype(qq)::value]; });
+            static_for<0, ilog2(WAVES)>([&](auto ll) {
+                constexpr int st = 1 << decltype(ll)::value;
+                static_for<0, WAVES / (2 * st)>([&](auto ii) { constexpr int i = decltype(ii)::value * 2 * st; t[i] += t[i + st]; });
+            });
+            return mean_quotient(t[0], p.L, p.inv_L);
+        };
 #ifdef DMEL_ABLATE
         const bool dbg_no_mean = (p.flags & 0x1000u) != 0;      // timing ablation: no clip sum (mean = 0)
 #else
@@ -590,12 +603,7 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
                     if constexpr (PAIR) ps += (seg && tA + 1 < p.T && ia + p.hop < p.L) ? xb2[0][pass][a] : 0.f;
                 });
             });
-            ps = wave_sum(ps);
-            if (lane == 0) red[wave] = ps;
-            __syncthreads();
-            float tot = 0.f;
-            for (int q = 0; q < WAVES; ++q) tot += red[q];
-            mean = tot * p.inv_L;
+            mean = mean_of(wave_sum(ps));
         } else if (p.remove_dc && p.psum == nullptr) {
             // short clips: every workgroup adds up its clip itself (L2 hits after the first toucher), in a
             // fixed order, instead of a separate pass over x
@@ -636,19 +644,13 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
                 static_for<0, KB>([&](auto jj) { v[decltype(jj)::value] = buf_f32(rx, (base + tid + THREADS * decltype(jj)::value) * 4); });
                 static_for<0, KB>([&](auto jj) { a0 += v[decltype(jj)::value]; });
             }
-            float ps = (a0 + a1) + (a2 + a3);
-            ps = wave_sum(ps);
-            if (lane == 0) red[wave] = ps;
-            __syncthreads();
-            float tot = 0.f;
-            for (int q = 0; q < WAVES; ++q) tot += red[q];
-            mean = tot * p.inv_L;
+            mean = mean_of(wave_sum((a0 + a1) + (a2 + a3)));
         } else {
             if constexpr (WIN_LDS) __syncthreads();              // window table complete
             if (p.remove_dc) {
                 // long clips: the <= 64 partial sums of the prep kernel, one per lane, one round trip, added
                 // in a fixed butterfly order (deterministic)
-                mean = wave_sum(ps_early) * p.inv_L;
+                mean = mean_quotient(wave_sum(ps_early), p.L, p.inv_L);
             }
         }
         STAMP(2);   // window table + clip mean done
@@ -728,11 +730,25 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
                     else wd2 = *reinterpret_cast<const float2*>(reinterpret_cast<const unsigned char*>(p.win2) + wbyte + G * 8 * a);
                     return v2f{wd2.x, wd2.y};
                 };
+#ifdef DMEL_ABLATE
+                // timing only (upper bound): the frames lose a mean the wave adds up from its own samples, and what is left of the
+                // clip mean is applied in the pairing pass as a frequency-domain correction (a table read + one packed FMA per bin pair)
+                float mean_w = mean;
+                if (p.flags & 0x200000u) {
+                    float sm_loc = 0.f;
+                    static_for<0, R>([&](auto aa) { sm_loc += xa[ti][pass][decltype(aa)::value]; });
+                    mean_w = wave_sum(sm_loc) * (1.0f / (64.f * R));
+                }
+                const float dlt_late = mean - mean_w;
+#define DMEL_MEAN_W mean_w
+#else
+#define DMEL_MEAN_W mean
+#endif
                 if (inside_w) {
                     static_for<0, R>([&](auto aa) {
                         constexpr int a = decltype(aa)::value;
                         const v2f wd = wload(aa);
-                        const float va = xa[ti][pass][a] - mean;
+                        const float va = xa[ti][pass][a] - DMEL_MEAN_W;
                         if constexpr (!PAIR) z[a] = splat(va) * wd;
                         else z[a] = v2f{va, xb2[ti][pass][a] - mean} * wd.xx;
                     });
@@ -977,7 +993,15 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
                             zn = v2f{__builtin_bit_cast(float, got_x), __builtin_bit_cast(float, got_y)};
                         }
                         const v2f zk = zr[p1];
-                        const float sx = zk.x + zn.x, sy = zk.y - zn.y, dx = zk.x - zn.x, dy = zk.y + zn.y;
+                        float sx = zk.x + zn.x, sy = zk.y - zn.y, dx = zk.x - zn.x, dy = zk.y + zn.y;
+#ifdef DMEL_ABLATE
+                        if constexpr (WIN_LDS) {
+                            if (p.flags & 0x200000u) {          // timing only: stand-in for (2 W[k], 2 W'[k]) of the window's own transform
+                                const float2 cw = *reinterpret_cast<const float2*>(smem_raw + wbyte + G * 8 * (p1 % (R / 2)));
+                                sx = fmaf(-dlt_late, cw.x, sx); dy = fmaf(-dlt_late, cw.y, dy);
+                            }
+                        }
+#endif
                         v2f pdv;
                         if constexpr (!PAIR) pdv = v2f{fmaf(sx, sx, sy * sy), fmaf(sx, dy, -(sy * dx))};
                         else pdv = v2f{fmaf(sx, sx, sy * sy), fmaf(dx, dx, dy * dy)};

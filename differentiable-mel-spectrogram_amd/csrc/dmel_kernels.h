@@ -74,6 +74,29 @@ struct LamState {
 };
 
 #if defined(__HIPCC__)
+// ---- the clip mean of models.py:38 ------------------------------------------------------------------------------------
+// The reference subtracts torch.mean(x[idx]) in fp32.  When a clip's offset is far above its signal, ONE ulp of that mean moves
+// the lowest mel bands by up to 3e-2 (tests/golden g13_dc_*: offset 500 x signal), and torch's own fp32 sum is an ulp off the
+// correctly rounded mean in a third of such clips: bit parity with it is not a property of the algorithm, staying within an ulp
+// or two of it is.  Here: short fp32 accumulator chains per thread, a pairwise fp32 tree over lanes and waves, and the QUOTIENT
+// sum / L rounded once (round 5 multiplied by fl32(1 / L): a second and third rounding).  Measured on the g13 fixtures: the
+// correctly rounded mean or its neighbour.  An fp64 tree from the accumulators on gives the correctly rounded mean in every clip
+// and was built and measured in round 6: +1 % on config 4's batch and config 3 (a chain of ~20 dependent fp64 operations between
+// the arrival of the clip and every wave's first window multiply) -- not kept: the reference itself is an ulp off.
+// Long clips: the <= 64 chunk sums of dmel_prep_kernel (fp64 inside a chunk, rounded per chunk: a 1 / sqrt(chunks) of the total's ulp).
+__device__ __forceinline__ float mean_quotient(float sum, int L, float inv)       // inv = fl32(1 / L), from the host
+{
+    const float fl = (float)L;                                   // (L < 2^24: exact)
+    const float q = sum * inv;
+    return fmaf(fmaf(-q, fl, sum), inv, q);                      // one Newton step: the correctly rounded quotient up to a 2^-24 of an ulp
+}
+__device__ __forceinline__ float clip_mean_psum(const float* psum, int nchunks, int b, int L)
+{
+    double s = 0.0;
+    for (int c = 0; c < nchunks; ++c) s += (double)psum[(size_t)b * nchunks + c];
+    return (float)(s / (double)L);
+}
+
 // time_frequency.py:39,60-65 on the device, bit for bit the host's dmel_n_fft: fp32 product, int() truncation,
 // 1 << bit_length(x-1).  lambd is uniform: after one multiply and one conversion the value is moved to a scalar register and
 // the rest is scalar integer arithmetic (the conversion saturates at INT_MAX, which lands in the same "too large" answer

@@ -50,9 +50,7 @@ __global__ void __launch_bounds__(kXgThreads) dmel_xgrad_frames_kernel(XgradPara
     const float* xb = p.x + (size_t)b * p.L;
     float mean = 0.f;
     {
-        double s = 0.0;
-        for (int c = 0; c < p.nchunks; ++c) s += (double)p.psum[(size_t)b * p.nchunks + c];
-        mean = (float)(s * (double)p.inv_L);
+        mean = clip_mean_psum(p.psum, p.nchunks, b, p.L);
     }
     for (int n = tid; n < N; n += kXgThreads) {
         const long long ia = (long long)tA * p.hop - N / 2 + n, ib = ia + p.hop;
@@ -325,19 +323,18 @@ __global__ void __launch_bounds__((XgPlan<N>::THREADS), (XgPlan<N>::MINW)) dmel_
                 win[n] = expf(-0.5f * (tq * tq));
             }
         });
+        // the forward's mean (dmel_kernels.h: "the clip mean"): fp32 tree, quotient rounded once
         float ps = wave_sum((a0 + a1) + (a2 + a3));
         float* redm = reinterpret_cast<float*>(smem_raw + p.tw2_off + (C > 1 ? R * C * 8 : 0));
         if (lane == 0) redm[wave] = ps;
         __syncthreads();
         float tot = 0.f;
         for (int q = 0; q < THREADS / 64; ++q) tot += redm[q];
-        mean = tot * p.inv_L;
+        mean = mean_quotient(tot, L, p.inv_L);
     } else {
         float wv[WPT];
         static_for<0, WPT>([&](auto ww) { constexpr int wi = decltype(ww)::value; const int n = tid + THREADS * wi; wv[wi] = p.win2[n < WN ? n : 0].x; });
-        double s = 0.0;
-        for (int c = 0; c < p.nchunks; ++c) s += (double)p.psum[(size_t)b * p.nchunks + c];
-        mean = (float)(s * (double)p.inv_L);
+        mean = clip_mean_psum(p.psum, p.nchunks, b, p.L);
         static_for<0, WPT>([&](auto ww) { constexpr int wi = decltype(ww)::value; const int n = tid + THREADS * wi; if (n < WN) win[n] = wv[wi]; });
     }
     if (total > 0) {

@@ -113,7 +113,7 @@ def run_case(models, tf, case):
         out["mel"] = mel_np
     else:
         out["mel_sampled"] = mel_np.reshape(-1)[idx]
-    if case["kind"] == "dc":
+    if case["kind"] in ("dc", "tone"):
         # the mean models.py:38 subtracted, clip by clip, in the input dtype (same expression, same torch)
         out["mean_ref"] = np.asarray([torch.mean(x[i]).item() for i in range(case["B"])], dtype=np.float64)
     return out
