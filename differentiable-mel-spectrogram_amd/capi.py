@@ -433,9 +433,11 @@ class Plan:
         self._mailbox = mailbox                       # keep it alive as long as the plan points at it
 
     def attach_adam(self, param_ptr, exp_avg_ptr=0, exp_avg_sq_ptr=0, step_ptr=0, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8,
-                    weight_decay=0.0, maximize=False):
+                    weight_decay=0.0, maximize=False, keep=None):
         """dmel_plan_attach_adam: every backward() on this plan ends with Adam's update of the fp32 device scalar at ``param_ptr`` by the
-        gradient it has just written (``param_ptr`` = 0 / None detaches)."""
+        gradient it has just written (``param_ptr`` = 0 / None detaches).  ``keep``: the objects that own the four addresses -- referenced
+        from the plan for as long as it carries them (the caching allocator must not hand that memory to anyone else meanwhile)."""
+        self._adam_keep = keep if param_ptr else None
         _check(load().dmel_plan_attach_adam(self._h, param_ptr or None, exp_avg_ptr or None, exp_avg_sq_ptr or None, step_ptr or None,
                                             C.c_double(float(lr)), C.c_double(float(beta1)), C.c_double(float(beta2)), C.c_double(float(eps)),
                                             C.c_double(float(weight_decay)), 1 if maximize else 0))

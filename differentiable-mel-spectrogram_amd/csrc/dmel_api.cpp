@@ -763,10 +763,9 @@ dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dm
     if (spec_out && (big || N < dmel::kMinFastNfft || mode != dmel::kTrain))
         return fail(DMEL_ERR_UNSUPPORTED, "the spectrogram is saved by the fused training kernel only (power-of-two n_fft from 32 to 16384, tangent requested)");
     if (big && (N & 1)) return fail(DMEL_ERR_UNSUPPORTED, "n_fft = " + std::to_string(N) + " is odd");
-    // DMEL_FLAG_X_INDIRECT: the kernels read the batch's address from a pointer cell -- the fused kernel and the partial sums of long clips
-    // (dmel_prep_kernel) do; the direct-DFT and the global-memory / chirp-z paths do not
-    if ((flags & DMEL_FLAG_X_INDIRECT) && (big || N < dmel::kMinFastNfft || N > dmel::kMaxFastNfft))
-        return fail(DMEL_ERR_UNSUPPORTED, "DMEL_FLAG_X_INDIRECT: a power-of-two n_fft from 32 to 16384 (n_fft " + std::to_string(N) + " here)");
+    // DMEL_FLAG_X_INDIRECT: every kernel of the forward reads the batch's address from a pointer cell (round 5: the fused kernel and the
+    // partial sums only; a lambd that left n_fft 32 ... 16384 inside a captured loop then ended in NaN + an error -- ADVICE r05)
+    const float* const* x_cell = (flags & DMEL_FLAG_X_INDIRECT) ? reinterpret_cast<const float* const*>(x) : nullptr;
     NfftTables* tb = nullptr;
     dmel_status st = build_tables(pl, N, &tb);
     if (st != DMEL_OK) return st;
@@ -826,7 +825,7 @@ dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dm
         const size_t m0 = prof_mark(pl, s);
         {
             dmel::PrepParams pp{};
-            pp.x = x; pp.psum = sc.psum; pp.win2 = pl->big_win;
+            pp.x = x_cell ? nullptr : x; pp.x_ind = x_cell; pp.psum = sc.psum; pp.win2 = pl->big_win;
             pp.B = need_sums ? batch : 0; pp.L = pl->cfg.n_points; pp.nchunks = pl->nchunks; pp.chunk = pl->chunk;
             pp.N = N; pp.normalize = pl->cfg.normalize_window; pp.win_half = win_half; pp.center = center;
             pp.lam = lam; pp.lam.role = dmel::kLamQuiet;
@@ -836,7 +835,7 @@ dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dm
         const size_t m1 = prof_mark(pl, s);
         prof_span(pl, m0, m1, 0);
         dmel::BigParams bp{};
-        bp.x = x; bp.out = out; bp.tangent = tangent; bp.psum = sc.psum; bp.win2 = pl->big_win;
+        bp.x = x_cell ? nullptr : x; bp.x_ind = x_cell; bp.out = out; bp.tangent = tangent; bp.psum = sc.psum; bp.win2 = pl->big_win;
         bp.tw = tw; bp.chirp = bt.chirp; bp.hbr = bt.hbr; bp.zws = pl->big_z; bp.fbT = tb->fbT; bp.band = tb->band;
         bp.B = batch; bp.L = pl->cfg.n_points; bp.T = pl->T; bp.hop = pl->cfg.hop_length; bp.M = pl->cfg.n_mels;
         bp.nchunks = pl->nchunks; bp.N = N; bp.F = tb->F; bp.mode = mode; bp.Mfft = bt.M; bp.logM = bt.logM;
@@ -875,7 +874,7 @@ dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dm
     const float inv_L = 1.0f / (float)pl->cfg.n_points;
     if (N < dmel::kMinFastNfft) {
         dmel::NaiveParams np{};
-        np.x = x; np.out = out; np.tangent = tangent; np.psum = sc.psum; np.win2 = sc.win; np.fb = tb->fb_dense;
+        np.x = x_cell ? nullptr : x; np.x_ind = x_cell; np.out = out; np.tangent = tangent; np.psum = sc.psum; np.win2 = sc.win; np.fb = tb->fb_dense;
         np.B = batch; np.L = pl->cfg.n_points; np.T = pl->T; np.hop = pl->cfg.hop_length; np.M = pl->cfg.n_mels;
         np.nchunks = pl->nchunks; np.N = N; np.F = tb->F; np.mode = mode;
         np.inv_L = inv_L; np.eps = (float)eps; np.flags = flags; np.remove_dc = remove_dc; np.lam = lam;
@@ -887,7 +886,7 @@ dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dm
     }
     dmel::FwdParams fp{};
     if (flags & DMEL_FLAG_X_INDIRECT) {
-        fp.x_ind = reinterpret_cast<const float* const*>(x);      // (the shapes this is for were checked at the top of this function)
+        fp.x_ind = reinterpret_cast<const float* const*>(x);
         x = nullptr;
         flags &= ~DMEL_FLAG_X_INDIRECT;
     }
@@ -1421,12 +1420,6 @@ dmel_status dmel_forward_dev(dmel_plan* plan, const float* x, int32_t batch, con
         NfftTables* tb = nullptr;
         for (int n : {N, 2 * N, N / 2})
             if (n >= 1 && n <= dmel::kMaxBigFft && (st = build_tables(plan, n, &tb)) != DMEL_OK) return st;
-    }
-    if (flags & DMEL_FLAG_X_INDIRECT) {
-        // a batch handed over by address is served at n_fft 32 ... 16384: a guard beyond that range is left out -- should lambd get there the
-        // launches that ran do not cover it, the output is NaN and the plan reports the error (the same loud end as any uncovered value)
-        if (2 * N > dmel::kMaxFastNfft) guards &= ~2;
-        if (N / 2 < dmel::kMinFastNfft) guards &= ~1;
     }
     int cand[3], nc = 0;
     cand[nc++] = N;

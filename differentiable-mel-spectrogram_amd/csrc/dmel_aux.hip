@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(128) dmel_naive_kernel(NaiveParams p)
     float* D = P + p.F;
     const int tid = threadIdx.x;
     const int b = blockIdx.x / p.T, t = blockIdx.x % p.T;
-    const float* xb = p.x + (size_t)b * p.L;
+    const float* xb = resolve_x(p.x, p.x_ind) + (size_t)b * p.L;
     const bool spec_mode = (p.mode == kSpec || p.mode == kSpecTrain);
     const LamState ls = lam_prologue(p.lam, p.N, blockIdx.x == 0 && tid == 0);
     if (ls.action != kLamRun) {

@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(kBigThreads) dmel_big_kernel(BigParams p)
     for (long long unit = blockIdx.x; unit < units; unit += gridDim.x) {
         const int b = (int)(unit / tiles), tile = (int)(unit % tiles);
         const int tA = pair ? 2 * tile : tile, tB = tA + 1;
-        const float* xb = p.x + (size_t)b * p.L;
+        const float* xb = resolve_x(p.x, p.x_ind) + (size_t)b * p.L;
         float mean = 0.f;
         if (p.remove_dc) {
             mean = clip_mean_psum(p.psum, p.nchunks, b, p.L);

@@ -381,7 +381,17 @@ bool forward_window_in_lds(int n_fft);     // the kernel builds its own window t
 hipError_t forward_prepare_attributes();   // raises the dynamic-LDS limit of every instantiation once
 
 // direct-DFT kernel for n_fft < 32 (and as an on-device cross-check of the fast path)
+// DMEL_FLAG_X_INDIRECT (every forward kernel since round 6): the batch's address comes from a pointer cell, read with one scalar load
+__device__ __forceinline__ const float* resolve_x(const float* x, const float* const* x_ind)
+{
+#if defined(__HIPCC__)
+    if (x_ind) { typedef const float* cfp; return *(const __attribute__((address_space(4))) cfp*)x_ind; }
+#endif
+    return x;
+}
+
 struct NaiveParams {
+    const float* const* x_ind;      // DMEL_FLAG_X_INDIRECT: the address of x is read from here (then x is nullptr), as in FwdParams
     const float* x; float* out; float* tangent; const float* psum; const float2* win2; const float* fb;
     int B, L, T, hop, M, nchunks, N, F, mode;
     float inv_L, eps; unsigned flags; int remove_dc;
@@ -395,6 +405,7 @@ hipError_t launch_naive(const NaiveParams& p, hipStream_t s);
 constexpr int kMaxBigFft = 1048576;    // largest power-of-two FFT of that path (n_fft itself, or >= 2 n_fft - 1 for Bluestein): BASELINE config 5's
                                        // 220 500-sample clip in the default optimized=False branch is n_fft 441 000 through 2^20-point FFTs
 struct BigParams {
+    const float* const* x_ind;      // DMEL_FLAG_X_INDIRECT, as in FwdParams
     const float* x; float* out; float* tangent; const float* psum; const float2* win2;
     const float2* tw;        // (Mfft/2): exp(-2 pi i k / Mfft)
     const float2* chirp;     // (N): exp(-i pi n^2 / N), or nullptr when N is a power of two (then Mfft == N)

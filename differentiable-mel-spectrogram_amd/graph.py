@@ -97,6 +97,11 @@ class _CudaBackend:
         with t.cuda.stream(stream):
             for d, s_ in zip(dsts, srcs):
                 d.copy_(s_, non_blocking=True)
+                # a device batch was allocated on ANOTHER stream: without this the caching allocator may hand its memory to the next
+                # allocation as soon as the caller drops the tensor (`gs.feed(inputs, labels.to(device))`), while this copy is still
+                # queued behind the event above -- a silent race on the training batch
+                if s_.is_cuda:
+                    s_.record_stream(stream)
 
     def pointer_cells(self, n):
         """(n int64 cells on the device, their pinned host staging): GraphedStep(zero_copy=...) publishes batch ADDRESSES through them"""

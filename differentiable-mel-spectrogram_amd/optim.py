@@ -13,16 +13,32 @@ keeps its own optimizer; ``torch.optim.Adam`` on ``lambd`` keeps working and is 
 the workgroup that finishes the backward's dot product (``dmel_plan_attach_adam``: the same arithmetic on the gradient it has just
 written), and ``step()`` launches nothing for that parameter -- the step of train.py:47-49 is then forward kernel + dot kernel.  For
 steps with ONE backward per update whose only gradient of the layer is ``lambd.grad`` (no trainable filterbank, no waveform gradient,
-no gradient accumulation, no all-reduce of ``lambd.grad`` outside the layer's mailbox).
+no gradient accumulation, no all-reduce of ``lambd.grad`` outside the layer's mailbox).  The plans carry the pointers to ``lambd`` and its
+Adam state only BETWEEN ``zero_grad()`` (which attaches them, and keeps the tensors referenced from the plan) and ``step()`` (which takes
+them off again): a backward outside that bracket -- an evaluation pass, a gradient check, another optimizer's step -- is a plain backward, and
+an optimizer that is dropped takes its attachment with it (a finalizer).  A HIP graph captured around the whole step holds the update
+in its dot-kernel node (and the step function, hence the optimizer and its state, through ``GraphedStep``).
 
 ``lr`` is passed by value at every ``step()``: a HIP graph captured around the step holds the value of the capture (as with
 torch's capturable Adam and a Python-float lr), so re-capture when a scheduler changes it.
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from . import capi
+
+
+def _detach_plans(plans: list) -> None:
+    """takes the fused update off every plan in `plans` (a list the optimizer shares with its finalizer) and empties it"""
+    while plans:
+        plan = plans.pop()
+        try:
+            plan.attach_adam(0)
+        except Exception:                                  # noqa: BLE001 -- interpreter shutdown: the library may be gone already
+            pass
 
 
 class LambdAdam(torch.optim.Optimizer):
@@ -33,7 +49,8 @@ class LambdAdam(torch.optim.Optimizer):
         if lr < 0.0 or eps < 0.0 or not (0.0 <= betas[0] < 1.0) or not (0.0 <= betas[1] < 1.0) or weight_decay < 0.0:
             raise ValueError("LambdAdam: lr / betas / eps / weight_decay out of range")
         self._fused_layer = fused_into_backward
-        self._fused_plans = []
+        self._fused_plans = []                     # plans that carry the update right now (shared with the finalizer below)
+        self._finalizer = weakref.finalize(self, _detach_plans, self._fused_plans)
         # capturable=True: torch's Optimizer.load_state_dict then moves state["step"] to the parameter's device as fp32 (its
         # _process_value_according_to_param_policy); without the key a checkpoint loaded with map_location="cpu" left the step count
         # on the host and step() handed a host pointer to the kernel
@@ -57,18 +74,17 @@ class LambdAdam(torch.optim.Optimizer):
         lay, group = self._fused_layer, self.param_groups[0]
         p = group["params"][0]
         st = self._checked_state(p)
-        plans = list(lay._plans.values())
         b1, b2 = group["betas"]
-        for plan in plans:
+        _detach_plans(self._fused_plans)                        # (plans of an earlier bracket that never reached step())
+        for plan in lay._plans.values():
             plan.attach_adam(p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr(), group["lr"], b1, b2,
-                             group["eps"], group["weight_decay"], group["maximize"])
-        self._fused_plans = plans
+                             group["eps"], group["weight_decay"], group["maximize"], keep=(p, st["exp_avg"], st["exp_avg_sq"], st["step"]))
+            self._fused_plans.append(plan)
 
     def detach(self):
-        """stops the fused update (the plans go back to writing the gradient only)"""
-        for plan in self._fused_plans:
-            plan.attach_adam(0)
-        self._fused_plans, self._fused_layer = [], None
+        """stops the fused update for good (the plans go back to writing the gradient only; step() launches the update again)"""
+        _detach_plans(self._fused_plans)
+        self._fused_layer = None
 
     def zero_grad(self, set_to_none: bool = True):
         # the natural place before every backward: hyper-parameters changed by a scheduler, plans created since, state loaded from a checkpoint
@@ -114,7 +130,8 @@ class LambdAdam(torch.optim.Optimizer):
         if self._fused_layer is not None:
             if not self._fused_plans:
                 raise RuntimeError("LambdAdam(fused_into_backward=layer): call zero_grad() before the backward (it attaches the update to the layer's plans)")
-            return loss                                  # the backward's dot kernel has applied the update
+            _detach_plans(self._fused_plans)             # the backward's dot kernel has applied the update; later backwards are plain ones
+            return loss
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:

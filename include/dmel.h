@@ -76,11 +76,10 @@ typedef struct dmel_plan dmel_plan;
 #define DMEL_FLAG_X_INDIRECT 32u /* dmel_forward_dev only (round 5): `x` is a device pointer to ONE device pointer -- the address of the batch, read by
                                    the kernel when it runs.  A step captured into a HIP graph reads static addresses; with this flag the static
                                    address is that of a pointer cell, and handing the step a new batch (train.py:25-49: one per iteration) is an
-                                   8-byte write instead of a copy of the batch (dmel_amd.GraphedStep.feed, zero_copy).  Wherever the fused
-                                   kernel runs (a power-of-two n_fft from 32 to 16384; clips of any length: the partial sums of long clips read the
-                                   cell too); the direct-DFT and global-memory paths return DMEL_ERR_UNSUPPORTED and the caller copies; a guard launch for a neighbouring n_fft outside that range is left out
-                                   (lambd arriving there ends in NaN + the plan's error report, as any uncovered value does).  The batch must stay
-                                   valid until the forward has executed. */
+                                   8-byte write instead of a copy of the batch (dmel_amd.GraphedStep.feed, zero_copy).  Every kernel of the
+                                   forward reads the cell (round 6: the direct-DFT kernel below n_fft 32 and the global-memory / chirp-z path beyond
+                                   16384 too, so a lambd that drifts out of the fused kernel's range inside a captured loop is served like any
+                                   other).  The batch must stay valid until the forward has executed. */
 #define DMEL_DTYPE_F32 0
 #define DMEL_DTYPE_BF16 1
 

@@ -97,16 +97,22 @@ def test_a_batch_passed_by_address_gives_the_bits_of_the_batch_passed_directly(l
             assert torch.equal(layer.lambd.grad, d0)
 
 
-def test_by_address_is_refused_outside_the_fused_kernel():
+def test_by_address_outside_the_fused_kernel():
+    """Round 6: the direct-DFT kernel (n_fft < 32) and the global-memory transform (n_fft > 16384) read the pointer cell too --
+    a lambd that leaves the fused kernel's range inside a by-address loop is served, bit for bit as with the batch passed directly."""
     from dmel_amd import MelSpectrogramLayer, SlotInput
     B, L, hop, M, sr = 2, 16000, 512, 64, 16000
     cell = torch.zeros(1, dtype=torch.int64, device=DEV)
     x = torch.randn(B, L, device=DEV)
     cell.fill_(x.data_ptr())
-    # n_fft 32768: the global-memory transform, several launches read x
-    big = MelSpectrogramLayer(torch.tensor(5000.0), n_mels=M, n_points=L, sample_rate=sr, hop_length=hop, device=DEV, optimized=True, log=True).to(DEV)
-    with pytest.raises(RuntimeError, match="X_INDIRECT"):
-        big(SlotInput(cell, (B, L)))
+    for lam in (5000.0, 2.0):                              # n_fft 32768 (several launches read x) and 16
+        a = MelSpectrogramLayer(torch.tensor(lam), n_mels=M, n_points=L, sample_rate=sr, hop_length=hop, device=DEV, optimized=True, log=True).to(DEV)
+        b = MelSpectrogramLayer(torch.tensor(lam), n_mels=M, n_points=L, sample_rate=sr, hop_length=hop, device=DEV, optimized=True, log=True).to(DEV)
+        ya, yb = a(SlotInput(cell, (B, L))), b(x)
+        ya.sum().backward(); yb.sum().backward()
+        torch.cuda.synchronize()
+        assert a.plan_info()["kernel_path"] in (1, 3) and a.lambd_status()["error"] == 0
+        assert torch.equal(ya, yb) and torch.equal(a.lambd.grad, b.lambd.grad)
     # optimized=False / a host-read lambd / a trainable filterbank: not the hot path
     for kw in (dict(optimized=False), dict(lambd_sync=True)):
         lay = MelSpectrogramLayer(torch.tensor(100.0), n_mels=M, n_points=L, sample_rate=sr, hop_length=hop, device=DEV, log=True,
@@ -206,4 +212,53 @@ def test_by_address_batches_may_be_dropped_by_the_caller_right_after_feed():
     torch.cuda.synchronize()
     assert layer2.lambd_status()["error"] == 0
     assert len(ptrs) > 1                                              # the batches really lived at different addresses
+    assert torch.equal(hist[:n], torch.stack(ref)), (hist[:n] - torch.stack(ref)).abs().max().item()
+
+
+def test_copied_batches_may_be_dropped_by_the_caller_right_after_feed():
+    """The same for COPIED inputs (ADVICE r05): feed() issues `slot.copy_(batch)` on its side stream, behind an event of an earlier replay;
+    a device batch that the caller drops at once went back to the caching allocator of the CURRENT stream and was handed to the next
+    allocation while the copy was still queued -- the slot then received the next tensor's contents.  copy_into() now records the side
+    stream on the source."""
+    from dmel_amd import GraphedStep
+    B, L, hop, M, sr, lam0, K, n = 8, 16000, 512, 64, 16000, 128.0, 4, 22
+    T = L // hop + 1
+    g = torch.randn(B, 1, M, T, generator=torch.Generator().manual_seed(2)).to(DEV)
+
+    def batches():
+        gen = torch.Generator(device=DEV).manual_seed(78)
+        for _ in range(n):
+            yield torch.randn(B, L, generator=gen, device=DEV)
+
+    layer, opt = _layer_opt(lam0, B, L, hop, M, sr)
+    ref = []
+    for x in batches():
+        opt.zero_grad(set_to_none=False)
+        layer(x).backward(g)
+        opt.step()
+        ref.append(layer.lambd.detach().clone())
+        del x
+    torch.cuda.synchronize()
+
+    layer2, opt2 = _layer_opt(lam0, B, L, hop, M, sr)
+    hist = torch.zeros(n + K, device=DEV)
+    k = torch.zeros(1, dtype=torch.long, device=DEV)
+
+    def step(x):
+        opt2.zero_grad(set_to_none=False)
+        layer2(x).backward(g)
+        opt2.step()
+        hist.index_copy_(0, k, layer2.lambd.detach().view(1))
+        k.add_(1)
+
+    gs = GraphedStep(step, [layer2], steps_per_replay=K, inputs=[torch.empty(B, L, device=DEV)])
+    for x in batches():
+        torch.cuda.current_stream().synchronize()                    # the batch is ready (feed() waits for nothing on the current stream)
+        gs.feed(x)
+        del x
+        junk = torch.full((B, L), float("nan"), device=DEV)          # what the allocator hands out next if the batch's block is free
+        del junk
+    gs.flush()
+    torch.cuda.synchronize()
+    assert layer2.lambd_status()["error"] == 0
     assert torch.equal(hist[:n], torch.stack(ref)), (hist[:n] - torch.stack(ref)).abs().max().item()

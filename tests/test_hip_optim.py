@@ -178,3 +178,49 @@ def test_adam_fused_into_the_backward_is_lambd_adam_bit_for_bit():
     assert torch.equal(la.lambd.detach(), before)
     with pytest.raises(ValueError):
         LambdAdam([lb.lambd], lr=0.05, fused_into_backward=la)           # not that layer's parameter
+
+
+def test_fused_adam_is_attached_only_between_zero_grad_and_step():
+    """the plan used to carry raw pointers to lambd and its Adam state from the first zero_grad() until an explicit
+    detach().  Now: a backward outside the zero_grad() ... step() bracket (an evaluation pass) is a plain backward; an optimizer that is
+    dropped inside the bracket takes its attachment with it; the plan references the state tensors while it carries their addresses."""
+    import gc
+    from dmel_amd import LambdAdam, MelSpectrogramLayer
+    case = C.BY_NAME["g1_c1"]
+    x = torch.from_numpy(C.make_input(case)).to(DEV)
+    g = torch.from_numpy(C.make_cotangent(case)).to(DEV)
+    lay = MelSpectrogramLayer(torch.tensor(float(case["lambd"])), n_mels=case["n_mels"], n_points=case["L"], sample_rate=case["sr"],
+                              hop_length=case["hop"], device=DEV, optimized=True, log=True).to(DEV)
+    lay(x)
+    plan = next(iter(lay._plans.values()))
+    opt = LambdAdam([lay.lambd], lr=0.05, fused_into_backward=lay)
+    opt.zero_grad()
+    assert plan._adam_keep is not None and plan._adam_keep[0] is lay.lambd
+    (lay(x) * g).sum().backward()
+    opt.step()
+    torch.cuda.synchronize()
+    after_step = lay.lambd.detach().clone()
+    assert float(after_step) != float(case["lambd"]) and plan._adam_keep is None
+    # an evaluation backward behind the step: lambd stays, the gradient is delivered
+    lay.lambd.grad = None
+    (lay(x) * g).sum().backward()
+    torch.cuda.synchronize()
+    assert torch.equal(lay.lambd.detach(), after_step) and lay.lambd.grad is not None
+    with pytest.raises(RuntimeError):
+        opt.step()                                               # no zero_grad() in front of that backward: nothing was applied, and step() says so
+    # dropped inside the bracket: the finalizer detaches
+    opt.zero_grad()
+    assert plan._adam_keep is not None
+    del opt
+    gc.collect()
+    assert plan._adam_keep is None
+    (lay(x) * g).sum().backward()
+    torch.cuda.synchronize()
+    assert torch.equal(lay.lambd.detach(), after_step)
+    # another optimizer takes over
+    opt2 = torch.optim.Adam([lay.lambd], lr=0.05, fused=True, capturable=True)
+    opt2.zero_grad()
+    (lay(x) * g).sum().backward()
+    opt2.step()
+    torch.cuda.synchronize()
+    assert not torch.equal(lay.lambd.detach(), after_step)
