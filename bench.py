@@ -814,14 +814,26 @@ def main():
     traffic = quoted.get(args.config, {}).get("dmel_fwd_kernel_bytes_per_launch")
     # the contraction stage on the matrix cores: executed fp32 MFMA flops of one launch = non-zero 4x16 filterbank blocks
     # x 16-row tiles x 2048 flop per v_mfma_f32_16x16x4_f32, against the dense fp32 matrix peak
-    mfma_flops = 2048.0 * info["fb_blocks"] * mfma_row_tiles(info, B, T) if info["kernel_path"] == 0 else 0.0
-    mfma = {"executed_tflops": round(mfma_flops / (fwd_us * 1e-6) / 1e12, 2), "peak_tflops": FP32_MFMA_PEAK_TFLOPS,
+    mfma_flops = mfma_flops_of(info, B, T)
+    dense_flops = 2.0 * 2.0 * B * T * (info["n_fft"] // 2 + 1) * M                      # 2 F M per frame, power and tangent rows
+    mfma = {"contraction": {0: "16x16x4 fp32 tiles over the non-zero 4x16 blocks", 1: "wave-local 4x4x1 fp32 (kTrainW)", 2: "dense bf16x3 (kTrainH)"}.get(info.get("contraction"), "none"),
+            "executed_tflops": round(mfma_flops / (fwd_us * 1e-6) / 1e12, 2), "peak_tflops": FP32_MFMA_PEAK_TFLOPS,
             "frac": round(mfma_flops / (fwd_us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
-            "note": "banded filterbank: only the non-zero blocks are multiplied (dense would be fb_blocks_dense); the kernel is not MFMA-bound"}
+            "executed_flops_per_launch": mfma_flops, "dense_equivalent_flops_per_launch": dense_flops,
+            "note": "banded HTK bank: only its non-zero band is multiplied (the dense product of SURVEY 8(d) would be dense_equivalent_flops); the whole kernel is the "
+                    "denominator and it is not MFMA-bound -- north_star's >= 50 % MFMA utilisation is unmet by design on this path (DESIGN 4.2)"}
     roofline = roofline_of(info, B, T, alg_bytes, fwd_us, mfma_flops)
     # what binds: the vector pipe's instruction stream -- SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel cycles) and the
     # vector instructions per wave, from the same PMC session as `traffic` (same source-sha rule)
-    roofline.update({"valu_busy": quoted.get(args.config, {}).get("valu_busy"), "valu_insts_per_wave": quoted.get(args.config, {}).get("valu_insts_per_wave")})
+    qc = quoted.get(args.config, {})
+    roofline.update({"valu_busy": qc.get("valu_busy"), "valu_insts_per_wave": qc.get("valu_insts_per_wave"), "kernel_cycles": qc.get("kernel_cycles"),
+                     "effective_clock_ghz": qc.get("effective_clock_ghz"), "valu_busy_note": qc.get("valu_busy_note")})
+    # SURVEY 8(d)'s strict forward bytes (read x + write Y: the tangent this launch also writes is the backward's operand there)
+    roofline["frac_section8d"] = round((4 * B * L + (2 if args.bf16_activations else 4) * B * M * T) / (fwd_us * 1e-6) / (HBM_PEAK_GBS * 1e9), 4)
+    roofline["frac_note"] = ("frac: x + out + tangent (every tensor this launch touches, once) over the launch's live-measured duration and 8 TB/s; "
+                             "frac_section8d: SURVEY 8(d)'s forward bytes only (x + out); hbm_frac_cold: the same launch on a batch no cache holds; "
+                             "steady_state_frac: per-launch bytes of config 4's batch on this GPU (8 rounds of resident workgroups: launch, first touch and "
+                             "drain paid once) over its un-profiled train time")
     roofline.update({"traffic": traffic, "traffic_source": traffic_src, "avg_launch_us_single_event_pair": round(fwd_pair_us, 2),
                      "other_kernels_us": {"prep": round(prep_us, 2), "backward_dot": round(bwd_us, 2)}, "mfma_stage": mfma})
 
@@ -840,6 +852,8 @@ def main():
                    if args.config == "c2" else f"{args.config}: batch {B} x {L} @ {sr}, lambd {lam}, hop {hop}, n_mels {M}",
                    "global_batch": B * world, "frames_per_step": frames_per_rank * world, "parallelism": par, "reducer": reducer,
                    "rccl_ranks_seen": ranks_seen,
+                   "step_contents": "forward + backward to lambd.grad + torch.optim.Adam(fused, capturable) update of lambd (two torch kernels for the one scalar); "
+                                    "SURVEY 8(d)'s metric asks for forward + backward only: that is c_abi_kernels (no autograd, no optimizer)",
                    "launch": ("eager from Python: torch.ops.dmel.mel_spectrogram + autograd + optimizer.step()" if chosen == "eager" else
                               f"HIP graph captured from the nn.Module step (dmel_amd.GraphedStep), {modes[chosen][1]} step(s) per replay") +
                              "; lambd stays on the device, no host synchronisation inside the timed region"},
@@ -858,6 +872,10 @@ def main():
         if cold:
             roofline["hbm_frac_cold"] = round(roofline["algorithmic_bytes_per_launch"] / (cold * 1e-6) / (HBM_PEAK_GBS * 1e9), 4)
             roofline["avg_launch_us_cold"] = cold
+        r4 = result["other_configs"].get("c4_on_one_gpu", {})
+        if r4.get("roofline", {}).get("frac") is not None:
+            roofline["steady_state_frac"] = r4["roofline"]["frac"]
+            roofline["steady_state_ns_per_frame"] = r4.get("ns_per_frame_forward")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg)
     if dist is not None:
@@ -873,6 +891,22 @@ def _flush_c_stdio():
         ctypes.CDLL(None).fflush(None)
     except Exception:               # noqa: BLE001
         pass
+
+
+def mfma_flops_of(info, B, T):
+    """executed fp32 MFMA flops of ONE launch of the fused forward, by the contraction it ran (dmel_plan_info.contraction, ABI 5):
+    0: non-zero 4x16 filterbank blocks x 16-row tiles x 2048 flop per v_mfma_f32_16x16x4_f32;
+    1 (kTrainW, the HTK bank at n_fft 1024 / 2048): every wave issues wl_steps v_mfma_f32_4x4x1_16b_f32 per tile -- 16 blocks of (4 x 1)(1 x 4):
+       512 flop per instruction whether or not a block's rows all carry frames -- x 8 waves per workgroup x the grid;
+    otherwise (spectrogram modes, direct DFT, global-memory transform, the bf16x3 dense contraction: priced on another pipe): 0."""
+    if info.get("kernel_path") != 0:
+        return 0.0
+    kind = info.get("contraction", 0)
+    if kind == 1:
+        return 512.0 * info["wl_steps"] * 8 * info["grid_fwd"]
+    if kind == 0:
+        return 2048.0 * info["fb_blocks"] * mfma_row_tiles(info, B, T)
+    return 0.0
 
 
 def mfma_row_tiles(info, B, T):
@@ -946,11 +980,13 @@ def other_configs(torch, capi, synth, dev, kernel_times):
         info = plan.info()
         fwd_us, _, prep_us, bwd_us, step_us = kernel_times(plan, x, g, out, tan, dl, lam, out.numel(), B, False)
         alg = 4 * (B * L + 2 * B * M * T)
-        mflops = 2048.0 * info["fb_blocks"] * mfma_row_tiles(info, B, T) if info["kernel_path"] == 0 else 0.0
+        mflops = mfma_flops_of(info, B, T)
         rl = roofline_of(info, B, T, alg, fwd_us, mflops)
+        rl["frac_section8d"] = round(4.0 * (B * L + B * M * T) / (fwd_us * 1e-6) / (HBM_PEAK_GBS * 1e9), 4)
         q = quoted.get({"c4_on_one_gpu": "c4", "esc50_x0.3": "esc_n4096", "esc50_lambd700": "esc_n8192"}.get(name, name), {})
         rl["traffic"] = q.get("dmel_fwd_kernel_bytes_per_launch")
         rl["valu_busy"], rl["valu_insts_per_wave"] = q.get("valu_busy"), q.get("valu_insts_per_wave")
+        rl["kernel_cycles"], rl["effective_clock_ghz"] = q.get("kernel_cycles"), q.get("effective_clock_ghz")
         return {"workload": f"batch {B} x {L} @ {sr} Hz, n_fft {info['n_fft']} (lambd {round(lam, 1)}), hop {hop}, n_mels {M}",
                 "frames_per_step": B * T, "step_us": round(step_us, 2), "frames_per_s": round(B * T / (step_us * 1e-6), 1),
                 "kernels_us": {"prep_partial_sums": round(prep_us, 2), "fused_forward": round(fwd_us, 2), "backward_dot": round(bwd_us, 2)},

@@ -54,7 +54,8 @@ class DmelConfig(C.Structure):
 class DmelPlanInfo(C.Structure):
     _fields_ = [("n_fft", C.c_int32), ("n_freqs", C.c_int32), ("n_time", C.c_int32),
                 ("frames_per_tile", C.c_int32), ("grid_fwd", C.c_int32), ("fb_blocks", C.c_int32),
-                ("fb_blocks_dense", C.c_int32), ("lds_bytes", C.c_int32), ("kernel_path", C.c_int32)]
+                ("fb_blocks_dense", C.c_int32), ("lds_bytes", C.c_int32), ("kernel_path", C.c_int32),
+                ("contraction", C.c_int32), ("wl_steps", C.c_int32)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}

@@ -846,6 +846,7 @@ dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dm
         pl->info.n_fft = N; pl->info.n_freqs = tb->F; pl->info.n_time = pl->T;
         pl->info.kernel_path = 3; pl->info.frames_per_tile = pair ? 2 : 1; pl->info.grid_fwd = grid;
         pl->info.fb_blocks = 0; pl->info.fb_blocks_dense = 0; pl->info.lds_bytes = dmel::big_uses_global(bt.M) ? 0 : bt.M * 8;
+        pl->info.contraction = -1; pl->info.wl_steps = 0;
         return DMEL_OK;
     }
 
@@ -882,6 +883,7 @@ dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dm
         prof_span(pl, m1, prof_mark(pl, s), 1);
         pl->info.kernel_path = 1; pl->info.frames_per_tile = 1; pl->info.grid_fwd = batch * pl->T;
         pl->info.fb_blocks = 0; pl->info.fb_blocks_dense = 0; pl->info.lds_bytes = (2 * N + 2 * tb->F) * 4;
+        pl->info.contraction = -1; pl->info.wl_steps = 0;
         return DMEL_OK;
     }
     dmel::FwdParams fp{};
@@ -931,6 +933,9 @@ dmel_status launch_forward_n(dmel_plan* pl, const float* x, int batch, int N, dm
     pl->info.kernel_path = 0; pl->info.frames_per_tile = fpt; pl->info.grid_fwd = (int)grid;
     pl->info.fb_blocks = tb->n_entries; pl->info.fb_blocks_dense = tb->n_dense;
     pl->info.lds_bytes = dmel::forward_lds_bytes(N, mode);
+    const bool spec_only = mode == dmel::kSpec || mode == dmel::kSpecTrain;
+    pl->info.contraction = spec_only ? -1 : (dmel::mode_wlc(mode) ? 1 : (mode == dmel::kTrainH ? 2 : 0));
+    pl->info.wl_steps = dmel::mode_wlc(mode) ? 4 * fp.wl_total4 : 0;
     return DMEL_OK;
 }
 

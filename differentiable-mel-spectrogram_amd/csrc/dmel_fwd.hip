@@ -32,6 +32,9 @@
 namespace dmel {
 
 
+#ifndef DMEL_TWC
+#define DMEL_TWC 8
+#endif
 #ifndef DMEL_FWD_PART
 #define DMEL_FWD_PART 0
 #endif
@@ -744,13 +747,23 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
 #else
 #define DMEL_MEAN_W mean
 #endif
+                // (every mode but the wave-local one, R = 32 or 64: the window multiply in groups of eight entries -- left alone the scheduler requested
+                // all R window entries at once, R register pairs on top of the R samples and the growing z, and spilled 6 ... 22 registers at
+                // n_fft 1024 ... 4096 (tools/kres.sh); kTrainW fits as it is and is not touched)
+#ifndef DMEL_WIN_GROUP
+#define DMEL_WIN_GROUP 8
+#endif
+                constexpr bool WIN_GROUPED = !WLC && R >= 32 && DMEL_WIN_GROUP > 0;
                 if (inside_w) {
+                    float mean_i = DMEL_MEAN_W;
+                    if constexpr (WIN_GROUPED) asm volatile("" : "+v"(mean_i));      // (its own copy: the R subtractions are then not hoisted above the branch as one block)
                     static_for<0, R>([&](auto aa) {
                         constexpr int a = decltype(aa)::value;
+                        if constexpr (WIN_GROUPED && a % (DMEL_WIN_GROUP > 0 ? DMEL_WIN_GROUP : 1) == 0 && a > 0) __builtin_amdgcn_sched_barrier(0);
                         const v2f wd = wload(aa);
-                        const float va = xa[ti][pass][a] - DMEL_MEAN_W;
+                        const float va = xa[ti][pass][a] - mean_i;
                         if constexpr (!PAIR) z[a] = splat(va) * wd;
-                        else z[a] = v2f{va, xb2[ti][pass][a] - mean} * wd.xx;
+                        else z[a] = v2f{va, xb2[ti][pass][a] - mean_i} * wd.xx;
                     });
                 } else {
                     static_for<0, R>([&](auto aa) {
@@ -764,6 +777,9 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
                             const int ib = f1 + n;
                             const float vb = ((ib >= 0) && (ib < p.L)) ? xb2[ti][pass][a] - mean : 0.f;
                             z[a] = v2f{va, vb} * wd.xx;
+                            // (the frames at a clip's edge, pair modes: four entries at a time.  Interleaved freely, the index arithmetic of all R entries
+                            // raised this RARE path's register demand past the budget, and what it spilled -- z[0 .. 4] -- was spilled on the interior path too)
+                            if constexpr (WIN_GROUPED && a % 4 == 3) __builtin_amdgcn_sched_barrier(0);
                         }
                     });
                 }
@@ -878,7 +894,7 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
                 // cross-lane stage (each read there was waited for on the spot)
                 // (R = 32: in chunks of 8, the next chunk requested while one is used -- all 31 at once cost 62 registers on top of
                 // the 64 of the transform)
-                constexpr int TWC = (R > 16) ? 8 : R;
+                constexpr int TWC = (R > 16) ? DMEL_TWC : R;
                 float2 tw2r[R];
                 auto tw2_fetch = [&](auto cc) {
                     constexpr int c0 = decltype(cc)::value;
@@ -1657,6 +1673,9 @@ template <int N> static hipError_t launch_n(int mode, int tpw, const FwdParams& 
 // instantiations of the large transforms -- minutes of compile time each -- build in parallel: part 0 holds everything that is
 // not a template instantiation plus the sizes up to 512, parts 1-3 hold 1024 / 2048 + 16384 / 4096 + 8192 and nothing else.
 // Without DMEL_FWD_SPLIT (the tools' one-command builds) everything is in this one translation unit.
+#ifndef DMEL_TWC
+#define DMEL_TWC 8
+#endif
 #ifndef DMEL_FWD_PART
 #define DMEL_FWD_PART 0
 #endif

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DMEL_ABI_VERSION 4   /* round 4: *_dev variants of the fixed-length paths, saved spectrogram, DMEL_FLAG_MFMA_BF16X3, mailbox time-out, plan registry */
+#define DMEL_ABI_VERSION 5   /* round 6: dmel_plan_info.contraction / wl_steps; DMEL_FLAG_X_INDIRECT served by every forward kernel (round 4 = 4: *_dev variants of the fixed-length paths, saved spectrogram, DMEL_FLAG_MFMA_BF16X3, mailbox time-out, plan registry) */
 
 typedef enum dmel_status {
     DMEL_OK = 0,
@@ -438,6 +438,10 @@ typedef struct dmel_plan_info {
     int32_t fb_blocks_dense;   /* the same count for a dense matrix                         */
     int32_t lds_bytes;         /* dynamic LDS of the fused kernel                           */
     int32_t kernel_path;       /* 0 = wave-FFT + MFMA kernel (32 <= n_fft <= 16384), 1 = direct-DFT kernel (n_fft < 32), 3 = global-memory FFT / chirp-z (dmel_big.hip) */
+    /* ABI 5 (round 6): which contraction the most recent fused forward ran, and its size -- what an MFMA-flop count has to be taken from */
+    int32_t contraction;       /* 0 = banded / dense 16x16x4 fp32 tiles (fb_blocks of them per 16-row tile), 1 = wave-local 4x4x1 fp32 (kTrainW:
+                                  wl_steps instructions per wave, 16 blocks of 4 x 4 each), 2 = dense bf16x3 (kTrainH), -1 = no MFMA stage */
+    int32_t wl_steps;          /* contraction 1: v_mfma_f32_4x4x1 instructions every wave issues per tile (all phases)     */
 } dmel_plan_info;
 dmel_status dmel_plan_get_info(const dmel_plan* plan, dmel_plan_info* info);
 

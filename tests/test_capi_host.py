@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert sorted(capi.SYMBOLS) == declared
     for name in declared:
         assert hasattr(L, name), f"libdmel_hip.so does not export {name}"
-    assert L.dmel_abi_version() == 4
+    assert L.dmel_abi_version() == 5
 
 
 def test_n_fft_rule_matches_oracle_and_fixtures():

@@ -5,7 +5,7 @@
 # two and four ranks sharing this GPU, the two-rank run five times), the optional gradients and the trainable-filterbank step.
 # Raw output under gpurun_out/prof_$TAG; tools/summarize_profile.py turns it into the files committed under profiles/.
 #   usage: tools/profile_session.sh <tag> [parts]      parts: any of  bench trace pmc shapes reducers extras stamps  (default: all)
-TAG=${1:-r05}
+TAG=${1:-r06}
 PARTS=${2:-"bench trace pmc shapes reducers extras stamps"}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -24,6 +24,8 @@ if has pmc; then
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $EAGER > $OUT/write.log 2>&1
   rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $OUT/sq1 -- $EAGER > $OUT/sq1.log 2>&1
   rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/sq2 -- $EAGER > $OUT/sq2.log 2>&1
+  # the kernel's length in CYCLES next to the vector pipe's busy cycles, one pass (roofline.valu_busy: VERDICT r05 #5)
+  rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVES --output-format csv -d $OUT/clk -- $EAGER > $OUT/clk.log 2>&1
 fi
 if has shapes; then
   # the other transform sizes: trains of forward launches (tools/ktime.py): kernel trace, then the same three counter passes per shape
@@ -33,6 +35,7 @@ if has shapes; then
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_$cfg -- python3 tools/ktime.py $cfg train 10 > $OUT/write_$cfg.log 2>&1
     rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_MFMA --output-format csv -d $OUT/sq_$cfg -- python3 tools/ktime.py $cfg train 10 > $OUT/sq_$cfg.log 2>&1
     rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $OUT/sq2_$cfg -- python3 tools/ktime.py $cfg train 10 > $OUT/sq2_$cfg.log 2>&1
+    rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVES --output-format csv -d $OUT/clk_$cfg -- python3 tools/ktime.py $cfg train 10 > $OUT/clk_$cfg.log 2>&1
     python3 tools/ktime.py $cfg train 2>&1 | tail -1 >> $OUT/ktime.txt
   done
   python3 tools/ktime.py c2 train 2>&1 | tail -1 >> $OUT/ktime.txt

@@ -87,14 +87,29 @@ def sq_digest(med):
     return d
 
 
-def valu_figures(med, avg_kernel_us):
-    """roofline.valu_busy / valu_insts_per_wave of bench.py: SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip's 1024 SIMDs"""
+def valu_figures(med, avg_kernel_us, clk=None):
+    """roofline.valu_busy / valu_insts_per_wave of bench.py.  SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip's 1024 SIMDs; the kernel's
+    length IN CYCLES comes from the `clk` pass of the same session (GRBM_GUI_ACTIVE: the sum over the 8 XCDs of the cycles the graphics block was
+    active during the dispatch -- MI355X_MICROARCH.md, DVFS give-back), not from wall time x a nominal clock: under dense vector issue the chip runs
+    well below 2.4 GHz (NOTEBOOK R5.1), so the round-5 figure (wall x 2.4 GHz) understated how busy the pipe is.  Counters of ONE pass are used together."""
     out_ = {}
     if med.get("SQ_WAVES") and "SQ_INSTS_VALU" in med:
         out_["valu_insts_per_wave"] = round(med["SQ_INSTS_VALU"] / med["SQ_WAVES"], 1)
-    if "SQ_ACTIVE_INST_VALU" in med and avg_kernel_us:
+    if clk and clk.get("GRBM_GUI_ACTIVE") and clk.get("SQ_ACTIVE_INST_VALU"):
+        cyc = clk["GRBM_GUI_ACTIVE"] / 8.0
+        out_["valu_busy"] = round(clk["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / cyc, 4)
+        out_["kernel_cycles"] = round(cyc, 1)
+        if clk.get("SQ_BUSY_CYCLES"):
+            out_["sq_busy_cycles_per_se"] = round(clk["SQ_BUSY_CYCLES"] / 32.0, 1)
+        if avg_kernel_us:
+            out_["effective_clock_ghz"] = round(cyc / (avg_kernel_us * 1e3), 3)
+            out_["valu_busy_wall_2p4ghz"] = round(clk["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (avg_kernel_us * 2400.0), 4)
+        out_["valu_busy_note"] = ("SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs, both from ONE --pmc pass "
+                                  "(tools/profile_session.sh: clk); effective_clock_ghz = those cycles over the kernel-trace average of the same session (reads high on "
+                                  "dispatches this short: launch and drain are in the wall time, not all of it in the busy cycles); valu_busy_wall_2p4ghz = round 5's definition")
+    elif "SQ_ACTIVE_INST_VALU" in med and avg_kernel_us:
         out_["valu_busy"] = round(med["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (avg_kernel_us * 2400.0), 4)
-        out_["valu_busy_note"] = "SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel cycles at 2.4 GHz, kernel-trace average of the same session)"
+        out_["valu_busy_note"] = "SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel cycles at 2.4 GHz, kernel-trace average of the same session) -- no clk pass in this session"
     return out_
 
 
@@ -156,7 +171,8 @@ if sq:
     if rows:
         ks = [k for k in kernel_summary(rows, only_dmel=False, min_calls=20) if FWD_C2 in k["kernel"]]
         avg_c2 = ks[0]["avg_ns"] / 1e3 if ks else None
-    hbm.setdefault("c2", {}).update(valu_figures(sq, avg_c2))
+    clk_c2 = {k: statistics.median(v) for k, v in counters("clk", FWD_C2).items()}
+    hbm.setdefault("c2", {}).update(valu_figures(sq, avg_c2, clk_c2))
     d = sq_digest(sq)
     d["_how"] = ("rocprofv3 --pmc, two separate passes (tools/profile_session.sh: sq1, sq2) around `bench.py --steps 30 --warmup 5 --mode eager`; medians over the "
                  "dispatches of dmel_fwd_kernel<1024, train>; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles")
@@ -196,7 +212,8 @@ for cfg in ("c3", "c5", "c4", "esc_n4096", "esc_n8192"):
     if s_:
         ent["sq"] = sq_digest(s_)
         fk = [k for k in ent["kernels"] if "dmel_fwd_kernel" in k["kernel"]]
-        hbm.setdefault(cfg, {}).update(valu_figures(s_, fk[0]["avg_ns"] / 1e3 if fk else None))
+        clk_ = {k: statistics.median(v) for k, v in counters(f"clk_{cfg}", "dmel_fwd_kernel").items()}
+        hbm.setdefault(cfg, {}).update(valu_figures(s_, fk[0]["avg_ns"] / 1e3 if fk else None, clk_))
         if "traffic" in ent:
             ent["traffic"] = hbm[cfg]
     shapes[cfg] = ent
