@@ -325,10 +325,22 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
     // BUFFER loads on purpose: with plain loads InstCombine folds the ring's phi(load, load) into load(phi(address)) at the loop
     // header and every group waits a cache round trip in front of its first use; an intrinsic call is not folded.  Groups past the
     // end of a phase re-read its last group.
+#ifndef DMEL_WL_UNCOND
+#define DMEL_WL_UNCOND 1
+#endif
+    // DMEL_WL_UNCOND (round 6): EVERY ring load is issued -- a group past the end of its phase re-reads the phase's last group, which nobody
+    // uses.  With conditional loads the compiler cannot know how many loads follow the one a slot waits for (a slot's `s_waitcnt vmcnt(N)`
+    // is only safe if N loads were issued behind it), so every turn of the ring opened with `vmcnt(0)`: the refill requested two
+    // instructions earlier was waited for in full, ~300 cycles per turn, 15-20 turns per tile at n_fft 2048 (NOTEBOOK R5.20).  Now the ring is
+    // a fixed pattern of WL_DEPTH loads per turn and the waits are `vmcnt(WL_DEPTH - 1)`.
     auto wl_bload = [&](floatx4& dst, int grp, int n4, int boff4) {
 #ifdef DMEL_ABLATE
         if (p.flags & 0x10000u) return;                          // timing only: no B operand loads
 #endif
+        if constexpr (DMEL_WL_UNCOND) {
+            const int gq = grp < n4 ? grp : n4 - 1;               // (n4 >= 1: the host builds no empty phase)
+            dst = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rbw, lane * 16, (boff4 + __builtin_amdgcn_readfirstlane(gq)) * 1024, 0));
+        } else
         if (grp < n4) dst = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rbw, lane * 16, (boff4 + __builtin_amdgcn_readfirstlane(grp)) * 1024, 0));
     };
     auto wl_ring_init = [&](int n4, int boff4) {
@@ -1218,6 +1230,12 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
                         constexpr int d = decltype(dd)::value;
                         group(dd);
                         wl_bload(wl_ring[d], s4 + d + WL_DEPTH, n4, off4 - n4);
+                        if constexpr (DMEL_WL_UNCOND) {
+                            // one group = the next group's A operands (two ds_read2), four MFMAs, the slot's refill -- in this order, group by group
+                            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        }
                     });
                     aaddr += WL_DEPTH * 32;
                 }
