@@ -225,6 +225,9 @@ NET_CASES = (
     ("conv_g1_lin", "MelConvNet", "g1_c1", False),
     ("linear_g1_log", "MelLinearNet", "g1_c1", True),
     ("linear_g4_log", "MelLinearNet", "g4_esc_hop441", True),
+    # round 6 (VERDICT r05 "missing" 5): models.py:80-103, the third wrapping net (fc 32 -> relu -> dropout -> fc)
+    ("mlp_g1_log", "MelMlpNet", "g1_c1", True),
+    ("mlp_g1_lin", "MelMlpNet", "g1_c1", False),
 )
 
 

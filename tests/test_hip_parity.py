@@ -1242,10 +1242,10 @@ def test_unusual_shapes_match_oracle(case):
 # ---- f1: logits of the caller nets against the reference's own (tests/golden/g11_nets.npz) --------------------------------
 @pytest.mark.parametrize("key,cls,cname,en", [("conv_g1_log", "MelConvNet", "g1_c1", True), ("conv_g1_lin", "MelConvNet", "g1_c1", False),
                                               ("linear_g1_log", "MelLinearNet", "g1_c1", True),
-                                              ("linear_g4_log", "MelLinearNet", "g4_esc_hop441", True)])
+                                              ("linear_g4_log", "MelLinearNet", "g4_esc_hop441", True),
+                                              ("mlp_g1_log", "MelMlpNet", "g1_c1", True), ("mlp_g1_lin", "MelMlpNet", "g1_c1", False)])
 def test_caller_nets_match_reference_logits(key, cls, cname, en, monkeypatch):
-    """`(logits, s)` of our MelConvNet / MelLinearNet on the G1 / G4 inputs against the reference's own nets (models.py:58-78,
-    105-136) with the same closed-form weights; F.dropout is the identity on both sides (models.py:75 keeps it always on)."""
+    """`(logits, s)` of our MelConvNet / MelLinearNet / MelMlpNet on the G1 / G4 inputs against the reference's own nets (models.py:58-136) with the same closed-form weights; F.dropout is the identity on both sides (models.py:75 keeps it always on)."""
     import os
     import torch.nn.functional as F
     from dmel_amd import nets

@@ -95,7 +95,7 @@ def test_load_cnn6_checkpoint_remaps_keys(tmp_path):
 
 # ---- f1: the reference's own logits (tests/golden/g11_nets.npz, make_golden.run_nets) ----------------------------------
 def test_net_heads_reproduce_reference_logits_on_cpu(monkeypatch):
-    """The heads of MelConvNet / MelLinearNet (stock torch ops on CPU) fed with the `s` the reference's own run produced give the
+    """The heads of MelConvNet / MelLinearNet / MelMlpNet (stock torch ops on CPU) fed with the `s` the reference's own run produced give the
     reference's logits: same closed-form weights (cases.fill_state), dropout replaced by the identity as in the capture."""
     import numpy as np
     import torch.nn.functional as F
@@ -104,7 +104,8 @@ def test_net_heads_reproduce_reference_logits_on_cpu(monkeypatch):
     gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "g11_nets.npz"))
     monkeypatch.setattr(F, "dropout", lambda x, *a, **k: x)
     case = C.BY_NAME["g1_c1"]
-    for key, cls, en in (("conv_g1_log", "MelConvNet", True), ("conv_g1_lin", "MelConvNet", False), ("linear_g1_log", "MelLinearNet", True)):
+    for key, cls, en in (("conv_g1_log", "MelConvNet", True), ("conv_g1_lin", "MelConvNet", False), ("linear_g1_log", "MelLinearNet", True),
+                         ("mlp_g1_log", "MelMlpNet", True), ("mlp_g1_lin", "MelMlpNet", False)):
         net = getattr(nets, cls)(C.NET_CLASSES, torch.tensor(float(case["lambd"])), "cpu", case["n_mels"], case["sr"], case["L"],
                                  hop_length=case["hop"], optimized=True, energy_normalize=en)
         C.fill_state(net, seed=C.NET_SEED)
