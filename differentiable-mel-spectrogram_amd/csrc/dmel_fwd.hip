@@ -218,7 +218,7 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
     constexpr bool BPERM = g.PAIRING == kPairBperm, PLANE = g.PAIRING == kPairPlane, SPLIT = g.SPLIT != 0, WIN_SYM = g.WIN_SYM != 0;
     constexpr bool KEEPZ = BPERM || PLANE;                      // the spectrum stays in registers until the pairing pass
     constexpr int WPF = g.WPF;                                  // waves per frame (n_fft 8192: 2, 16384: 4)
-    static_assert(!BPERM || (G <= 64 && PASSES == 1 && (G == 64 || C == 1)), "the bpermute pairing pass: whole frames inside one wave");
+    static_assert(!BPERM || (G <= 64 && PASSES == 1 && (G == 64 || C == 1 || (WLC && C == 2))), "the bpermute pairing pass: whole frames inside one wave");
     static_assert(!SPLIT || KEEPZ, "a one-plane slot cannot hold the whole spectrum");
     static_assert(!WIN_SYM || G <= 64, "half window table: frames inside one wave");
     static_assert(WPF == 1 || (PLANE && SPLIT && PASSES == 1 && !WIN_LDS), "frames spread over several waves exchange through planes");
@@ -1691,9 +1691,6 @@ template <int N> static hipError_t launch_n(int mode, int tpw, const FwdParams& 
 // instantiations of the large transforms -- minutes of compile time each -- build in parallel: part 0 holds everything that is
 // not a template instantiation plus the sizes up to 512, parts 1-3 hold 1024 / 2048 + 16384 / 4096 + 8192 and nothing else.
 // Without DMEL_FWD_SPLIT (the tools' one-command builds) everything is in this one translation unit.
-#ifndef DMEL_TWC
-#define DMEL_TWC 8
-#endif
 #ifndef DMEL_FWD_PART
 #define DMEL_FWD_PART 0
 #endif
@@ -1789,6 +1786,7 @@ int forward_lds_bytes(int n_fft, int mode)
     if (mode == kTrainWW && n_fft == 1024 && wlc_wide_size(1024)) return geom<1024, false, true, true>().LDS_BYTES;
     if (mode == kTrainW) {
         switch (n_fft) {                                   // (the sizes kTrainW may be built for)
+            case 512: v = geom<512, false, true>().LDS_BYTES; break;
             case 1024: v = geom<1024, false, true>().LDS_BYTES; break;
             case 2048: v = geom<2048, false, true>().LDS_BYTES; break;
             case 4096: v = geom<4096, false, true>().LDS_BYTES; break;
@@ -1808,6 +1806,7 @@ int forward_frames_per_tile(int n_fft, int mode)
 
 bool forward_two_tiles(int n_fft, int mode)
 {
+    if (mode_wlc(mode) || mode == kTrainH) return false;          // one tile per workgroup (launch_mode)
     const bool pr = mode_pairs(mode);
     switch (n_fft) {
         case 256: return pr ? has_tpw2<256, true>() : has_tpw2<256, false>();

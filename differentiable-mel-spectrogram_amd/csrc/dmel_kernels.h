@@ -33,7 +33,12 @@ constexpr bool mode_wlc(int mode) { return mode == kTrainW || mode == kTrainWW; 
 #ifndef DMEL_WLC_4096
 #define DMEL_WLC_4096 0
 #endif
-constexpr bool wlc_size(int n_fft) { return n_fft == 1024 || n_fft == 2048 || (DMEL_WLC_4096 && n_fft == 4096); }
+// (round 6: n_fft 512 -- BASELINE config 1 and the reference's x = 0.035 grid point, search_spaces.py:29 -- with a plan of its own: the
+// 16 x 16 x 2 transform of the other modes in the compact layout, FftPlanWl below; DMEL_WLC_512=0 keeps round 5's path)
+#ifndef DMEL_WLC_512
+#define DMEL_WLC_512 1
+#endif
+constexpr bool wlc_size(int n_fft) { return (DMEL_WLC_512 && n_fft == 512) || n_fft == 1024 || n_fft == 2048 || (DMEL_WLC_4096 && n_fft == 4096); }
 constexpr int kWlMaxPhases = 8;    // phases of 16 mel quads each: up to 512 mel bands (more: the host falls back to kTrain)
 constexpr int kHsplitMinNfft = 64, kHsplitMaxNfft = 4096;    // sizes kTrainH is built for (frames inside one wave, N/2 a multiple of 32)
 constexpr int hsplit_plane_stride(int n_fft) { return n_fft / 2 + 8; }   // bf16 entries per plane: bins 0 .. N/2, rows stay 16-byte aligned
@@ -226,6 +231,11 @@ template <> struct FftPlan<16384> { static constexpr int R = 64, C = 4, PASSES =
 template <int N, bool PAIR> struct FftPlanSel : FftPlan<N> {};
 template <> struct FftPlanSel<1024, true> { static constexpr int R = 16, C = 4, PASSES = 1, WAVES = 8, NBPRE = 20, MINW = 4, PAIRING = 0, SPLIT = 0; };
 constexpr bool mode_pairs(int mode) { return mode == kInfer || mode == kSpec; }
+// ... and on the CONTRACTION: kTrainW needs whole frames inside one wave in the compact layout (spectrum kept in registers, pairing by
+// ds_bpermute, PD[0 .. N/2] unpadded over one plane).  n_fft 512 = 16 x 16 x 2 has two frames per wave (G = 32 lanes each, as n_fft 1024) and a
+// radix-2 stage across adjacent lanes (as n_fft 2048): same radix, same twiddle tables as FftPlan<512>, other LDS layout.
+template <int N, bool PAIR, bool WL> struct FftPlanSel3 : FftPlanSel<N, PAIR> {};
+template <> struct FftPlanSel3<512, false, true> { static constexpr int R = 16, C = 2, PASSES = 1, WAVES = 4, NBPRE = 20, MINW = 4, PAIRING = 1, SPLIT = 1; };
 
 // internal bit of FwdParams::flags (the public ones are DMEL_FLAG_* of include/dmel.h, the 0x100.. bits belong to -DDMEL_ABLATE builds):
 // the launch fits the chip in ONE round of resident workgroups, see dmel_fwd_kernel's prologue
@@ -262,7 +272,7 @@ constexpr int slot_stride_f2(int N, int R, int C, int pairing = 0, int split = 0
 
 template <int N, bool PAIR = false, bool WL = false, bool WIDE = false> constexpr FftGeom geom()
 {
-    using P = FftPlanSel<N, PAIR>;
+    using P = FftPlanSel3<N, PAIR, WL>;
     FftGeom g{};
     g.N = N; g.R = P::R; g.C = P::C; g.G = N / P::R; g.PASSES = P::PASSES;
     g.WPF = g.G > kWave ? g.G / kWave : 1;                // waves per frame

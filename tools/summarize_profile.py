@@ -89,24 +89,25 @@ def sq_digest(med):
 
 def valu_figures(med, avg_kernel_us, clk=None):
     """roofline.valu_busy / valu_insts_per_wave of bench.py.  SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip's 1024 SIMDs; the kernel's
-    length IN CYCLES comes from the `clk` pass of the same session (GRBM_GUI_ACTIVE: the sum over the 8 XCDs of the cycles the graphics block was
-    active during the dispatch -- MI355X_MICROARCH.md, DVFS give-back), not from wall time x a nominal clock: under dense vector issue the chip runs
-    well below 2.4 GHz (NOTEBOOK R5.1), so the round-5 figure (wall x 2.4 GHz) understated how busy the pipe is.  Counters of ONE pass are used together."""
+    length IN CYCLES is SQ_BUSY_CYCLES / 32 (the counter sums the busy cycles of the 32 shader engines: 8 XCDs x 4) from the SAME --pmc pass (`clk`),
+    not wall time x a nominal 2.4 GHz: under dense vector issue the chip clocks lower (NOTEBOOK R5.1), so round 5's figure understated how busy
+    the pipe is.  GRBM_GUI_ACTIVE / 8 of the same pass is kept beside it: MI355X_MICROARCH.md's clock estimate, which reads high on
+    dispatches this short (3.6 GHz at config 2's 18 us, 2.1-2.4 GHz on the 0.1-0.4 ms shapes)."""
     out_ = {}
     if med.get("SQ_WAVES") and "SQ_INSTS_VALU" in med:
         out_["valu_insts_per_wave"] = round(med["SQ_INSTS_VALU"] / med["SQ_WAVES"], 1)
-    if clk and clk.get("GRBM_GUI_ACTIVE") and clk.get("SQ_ACTIVE_INST_VALU"):
-        cyc = clk["GRBM_GUI_ACTIVE"] / 8.0
+    if clk and clk.get("SQ_BUSY_CYCLES") and clk.get("SQ_ACTIVE_INST_VALU"):
+        cyc = clk["SQ_BUSY_CYCLES"] / 32.0
         out_["valu_busy"] = round(clk["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / cyc, 4)
         out_["kernel_cycles"] = round(cyc, 1)
-        if clk.get("SQ_BUSY_CYCLES"):
-            out_["sq_busy_cycles_per_se"] = round(clk["SQ_BUSY_CYCLES"] / 32.0, 1)
         if avg_kernel_us:
             out_["effective_clock_ghz"] = round(cyc / (avg_kernel_us * 1e3), 3)
             out_["valu_busy_wall_2p4ghz"] = round(clk["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (avg_kernel_us * 2400.0), 4)
-        out_["valu_busy_note"] = ("SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs, both from ONE --pmc pass "
-                                  "(tools/profile_session.sh: clk); effective_clock_ghz = those cycles over the kernel-trace average of the same session (reads high on "
-                                  "dispatches this short: launch and drain are in the wall time, not all of it in the busy cycles); valu_busy_wall_2p4ghz = round 5's definition")
+        if clk.get("GRBM_GUI_ACTIVE"):
+            out_["grbm_gui_active_per_xcd"] = round(clk["GRBM_GUI_ACTIVE"] / 8.0, 1)
+        out_["valu_busy_note"] = ("SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel cycles), kernel cycles = SQ_BUSY_CYCLES / 32 shader engines, both from ONE --pmc pass "
+                                  "(tools/profile_session.sh: clk); effective_clock_ghz = those cycles over the kernel-trace average of the same session; "
+                                  "valu_busy_wall_2p4ghz = round 5's definition (wall x 2.4 GHz)")
     elif "SQ_ACTIVE_INST_VALU" in med and avg_kernel_us:
         out_["valu_busy"] = round(med["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (avg_kernel_us * 2400.0), 4)
         out_["valu_busy_note"] = "SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel cycles at 2.4 GHz, kernel-trace average of the same session) -- no clk pass in this session"
