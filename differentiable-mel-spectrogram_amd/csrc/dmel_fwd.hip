@@ -1798,6 +1798,7 @@ int forward_lds_bytes(int n_fft, int mode)
 int forward_frames_per_tile(int n_fft, int mode)
 {
     if (mode == kTrainWW && n_fft == 1024 && wlc_wide_size(1024)) return geom<1024, false, true, true>().SLOTS;
+    if (mode == kTrainW && n_fft == 512) return geom<512, false, true>().SLOTS;          // (its plan has its own number of waves)
     int slots = -1;
     with_geom(n_fft, mode_pairs(mode), [&](const FftGeom& g) { slots = g.SLOTS; });
     if (slots < 0) return -1;
@@ -1828,7 +1829,7 @@ int forward_resident_workgroups(int n_fft, int mode)
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
         return n;
     }();
-    const int lds = forward_lds_bytes(n_fft, mode), waves = forward_waves(n_fft);
+    const int lds = forward_lds_bytes(n_fft, mode), waves = (mode == kTrainW && n_fft == 512) ? geom<512, false, true>().WAVES : forward_waves(n_fft);
     int per_cu = (lds > 0 && 163840 / lds > 0) ? 163840 / lds : 1;
     if (waves > 0 && per_cu * waves > 32) per_cu = 32 / waves;
     return cus * (per_cu > 0 ? per_cu : 1);

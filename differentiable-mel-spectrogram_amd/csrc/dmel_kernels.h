@@ -33,10 +33,13 @@ constexpr bool mode_wlc(int mode) { return mode == kTrainW || mode == kTrainWW; 
 #ifndef DMEL_WLC_4096
 #define DMEL_WLC_4096 0
 #endif
-// (round 6: n_fft 512 -- BASELINE config 1 and the reference's x = 0.035 grid point, search_spaces.py:29 -- with a plan of its own: the
-// 16 x 16 x 2 transform of the other modes in the compact layout, FftPlanWl below; DMEL_WLC_512=0 keeps round 5's path)
+// (round 6: n_fft 512 -- BASELINE config 1 and the reference's x = 0.035 grid point, search_spaces.py:29 -- in this scheme with a plan of its own
+// (FftPlanSel3 below: the 16 x 16 x 2 transform of the other modes in the compact layout, bpermute pairing for G = 32, C = 2): built, parity-green
+// (270 tests), and SLOWER -- the reference's ESC-50 shape 24.3 us with 16-frame workgroups, 23.6 with 8-frame ones, against 22.9 for the
+// 16 x 16 x 4 tiles with two tiles per workgroup; 256 clips of config 1's layer 23.1 / 24.3 against 22.0.  One phase of 16 quads is as long as
+// the widest quad's band (64 mel bands on 257 bins), and the one-tile workgroups pay the prologue twice as often.  Not built by default.)
 #ifndef DMEL_WLC_512
-#define DMEL_WLC_512 1
+#define DMEL_WLC_512 0
 #endif
 constexpr bool wlc_size(int n_fft) { return (DMEL_WLC_512 && n_fft == 512) || n_fft == 1024 || n_fft == 2048 || (DMEL_WLC_4096 && n_fft == 4096); }
 constexpr int kWlMaxPhases = 8;    // phases of 16 mel quads each: up to 512 mel bands (more: the host falls back to kTrain)
@@ -235,7 +238,10 @@ constexpr bool mode_pairs(int mode) { return mode == kInfer || mode == kSpec; }
 // ds_bpermute, PD[0 .. N/2] unpadded over one plane).  n_fft 512 = 16 x 16 x 2 has two frames per wave (G = 32 lanes each, as n_fft 1024) and a
 // radix-2 stage across adjacent lanes (as n_fft 2048): same radix, same twiddle tables as FftPlan<512>, other LDS layout.
 template <int N, bool PAIR, bool WL> struct FftPlanSel3 : FftPlanSel<N, PAIR> {};
-template <> struct FftPlanSel3<512, false, true> { static constexpr int R = 16, C = 2, PASSES = 1, WAVES = 4, NBPRE = 20, MINW = 4, PAIRING = 1, SPLIT = 1; };
+#ifndef DMEL_WL512_WAVES
+#define DMEL_WL512_WAVES 8
+#endif
+template <> struct FftPlanSel3<512, false, true> { static constexpr int R = 16, C = 2, PASSES = 1, WAVES = DMEL_WL512_WAVES, NBPRE = 20, MINW = 4, PAIRING = 1, SPLIT = 1; };
 
 // internal bit of FwdParams::flags (the public ones are DMEL_FLAG_* of include/dmel.h, the 0x100.. bits belong to -DDMEL_ABLATE builds):
 // the launch fits the chip in ONE round of resident workgroups, see dmel_fwd_kernel's prologue

@@ -14,7 +14,9 @@ mode = sys.argv[2] if len(sys.argv) > 2 else "train"
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 300
 # besides bench.py's configs: BASELINE config 4's global batch on one GPU, and the reference's ESC-50 shape (search_spaces.py:4-33) at its
 # largest starting lambd (n_fft 4096) and one lambd a run drifts to (n_fft 8192)
-EXTRA = {"c4": (2048, 16000, 16000, 128.0, 512, 128), "esc_n4096": (32, 40000, 8000, 400.0, 80, 64), "esc_n8192": (32, 40000, 8000, 700.0, 80, 64)}
+EXTRA = {"c4": (2048, 16000, 16000, 128.0, 512, 128), "esc_n4096": (32, 40000, 8000, 400.0, 80, 64), "esc_n8192": (32, 40000, 8000, 700.0, 80, 64),
+         "esc_n512": (32, 40000, 8000, 8000 * 0.035 / 6, 80, 64), "esc_n128": (32, 40000, 8000, 8000 * 0.01 / 6, 80, 64),
+         "c1x64": (256, 16000, 16000, 64.0, 256, 64)}       # (BASELINE config 1's layer on 256 clips: n_fft 512 on short clips, no prep kernel)
 B, L, sr, lam, hop, M = CONFIGS[name] if name in CONFIGS else EXTRA[name]
 T = L // hop + 1
 x = torch.from_numpy(synth.waveforms(B, L, seed=0)).cuda()
