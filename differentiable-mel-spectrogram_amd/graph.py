@@ -288,7 +288,11 @@ class GraphedStep:
         return self._copy_stream
 
     def feed(self, *batch) -> bool:
-        """one batch into the next slot (side stream); after the K-th: join, then the K steps (one replay).  True when they were issued."""
+        """one batch into the next slot (side stream); after the K-th: join, then the K steps (one replay).  True when they were issued.
+
+        Host waits: with by-address inputs the first ``feed`` of a set BLOCKS the host until the replay that last read that set's
+        address staging has finished (an event synchronise: the pinned staging is rewritten right after) -- the host therefore runs at most one
+        replay (K steps) ahead of the device whatever ``max_ahead`` says; copied inputs wait on the device (a stream wait), not on the host."""
         if self.inputs is None:
             raise ValueError("feed() needs GraphedStep(inputs=[...])")
         if len(batch) != len(self.inputs):
@@ -320,7 +324,11 @@ class GraphedStep:
         return True
 
     def flush(self) -> int:
-        """runs the batches of a partly filled set eagerly (no graph holds fewer than K steps); returns how many"""
+        """runs the batches of a partly filled set eagerly (no graph holds fewer than K steps); returns how many.
+
+        Ends with a device-wide synchronise (the eager forwards are not the graph's: the next call needs an exact picture of lambd).  With several
+        ranks every rank must call ``flush()`` at the same step with the same fill: a rank that flushes while the others replay holds their mailbox
+        / RCCL exchange until it arrives there too (``feed`` counts are a pure function of the batch count, so an SPMD loop does this by itself)."""
         n, self._fill = self._fill, 0
         if n == 0 or self.inputs is None:
             return 0
