@@ -1,7 +1,7 @@
 """The figures DESIGN.md and profiles/README.md quote from the committed profiles must BE the figures in those files (VERDICT r03 weak #7:
 the documents said 20.77 us where the file said 20.28, and 325 M frames/s where the file said 178.8 M).
 
-`profiles/r05_quoted.json` (round 4: `r04_quoted.json`) lists every such figure: the document, the exact text around it (must occur in the document), the file
+`profiles/r06_quoted.json` (rounds 4, 5: `r04_quoted.json`, `r05_quoted.json`) lists every such figure: the document, the exact text around it (must occur in the document), the file
 and the path inside it, a scale (file units -> quoted units) and a relative tolerance (rounding of the quoted text).  A figure that
 is re-measured changes the file; this test then fails until the document follows."""
 import json
@@ -11,7 +11,8 @@ import re
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-QUOTED = json.load(open(os.path.join(ROOT, "profiles", "r05_quoted.json")))
+QUOTED_PATH = os.path.join(ROOT, "profiles", "r06_quoted.json")
+QUOTED = json.load(open(QUOTED_PATH))
 
 
 def resolve(obj, path):
@@ -31,8 +32,12 @@ def test_quoted_figure_matches_its_file(q):
     text = open(os.path.join(ROOT, q["doc"])).read()
     assert q["quote"] in text, f'{q["doc"]} no longer contains the quoted text {q["quote"]!r}'
     pat = r"-?\d+(?:\.\d+)?(?:e-?\d+)?" if q.get("sci") else r"-?\d+(?:\.\d+)?"
-    nums = re.findall(pat, q["quote"].replace(" ", "") if q.get("strip_spaces") else q["quote"])
-    said = float(nums[q.get("which", 0)])
+    if "find" in q:                                              # the exact number text inside the quote (table rows hold many numbers)
+        assert q["find"] in q["quote"], (q["find"], q["quote"])
+        said = float(re.findall(pat, q["find"])[0])
+    else:
+        nums = re.findall(pat, q["quote"].replace(" ", "") if q.get("strip_spaces") else q["quote"])
+        said = float(nums[q.get("which", 0)])
     data = json.load(open(os.path.join(ROOT, q["file"])))
     have = float(resolve(data, q["path"])) * q.get("scale", 1.0)
     if q.get("transform") == "spread_percent":                   # max / min  ->  per cent of spread
@@ -81,3 +86,16 @@ def test_claim_about_the_bench_line_holds_in_the_committed_one(c):
         except (KeyError, IndexError, StopIteration, TypeError):
             v = None
         assert v is not None, f'{c["doc"]} claims {c["quote"]!r} but {c["file"]} holds nothing at {path}'
+
+
+def test_every_multi_rank_reducer_entry_is_quoted():
+    """DESIGN.md quoted the 2- and 4-rank shared-GPU mailbox throughputs and left out the 8-rank run's 145 x collapse.  Every
+    entry of the round's reducers file that ran with two or more ranks must be quoted (an entry of `quotes` pointing at it)."""
+    red = QUOTED.get("reducers")
+    assert red, "r06_quoted.json names the reducers file"
+    data = json.load(open(os.path.join(ROOT, red["file"])))
+    multi = [k for k, v in data.items() if isinstance(v, dict) and ((v.get("n_ranks") or 0) >= 2 or re.search(r"_([2-9]|\d\d)ranks_", k))]
+    assert len(multi) >= 3, multi
+    quoted = {q["path"][0] for q in QUOTED["quotes"] if q["file"] == red["file"] and q["doc"] == red["doc"]}
+    missing = [k for k in multi if k not in quoted]
+    assert not missing, f'{red["doc"]} does not quote {missing} of {red["file"]}'

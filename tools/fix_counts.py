@@ -5,7 +5,7 @@ import json, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_docs_quote_profiles as T
-qpath = T.QUOTED_PATH if hasattr(T, "QUOTED_PATH") else os.path.join(ROOT, "profiles", "r05_quoted.json")
+qpath = T.QUOTED_PATH if hasattr(T, "QUOTED_PATH") else os.path.join(ROOT, "profiles", "r06_quoted.json")
 Q = json.load(open(qpath))
 for c in Q.get("test_counts", []):
     have = T._collected(c["marker"])

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""After a re-measurement: rewrite the figures DESIGN.md / profiles/README.md quote (profiles/r05_quoted.json) so that they are the figures
+"""After a re-measurement: rewrite the figures DESIGN.md / profiles/README.md quote (profiles/r06_quoted.json) so that they are the figures
 of the committed files again, keeping each number's format.  tests/test_docs_quote_profiles.py is the check; this is the pen.
 Entries whose text holds digit groups separated by spaces (strip_spaces) are reported, not rewritten."""
 import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from test_docs_quote_profiles import resolve
-QP = os.path.join(ROOT, "profiles", "r05_quoted.json")
+QP = os.path.join(ROOT, "profiles", "r06_quoted.json")
 Q = json.load(open(QP))
 groups = {}
 for q in Q["quotes"]:

@@ -178,8 +178,7 @@ if sq:
     d["_how"] = ("rocprofv3 --pmc, two separate passes (tools/profile_session.sh: sq1, sq2) around `bench.py --steps 30 --warmup 5 --mode eager`; medians over the "
                  "dispatches of dmel_fwd_kernel<1024, train>; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles")
     dump(f"{tag}_pmc_sq_c2.json", d)
-if bench:
-    dump(f"{tag}_bench_c2.json", bench)
+# (the bench line is written at the end: the counters of the other shapes are filled into it too)
 
 # ---- the other shapes ------------------------------------------------------------------------------------------------
 ALG = {"c3": 4 * (32 * 160000 + 2 * 32 * 128 * 313), "c5": 4 * (32 * 220500 + 2 * 32 * 128 * 501), "c4": 4 * (2048 * 16000 + 2 * 2048 * 128 * 32),
@@ -225,6 +224,24 @@ if shapes:
     dump(f"{tag}_shapes.json", shapes)
 if len(hbm) > 2:
     dump("hbm_traffic.json", hbm)
+if bench:
+    # what bench.py quotes from hbm_traffic.json when it runs AFTER this session (the line of this session ran before the file existed for this source)
+    def fill(rl, q):
+        for k_ in ("valu_busy", "valu_insts_per_wave", "kernel_cycles", "effective_clock_ghz", "valu_busy_note"):
+            if q.get(k_) is not None and rl.get(k_) is None:
+                rl[k_] = q[k_]
+        if rl.get("traffic") is None and q.get("dmel_fwd_kernel_bytes_per_launch") is not None:
+            rl["traffic"] = q["dmel_fwd_kernel_bytes_per_launch"]
+    fill(bench["roofline"], hbm.get("c2", {}))
+    oc = bench.get("other_configs", {})
+    for name, key in (("c3", "c3"), ("c5", "c5"), ("c4_on_one_gpu", "c4")):
+        if isinstance(oc.get(name), dict) and "roofline" in oc[name]:
+            fill(oc[name]["roofline"], hbm.get(key, {}))
+    for name, key in (("esc50_x0.3", "esc_n4096"), ("esc50_lambd700", "esc_n8192")):
+        e = oc.get("reference_experiment_shapes", {}).get(name)
+        if isinstance(e, dict) and "roofline" in e:
+            fill(e["roofline"], hbm.get(key, {}))
+    dump(f"{tag}_bench_c2.json", bench)
 for nm, fn in (("reference_shapes", "reference_shapes.json"), ("batch_sweep", "batch_sweep.json")):
     d = last_json(os.path.join(src, fn))
     if d:
