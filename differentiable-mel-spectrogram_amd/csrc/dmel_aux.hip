@@ -169,8 +169,18 @@ __global__ void __launch_bounds__(kDotThreads) dmel_dot_kernel(const void* __res
     if (tid == 0) {
         __hip_atomic_store(&partials[blockIdx.x], bsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = (ticket == gridDim.x - 1);
+        // two levels of tickets (dmel_kernels.h: kDotGroup): a group's counter orders its members' partials before the group's last member,
+        // the kernel's counter orders the groups' last members before the one that combines -- every store completed (vmcnt(0)) before its
+        // workgroup's first atomic was issued, and an atomic's return orders what follows it
+        const unsigned grp = blockIdx.x / kDotGroup, ngroups = (gridDim.x + kDotGroup - 1) / kDotGroup;
+        const unsigned gsize = grp + 1 < ngroups ? (unsigned)kDotGroup : gridDim.x - grp * kDotGroup;
+        unsigned* gc = dot_group_counters(counter) + 16 * grp;
+        bool last = false;
+        if (__hip_atomic_fetch_add(gc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1u) {
+            __hip_atomic_store(gc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                 // armed for the next launch
+            last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1u;
+        }
+        is_last = last;
     }
     __syncthreads();
     if (!is_last) return;
@@ -197,10 +207,12 @@ __global__ void __launch_bounds__(kDotThreads) dmel_dot_kernel(const void* __res
 
 int dot_blocks_for(long long count, int max_partials)
 {
-    // 8192 floats per workgroup and tensor: few workgroups on purpose -- every workgroup ends with one ticket on a single
-    // counter (~11 ns each, serialised), which cost more than the loads at 256+ workgroups
-    const long long want = (count + 8191) / 8192;
-    return (int)(want < 1 ? 1 : (want > max_partials ? max_partials : want));
+    // (round 6: 4096 floats per workgroup and tensor -- 4.0-4.1 us at BASELINE config 2 against 4.3 for 2048 or 8192 --, at most kDotMaxBlocks workgroups -- the tickets are a two-level tree now.  Until round 5:
+    // 8192 per workgroup, few workgroups on purpose -- every workgroup ended with one ticket on a single counter, ~11.7 ns each, serialised)
+    static const long long per_wg = [] { const char* e = std::getenv("DMEL_DOT_PER_WG"); const long long v = e ? std::atoll(e) : 0; return v >= 1024 ? v : 4096LL; }();   // (diagnostics)
+    const long long want = (count + per_wg - 1) / per_wg;
+    const long long cap = max_partials < kDotMaxBlocks ? max_partials : kDotMaxBlocks;
+    return (int)(want < 1 ? 1 : (want > cap ? cap : want));
 }
 
 hipError_t launch_dot(const void* g, int g_bf16, const float* t, long long count, int accumulate, double* partials,

@@ -73,6 +73,17 @@ struct LamArgs {
     unsigned* dot_counter;            // ticket word of the caller's dot scratch, zeroed by the first launch (or nullptr)
 };
 
+// The dot kernel's hand-off (dmel_aux.hip) is a TREE of tickets since round 6: workgroups in groups of kDotGroup draw a ticket on their group's
+// counter, the last of a group draws one on the kernel's counter, the last of those combines.  (One counter for all: ~11.7 ns per ticket,
+// serialised -- 128 workgroups of 8192 elements were the optimum at BASELINE config 2 and 256 cost +1 us, 512 +4 us.)  Scratch layout
+// (dmel_api.cpp: carve): 1024 fp64 partials, then the ticket word; at most kDotMaxBlocks partials are used and the group counters sit in
+// the upper half of that array, 64 bytes apart: word 16 g of (partials + kDotMaxBlocks) = 4096 bytes in front of the ticket word.
+constexpr int kDotGroup = 16, kDotMaxBlocks = 512;
+__host__ __device__ inline unsigned* dot_group_counters(unsigned* ticket_word)
+{
+    return reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(ticket_word) - 4096);
+}
+
 enum LamAction : int { kLamRun = 0, kLamSkip = 1, kLamPoison = 2 };
 struct LamState {
     float lam, a, denom;              // lambd, |lambd| (models.py:38), |lambd| + 1e-15 (time_frequency.py:24)
@@ -156,7 +167,12 @@ __device__ __forceinline__ LamState lam_prologue(const LamArgs& la, int n_launch
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if (la.handled) la.handled[1] = num;
             }
-            if (la.dot_counter) *la.dot_counter = 0u;
+            if (la.dot_counter) {
+                *la.dot_counter = 0u;
+                // ... and the dot kernel's group counters (kDotGroupCounters below), which live 4 KB in front of the ticket word in the caller's scratch
+                unsigned* gc = dot_group_counters(la.dot_counter);
+                for (int g2 = 0; g2 < kDotMaxBlocks / kDotGroup; ++g2) gc[16 * g2] = 0u;
+            }
             if (la.handled) la.handled[0] = match ? 1u : 0u;
         }
     } else if (match && leader && la.handled) {
