@@ -614,6 +614,9 @@ dmel_status build_tables(dmel_plan* pl, int N, NfftTables** out)
 // [8320] window table (w, w d^2 2^-2e) for the kernels that read it from memory | [kScratchPsum] partial clip sums
 constexpr size_t kScratchPartials = 64, kScratchCounter = 64 + 8192, kScratchWin = 8320;
 constexpr size_t kScratchPsum = kScratchWin + (size_t)dmel::kMaxNfft * 8;
+// the dot kernel's group counters live in the upper half of the partials array, found from the ticket word (dmel_kernels.h: dot_group_counters)
+static_assert(kScratchCounter - kScratchPartials == 1024 * sizeof(double) && dmel::kDotMaxBlocks * sizeof(double) == 4096 &&
+              (dmel::kDotMaxBlocks / dmel::kDotGroup) * 64 <= 4096, "scratch layout the ticket tree relies on");
 
 struct Scratch {
     unsigned* handled = nullptr; double* partials = nullptr; unsigned* counter = nullptr; float2* win = nullptr; float* psum = nullptr;
