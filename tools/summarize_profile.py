@@ -228,9 +228,9 @@ if bench:
     # what bench.py quotes from hbm_traffic.json when it runs AFTER this session (the line of this session ran before the file existed for this source)
     def fill(rl, q):
         for k_ in ("valu_busy", "valu_insts_per_wave", "kernel_cycles", "effective_clock_ghz", "valu_busy_note"):
-            if q.get(k_) is not None and rl.get(k_) is None:
-                rl[k_] = q[k_]
-        if rl.get("traffic") is None and q.get("dmel_fwd_kernel_bytes_per_launch") is not None:
+            if q.get(k_) is not None:
+                rl[k_] = q[k_]                                   # (this session's counters, whatever an older hbm_traffic.json said when the line ran)
+        if q.get("dmel_fwd_kernel_bytes_per_launch") is not None:
             rl["traffic"] = q["dmel_fwd_kernel_bytes_per_launch"]
     fill(bench["roofline"], hbm.get("c2", {}))
     oc = bench.get("other_configs", {})
