@@ -327,3 +327,33 @@ np.savez(sys.argv[2], **out)
             assert int(b) < int(a), (k, int(a), int(b))                 # the forced launches really used two-tile workgroups
         else:
             assert np.isfinite(a).all() and np.array_equal(a, b), (k, float(np.abs(a - b).max()))
+
+
+def test_dot_ticket_tree_at_every_group_boundary():
+    """Round 6: the dot kernel's hand-off is a tree of tickets (groups of 16 workgroups of 4096 elements; csrc/dmel_kernels.h: kDotGroup).  Element
+    counts around every boundary of that scheme -- one workgroup, a partly filled group, exactly one group, one workgroup more, many groups with a
+    short last one, the cap of 512 workgroups and beyond it -- each launched several times on the same scratch (the counters re-arm themselves),
+    with and without accumulation, against an fp64 sum."""
+    import torch
+    from dmel_amd import capi
+    dev = "cuda:0"
+    plan = capi.Plan(4000, 128, 32, 8000)
+    s = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator(device=dev).manual_seed(5)
+    per = 4096
+    counts = [1, 3, per - 1, per, per + 1, 15 * per + 7, 16 * per, 16 * per + 1, 17 * per, 33 * per + 5, 255 * per + 9, 256 * per, 511 * per + 1, 512 * per,
+              512 * per + 3, 3 * 512 * per + 11]
+    dl = torch.zeros(1, device=dev)
+    for n in counts:
+        g = torch.randn(n, generator=gen, device=dev)
+        t = torch.randn(n, generator=gen, device=dev)
+        ref = float((g.double() * t.double()).sum())
+        scale = float((g.double() * t.double()).abs().sum())
+        for rep in range(3):
+            plan.backward(g.data_ptr(), t.data_ptr(), n, dl.data_ptr(), s)
+            torch.cuda.synchronize()
+            assert abs(float(dl) - ref) <= 2e-7 * scale + 1e-6, (n, rep, float(dl), ref)
+        first = float(dl)
+        plan.backward_scratch(g.data_ptr(), t.data_ptr(), n, dl.data_ptr(), s, None, accumulate=True)
+        torch.cuda.synchronize()
+        assert abs(float(dl) - 2.0 * ref) <= 4e-7 * scale + 2e-6, (n, float(dl), 2 * ref, first)
