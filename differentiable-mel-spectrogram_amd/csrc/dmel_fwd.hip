@@ -338,12 +338,21 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
         if (p.flags & 0x10000u) return;                          // timing only: no B operand loads
 #endif
         if constexpr (DMEL_WL_UNCOND) {
-            const int gq = grp < n4 ? grp : n4 - 1;               // (n4 >= 1: the host builds no empty phase)
-            dst = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rbw, lane * 16, (boff4 + __builtin_amdgcn_readfirstlane(gq)) * 1024, 0));
+            // the table index stays inside [0, wl_total4 - 1] whatever the phase holds: a phase of quads whose bands are all empty (many mel bands on few
+            // bins) has n4 = 0, and the buffer's range check does not cover the scalar offset
+            // (`n4` carries the phase's LAST table index here -- wl_last() -- so that a load costs one scalar add and one scalar min)
+            const int gi = boff4 + grp < n4 ? boff4 + grp : n4;
+            dst = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rbw, lane * 16, __builtin_amdgcn_readfirstlane(gi) * 1024, 0));
         } else
         if (grp < n4) dst = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rbw, lane * 16, (boff4 + __builtin_amdgcn_readfirstlane(grp)) * 1024, 0));
     };
+    // last table index a phase of n4 groups at offset boff4 may read: inside [0, wl_total4 - 1] even for an empty phase
+    auto wl_last = [&](int n4, int boff4) -> int {
+        int l = boff4 + n4; l = l < p.wl_total4 ? l : p.wl_total4; l -= 1;
+        return l > 0 ? l : 0;
+    };
     auto wl_ring_init = [&](int n4, int boff4) {
+        if constexpr (DMEL_WL_UNCOND) n4 = wl_last(n4, boff4);
         // (a slot whose group does not exist in this phase is never used -- the tail groups are guarded -- so it is "defined" by an empty asm
         // statement instead of four zeros: 24 moves less per ring start, 48-72 vector instructions per wave)
         if constexpr (WLC) static_for<0, WL_DEPTH>([&](auto dd) { constexpr int d = decltype(dd)::value; asm volatile("" : "=v"(wl_ring[d])); wl_bload(wl_ring[d], d, n4, boff4); });
@@ -1225,11 +1234,12 @@ __global__ void __launch_bounds__((geom_mode<N, MODE>().THREADS), (geom_mode<N, 
                     static_for<0, 4>([&](auto uu) { constexpr int u = decltype(uu)::value; a_cur[u] = a_nxt[u]; });
                 };
                 int s4 = 0;
+                const int ring_n4 = DMEL_WL_UNCOND ? wl_last(n4, off4 - n4) : n4;
                 for (; s4 + WL_DEPTH <= n4; s4 += WL_DEPTH) {
                     static_for<0, WL_DEPTH>([&](auto dd) {
                         constexpr int d = decltype(dd)::value;
                         group(dd);
-                        wl_bload(wl_ring[d], s4 + d + WL_DEPTH, n4, off4 - n4);
+                        wl_bload(wl_ring[d], s4 + d + WL_DEPTH, ring_n4, off4 - n4);
                         if constexpr (DMEL_WL_UNCOND) {
                             // one group = the next group's A operands (two ds_read2), four MFMAs, the slot's refill -- in this order, group by group
                             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);

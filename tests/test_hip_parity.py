@@ -1435,3 +1435,33 @@ def test_quads_split_over_blocks_give_what_whole_quads_give(sr, L, hop, lam, M, 
         assert (np.abs(a - b) / scale).max() <= 1e-5, float((np.abs(a - b) / scale).max())
     y_ref, _ = O.forward(x.cpu().numpy(), lam, hop, M, sr, want_tangent=False)
     assert _rel_err(res[0][0].reshape(-1), y_ref.reshape(-1)) <= TOL
+
+
+@pytest.mark.parametrize("n_mels,lam", [(512, 128.0), (400, 100.0), (509, 300.0)])
+def test_wave_local_contraction_with_empty_quads(n_mels, lam):
+    """Many mel bands on few bins: bands, whole quads and (sorted by width, 16 to a phase) whole PHASES of the wave-local contraction are empty.
+    Round 6 issues every load of the B ring (a group past the end of its phase re-reads the last one): with a phase of no groups at all the index
+    must still stay inside the table.  Every element and the tangent against the oracle; zero-width bands are exact zeros (log: log(eps))."""
+    from dmel_amd import capi
+    L, hop, sr, B = 6000, 128, 16000, 3
+    case = dict(name=f"emptyq_m{n_mels}", B=B, L=L, sr=sr, lambd=lam, hop=hop, n_mels=n_mels, kind="noise", normalize_window=False, dtype="float32",
+                seed=91, f_min=0.0, f_max=None, optimized=True)
+    x_np = C.make_input(case)
+    x = torch.from_numpy(x_np).to("cuda:0")
+    plan = capi.Plan(L, hop, n_mels, sr)
+    out = torch.empty(C.out_shape(case), dtype=torch.float32, device="cuda:0")
+    tan = torch.empty_like(out)
+    for log in (False, True):
+        plan.forward(x.data_ptr(), B, lam, out.data_ptr(), tan.data_ptr(), log, 1e-10, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        info = plan.info()
+        o_ref, t_ref = O.forward(x_np, lam, hop, n_mels, sr, apply_log=log)
+        o, t = out.cpu().numpy(), tan.cpu().numpy()
+        assert np.isfinite(o).all() and np.isfinite(t).all()
+        if log:
+            assert _log_err(o, o_ref) <= TOL
+        else:
+            assert _rel_err(o, o_ref) <= TOL
+            assert (o[o_ref == 0] == 0).all() and (o_ref == 0).any(), "the case must hold empty bands, and they must be exact zeros"
+        assert float(np.abs(t - t_ref).max()) / (np.abs(t_ref).max() + 1e-30) <= TOL
+    assert info["n_fft"] in (1024, 2048)
